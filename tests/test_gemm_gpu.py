@@ -1,0 +1,157 @@
+"""GPU: the MFMA GEMM / implicit-conv kernel (tts_king_amd/csrc/gemm.hip) through the C ABI, against fp64
+CPU math on the same bf16-rounded operands.  Integer-valued cases are exact (they pin the operand/fragment
+layouts, including the ds_read_b64_tr_b16 transposed reads); random cases use a tolerance scaled by K
+(bf16 products are exact in fp32, only the summation order differs)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rnd(*shape, seed=0, ints=False):
+    g = torch.Generator().manual_seed(seed)
+    if ints:
+        return torch.randint(-3, 4, shape, generator=g).float()
+    return torch.randn(*shape, generator=g)
+
+
+def check(out, ref, K, exact=False, out_bf16=True):
+    out = out.float().cpu().double()
+    ref = ref.double()
+    if exact:
+        assert torch.equal(out, ref), float((out - ref).abs().max())
+        return
+    tol = 2e-6 * K ** 0.5 * float(ref.abs().max() + 1) + (float(ref.abs().max()) * 2 ** -8 if out_bf16 else 0)
+    err = float((out - ref).abs().max())
+    assert err <= tol, (err, tol)
+
+
+@pytest.mark.parametrize("ints", [True, False])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 264), (1024, 768, 256), (77, 80, 256)])
+def test_nt_bias_relu(M, N, K, ints):
+    from tts_king_amd import ops
+    a, w, b = bf(rnd(M, K, seed=1, ints=ints)), bf(rnd(N, K, seed=2, ints=ints)), rnd(N, seed=3, ints=ints)
+    ref = torch.relu(a.double() @ w.double().t() + b.double())
+    out32 = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV), flags=ops.RELU, out_dtype=torch.float32)
+    check(out32, ref, K, exact=ints, out_bf16=False)
+    out16 = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV), flags=ops.RELU)
+    check(out16, bf(ref.float()).double() if ints else ref, K, exact=ints)
+
+
+@pytest.mark.parametrize("ints", [True, False])
+def test_batched_scores_like(ints):
+    """S[z] = alpha * Q[z] K[z]^T with two-level batch strides into a fused [rows][768] QKV buffer; N = 423."""
+    from tts_king_amd import ops
+    Bsz, H, S, dk = 3, 2, 423, 128
+    qkv = bf(rnd(Bsz * S, 3 * H * dk, seed=4, ints=ints)).to(DEV)
+    Sp = (S + 7) // 8 * 8
+    out = torch.zeros(Bsz * H, S, Sp, dtype=torch.float32, device=DEV)
+    alpha = 0.5 if ints else dk ** -0.5
+    ops.gemm(qkv, qkv[:, H * dk:], out, S, S, dk, 3 * H * dk, 3 * H * dk, Sp, alpha=alpha, nz1=Bsz, nz2=H,
+             sA=(S * 3 * H * dk, dk), sB=(S * 3 * H * dk, dk), sC=(H * S * Sp, S * Sp))
+    q = qkv.cpu().double().view(Bsz, S, 3, H, dk)
+    ref = alpha * torch.einsum("bqhd,bkhd->bhqk", q[:, :, 0], q[:, :, 1]).reshape(Bsz * H, S, S)
+    check(out[:, :, :S], ref, dk, exact=ints, out_bf16=False)
+    assert float(out[:, :, S:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("ints", [True, False])
+@pytest.mark.parametrize("M,N,K", [(423, 128, 423), (200, 256, 768), (128, 80, 64)])
+def test_b_transposed(M, N, K, ints):
+    """C = A[M,K] @ B[K,N] with B read in place (P·V, dX = dY·W)."""
+    from tts_king_amd import ops
+    Kp = (K + 7) // 8 * 8
+    a = torch.zeros(M, Kp)
+    a[:, :K] = rnd(M, K, seed=5, ints=ints)
+    a, b = bf(a), bf(rnd(K, N, seed=6, ints=ints))
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(a.to(DEV), b.to(DEV), out, M, N, K, Kp, N, N, flags=ops.B_TR)
+    check(out, a[:, :K].double() @ b.double(), K, exact=ints, out_bf16=False)
+
+
+@pytest.mark.parametrize("ints", [True, False])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 1000), (768, 256, 6768), (423, 128, 423), (80, 512, 300)])
+def test_both_transposed_splitk(M, N, K, ints):
+    """C = A[K,M]^T @ B[K,N] (dW, dK, dV) incl. split-K slabs + reduce with accumulate."""
+    from tts_king_amd import ops
+    Mp = (M + 7) // 8 * 8
+    a = torch.zeros(K, Mp)
+    a[:, :M] = rnd(K, M, seed=7, ints=ints)
+    a, b = bf(a), bf(rnd(K, N, seed=8, ints=ints))
+    ref = a[:, :M].double().t() @ b.double()
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(a.to(DEV), b.to(DEV), out, M, N, K, Mp, N, N, flags=ops.A_TR | ops.B_TR)
+    check(out, ref, K, exact=ints, out_bf16=False)
+    if Mp == M:
+        dst = torch.ones(M, N, dtype=torch.float32, device=DEV)
+        ops.linear_dw(a.to(DEV), b.to(DEV), dst, accumulate=True)
+        check(dst, ref + 1, K, exact=ints, out_bf16=False)
+
+
+@pytest.mark.parametrize("ints", [True, False])
+@pytest.mark.parametrize("Bsz,T,Cin,Cout,k,dil", [(3, 50, 256, 1024, 9, 1), (2, 423, 80, 512, 5, 1), (2, 131, 128, 128, 7, 3),
+                                                  (1, 300, 32, 32, 11, 5), (2, 64, 256, 256, 3, 1), (2, 40, 1024, 256, 1, 1)])
+def test_conv1d_fwd_dx_dw(Bsz, T, Cin, Cout, k, dil, ints):
+    from tts_king_amd import ops
+    x = bf(rnd(Bsz, T, Cin, seed=9, ints=ints))
+    w = bf(rnd(Cout, Cin, k, seed=10, ints=ints) * (1.0 if ints else (Cin * k) ** -0.5))
+    b = rnd(Cout, seed=11, ints=ints)
+    dy = bf(rnd(Bsz, T, Cout, seed=12, ints=ints))
+    pad = dil * (k - 1) // 2
+    xd = x.double().transpose(1, 2).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    y = F.conv1d(xd, wd, b.double(), dilation=dil, padding=pad)
+    y.backward(dy.double().transpose(1, 2))
+    wk = w.permute(0, 2, 1).contiguous().to(DEV)           # (Cout, k, Cin)
+    out = ops.conv1d(x.to(DEV), wk, b.to(DEV), dilation=dil, out_dtype=torch.float32)
+    check(out, y.detach().transpose(1, 2), Cin * k, exact=ints, out_bf16=False)
+    dx = torch.empty(Bsz, T, Cin, dtype=torch.float32, device=DEV)
+    ops.conv1d_dx(dy.to(DEV), wk, dilation=dil, out=dx)
+    check(dx, xd.grad.transpose(1, 2), Cout * k, exact=ints, out_bf16=False)
+    dw = torch.zeros(Cout, k, Cin, dtype=torch.float32, device=DEV)
+    ops.conv1d_dw(dy.to(DEV), x.to(DEV), dw, dilation=dil, k=k, accumulate=True)
+    check(dw, wd.grad.permute(0, 2, 1), Bsz * T, exact=ints, out_bf16=False)
+
+
+def test_conv_lrelu_in_and_epilogues():
+    from tts_king_amd import ops
+    Bsz, T, C, k, dil = 2, 100, 64, 3, 3
+    x = bf(rnd(Bsz, T, C, seed=13))
+    w = bf(rnd(C, C, k, seed=14) * (C * k) ** -0.5)
+    b = rnd(C, seed=15)
+    r = bf(rnd(Bsz, T, C, seed=16))
+    xin = bf(F.leaky_relu(x.float(), 0.1))                 # kernel rounds lrelu(x) to bf16 before the MFMA
+    ref = F.conv1d(xin.double().transpose(1, 2), w.double(), b.double(), dilation=dil, padding=dil).transpose(1, 2) + r.double()
+    wk = w.permute(0, 2, 1).contiguous().to(DEV)
+    c2 = torch.empty(Bsz, T, C, dtype=torch.bfloat16, device=DEV)
+    out = ops.conv1d(x.to(DEV), wk, b.to(DEV), dilation=dil, flags=ops.LRELU_IN, in_slope=0.1, R=r.to(DEV),
+                     out_dtype=torch.float32, C2=c2)
+    check(out, ref, C * k, out_bf16=False)
+    check(c2, ref, C * k)
+    g = bf(rnd(Bsz * T, C, seed=17))
+    out2 = ops.linear(x.view(-1, C).to(DEV), w[:, :, 0].contiguous().to(DEV), None, G=g.to(DEV), flags=ops.TANH,
+                      out_dtype=torch.float32)
+    ref2 = torch.tanh(torch.where(g.double() > 0, x.view(-1, C).double() @ w[:, :, 0].double().t(), torch.zeros(())))
+    check(out2, ref2, C, out_bf16=False)
+
+
+@pytest.mark.parametrize("ints", [True, False])
+@pytest.mark.parametrize("Cin,Cout,k,s,T", [(512, 256, 16, 8, 37), (128, 64, 4, 2, 301), (64, 32, 4, 2, 128)])
+def test_conv_transpose_polyphase(Cin, Cout, k, s, T, ints):
+    from tts_king_amd import ops
+    Bsz = 2
+    x = bf(rnd(Bsz, T, Cin, seed=18, ints=ints))
+    w = bf(rnd(Cin, Cout, k, seed=19, ints=ints) * (1.0 if ints else (Cin * k / s) ** -0.5))
+    b = rnd(Cout, seed=20, ints=ints)
+    xin = bf(F.leaky_relu(x.float(), 0.1)) if not ints else x
+    ref = F.conv_transpose1d(xin.double().transpose(1, 2), w.double(), b.double(), stride=s, padding=(k - s) // 2).transpose(1, 2)
+    wp = w.permute(2, 1, 0).contiguous().to(DEV)           # (k, Cout, Cin)
+    out = ops.conv_transpose1d(x.to(DEV), wp, b.to(DEV), s, k, in_slope=0.0 if ints else 0.1)
+    assert out.shape == (Bsz, T * s, Cout)
+    check(out, bf(ref.float()).double() if ints else ref, Cin * k // s, exact=ints)

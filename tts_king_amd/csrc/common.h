@@ -1,0 +1,73 @@
+// Shared device/host helpers for libttsk_hip (gfx950 only: wave = 64 lanes, no portability shims).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/ttsk.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+__device__ __forceinline__ unsigned pack_bf2(float a, float b) {
+  return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Philox4x32-10 counter RNG: dropout masks are regenerated in backward from (seed, site, element index),
+// never stored (reference dropout sites: SubLayers.py:62,99; modules.py:286,298; Layers.py:137-141).
+struct Philox {
+  __device__ static __forceinline__ uint4 gen(uint2 key, uint4 ctr) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      unsigned hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
+      unsigned hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
+      ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+      key.x += 0x9E3779B9u;
+      key.y += 0xBB67AE85u;
+    }
+    return ctr;
+  }
+};
+// keep-mask bits for 4 consecutive elements starting at element index e4*4 of dropout site `site`
+__device__ __forceinline__ uint4 dropout_bits(uint64_t seed, unsigned site, unsigned e4) {
+  return Philox::gen(make_uint2((unsigned)seed, (unsigned)(seed >> 32)), make_uint4(e4, site, 0x5eedu, 0u));
+}
+__device__ __forceinline__ unsigned keep_threshold(float p) {  // keep iff bits >= thr  (P(keep) = 1-p)
+  double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+}
+
+// host-side error plumbing
+void ttsk_set_error(const char* fmt, ...);
+#define TTSK_REQUIRE(cond, ...)                 \
+  do {                                          \
+    if (!(cond)) {                              \
+      ttsk_set_error(__VA_ARGS__);              \
+      return TTSK_EINVAL;                       \
+    }                                           \
+  } while (0)
+#define TTSK_CHECK_LAUNCH()                                                    \
+  do {                                                                         \
+    hipError_t e__ = hipGetLastError();                                        \
+    if (e__ != hipSuccess) {                                                   \
+      ttsk_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+      return TTSK_ELAUNCH;                                                     \
+    }                                                                          \
+  } while (0)

@@ -1,0 +1,102 @@
+"""ctypes binding of libttsk_hip.so (include/ttsk.h).
+
+The product path has no CPU fallback: if the shared library is missing or was built without a symbol
+declared in the header, importing/using the kernels raises immediately.
+"""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libttsk_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ttsk.h")
+
+
+class TtskError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    """Mirror of `ttsk_gemm_desc` (include/ttsk.h) — field order and types must match exactly."""
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("C2", C.c_void_p),
+        ("bias", C.c_void_p), ("R", C.c_void_p), ("G", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32), ("ldg", C.c_int32),
+        ("flags", C.c_int32), ("alpha", C.c_float), ("in_slope", C.c_float), ("out_slope", C.c_float),
+        ("nz1", C.c_int32), ("nz2", C.c_int32),
+        ("sA1", C.c_int64), ("sA2", C.c_int64), ("sB1", C.c_int64), ("sB2", C.c_int64),
+        ("sC1", C.c_int64), ("sC2", C.c_int64), ("sR1", C.c_int64), ("sR2", C.c_int64),
+        ("taps", C.c_int32), ("seg_len", C.c_int32), ("tap_shift0", C.c_int32), ("tap_dshift", C.c_int32),
+        ("b_tap_stride", C.c_int64),
+        ("bseg_len", C.c_int32), ("bshift0", C.c_int32), ("bdshift", C.c_int32),
+        ("out_seg", C.c_int32), ("out_mul", C.c_int32), ("out_add", C.c_int32),
+        ("splits", C.c_int32), ("sCs", C.c_int64),
+    ]
+
+
+# flags (include/ttsk.h)
+A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT = [1 << i for i in range(11)]
+
+
+def declared_symbols(header_path=HEADER_PATH):
+    """Every function name declared in include/ttsk.h (used by the CPU test that checks the exports)."""
+    with open(header_path) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(ttsk_[a-z0-9_]+)\s*\(", text)))
+
+
+def _ctype_of(arg):
+    arg = arg.strip()
+    if arg in ("void", ""):
+        return None
+    if "*" in arg:
+        return C.c_void_p
+    for key, ct in (("uint64_t", C.c_uint64), ("int64_t", C.c_int64), ("uint32_t", C.c_uint32), ("int32_t", C.c_int32),
+                    ("double", C.c_double), ("float", C.c_float), ("int", C.c_int)):
+        if re.search(r"\b%s\b" % key, arg):
+            return ct
+    raise TtskError("cannot map C parameter %r" % arg)
+
+
+def declared_prototypes(header_path=HEADER_PATH):
+    """name -> ctypes argtypes, parsed from the header so the binding cannot drift from it."""
+    with open(header_path) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(ttsk_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = [a for a in (_ctype_of(x) for x in m.group(2).split(",")) if a is not None]
+        out[m.group(1)] = args
+    return out
+
+
+_lib = None
+
+
+def load(path=LIB_PATH):
+    """Load the library (once).  Raises TtskError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise TtskError(
+            "libttsk_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C tts_king_amd/csrc`). There is no CPU fallback for the hot path." % path)
+    lib = C.CDLL(path)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    if missing:
+        raise TtskError("libttsk_hip.so is stale: missing symbols %s — rebuild" % missing)
+    lib.ttsk_last_error.restype = C.c_char_p
+    for name, argtypes in declared_prototypes().items():
+        fn = getattr(lib, name)
+        if name != "ttsk_last_error":
+            fn.restype = C.c_int
+        fn.argtypes = argtypes
+    lib.ttsk_gemm.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise TtskError("%s failed (%d): %s" % (what, rc, load().ttsk_last_error().decode()))

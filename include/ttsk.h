@@ -109,6 +109,110 @@ int ttsk_length_regulator_fwd(const void* x_bf16, const void* dur, int dur_dtype
 int ttsk_length_regulator_bwd(const void* dout_bf16, const int32_t* cumsum, void* dx_bf16, int B, int L, int T, int D,
                               void* stream);
 
+/* ------------------------------------------------------------------------------ LayerNorm (fused block tail)
+ * out = mask( dropout_post( LN( dropout_pre(y) + res ) ) ),  optional head_out[row] = mask(<out, head_w> + head_b)
+ * reference: SubLayers.py:62-63,99-101 (LN(dropout(sublayer)+residual)), Layers.py:29,32 (masked_fill of PAD rows),
+ *            model/modules.py:270-309 (VariancePredictor: ReLU -> LN -> Dropout; Linear(256,1) -> masked_fill).
+ * rows are (segment, position) pairs; a row is PAD when position >= lens[segment] (lens may be NULL).
+ * `rng` points at {uint64 seed, uint64 step} in device memory; masks are functions of (seed, step, site, element).
+ * z_save receives the LN input (bf16) for the backward; mean/rstd are per-row fp32.
+ */
+int ttsk_layernorm_fwd(const void* y_bf16, const void* res_bf16, const float* gamma, const float* beta, void* out_bf16,
+                       void* z_save_bf16, float* mean, float* rstd, const int64_t* lens, int seg_len, int rows, int D,
+                       float eps, float p_pre, uint32_t site_pre, float p_post, uint32_t site_post, const uint64_t* rng,
+                       const float* head_w, const float* head_b, float* head_out, void* stream);
+int ttsk_layernorm_bwd_nblocks(int rows);
+/* partials: [nblocks][3*D] = dgamma | dbeta | dbias(sum of dy), or [nblocks][4*D + 1] with the head (| dhead_w | dhead_b).
+ * dz = grad wrt the LN input (bf16; times (z > 0) when relu_in); dy = dz through the pre-dropout mask (only if p_pre > 0). */
+int ttsk_layernorm_bwd(const void* dout_bf16, const float* dhead, const float* head_w, const void* z_bf16, const float* mean,
+                       const float* rstd, const float* gamma, const float* beta, const int64_t* lens, int seg_len, int rows,
+                       int D, int relu_in, float p_pre, uint32_t site_pre, float p_post, uint32_t site_post,
+                       const uint64_t* rng, void* dz_bf16, void* dy_bf16, float* partials, void* stream);
+/* dst[c] (+)= scale * sum_b partials[b*ld + c]  in fixed order */
+int ttsk_colsum_finalize(const float* partials, int nblk, int ncols, int ld, float* dst, int accumulate, float scale,
+                         void* stream);
+int ttsk_colsum_nblocks(int rows);
+/* per-block column sums of x [rows][C] (bf16, or fp32 when is_f32) -> partials[nblocks][C]  (bias gradients) */
+int ttsk_colsum(const void* x, int is_f32, int rows, int C, int ld, float* partials, void* stream);
+
+/* ------------------------------------------------------------------------------------------ attention softmax
+ * reference: fs_two/transformer/Modules.py:15-22.  scores fp32 [nz][S][Sp] (already scaled by 1/sqrt(d_k) in the
+ * Q.K^T GEMM epilogue), z = b*H + h; keys >= lens[b] get -inf; probs bf16 [nz][S][Sp] with zero pad columns.
+ * bwd: dscores = alpha * P o (dP - rowsum(dP o P)).
+ */
+int ttsk_softmax_fwd(const float* scores, void* probs_bf16, const int64_t* lens, int nz, int H, int S, int Sp, void* stream);
+int ttsk_softmax_bwd(const void* probs_bf16, const float* dprobs, void* dscores_bf16, int nz, int S, int Sp, float alpha,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------- embeddings / variance adaptor
+ * bucketize: idx = #{bins < v*scale} (torch.bucketize right=False; reference: model/modules.py:95-100,134-139)
+ * gather_add: out[row] = (in ? in[row] : 0) + table[idx[row / idx_div]] + (pe ? pe[row % pe_mod] : 0)
+ *             reference: Models.py:101-103, fastspeech2.py:72-75 + modules.py:159, modules.py:95-100,134-139
+ * scatter_sum: dtable[v] (+)= sum of dx rows whose index is v, ascending row order, no atomics; skip_row = padding_idx
+ */
+int ttsk_bucketize(const float* values, const float* bins, int n_bins, float scale, int32_t* idx, int n, void* stream);
+int ttsk_gather_add(const void* in_bf16, const float* table, const void* idx, int idx_is_i64, int idx_div, const float* pe,
+                    int pe_mod, void* out_bf16, int rows, int D, void* stream);
+int ttsk_scatter_sum(const void* dx_bf16, const void* idx, int idx_is_i64, int idx_div, int n_idx, float* dtable,
+                     int n_table_rows, int D, int skip_row, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ conversions */
+int ttsk_cast_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
+int ttsk_nct_to_ntc_bf16(const float* src, void* dst_bf16, int B, int C, int T, void* stream);
+/* (x * scale) truncated toward zero to int16 — reference: hifiapi.py:50-51 */
+int ttsk_to_int16(const float* src, int16_t* dst, int64_t n, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------- PostNet BatchNorm1d
+ * reference: fs_two/transformer/Layers.py:133-143 — training statistics over ALL rows (PAD rows included),
+ * eps 1e-5, momentum 0.1, running_var updated with the unbiased variance; tanh (all but the last layer) and
+ * F.dropout(0.5) follow; the last layer adds the mel residual (fastspeech2.py:104).
+ */
+int ttsk_bn_nblocks(int rows);
+int ttsk_bn_stats(const void* x_bf16, int rows, int C, float* partials /* [nblocks][2C] */, void* stream);
+int ttsk_bn_finalize(const float* partials, int nblk, int C, int rows, float eps, float momentum, float* mean, float* rstd,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream);
+int ttsk_rsqrt_eps(const float* var, float eps, float* rstd, int n, void* stream);
+int ttsk_bn_apply(const void* x_bf16, const float* mean, const float* rstd, const float* gamma, const float* beta, int rows,
+                  int C, int use_tanh, float p, uint32_t site, const uint64_t* rng, const float* resid_f32, void* out_bf16,
+                  float* out_f32, void* stream);
+int ttsk_bn_bwd_stats(const void* dout, int dout_is_f32, const void* x_bf16, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
+                      const uint64_t* rng, float* partials /* [nblocks][2C]: sum dy | sum dy*xhat */, void* stream);
+int ttsk_bn_bwd_apply(const void* dout, int dout_is_f32, const void* x_bf16, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
+                      const uint64_t* rng, const float* sums /* [2C] */, void* dx_bf16, float* dgamma, float* dbeta,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------- loss
+ * reference: fs_two/model/loss.py:24-134 (use_cwt False).  losses[8] = {total, mel_total, pitch, energy, duration,
+ * 0, 0, n_valid_phonemes}; gradients of grad_scale*total: dmel_sum = d/dmel + d/dpost (postnet adds mel back),
+ * dpost, dpitch, denergy, dlogd.  partials: [ttsk_fs2_loss_nblocks()][6] fp32.
+ */
+int ttsk_fs2_loss_nblocks(void);
+int ttsk_fs2_loss(const float* mel, const float* post, const float* mel_target, const int64_t* mel_lens, const float* pitch,
+                  const float* energy, const float* logd, const float* pitch_target, const float* energy_target,
+                  const int64_t* dur_target, const int64_t* src_lens, int B, int T, int T_target, int n_mel, int L,
+                  float grad_scale, float* dmel_sum, float* dpost, float* dpitch, float* denergy, float* dlogd,
+                  float* partials, float* losses, void* stream);
+
+/* ------------------------------------------------------------------------------------------- optimiser
+ * reference: train.py:47-54, fs_two/model/optimizer.py:5-53, torch.optim.Adam.
+ * `state` is a device block of ttsk_optim_state_bytes() bytes:
+ *   { int64 sched_step; int64 adam_t; uint64 rng_seed; uint64 rng_step; float lr, bc1, bc2, clip_coef, gnorm; ... }
+ * (its address + 16 is the `rng` pointer handed to the dropout kernels).
+ * optim_advance: ++sched_step, ++adam_t, recompute lr/bc1/bc2 on device (graph-replay safe).
+ * clip_adam_step: ||g|| -> clip_coef = min(1, max_norm/(||g||+1e-6)) -> Adam on the flat buffers, writes the bf16
+ * weight shadow and (optionally) zeroes the gradients.  n % 4 == 0.  partials: 1024 floats.
+ */
+int ttsk_optim_state_bytes(void);
+int ttsk_optim_advance(void* state, float d_model, float warmup, const float* anneal_steps_host, int n_anneal,
+                       float anneal_rate, float beta1, float beta2, void* stream);
+int ttsk_rng_advance(void* state, void* stream);
+int ttsk_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n,
+                        void* state, float* partials, float max_norm, float beta1, float beta2, float eps, int zero_grad,
+                        void* stream);
+int ttsk_grad_sumsq(const float* grads, int64_t n, float* partials, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

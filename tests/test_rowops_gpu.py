@@ -1,0 +1,299 @@
+"""GPU: the memory-bound row kernels (LayerNorm tail, softmax, embeddings, BatchNorm, loss, clip+Adam) through the
+C ABI against fp32/fp64 CPU torch math on the same bf16-rounded inputs.
+
+Tolerances: bf16 outputs carry one rounding (rel 2^-8); fp32 outputs are compared at 1e-5..1e-4; integer outputs
+(bucketize, int16 audio) are exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def close_bf16(out, ref, extra=0.0):
+    out, ref = out.float().cpu().double(), ref.double()
+    tol = 2 ** -7 * ref.abs() + 2 ** -7 * float(ref.abs().mean()) + extra
+    bad = (out - ref).abs() > tol
+    assert not bool(bad.any()), (int(bad.sum()), float((out - ref).abs().max()))
+
+
+def close_f32(out, ref, rtol=1e-4, atol=1e-5):
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.float().numpy(), rtol=rtol, atol=atol)
+
+
+def lens_mask(lens, seg):
+    return (torch.arange(seg)[None, :] >= lens[:, None]).reshape(-1)
+
+
+@pytest.mark.parametrize("rows_seg", [(4, 100), (16, 64)])
+def test_layernorm_residual_mask_fwd_bwd(rows_seg):
+    from tts_king_amd import ops
+    Bn, seg = rows_seg
+    rows, D = Bn * seg, 256
+    y, res = rnd(rows, D, seed=1).to(BF), rnd(rows, D, seed=2).to(BF)
+    gamma, beta = 1 + 0.1 * rnd(D, seed=3), 0.1 * rnd(D, seed=4)
+    lens = torch.randint(seg // 2, seg + 1, (Bn,), generator=torch.Generator().manual_seed(5))
+    dout = rnd(rows, D, seed=6).to(BF)
+    pad = lens_mask(lens, seg)
+    zf = (y.float() + res.float()).to(BF).float().requires_grad_(True)   # kernel's backward sees the rounded z
+    g2, b2 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(zf, (D,), g2, b2).masked_fill(pad[:, None], 0)
+    ref.backward(dout.float())
+    out, z, mean, rstd, _ = ops.layernorm_fwd(y.to(DEV), res.to(DEV), gamma.to(DEV), beta.to(DEV), lens.to(DEV), seg)
+    ref_fwd = F.layer_norm(y.float() + res.float(), (D,), gamma, beta).masked_fill(pad[:, None], 0)
+    close_bf16(out, ref_fwd)
+    assert torch.equal(z.cpu(), (y.float() + res.float()).to(BF))
+    dz, dy, partials, nblk = ops.layernorm_bwd(dout.to(DEV), z, mean, rstd, gamma.to(DEV), beta.to(DEV), lens.to(DEV), seg)
+    assert dy is dz
+    close_bf16(dz, zf.grad, extra=1e-3)
+    sums = partials.sum(0).cpu()
+    close_f32(sums[:D], g2.grad, rtol=2e-3, atol=2e-2)
+    close_f32(sums[D:2 * D], b2.grad, rtol=2e-3, atol=2e-2)
+    close_f32(sums[2 * D:], zf.grad.to(BF).float().sum(0), rtol=2e-2, atol=0.1)
+
+
+def test_layernorm_predictor_tail_head_relu():
+    """VariancePredictor tail: h = relu(...) -> LN -> Linear(256,1) -> masked_fill; backward gates by (h > 0)."""
+    from tts_king_amd import ops
+    Bn, seg, D = 4, 64, 256
+    rows = Bn * seg
+    h = torch.relu(rnd(rows, D, seed=7)).to(BF)
+    gamma, beta = 1 + 0.1 * rnd(D, seed=8), 0.1 * rnd(D, seed=9)
+    w, b = rnd(D, seed=10, scale=D ** -0.5), torch.tensor([0.3])
+    lens = torch.tensor([64, 40, 33, 64])
+    pad = lens_mask(lens, seg)
+    dhead = rnd(rows, seed=11)
+    pre = rnd(rows, D, seed=12)       # stand-in for the pre-activation: only its sign pattern matters
+    hf = h.float().requires_grad_(True)
+    g2, b2, w2, bb2 = [t.clone().requires_grad_(True) for t in (gamma, beta, w, b)]
+    ref = (F.layer_norm(hf, (D,), g2, b2) @ w2 + bb2).masked_fill(pad, 0.0)
+    ref.backward(dhead)
+    _, _, mean, rstd, ho = ops.layernorm_fwd(h.to(DEV), None, gamma.to(DEV), beta.to(DEV), lens.to(DEV), seg, save_z=False,
+                                             head=(w.to(DEV), b.to(DEV)), want_out=False)
+    close_f32(ho, ref.detach(), rtol=1e-4, atol=1e-4)
+    dz, _, partials, nblk = ops.layernorm_bwd(None, h.to(DEV), mean, rstd, gamma.to(DEV), beta.to(DEV), lens.to(DEV), seg,
+                                              relu_in=True, dhead=dhead.to(DEV), head_w=w.to(DEV))
+    want = hf.grad * (h.float() > 0)
+    close_bf16(dz, want, extra=1e-3)
+    sums = partials.sum(0).cpu()
+    close_f32(sums[:D], g2.grad, rtol=2e-3, atol=2e-2)
+    close_f32(sums[D:2 * D], b2.grad, rtol=2e-3, atol=2e-2)
+    close_f32(sums[3 * D:4 * D], w2.grad, rtol=2e-3, atol=2e-2)
+    close_f32(sums[4 * D:], bb2.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_layernorm_dropout_masks_consistent():
+    from tts_king_amd import ops
+    rows, D, p = 512, 256, 0.2
+    y = (rnd(rows, D, seed=13).abs() + 0.5).to(BF)
+    gamma, beta = torch.ones(D), torch.zeros(D)
+    st = ops.optim_state(DEV, seed=99)
+    rng = ops.rng_of(st)
+    out, z, mean, rstd, _ = ops.layernorm_fwd(y.to(DEV), None, gamma.to(DEV), beta.to(DEV), p_pre=p, site_pre=5, rng=rng)
+    zc = z.cpu().float()
+    keep = zc != 0
+    frac = float(keep.float().mean())
+    assert abs(frac - (1 - p)) < 0.01, frac
+    close_bf16(zc[keep], y.float()[keep] / (1 - p))
+    out2, z2, *_ = ops.layernorm_fwd(y.to(DEV), None, gamma.to(DEV), beta.to(DEV), p_pre=p, site_pre=5, rng=rng)
+    assert torch.equal(z2, z)                                     # same (seed, step, site) -> same mask
+    _, z3, *_ = ops.layernorm_fwd(y.to(DEV), None, gamma.to(DEV), beta.to(DEV), p_pre=p, site_pre=6, rng=rng)
+    assert not torch.equal(z3, z)                                 # another site -> another mask
+    ops.rng_advance(st)
+    _, z4, *_ = ops.layernorm_fwd(y.to(DEV), None, gamma.to(DEV), beta.to(DEV), p_pre=p, site_pre=5, rng=rng)
+    assert not torch.equal(z4, z)                                 # next step -> another mask
+    # backward regenerates the step's mask
+    st2 = ops.optim_state(DEV, seed=99)
+    dout = rnd(rows, D, seed=14).to(BF)
+    dz, dy, _, _ = ops.layernorm_bwd(dout.to(DEV), z, mean, rstd, gamma.to(DEV), beta.to(DEV), p_pre=p, site_pre=5,
+                                     rng=ops.rng_of(st2))
+    dzc, dyc = dz.cpu().float(), dy.cpu().float()
+    assert torch.equal(dyc != 0, keep & (dzc != 0))
+    close_bf16(dyc[keep], dzc[keep] / (1 - p))
+    # post-LN dropout (predictor style)
+    out5, *_ = ops.layernorm_fwd(y.to(DEV), None, gamma.to(DEV), beta.to(DEV), p_post=0.5, site_post=7, rng=rng, save_z=False)
+    f5 = float((out5.cpu().float() != 0).float().mean())
+    assert abs(f5 - 0.5) < 0.01, f5
+
+
+@pytest.mark.parametrize("S", [64, 423])
+def test_softmax_fwd_bwd(S):
+    from tts_king_amd import ops
+    Bn, H = 3, 2
+    Sp = (S + 7) // 8 * 8
+    s = torch.zeros(Bn * H, S, Sp)
+    s[:, :, :S] = rnd(Bn * H, S, S, seed=15, scale=2.0)
+    lens = torch.tensor([S, S // 2, 5])
+    mask = torch.arange(S)[None, None, :] >= lens.repeat_interleave(H)[:, None, None]
+    sf = s[:, :, :S].clone().requires_grad_(True)
+    ref = torch.softmax(sf.masked_fill(mask, float("-inf")), dim=2)
+    P = ops.softmax_fwd(s.to(DEV), lens.to(DEV), H)
+    close_bf16(P[:, :, :S], ref.detach(), extra=1e-4)
+    assert float(P[:, :, S:].float().abs().max()) == 0 if Sp > S else True
+    dP = torch.zeros(Bn * H, S, Sp)
+    dP[:, :, :S] = rnd(Bn * H, S, S, seed=16)
+    Pb = P.cpu().float()[:, :, :S]
+    want = 0.25 * Pb * (dP[:, :, :S] - (dP[:, :, :S] * Pb).sum(-1, keepdim=True))
+    dS = ops.softmax_bwd(P, dP.to(DEV), 0.25)
+    close_bf16(dS[:, :, :S], want, extra=1e-4)
+
+
+def test_bucketize_exact(cfg):
+    import json, os
+    from tts_king_amd import ops
+    with open(os.path.join(cfg.preprocess_config.path.preprocessed_path, "stats.json")) as f:
+        stats = json.load(f)
+    for key in ("pitch", "energy"):
+        bins = torch.linspace(stats[key][0], stats[key][1], 255)
+        v = torch.cat([rnd(4000, seed=17, scale=3.0), bins, bins + 1e-6, bins - 1e-6,
+                       torch.tensor([-1e9, 1e9, stats[key][0], stats[key][1], 0.0])])
+        for scale in (1.0, 1.5):
+            got = ops.bucketize(v.to(DEV), bins.to(DEV), scale).cpu()
+            assert torch.equal(got.long(), torch.bucketize(v * scale, bins))
+
+
+def test_gather_add_scatter_sum():
+    from tts_king_amd import ops
+    Bn, Lp, D, V = 4, 64, 256, 207
+    g = torch.Generator().manual_seed(18)
+    tok = torch.randint(0, V, (Bn, Lp), generator=g)
+    tok[:, -5:] = 0
+    table, pe = rnd(V, D, seed=19), rnd(Lp + 3, D, seed=20)
+    out = ops.gather_add(None, table.to(DEV), tok.to(DEV), pe=pe.to(DEV), pe_mod=Lp, rows=Bn * Lp)
+    ref = table[tok].reshape(-1, D) + pe[:Lp].repeat(Bn, 1)
+    assert torch.equal(out.cpu(), ref.to(BF))
+    spk_tab, spk = rnd(65, D, seed=21), torch.tensor([3, 64, 0, 3])
+    out2 = ops.gather_add(out, spk_tab.to(DEV), spk.to(DEV), idx_div=Lp)
+    ref2 = out.cpu().float() + spk_tab[spk].repeat_interleave(Lp, 0)
+    assert torch.equal(out2.cpu(), ref2.to(BF))
+    idx32 = torch.randint(0, 256, (Bn * Lp,), generator=g).int()
+    out3 = ops.gather_add(out, rnd(256, D, seed=22).to(DEV), idx32.to(DEV))
+    assert torch.equal(out3.cpu(), (out.cpu().float() + rnd(256, D, seed=22)[idx32.long()]).to(BF))
+    # backward: deterministic scatter sums
+    dx = rnd(Bn * Lp, D, seed=23).to(BF)
+    dt = torch.ones(V, D)
+    got = ops.scatter_sum(dx.to(DEV), tok.to(DEV), dt.to(DEV), skip_row=0, accumulate=True).cpu()
+    want = torch.ones(V, D).double().index_add_(0, tok.reshape(-1), dx.double())
+    want[0] = 1.0
+    close_f32(got, want.float(), rtol=1e-5, atol=1e-5)
+    ds = ops.scatter_sum(dx.to(DEV), spk.to(DEV), torch.zeros(65, D, device=DEV), idx_div=Lp, accumulate=False).cpu()
+    wants = torch.zeros(65, D).double().index_add_(0, spk.repeat_interleave(Lp), dx.double())
+    close_f32(ds, wants.float(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("C,use_tanh", [(512, True), (80, False)])
+def test_batchnorm_train_fwd_bwd(C, use_tanh):
+    from tts_king_amd import ops
+    rows = 2 * 423
+    x = rnd(rows, C, seed=24, scale=1.5).to(BF)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=25), 0.1 * rnd(C, seed=26)
+    rm, rv = 0.02 * rnd(C, seed=27), 0.5 + torch.rand(C, generator=torch.Generator().manual_seed(28))
+    resid = rnd(rows, C, seed=29)
+    dout = rnd(rows, C, seed=30)
+    xf = x.float().requires_grad_(True)
+    g2, b2 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm2, rv2 = rm.clone(), rv.clone()
+    y = F.batch_norm(xf, rm2, rv2, g2, b2, training=True, momentum=0.1, eps=1e-5)
+    y = torch.tanh(y) if use_tanh else y
+    (y + resid).backward(dout)
+    drm, drv, nbt = rm.to(DEV), rv.to(DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+    mean, rstd = ops.bn_train_stats(x.to(DEV), drm, drv, nbt)
+    close_f32(drm, rm2, rtol=1e-4, atol=1e-5)
+    close_f32(drv, rv2, rtol=1e-4, atol=1e-5)
+    assert int(nbt) == 1
+    out = ops.bn_apply(x.to(DEV), mean, rstd, gamma.to(DEV), beta.to(DEV), use_tanh, resid=resid.to(DEV), out_f32=True)
+    close_f32(out, (y + resid).detach(), rtol=1e-4, atol=1e-4)
+    out16 = ops.bn_apply(x.to(DEV), mean, rstd, gamma.to(DEV), beta.to(DEV), use_tanh)
+    close_bf16(out16, y.detach(), extra=1e-3)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = ops.bn_bwd(dout.to(DEV), x.to(DEV), mean, rstd, gamma.to(DEV), beta.to(DEV), use_tanh, dgamma=dg, dbeta=db)
+    close_bf16(dx, xf.grad, extra=2e-3)
+    close_f32(dg, g2.grad, rtol=1e-3, atol=1e-2)
+    close_f32(db, b2.grad, rtol=1e-3, atol=1e-2)
+    # dropout keep-rate and fwd/bwd mask agreement
+    st = ops.optim_state(DEV, seed=7)
+    o = ops.bn_apply(x.to(DEV), mean, rstd, gamma.to(DEV), torch.ones(C, device=DEV) * 3, False, p=0.5, site=3, rng=ops.rng_of(st))
+    keep = o.cpu().float() != 0
+    assert abs(float(keep.float().mean()) - 0.5) < 0.02
+    dxd = ops.bn_bwd(torch.ones(rows, C, device=DEV), x.to(DEV), mean, rstd, gamma.to(DEV), beta.to(DEV), False, p=0.5, site=3,
+                     rng=ops.rng_of(st))
+    assert dxd.shape == (rows, C)
+
+
+def test_loss_and_grads():
+    from oracle import fs2 as ofs2
+    from tts_king_amd import ops
+    from tts_king_amd.synthetic import make_batch
+    b = make_batch(4, 32, seed=31, ragged=True)
+    Bn, Lp, T = 4, 32, b[8]
+    mel = rnd(Bn, T, 80, seed=32).requires_grad_(True)
+    post = rnd(Bn, T, 80, seed=33).requires_grad_(True)
+    p, e, d = [rnd(Bn, Lp, seed=s).requires_grad_(True) for s in (34, 35, 36)]
+    src_pad, mel_pad = ofs2.mask_from_lengths(b[4], Lp), ofs2.mask_from_lengths(b[7], T)
+    out = (mel, p, e, d, None, src_pad, mel_pad, b[4], b[7], post, None, None)
+    ls = ofs2.fs2_loss(b, out)
+    (ls[0].sum() * 0.25).backward()
+    dev = lambda t: t.detach().to(DEV)
+    losses, dmel, dpost, dp, de, dd = ops.fs2_loss(dev(mel), dev(post), dev(b[6]), dev(b[7]), dev(p), dev(e), dev(d), dev(b[11]),
+                                                   dev(b[9]), dev(b[10]), dev(b[4]), grad_scale=0.25)
+    close_f32(losses[:5], torch.stack([l.sum().detach() for l in ls[:5]]), rtol=2e-5, atol=1e-6)
+    assert float(losses[7]) == float(b[4].sum())
+    close_f32(dpost, post.grad, rtol=1e-5, atol=1e-9)
+    close_f32(dmel, mel.grad + post.grad, rtol=1e-5, atol=1e-9)
+    close_f32(dp, p.grad, rtol=1e-5, atol=1e-9)
+    close_f32(de, e.grad, rtol=1e-5, atol=1e-9)
+    close_f32(dd, d.grad, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("start", [0, 3999, 300000])
+def test_clip_adam_lr(start):
+    from oracle import fs2 as ofs2
+    from tts_king_amd import ops
+    n = 100000
+    p, g = rnd(n, seed=37), rnd(n, seed=38, scale=0.05)
+    st = ops.optim_state(DEV, seed=1, sched_step=start)
+    dp, dg = p.to(DEV), g.to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    shadow = torch.empty(n, dtype=BF, device=DEV)
+    partials = torch.empty(1024, device=DEV)
+    b1, b2, eps = 0.95, 0.999, 1e-5
+    pr, mr, vr = p.double().clone(), torch.zeros(n).double(), torch.zeros(n).double()
+    for t in range(1, 4):
+        dg.copy_(g * t)
+        ops.optim_advance(st, 256, 4000, [300000, 400000, 500000], 0.7, b1, b2)
+        ops.clip_adam_step(dp, dg, m, v, shadow, st, partials, 1.0, b1, b2, eps, zero_grad=True)
+        gg = (g * t).double()
+        coef = min(1.0, 1.0 / (float(gg.norm()) + 1e-6))
+        gg = gg * coef
+        lr = ofs2.lr_at(start + t)
+        mr = b1 * mr + (1 - b1) * gg
+        vr = b2 * vr + (1 - b2) * gg * gg
+        pr = pr - lr / (1 - b1 ** t) * mr / (vr.sqrt() / math.sqrt(1 - b2 ** t) + eps)
+        assert float(dg.abs().max()) == 0.0
+    stc = st.cpu()
+    assert int(stc[0]) == start + 3 and int(stc[1]) == 3
+    lr_dev = stc[4:5].view(torch.float32)[0]
+    assert abs(float(lr_dev) - ofs2.lr_at(start + 3)) < 1e-9 + 1e-6 * ofs2.lr_at(start + 3)
+    np.testing.assert_allclose((dp.cpu().double() - p.double()).numpy(), (pr - p.double()).numpy(), rtol=2e-3, atol=1e-7)
+    assert torch.equal(shadow.cpu(), dp.cpu().to(BF))
+
+
+def test_conversions():
+    from tts_king_amd import ops
+    x = rnd(3, 80, 50, seed=39)
+    assert torch.equal(ops.nct_to_ntc_bf16(x.to(DEV)).cpu(), x.transpose(1, 2).to(BF))
+    w = rnd(1003, seed=40)
+    w4 = torch.zeros(1004); w4[:1003] = w
+    assert torch.equal(ops.cast_bf16(w4.to(DEV)).cpu(), w4.to(BF))
+    a = torch.tensor([0.99999, -0.99999, 0.5, -0.5, 1e-5, -1e-5, 0.123456, -0.654321, 0.0])
+    got = ops.to_int16(a.to(DEV), 32768.0).cpu().numpy()
+    np.testing.assert_array_equal(got, (a * 32768).numpy().astype("int16"))

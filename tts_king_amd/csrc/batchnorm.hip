@@ -1,0 +1,285 @@
+// batchnorm.hip — PostNet BatchNorm1d (training: two-pass batch statistics over ALL B*T rows, PAD rows included)
+// fused with tanh, dropout(0.5) and the final residual add; and its backward.
+// reference: fs_two/transformer/Layers.py:133-143 (PostNet.forward), :85-129 (Conv1d + BatchNorm1d stacks),
+//            fastspeech2.py:104 (postnet(output) + output).
+// Layout: x [rows][C] bf16 (conv output), a thread owns 4 contiguous channels (C % 4 == 0).
+#include "common.h"
+
+namespace {
+
+struct BnCommon {
+  const bf16_t* x;
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const float* beta;
+  const uint64_t* rng;
+  int rows, C, use_tanh;
+  float p;
+  unsigned site;
+};
+
+__device__ __forceinline__ void ld4(const bf16_t* p, float v[4]) {
+  const uint2 u = *(const uint2*)p;
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
+  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
+}
+__device__ __forceinline__ uint4 bits4(const uint64_t* rng, unsigned site, unsigned e4) {
+  const uint64_t seed = rng[0], step = rng[1];
+  return Philox::gen(make_uint2((unsigned)seed, (unsigned)(seed >> 32)), make_uint4(e4, site, (unsigned)step, (unsigned)(step >> 32)));
+}
+
+// ---- pass 1: per-column sum and sum of squares -> partials[blk][2C]
+__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict__ x, int rows, int C, float* __restrict__ partials) {
+  extern __shared__ float red[];  // [rpi][4*tpr] x 2
+  const int tpr = C >> 2, rpi = 256 / tpr;
+  const int r0 = threadIdx.x / tpr, c4 = (threadIdx.x % tpr) * 4;
+  const int per = (rows + gridDim.x - 1) / gridDim.x;
+  const int rb = blockIdx.x * per;
+  const int re = min(rb + per, rows);
+  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (r0 < rpi)
+    for (int r = rb + r0; r < re; r += rpi) {
+      float v[4];
+      ld4(x + (int64_t)r * C + c4, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+    }
+  if (r0 < rpi) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[r0 * C + c4 + e] = s[e]; red[rpi * C + r0 * C + c4 + e] = q[e]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < rpi; ++k) { a += red[k * C + c]; b += red[rpi * C + k * C + c]; }
+    partials[(int64_t)blockIdx.x * 2 * C + c] = a;
+    partials[(int64_t)blockIdx.x * 2 * C + C + c] = b;
+  }
+}
+
+// mean / rstd from the partials (double accumulation), running statistics update (momentum, unbiased variance)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nblk, int C, int rows, float eps,
+                                                          float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                          long long* __restrict__ nbt) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0 && nbt) nbt[0] += 1;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; ++b) { s += partials[(int64_t)b * 2 * C + c]; q += partials[(int64_t)b * 2 * C + C + c]; }
+  const double m = s / rows;
+  double var = q / rows - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (run_mean) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * rows / (rows > 1 ? rows - 1 : 1));
+  }
+}
+
+__global__ __launch_bounds__(256) void rsqrt_eps_kernel(const float* __restrict__ var, float eps, float* __restrict__ rstd, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) rstd[i] = 1.f / sqrtf(var[i] + eps);
+}
+
+// ---- pass 2: y = tanh?(gamma * xhat + beta) -> dropout -> (+ residual) -> out
+__global__ __launch_bounds__(256) void bn_apply_kernel(const BnCommon a, const float* __restrict__ resid, bf16_t* __restrict__ out16,
+                                                       float* __restrict__ out32) {
+  const int tpr = a.C >> 2;
+  const int64_t n = (int64_t)a.rows * tpr;
+  const unsigned thr = keep_threshold(a.p);
+  const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / tpr), c4 = (int)(i - (int64_t)r * tpr) * 4;
+    float v[4];
+    ld4(a.x + (int64_t)r * a.C + c4, v);
+    const f32x4 m = *(const f32x4*)(a.mean + c4), rs = *(const f32x4*)(a.rstd + c4);
+    const f32x4 g = *(const f32x4*)(a.gamma + c4), b = *(const f32x4*)(a.beta + c4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = (v[e] - m[e]) * rs[e] * g[e] + b[e];
+      if (a.use_tanh) v[e] = tanhf(v[e]);
+    }
+    if (a.p > 0.f) {
+      const uint4 bb = bits4(a.rng, a.site, (unsigned)i);
+      v[0] = bb.x >= thr ? v[0] * scale : 0.f; v[1] = bb.y >= thr ? v[1] * scale : 0.f;
+      v[2] = bb.z >= thr ? v[2] * scale : 0.f; v[3] = bb.w >= thr ? v[3] * scale : 0.f;
+    }
+    if (resid) {
+      const f32x4 rr = *(const f32x4*)(resid + (int64_t)r * a.C + c4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += rr[e];
+    }
+    if (out16) *(uint2*)(out16 + (int64_t)r * a.C + c4) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    if (out32) *(f32x4*)(out32 + (int64_t)r * a.C + c4) = f32x4{v[0], v[1], v[2], v[3]};
+  }
+}
+
+// gradient wrt the BN output y (before tanh/dropout) for 4 channels of one row
+__device__ __forceinline__ void bn_dy(const BnCommon& a, const void* dout, int dout_f32, int r, int c4, int64_t i, unsigned thr,
+                                      float scale, float xh[4], float dy[4]) {
+  float v[4];
+  ld4(a.x + (int64_t)r * a.C + c4, v);
+  const f32x4 m = *(const f32x4*)(a.mean + c4), rs = *(const f32x4*)(a.rstd + c4);
+  if (dout_f32) {
+    const f32x4 d = *(const f32x4*)((const float*)dout + (int64_t)r * a.C + c4);
+    dy[0] = d[0]; dy[1] = d[1]; dy[2] = d[2]; dy[3] = d[3];
+  } else {
+    ld4((const bf16_t*)dout + (int64_t)r * a.C + c4, dy);
+  }
+  if (a.p > 0.f) {
+    const uint4 bb = bits4(a.rng, a.site, (unsigned)i);
+    dy[0] = bb.x >= thr ? dy[0] * scale : 0.f; dy[1] = bb.y >= thr ? dy[1] * scale : 0.f;
+    dy[2] = bb.z >= thr ? dy[2] * scale : 0.f; dy[3] = bb.w >= thr ? dy[3] * scale : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) xh[e] = (v[e] - m[e]) * rs[e];
+  if (a.use_tanh) {
+    const f32x4 g = *(const f32x4*)(a.gamma + c4), b = *(const f32x4*)(a.beta + c4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float t = tanhf(xh[e] * g[e] + b[e]); dy[e] *= 1.f - t * t; }
+  }
+}
+
+// ---- backward pass 1: Σ dy and Σ dy·xhat per column -> partials[blk][2C]
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const BnCommon a, const void* __restrict__ dout, int dout_f32,
+                                                           float* __restrict__ partials) {
+  extern __shared__ float red[];
+  const int C = a.C, tpr = C >> 2, rpi = 256 / tpr;
+  const int r0 = threadIdx.x / tpr, c4 = (threadIdx.x % tpr) * 4;
+  const int per = (a.rows + gridDim.x - 1) / gridDim.x;
+  const int rb = blockIdx.x * per;
+  const int re = min(rb + per, a.rows);
+  const unsigned thr = keep_threshold(a.p);
+  const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (r0 < rpi)
+    for (int r = rb + r0; r < re; r += rpi) {
+      float xh[4], dy[4];
+      bn_dy(a, dout, dout_f32, r, c4, (int64_t)r * tpr + (c4 >> 2), thr, scale, xh, dy);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[e] += dy[e]; q[e] += dy[e] * xh[e]; }
+    }
+  if (r0 < rpi) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[r0 * C + c4 + e] = s[e]; red[rpi * C + r0 * C + c4 + e] = q[e]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float x1 = 0.f, x2 = 0.f;
+    for (int k = 0; k < rpi; ++k) { x1 += red[k * C + c]; x2 += red[rpi * C + k * C + c]; }
+    partials[(int64_t)blockIdx.x * 2 * C + c] = x1;
+    partials[(int64_t)blockIdx.x * 2 * C + C + c] = x2;
+  }
+}
+
+// ---- backward pass 2: dx = gamma * rstd * (dy − mean(dy) − xhat * mean(dy·xhat)); block 0 adds dgamma/dbeta
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnCommon a, const void* __restrict__ dout, int dout_f32,
+                                                           const float* __restrict__ sums, bf16_t* __restrict__ dx,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int tpr = a.C >> 2;
+  const int64_t n = (int64_t)a.rows * tpr;
+  const unsigned thr = keep_threshold(a.p);
+  const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+  const float inv_n = 1.f / a.rows;
+  if (blockIdx.x == 0 && dgamma)
+    for (int c = threadIdx.x; c < a.C; c += 256) { dbeta[c] += sums[c]; dgamma[c] += sums[a.C + c]; }
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / tpr), c4 = (int)(i - (int64_t)r * tpr) * 4;
+    float xh[4], dy[4];
+    bn_dy(a, dout, dout_f32, r, c4, i, thr, scale, xh, dy);
+    const f32x4 g = *(const f32x4*)(a.gamma + c4), rs = *(const f32x4*)(a.rstd + c4);
+    const f32x4 s1 = *(const f32x4*)(sums + c4), s2 = *(const f32x4*)(sums + a.C + c4);
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = g[e] * rs[e] * (dy[e] - s1[e] * inv_n - xh[e] * s2[e] * inv_n);
+    *(uint2*)(dx + (int64_t)r * a.C + c4) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+  }
+}
+
+inline int bn_blocks(int rows) { int n = (rows + 63) / 64; return n > 256 ? 256 : (n < 1 ? 1 : n); }
+
+}  // namespace
+
+extern "C" int ttsk_bn_nblocks(int rows) { return bn_blocks(rows); }
+
+static int bn_check(int rows, int C) {
+  TTSK_REQUIRE(rows > 0 && C >= 4 && C <= 1024 && (C & 3) == 0, "batchnorm: C must be a multiple of 4, <= 1024 (got %d)", C);
+  return 0;
+}
+
+extern "C" int ttsk_bn_stats(const void* x_bf16, int rows, int C, float* partials, void* stream) {
+  TTSK_REQUIRE(x_bf16 && partials, "bn_stats: null pointer");
+  if (int rc = bn_check(rows, C)) return rc;
+  const int rpi = 256 / (C >> 2);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(bn_blocks(rows)), dim3(256), 2 * rpi * C * sizeof(float), (hipStream_t)stream,
+                     (const bf16_t*)x_bf16, rows, C, partials);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_bn_finalize(const float* partials, int nblk, int C, int rows, float eps, float momentum, float* mean,
+                                float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                void* stream) {
+  TTSK_REQUIRE(partials && mean && rstd && nblk > 0, "bn_finalize: null pointer");
+  TTSK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats come in pairs");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, nblk, C, rows, eps,
+                     momentum, mean, rstd, running_mean, running_var, (long long*)num_batches_tracked);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_rsqrt_eps(const float* var, float eps, float* rstd, int n, void* stream) {
+  TTSK_REQUIRE(var && rstd && n > 0, "rsqrt_eps: bad arguments");
+  hipLaunchKernelGGL(rsqrt_eps_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, var, eps, rstd, n);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_bn_apply(const void* x_bf16, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                             int rows, int C, int use_tanh, float p, uint32_t site, const uint64_t* rng, const float* resid_f32,
+                             void* out_bf16, float* out_f32, void* stream) {
+  TTSK_REQUIRE(x_bf16 && mean && rstd && gamma && beta && (out_bf16 || out_f32), "bn_apply: null pointer");
+  TTSK_REQUIRE(p == 0.f || rng, "bn_apply: dropout needs rng");
+  if (int rc = bn_check(rows, C)) return rc;
+  BnCommon a{(const bf16_t*)x_bf16, mean, rstd, gamma, beta, rng, rows, C, use_tanh, p, site};
+  int64_t n = (int64_t)rows * (C >> 2);
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, resid_f32, (bf16_t*)out_bf16, out_f32);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_bn_bwd_stats(const void* dout, int dout_is_f32, const void* x_bf16, const float* mean, const float* rstd,
+                                 const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
+                                 const uint64_t* rng, float* partials, void* stream) {
+  TTSK_REQUIRE(dout && x_bf16 && mean && rstd && gamma && beta && partials, "bn_bwd_stats: null pointer");
+  TTSK_REQUIRE(p == 0.f || rng, "bn_bwd_stats: dropout needs rng");
+  if (int rc = bn_check(rows, C)) return rc;
+  BnCommon a{(const bf16_t*)x_bf16, mean, rstd, gamma, beta, rng, rows, C, use_tanh, p, site};
+  const int rpi = 256 / (C >> 2);
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(bn_blocks(rows)), dim3(256), 2 * rpi * C * sizeof(float), (hipStream_t)stream, a,
+                     dout, dout_is_f32, partials);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_bn_bwd_apply(const void* dout, int dout_is_f32, const void* x_bf16, const float* mean, const float* rstd,
+                                 const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
+                                 const uint64_t* rng, const float* sums, void* dx_bf16, float* dgamma, float* dbeta,
+                                 void* stream) {
+  TTSK_REQUIRE(dout && x_bf16 && mean && rstd && gamma && beta && sums && dx_bf16, "bn_bwd_apply: null pointer");
+  TTSK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bn_bwd_apply: dgamma/dbeta come in pairs");
+  if (int rc = bn_check(rows, C)) return rc;
+  BnCommon a{(const bf16_t*)x_bf16, mean, rstd, gamma, beta, rng, rows, C, use_tanh, p, site};
+  int64_t n = (int64_t)rows * (C >> 2);
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, dout, dout_is_f32, sums,
+                     (bf16_t*)dx_bf16, dgamma, dbeta);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}

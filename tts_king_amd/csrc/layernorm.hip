@@ -1,0 +1,339 @@
+// layernorm.hip — fused [dropout] + [residual] + LayerNorm + [dropout] + [PAD-row zeroing] + [Linear(D,1) head]
+// and its backward.  One wavefront per row, 4 contiguous channels per lane (8-byte bf16 accesses).
+// reference: SubLayers.py:62-63 (MHA: LN(dropout(fc)+residual)), SubLayers.py:99-101 (FFN), Layers.py:29-32
+// (masked_fill of PAD rows), model/modules.py:270-309 (VariancePredictor: LN -> Dropout, final Linear + mask).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXJ = 4;  // D <= 1024
+
+struct LnArgs {
+  const bf16_t* y;        // [rows][D] main input (sub-layer output incl. bias)
+  const bf16_t* res;      // [rows][D] residual or null
+  const float* gamma;
+  const float* beta;
+  bf16_t* out;            // [rows][D]
+  bf16_t* z_save;         // [rows][D] LN input (after dropout+residual), null = do not save
+  float* mean;            // [rows]
+  float* rstd;            // [rows]
+  const long long* lens;  // [B] valid length per segment, null = no masking
+  const uint64_t* rng;    // {seed, step}
+  const float* head_w;    // [D] or null
+  const float* head_b;    // [1]
+  float* head_out;        // [rows]
+  int rows, D, seg_len;
+  float p_pre, p_post, eps;
+  unsigned site_pre, site_post;
+};
+
+__device__ __forceinline__ void load4(const bf16_t* p, float v[4]) {
+  const uint2 u = *(const uint2*)p;
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
+  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
+  *(uint2*)p = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+}
+__device__ __forceinline__ void drop4(float v[4], uint64_t seed, uint64_t step, unsigned site, unsigned e4, unsigned thr, float scale) {
+  const uint4 b = Philox::gen(make_uint2((unsigned)seed, (unsigned)(seed >> 32)),
+                              make_uint4(e4, site, (unsigned)step, (unsigned)(step >> 32)));
+  v[0] = b.x >= thr ? v[0] * scale : 0.f;
+  v[1] = b.y >= thr ? v[1] * scale : 0.f;
+  v[2] = b.z >= thr ? v[2] * scale : 0.f;
+  v[3] = b.w >= thr ? v[3] * scale : 0.f;
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const int D = a.D, nj = D >> 8;
+  const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
+  float z[MAXJ][4];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    if (j < nj) {
+      const int c = j * 256 + lane * 4;
+      load4(a.y + (int64_t)row * D + c, z[j]);
+      if (a.p_pre > 0.f)
+        drop4(z[j], seed, step, a.site_pre, (unsigned)(((int64_t)row * D + c) >> 2), keep_threshold(a.p_pre), 1.f / (1.f - a.p_pre));
+      if (a.res) {
+        float r[4];
+        load4(a.res + (int64_t)row * D + c, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[j][e] += r[e];
+      }
+      if (a.z_save) {  // backward sees exactly the rounded value
+        store4(a.z_save + (int64_t)row * D + c, z[j]);
+      }
+      s += z[j][0] + z[j][1] + z[j][2] + z[j][3];
+    }
+  }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+    if (j < nj)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = z[j][e] - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) / D + a.eps);
+  if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+  bool masked = false;
+  if (a.lens) { const int b = row / a.seg_len, t = row - b * a.seg_len; masked = t >= a.lens[b]; }
+  float hs = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    if (j < nj) {
+      const int c = j * 256 + lane * 4;
+      const f32x4 g = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (z[j][e] - mean) * rstd * g[e] + bt[e];
+      if (a.p_post > 0.f)
+        drop4(o, seed, step, a.site_post, (unsigned)(((int64_t)row * D + c) >> 2), keep_threshold(a.p_post), 1.f / (1.f - a.p_post));
+      if (masked) o[0] = o[1] = o[2] = o[3] = 0.f;
+      if (a.out) store4(a.out + (int64_t)row * D + c, o);
+      if (a.head_w) {
+        const f32x4 w = *(const f32x4*)(a.head_w + c);
+        hs += o[0] * w[0] + o[1] * w[1] + o[2] * w[2] + o[3] * w[3];
+      }
+    }
+  }
+  if (a.head_w) {
+    hs = wave_sum(hs);
+    if (lane == 0) a.head_out[row] = masked ? 0.f : hs + a.head_b[0];
+  }
+}
+
+struct LnBwdArgs {
+  const bf16_t* dout;     // [rows][D] grad of the LN output, or null when the head is the only consumer
+  const float* dhead;     // [rows] grad of the head output (head mode)
+  const float* head_w;    // [D]
+  const bf16_t* z;        // [rows][D] saved LN input
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const float* beta;      // needed only in head mode / post dropout (recompute of the LN output)
+  const long long* lens;
+  const uint64_t* rng;
+  bf16_t* dz;             // [rows][D] grad wrt LN input (the residual branch's grad)
+  bf16_t* dy;             // [rows][D] grad wrt the sub-layer output (dz with the pre-dropout mask); null if p_pre == 0
+  float* partials;        // [nblk][nq*D (+1)]: dgamma | dbeta | dbias (| dhead_w | dhead_b)
+  int rows, D, seg_len, relu_in;
+  float p_pre, p_post;
+  unsigned site_pre, site_post;
+};
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
+  __shared__ float red[4][MAXJ * 256];
+  __shared__ float redb[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D = a.D, nj = D >> 8;
+  const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
+  const bool head = a.dhead != nullptr;
+  float dg[MAXJ][4], db[MAXJ][4], dbias[MAXJ][4], dhw[MAXJ][4];
+  float dhb = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dg[j][e] = db[j][e] = dbias[j][e] = dhw[j][e] = 0.f;
+
+  for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
+    bool masked = false;
+    if (a.lens) { const int b = row / a.seg_len, t = row - b * a.seg_len; masked = t >= a.lens[b]; }
+    const float mean = a.mean[row], rstd = a.rstd[row];
+    const float dh = head ? (masked ? 0.f : a.dhead[row]) : 0.f;
+    float xh[MAXJ][4], g[MAXJ][4];
+    float c1 = 0.f, c2 = 0.f;
+    unsigned closed = 0;  // bit j*4+e set: the ReLU that produced z was inactive (relu_in mode)
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      if (j < nj) {
+        const int c = j * 256 + lane * 4;
+        float zz[4], d[4] = {0.f, 0.f, 0.f, 0.f};
+        load4(a.z + (int64_t)row * D + c, zz);
+        if (a.dout && !masked) load4(a.dout + (int64_t)row * D + c, d);
+        const f32x4 gm = *(const f32x4*)(a.gamma + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xh[j][e] = (zz[e] - mean) * rstd;
+        if (head) {
+          const f32x4 w = *(const f32x4*)(a.head_w + c), bt = *(const f32x4*)(a.beta + c);
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e] = xh[j][e] * gm[e] + bt[e]; d[e] += dh * w[e]; }
+          if (a.p_post > 0.f)
+            drop4(o, seed, step, a.site_post, (unsigned)(((int64_t)row * D + c) >> 2), keep_threshold(a.p_post), 1.f / (1.f - a.p_post));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dhw[j][e] += dh * o[e];
+        }
+        if (a.p_post > 0.f)
+          drop4(d, seed, step, a.site_post, (unsigned)(((int64_t)row * D + c) >> 2), keep_threshold(a.p_post), 1.f / (1.f - a.p_post));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dg[j][e] += d[e] * xh[j][e];
+          db[j][e] += d[e];
+          g[j][e] = d[e] * gm[e];
+          c1 += g[j][e];
+          c2 += g[j][e] * xh[j][e];
+        }
+        if (a.relu_in) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (!(zz[e] > 0.f)) closed |= 1u << (j * 4 + e);
+        }
+      }
+    }
+    dhb += dh;
+    c1 = wave_sum(c1) / D;
+    c2 = wave_sum(c2) / D;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      if (j < nj) {
+        const int c = j * 256 + lane * 4;
+        float dzv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dzv[e] = ((closed >> (j * 4 + e)) & 1u) ? 0.f : rstd * (g[j][e] - c1 - xh[j][e] * c2);
+        }
+        if (a.dz) store4(a.dz + (int64_t)row * D + c, dzv);
+        if (a.p_pre > 0.f) {
+          drop4(dzv, seed, step, a.site_pre, (unsigned)(((int64_t)row * D + c) >> 2), keep_threshold(a.p_pre), 1.f / (1.f - a.p_pre));
+          if (a.dy) store4(a.dy + (int64_t)row * D + c, dzv);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dbias[j][e] += dzv[e];
+      }
+    }
+  }
+  // cross-wave reduction of the per-lane column sums, one quantity at a time
+  const int nq = head ? 4 : 3;
+  float* P = a.partials + (int64_t)blockIdx.x * (nq * D + (head ? 1 : 0));
+  for (int qn = 0; qn < nq; ++qn) {
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j)
+      if (j < nj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = qn == 0 ? dg[j][e] : qn == 1 ? db[j][e] : qn == 2 ? dbias[j][e] : dhw[j][e];
+          red[wave][j * 256 + lane * 4 + e] = v;
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) P[qn * D + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    __syncthreads();
+  }
+  if (head) {
+    dhb = wave_sum(dhb);
+    if (lane == 0) redb[wave] = dhb;
+    __syncthreads();
+    if (threadIdx.x == 0) P[nq * D] = redb[0] + redb[1] + redb[2] + redb[3];
+  }
+}
+
+// dst[c] (+)= sum_b partials[b][c]   (fixed order: deterministic)
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partials, int nblk, int ncols,
+                                                              int ld, float* __restrict__ dst, int accumulate, float scale) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncols) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partials[(int64_t)b * ld + c];
+  s *= scale;
+  dst[c] = accumulate ? dst[c] + s : s;
+}
+
+// column sums of a [rows][C] matrix (bf16 or fp32) -> partials[nblk][C]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int rows, int C, int ld, float* __restrict__ partials) {
+  __shared__ float red[256];
+  const int tpr = C < 256 ? C : 256;            // threads per row pass
+  const int rpi = 256 / tpr;                    // rows per iteration
+  const int r0 = threadIdx.x / tpr, c0 = threadIdx.x % tpr;
+  const int rows_per_blk = (rows + gridDim.x - 1) / gridDim.x;
+  const int rb = blockIdx.x * rows_per_blk;
+  int re = rb + rows_per_blk;
+  if (re > rows) re = rows;
+  for (int cb = 0; cb < C; cb += tpr) {
+    const int c = cb + c0;
+    float s = 0.f;
+    if (r0 < rpi && c < C)
+      for (int r = rb + r0; r < re; r += rpi) {
+        if constexpr (sizeof(T) == 2) s += bf2f(((const bf16_t*)x)[(int64_t)r * ld + c]);
+        else s += ((const float*)x)[(int64_t)r * ld + c];
+      }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < tpr && c < C) {
+      float t = 0.f;
+      for (int k = 0; k < rpi; ++k) t += red[k * tpr + threadIdx.x];
+      partials[(int64_t)blockIdx.x * C + c] = t;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int ttsk_layernorm_fwd(const void* y, const void* res, const float* gamma, const float* beta, void* out,
+                                  void* z_save, float* mean, float* rstd, const int64_t* lens, int seg_len, int rows, int D,
+                                  float eps, float p_pre, uint32_t site_pre, float p_post, uint32_t site_post,
+                                  const uint64_t* rng, const float* head_w, const float* head_b, float* head_out,
+                                  void* stream) {
+  TTSK_REQUIRE(y && gamma && beta && mean && rstd, "layernorm_fwd: null pointer");
+  TTSK_REQUIRE(rows > 0 && D >= 256 && D <= 1024 && (D & 255) == 0, "layernorm_fwd: D must be 256..1024 step 256 (got %d)", D);
+  TTSK_REQUIRE(!lens || seg_len > 0, "layernorm_fwd: lens needs seg_len");
+  TTSK_REQUIRE((p_pre == 0.f && p_post == 0.f) || rng, "layernorm_fwd: dropout needs rng state");
+  TTSK_REQUIRE(!head_w || (head_b && head_out), "layernorm_fwd: head needs bias and output");
+  LnArgs a{(const bf16_t*)y, (const bf16_t*)res, gamma, beta, (bf16_t*)out, (bf16_t*)z_save, mean, rstd,
+           (const long long*)lens, rng, head_w, head_b, head_out, rows, D, seg_len, p_pre, p_post, eps, site_pre, site_post};
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_layernorm_bwd_nblocks(int rows) {
+  int n = (rows + 3) / 4;
+  return n > 256 ? 256 : n;
+}
+
+extern "C" int ttsk_layernorm_bwd(const void* dout, const float* dhead, const float* head_w, const void* z,
+                                  const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  const int64_t* lens, int seg_len, int rows, int D, int relu_in, float p_pre,
+                                  uint32_t site_pre, float p_post, uint32_t site_post, const uint64_t* rng, void* dz, void* dy,
+                                  float* partials, void* stream) {
+  TTSK_REQUIRE(z && mean && rstd && gamma && partials, "layernorm_bwd: null pointer");
+  TTSK_REQUIRE(dout || dhead, "layernorm_bwd: need dout or dhead");
+  TTSK_REQUIRE(!dhead || (head_w && beta), "layernorm_bwd: head mode needs head_w and beta");
+  TTSK_REQUIRE(rows > 0 && D >= 256 && D <= 1024 && (D & 255) == 0, "layernorm_bwd: bad D %d", D);
+  TTSK_REQUIRE((p_pre == 0.f && p_post == 0.f) || rng, "layernorm_bwd: dropout needs rng state");
+  TTSK_REQUIRE(p_post == 0.f || beta, "layernorm_bwd: post dropout needs beta");
+  LnBwdArgs a{(const bf16_t*)dout, dhead, head_w, (const bf16_t*)z, mean, rstd, gamma, beta, (const long long*)lens, rng,
+              (bf16_t*)dz, (bf16_t*)dy, partials, rows, D, seg_len, relu_in, p_pre, p_post, site_pre, site_post};
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(ttsk_layernorm_bwd_nblocks(rows)), dim3(256), 0, (hipStream_t)stream, a);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_colsum_finalize(const float* partials, int nblk, int ncols, int ld, float* dst, int accumulate,
+                                    float scale, void* stream) {
+  TTSK_REQUIRE(partials && dst && nblk > 0 && ncols > 0 && ld >= ncols, "colsum_finalize: bad arguments");
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, nblk,
+                     ncols, ld, dst, accumulate, scale);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_colsum_nblocks(int rows) {
+  int n = (rows + 63) / 64;
+  return n > 256 ? 256 : (n < 1 ? 1 : n);
+}
+
+extern "C" int ttsk_colsum(const void* x, int is_f32, int rows, int C, int ld, float* partials, void* stream) {
+  TTSK_REQUIRE(x && partials && rows > 0 && C > 0 && ld >= C, "colsum: bad arguments");
+  const int nblk = ttsk_colsum_nblocks(rows);
+  if (is_f32)
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, C, ld, partials);
+  else
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, rows, C, ld, partials);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}

@@ -1,0 +1,123 @@
+// loss.hip — FastSpeech2Loss forward AND its gradient in one pass.
+// reference: fs_two/model/loss.py:24-134 (use_cwt False):
+//   mel terms: predictions and targets are zeroed on PAD rows, then MSE + L1 (mel) + L1 (postnet mel), each a mean
+//   over ALL B*T*n_mel elements (PAD rows stay in the denominator);
+//   pitch / energy / log-duration: MSE over valid phonemes only; log_d_target = log(d + 1).
+// Outputs: losses[8] = {total, mel_total, pitch, energy, duration, 0, 0, n_valid_phonemes} and the gradients of
+// `grad_scale * total` wrt every prediction (grad_scale = 1/grad_acc_step, train.py:43).
+#include "common.h"
+
+namespace {
+
+struct LossArgs {
+  const float* mel;      // [B][T][nm]
+  const float* post;     // [B][T][nm]
+  const float* mel_t;    // [B][Tt][nm] (Tt >= T; targets are cropped to T, loss.py:57)
+  const long long* mel_lens;
+  const float* pitch; const float* energy; const float* logd;       // [B][L]
+  const float* pitch_t; const float* energy_t; const long long* dur_t;
+  const long long* src_lens;
+  float* dmel_sum;       // d/dmel of the two mel terms + d/dpost (postnet output = postnet(mel) + mel)
+  float* dpost;          // d/dpost
+  float* dpitch; float* denergy; float* dlogd;
+  float* partials;       // [nblk][6]
+  int B, T, Tt, nm, L;
+  float grad_scale;
+};
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
+  __shared__ float red[6][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[6] = {0, 0, 0, 0, 0, 0};
+  const int nm4 = a.nm >> 2;
+  const int64_t n4 = (int64_t)a.B * a.T * nm4;
+  const float inv_n = 1.f / ((float)a.B * a.T * a.nm);
+  const float gs = a.grad_scale * inv_n;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int64_t rt = i / nm4;
+    const int c = (int)(i - rt * nm4) * 4;
+    const int b = (int)(rt / a.T), t = (int)(rt - (int64_t)b * a.T);
+    const bool ok = t < a.mel_lens[b];
+    f32x4 dm = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+    if (ok) {
+      const f32x4 m = *(const f32x4*)(a.mel + rt * a.nm + c), p = *(const f32x4*)(a.post + rt * a.nm + c);
+      const f32x4 tg = *(const f32x4*)(a.mel_t + ((int64_t)b * a.Tt + t) * a.nm + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d1 = m[e] - tg[e], d2 = p[e] - tg[e];
+        acc[0] += d1 * d1; acc[1] += fabsf(d1); acc[2] += fabsf(d2);
+        dp[e] = gs * sgn(d2);
+        dm[e] = gs * (2.f * d1 + sgn(d1)) + dp[e];
+      }
+    }
+    *(f32x4*)(a.dmel_sum + rt * a.nm + c) = dm;
+    *(f32x4*)(a.dpost + rt * a.nm + c) = dp;
+  }
+  // phoneme-level terms
+  float nv = 0.f;
+  for (int b = 0; b < a.B; ++b) nv += (float)a.src_lens[b];
+  const float gv = a.grad_scale * 2.f / nv;
+  const int nph = a.B * a.L;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nph; i += gridDim.x * 256) {
+    const int b = i / a.L, l = i - b * a.L;
+    const bool ok = l < a.src_lens[b];
+    float g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    if (ok) {
+      const float d1 = a.pitch[i] - a.pitch_t[i], d2 = a.energy[i] - a.energy_t[i];
+      const float d3 = a.logd[i] - logf((float)a.dur_t[i] + 1.f);
+      acc[3] += d1 * d1; acc[4] += d2 * d2; acc[5] += d3 * d3;
+      g1 = gv * d1; g2 = gv * d2; g3 = gv * d3;
+    }
+    a.dpitch[i] = g1; a.denergy[i] = g2; a.dlogd[i] = g3;
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) { const float s = wave_sum(acc[q]); if (lane == 0) red[q][wave] = s; }
+  __syncthreads();
+  if (threadIdx.x < 6) a.partials[blockIdx.x * 6 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+__global__ __launch_bounds__(64) void loss_finalize_kernel(const float* __restrict__ partials, int nblk, const long long* __restrict__ src_lens,
+                                                           int B, float n_mel_elems, float* __restrict__ losses) {
+  __shared__ double tot[6];
+  const int q = threadIdx.x;
+  if (q < 6) {
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partials[b * 6 + q];
+    tot[q] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double nv = 0.0;
+    for (int b = 0; b < B; ++b) nv += (double)src_lens[b];
+    const double mel_total = (tot[0] + tot[1] + tot[2]) / n_mel_elems;
+    const double pl = tot[3] / nv, el = tot[4] / nv, dl = tot[5] / nv;
+    losses[0] = (float)(mel_total + dl + pl + el);
+    losses[1] = (float)mel_total; losses[2] = (float)pl; losses[3] = (float)el; losses[4] = (float)dl;
+    losses[5] = 0.f; losses[6] = 0.f; losses[7] = (float)nv;
+  }
+}
+
+}  // namespace
+
+extern "C" int ttsk_fs2_loss_nblocks(void) { return 256; }
+
+extern "C" int ttsk_fs2_loss(const float* mel, const float* post, const float* mel_target, const int64_t* mel_lens,
+                             const float* pitch, const float* energy, const float* logd, const float* pitch_target,
+                             const float* energy_target, const int64_t* dur_target, const int64_t* src_lens, int B, int T,
+                             int T_target, int n_mel, int L, float grad_scale, float* dmel_sum, float* dpost, float* dpitch,
+                             float* denergy, float* dlogd, float* partials, float* losses, void* stream) {
+  TTSK_REQUIRE(mel && post && mel_target && mel_lens && pitch && energy && logd && pitch_target && energy_target && dur_target &&
+                   src_lens && dmel_sum && dpost && dpitch && denergy && dlogd && partials && losses, "fs2_loss: null pointer");
+  TTSK_REQUIRE(B > 0 && T > 0 && T_target >= T && L > 0 && n_mel > 0 && (n_mel & 3) == 0, "fs2_loss: bad sizes");
+  LossArgs a{mel, post, mel_target, (const long long*)mel_lens, pitch, energy, logd, pitch_target, energy_target,
+             (const long long*)dur_target, (const long long*)src_lens, dmel_sum, dpost, dpitch, denergy, dlogd, partials,
+             B, T, T_target, n_mel, L, grad_scale};
+  const int nblk = ttsk_fs2_loss_nblocks();
+  hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, nblk, (const long long*)src_lens, B,
+                     (float)B * T * n_mel, losses);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}

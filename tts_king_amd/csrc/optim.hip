@@ -1,0 +1,133 @@
+// optim.hip — global-norm gradient clipping + Adam + LR schedule + bf16 weight shadow, over ONE flat buffer.
+// reference: train.py:47-54 (clip_grad_norm_(1.0) -> step_and_update_lr -> zero_grad),
+//            fs_two/model/optimizer.py:35-53 (lr = d^-0.5 * min(s^-0.5, warmup^-1.5 * s) * anneal^{#(s > a_k)}),
+//            torch.optim.Adam (betas (0.95, 0.999), eps 1e-5, bias correction, no weight decay).
+// The step counters, learning rate and bias corrections live in a small DEVICE state block so that a captured
+// hipGraph of the train step replays with fresh values (kernel arguments are frozen at capture).
+#include "common.h"
+
+namespace {
+
+struct OptState {          // mirrors tts_king_amd/optimizer.py: 8 x 8 bytes
+  long long sched_step;    // ScheduledOptim.current_step (counts optimizer updates)
+  long long adam_t;        // Adam's per-parameter step
+  unsigned long long rng_seed, rng_step;   // dropout counter state (rng = &rng_seed)
+  float lr, bc1, bc2, clip_coef;
+  float gnorm, pad0;
+  long long pad1;
+};
+
+__global__ void optim_advance_kernel(OptState* st, float d_model, float warmup, float a0, float a1, float a2, float a3,
+                                     int n_anneal, float anneal_rate, float b1, float b2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const long long s = ++st->sched_step;
+  const long long t = ++st->adam_t;
+  double lr = fmin(pow((double)s, -0.5), pow((double)warmup, -1.5) * (double)s);
+  const float an[4] = {a0, a1, a2, a3};
+  for (int i = 0; i < n_anneal; ++i)
+    if ((double)s > (double)an[i]) lr *= (double)anneal_rate;
+  st->lr = (float)(pow((double)d_model, -0.5) * lr);
+  st->bc1 = (float)(1.0 - pow((double)b1, (double)t));
+  st->bc2 = (float)(1.0 - pow((double)b2, (double)t));
+}
+
+__global__ void rng_advance_kernel(OptState* st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) st->rng_step += 1;
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partials) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 v = *(const f32x4*)(g + i * 4);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[n4 * 4 + threadIdx.x]; s += v * v; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// clip_coef = min(1, max_norm / (||g|| + 1e-6))   (torch.nn.utils.clip_grad_norm_)
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partials, int nblk, float max_norm, OptState* st) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += partials[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt(red[0]);
+    st->gnorm = norm;
+    const float c = max_norm / (norm + 1e-6f);
+    st->clip_coef = c < 1.f ? c : 1.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, bf16_t* __restrict__ shadow, int64_t n,
+                                                   const OptState* __restrict__ st, float b1, float b2, float eps, int zero_grad) {
+  const float lr = st->lr, bc1 = st->bc1, coef = st->clip_coef;
+  const float isb2 = 1.f / sqrtf(st->bc2);
+  const float step = lr / bc1;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 pp = *(f32x4*)(p + i * 4), gg = *(const f32x4*)(g + i * 4), mm = *(f32x4*)(m + i * 4), vv = *(f32x4*)(v + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ge = gg[e] * coef;
+      mm[e] = b1 * mm[e] + (1.f - b1) * ge;
+      vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
+      pp[e] -= step * mm[e] / (sqrtf(vv[e]) * isb2 + eps);
+    }
+    *(f32x4*)(p + i * 4) = pp; *(f32x4*)(m + i * 4) = mm; *(f32x4*)(v + i * 4) = vv;
+    if (zero_grad) *(f32x4*)(g + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (shadow) *(uint2*)(shadow + i * 4) = make_uint2(pack_bf2(pp[0], pp[1]), pack_bf2(pp[2], pp[3]));
+  }
+}
+
+}  // namespace
+
+extern "C" int ttsk_optim_state_bytes(void) { return (int)sizeof(OptState); }
+
+extern "C" int ttsk_optim_advance(void* state, float d_model, float warmup, const float* anneal_steps_host, int n_anneal,
+                                  float anneal_rate, float beta1, float beta2, void* stream) {
+  TTSK_REQUIRE(state && n_anneal >= 0 && n_anneal <= 4, "optim_advance: at most 4 anneal steps");
+  float a[4] = {0, 0, 0, 0};
+  for (int i = 0; i < n_anneal; ++i) a[i] = anneal_steps_host[i];
+  hipLaunchKernelGGL(optim_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (OptState*)state, d_model, warmup, a[0], a[1],
+                     a[2], a[3], n_anneal, anneal_rate, beta1, beta2);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_rng_advance(void* state, void* stream) {
+  TTSK_REQUIRE(state, "rng_advance: null state");
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (OptState*)state);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n,
+                                   void* state, float* partials /* >= 1024 floats */, float max_norm, float beta1, float beta2,
+                                   float eps, int zero_grad, void* stream) {
+  TTSK_REQUIRE(params && grads && exp_avg && exp_avg_sq && state && partials && n > 0, "clip_adam_step: null pointer");
+  TTSK_REQUIRE((n & 3) == 0, "clip_adam_step: n must be a multiple of 4 (pad the flat buffer)");
+  TTSK_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0, "clip_adam_step: alignment");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, s, grads, n, partials);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, s, partials, 1024, max_norm, (OptState*)state);
+  hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (bf16_t*)shadow_bf16, n,
+                     (const OptState*)state, beta1, beta2, eps, zero_grad);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_grad_sumsq(const float* grads, int64_t n, float* partials /* 1024 floats */, void* stream) {
+  TTSK_REQUIRE(grads && partials && n > 0, "grad_sumsq: bad arguments");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, grads, n, partials);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}

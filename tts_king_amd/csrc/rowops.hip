@@ -1,0 +1,266 @@
+// rowops.hip — memory-bound row kernels of the FS2 path: masked softmax (+backward), embedding gathers and their
+// deterministic scatter-sums, bucketize, dtype/layout conversions.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- softmax
+// reference: fs_two/transformer/Modules.py:15-22 — scores were already scaled by 1/sqrt(d_k) in the Q·Kᵀ GEMM
+// epilogue; keys at or past the utterance length get -inf.  One wavefront per (head-batch, query) row.
+constexpr int SM_MAXE = 16;  // keys per lane: S <= 1024
+
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ s, bf16_t* __restrict__ p,
+                                                          const long long* __restrict__ lens, int nrows, int S, int Sp,
+                                                          int H) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int z = row / S;              // z = b*H + h
+  const int len = lens ? (int)lens[z / H] : S;
+  const float* sr = s + (int64_t)row * Sp;
+  float v[SM_MAXE];
+  float m = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < SM_MAXE; ++e) {
+    const int k = e * 64 + lane;
+    v[e] = (k < S && k < len) ? sr[k] : -INFINITY;
+    m = fmaxf(m, v[e]);
+  }
+  m = wave_max(m);
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < SM_MAXE; ++e) { v[e] = __expf(v[e] - m); sum += v[e]; }
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  bf16_t* pr = p + (int64_t)row * Sp;
+#pragma unroll
+  for (int e = 0; e < SM_MAXE; ++e) {
+    const int k = e * 64 + lane;
+    if (k < Sp) pr[k] = f2bf(k < S ? v[e] * inv : 0.f);
+  }
+}
+
+// dS = alpha * P ∘ (dP − Σ_k dP∘P)
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ p, const float* __restrict__ dp,
+                                                          bf16_t* __restrict__ ds, int nrows, int S, int Sp, float alpha) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const bf16_t* pr = p + (int64_t)row * Sp;
+  const float* dr = dp + (int64_t)row * Sp;
+  float pv[SM_MAXE], dv[SM_MAXE];
+  float dot = 0.f;
+#pragma unroll
+  for (int e = 0; e < SM_MAXE; ++e) {
+    const int k = e * 64 + lane;
+    pv[e] = k < S ? bf2f(pr[k]) : 0.f;
+    dv[e] = k < S ? dr[k] : 0.f;
+    dot += pv[e] * dv[e];
+  }
+  dot = wave_sum(dot);
+  bf16_t* o = ds + (int64_t)row * Sp;
+#pragma unroll
+  for (int e = 0; e < SM_MAXE; ++e) {
+    const int k = e * 64 + lane;
+    if (k < Sp) o[k] = f2bf(k < S ? alpha * pv[e] * (dv[e] - dot) : 0.f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- bucketize
+// reference: torch.bucketize(v, bins) (right=False) at model/modules.py:95-100,134-139: index = #{bins < v}
+__global__ __launch_bounds__(256) void bucketize_kernel(const float* __restrict__ v, const float* __restrict__ bins, int nb,
+                                                        float scale, int* __restrict__ idx, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = v[i] * scale;
+  int lo = 0, hi = nb;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (bins[mid] < x) lo = mid + 1; else hi = mid; }
+  idx[i] = (x != x) ? nb : lo;   // NaN sorts last, as in torch
+}
+
+// ---------------------------------------------------------------------------------------------- gather + add
+// out[row] = (in ? in[row] : 0) + table[idx[row / idx_div]] + (pe ? pe[row % pe_mod] : 0)
+// reference: Models.py:101-103 (word embedding + position table), fastspeech2.py:72-75 + modules.py:159 (speaker
+// embedding broadcast over phonemes), modules.py:95-100,134-139 (pitch / energy embeddings).
+__global__ __launch_bounds__(256) void gather_add_kernel(const bf16_t* __restrict__ in, const float* __restrict__ table,
+                                                         const void* __restrict__ idx, int idx_i64, int idx_div,
+                                                         const float* __restrict__ pe, int pe_mod,
+                                                         bf16_t* __restrict__ out, int rows, int D) {
+  const int cpr = D >> 2;
+  const int64_t n = (int64_t)rows * cpr;
+  for (int64_t c = blockIdx.x * 256 + threadIdx.x; c < n; c += (int64_t)gridDim.x * 256) {
+    const int row = (int)(c / cpr), ch = (int)(c - (int64_t)row * cpr) * 4;
+    const int64_t ir = row / idx_div;
+    const int64_t t = idx_i64 ? ((const long long*)idx)[ir] : ((const int*)idx)[ir];
+    f32x4 v = *(const f32x4*)(table + t * D + ch);
+    if (pe) v += *(const f32x4*)(pe + (int64_t)(row % pe_mod) * D + ch);
+    if (in) {
+      const uint2 u = *(const uint2*)(in + (int64_t)row * D + ch);
+      v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xFFFF0000u);
+      v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xFFFF0000u);
+    }
+    *(uint2*)(out + (int64_t)row * D + ch) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+  }
+}
+
+// dtable[v] (+)= Σ_{rows with idx[row/idx_div] == v} dx[row]   — one workgroup per table row, rows visited in
+// ascending order (deterministic; no atomics).  `skip` = padding_idx that receives no gradient (-1: none).
+__global__ __launch_bounds__(256) void scatter_sum_kernel(const bf16_t* __restrict__ dx, const void* __restrict__ idx,
+                                                          int idx_i64, int idx_div, int nidx, float* __restrict__ dtable,
+                                                          int D, int skip, int accumulate) {
+  __shared__ int hits[1024];
+  __shared__ int nh;
+  const int v = blockIdx.x;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};   // D <= 1024: thread handles channels tid + 256*j
+  if (v != skip) {
+    for (int base = 0; base < nidx; base += 1024) {
+      if (threadIdx.x == 0) nh = 0;
+      __syncthreads();
+      // ordered compaction of the matching indices in this chunk (single wave does it serially in order)
+      if (threadIdx.x < 64) {
+        int count = 0;
+        for (int i0 = base; i0 < base + 1024 && i0 < nidx; i0 += 64) {
+          const int i = i0 + threadIdx.x;
+          const bool hit = i < nidx && (idx_i64 ? ((const long long*)idx)[i] : ((const int*)idx)[i]) == v;
+          const unsigned long long bal = __ballot(hit);
+          if (hit) hits[count + __popcll(bal & ((1ull << threadIdx.x) - 1ull))] = i;
+          count += __popcll(bal);
+        }
+        if (threadIdx.x == 0) nh = count;
+      }
+      __syncthreads();
+      for (int h = 0; h < nh; ++h) {
+        const int i = hits[h];
+        for (int r = 0; r < idx_div; ++r) {
+          const int64_t row = (int64_t)i * idx_div + r;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int c = threadIdx.x + 256 * j;
+            if (c < D) acc[j] += bf2f(dx[row * D + c]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = threadIdx.x + 256 * j;
+    if (c < D) dtable[(int64_t)v * D + c] = accumulate ? dtable[(int64_t)v * D + c] + acc[j] : acc[j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- conversions
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 v = *(const f32x4*)(src + i * 4);
+    *(uint2*)(dst + i * 4) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] = f2bf(src[n4 * 4 + threadIdx.x]);
+}
+
+// (B,C,T) fp32 -> (B,T,C) bf16 through a 32x33 LDS tile (HiFi-GAN takes mel as (B,80,T); kernels are channels-last)
+__global__ __launch_bounds__(256) void nct_to_ntc_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int C, int T) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, t = t0 + tx;
+    tile[r][tx] = (c < C && t < T) ? src[((int64_t)b * C + c) * T + t] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int t = t0 + r, c = c0 + tx;
+    if (t < T && c < C) dst[((int64_t)b * T + t) * C + c] = f2bf(tile[tx][r]);
+  }
+}
+
+// audio fp32 -> int16: (x * max_wav).astype(int16), C truncation toward zero (reference: hifiapi.py:50-51)
+__global__ __launch_bounds__(256) void to_int16_kernel(const float* __restrict__ src, short* __restrict__ dst, int64_t n, float scale) {
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int v = (int)(src[i] * scale);            // trunc toward zero
+    dst[i] = (short)v;                              // wraps like numpy's int32->int16 cast path on overflow
+  }
+}
+
+}  // namespace
+
+static inline int grid_for(int64_t n, int cap = 2048) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+extern "C" int ttsk_softmax_fwd(const float* scores, void* probs_bf16, const int64_t* lens, int nz, int H, int S, int Sp,
+                                void* stream) {
+  TTSK_REQUIRE(scores && probs_bf16 && nz > 0 && H > 0, "softmax_fwd: bad arguments");
+  TTSK_REQUIRE(S > 0 && S <= 1024 && Sp >= S && Sp <= 1024, "softmax_fwd: S=%d Sp=%d out of range (<=1024)", S, Sp);
+  const int nrows = nz * S;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((nrows + 3) / 4), dim3(256), 0, (hipStream_t)stream, scores,
+                     (bf16_t*)probs_bf16, (const long long*)lens, nrows, S, Sp, H);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_softmax_bwd(const void* probs_bf16, const float* dprobs, void* dscores_bf16, int nz, int S, int Sp,
+                                float alpha, void* stream) {
+  TTSK_REQUIRE(probs_bf16 && dprobs && dscores_bf16 && nz > 0, "softmax_bwd: bad arguments");
+  TTSK_REQUIRE(S > 0 && S <= 1024 && Sp >= S && Sp <= 1024, "softmax_bwd: S out of range");
+  const int nrows = nz * S;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((nrows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)probs_bf16,
+                     dprobs, (bf16_t*)dscores_bf16, nrows, S, Sp, alpha);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_bucketize(const float* values, const float* bins, int n_bins, float scale, int32_t* idx, int n,
+                              void* stream) {
+  TTSK_REQUIRE(values && bins && idx && n > 0 && n_bins > 0, "bucketize: bad arguments");
+  hipLaunchKernelGGL(bucketize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, values, bins, n_bins, scale,
+                     idx, n);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_gather_add(const void* in_bf16, const float* table, const void* idx, int idx_is_i64, int idx_div,
+                               const float* pe, int pe_mod, void* out_bf16, int rows, int D, void* stream) {
+  TTSK_REQUIRE(table && idx && out_bf16 && rows > 0 && D > 0 && (D & 3) == 0, "gather_add: bad arguments");
+  TTSK_REQUIRE(idx_div > 0 && (!pe || pe_mod > 0), "gather_add: idx_div/pe_mod");
+  hipLaunchKernelGGL(gather_add_kernel, dim3(grid_for((int64_t)rows * (D >> 2))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)in_bf16, table, idx, idx_is_i64, idx_div, pe, pe_mod, (bf16_t*)out_bf16, rows, D);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_scatter_sum(const void* dx_bf16, const void* idx, int idx_is_i64, int idx_div, int n_idx, float* dtable,
+                                int n_table_rows, int D, int skip_row, int accumulate, void* stream) {
+  TTSK_REQUIRE(dx_bf16 && idx && dtable && n_idx > 0 && n_table_rows > 0, "scatter_sum: bad arguments");
+  TTSK_REQUIRE(D > 0 && D <= 1024 && idx_div > 0, "scatter_sum: D must be <= 1024");
+  hipLaunchKernelGGL(scatter_sum_kernel, dim3(n_table_rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx_bf16, idx,
+                     idx_is_i64, idx_div, n_idx, dtable, D, skip_row, accumulate);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_cast_bf16(const float* src, void* dst_bf16, int64_t n, void* stream) {
+  TTSK_REQUIRE(src && dst_bf16 && n > 0, "cast_bf16: bad arguments");
+  TTSK_REQUIRE((((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst_bf16) & 7) == 0, "cast_bf16: alignment");
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n >> 2, 4096)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst_bf16, n);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_nct_to_ntc_bf16(const float* src, void* dst_bf16, int B, int C, int T, void* stream) {
+  TTSK_REQUIRE(src && dst_bf16 && B > 0 && C > 0 && T > 0 && B <= 65535, "nct_to_ntc: bad arguments");
+  hipLaunchKernelGGL(nct_to_ntc_kernel, dim3((T + 31) / 32, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, src,
+                     (bf16_t*)dst_bf16, C, T);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_to_int16(const float* src, int16_t* dst, int64_t n, float scale, void* stream) {
+  TTSK_REQUIRE(src && dst && n > 0, "to_int16: bad arguments");
+  hipLaunchKernelGGL(to_int16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, (short*)dst, n, scale);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}

@@ -201,3 +201,235 @@ def conv_transpose1d(x, Wp, bias, stride, k, out=None, in_slope=0.0, flags=0):
              bias=bias, taps=taps, seg_len=T, tap_shift0=qoff, tap_dshift=-1, b_tap_stride=stride * Cout * Cin,
              out_seg=T * stride, out_mul=stride, out_add=qoff * stride + r - p, in_slope=in_slope)
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# row kernels
+
+def _f32(*shape, device):
+    return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
+def layernorm_fwd(y, res, gamma, beta, lens=None, seg_len=0, p_pre=0.0, site_pre=0, p_post=0.0, site_post=0, rng=None,
+                  save_z=True, head=None, want_out=True, eps=1e-5):
+    """Fused block tail (see include/ttsk.h).  y/res (rows,D) bf16.  Returns (out, z, mean, rstd, head_out)."""
+    _dev(y, res, gamma, beta, lens, rng)
+    rows, D = y.shape
+    dev = y.device
+    out = torch.empty(rows, D, dtype=bf16, device=dev) if want_out else None
+    z = torch.empty(rows, D, dtype=bf16, device=dev) if save_z else None
+    mean, rstd = _f32(rows, device=dev), _f32(rows, device=dev)
+    hw = hb = ho = None
+    if head is not None:
+        hw, hb = head
+        ho = _f32(rows, device=dev)
+    check(L.load().ttsk_layernorm_fwd(_ptr(y), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(z), _ptr(mean), _ptr(rstd),
+                                      _ptr(lens), seg_len, rows, D, eps, p_pre, site_pre, p_post, site_post, _ptr(rng),
+                                      _ptr(hw), _ptr(hb), _ptr(ho), _stream()), "ttsk_layernorm_fwd")
+    return out, z, mean, rstd, ho
+
+
+def layernorm_bwd(dout, z, mean, rstd, gamma, beta, lens=None, seg_len=0, relu_in=False, p_pre=0.0, site_pre=0,
+                  p_post=0.0, site_post=0, rng=None, dhead=None, head_w=None, want_dz=True):
+    """Returns (dz, dy, partials, nblk).  dy is dz when p_pre == 0.  partials layout: see include/ttsk.h."""
+    _dev(dout, z, dhead)
+    rows, D = z.shape
+    dev = z.device
+    lib = L.load()
+    nblk = lib.ttsk_layernorm_bwd_nblocks(rows)
+    ncol = (4 * D + 1) if dhead is not None else 3 * D
+    partials = _f32(nblk, ncol, device=dev)
+    dz = torch.empty(rows, D, dtype=bf16, device=dev) if (want_dz or p_pre == 0.0) else None
+    dy = torch.empty(rows, D, dtype=bf16, device=dev) if p_pre > 0.0 else None
+    check(lib.ttsk_layernorm_bwd(_ptr(dout), _ptr(dhead), _ptr(head_w), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma),
+                                 _ptr(beta), _ptr(lens), seg_len, rows, D, int(relu_in), p_pre, site_pre, p_post,
+                                 site_post, _ptr(rng), _ptr(dz), _ptr(dy), _ptr(partials), _stream()), "ttsk_layernorm_bwd")
+    return dz, (dy if dy is not None else dz), partials, nblk
+
+
+def colsum_finalize(partials, nblk, ncols, ld, dst, accumulate=True, scale=1.0):
+    check(L.load().ttsk_colsum_finalize(_ptr(partials), nblk, ncols, ld, _ptr(dst), int(accumulate), scale, _stream()),
+          "ttsk_colsum_finalize")
+    return dst
+
+
+def colsum_into(x, dst, accumulate=True):
+    """dst[C] (+)= column sums of x (rows, C) — bias gradients."""
+    _dev(x, dst)
+    rows, Cn = x.shape
+    lib = L.load()
+    nblk = lib.ttsk_colsum_nblocks(rows)
+    partials = _f32(nblk, Cn, device=x.device)
+    check(lib.ttsk_colsum(_ptr(x), int(x.dtype == torch.float32), rows, Cn, x.stride(0), _ptr(partials), _stream()), "ttsk_colsum")
+    return colsum_finalize(partials, nblk, Cn, Cn, dst, accumulate)
+
+
+def softmax_fwd(scores, lens, H):
+    """scores (nz,S,Sp) fp32 -> probs (nz,S,Sp) bf16; keys >= lens[z // H] masked."""
+    _dev(scores, lens)
+    nz, S, Sp = scores.shape
+    probs = torch.empty(nz, S, Sp, dtype=bf16, device=scores.device)
+    check(L.load().ttsk_softmax_fwd(_ptr(scores), _ptr(probs), _ptr(lens), nz, H, S, Sp, _stream()), "ttsk_softmax_fwd")
+    return probs
+
+
+def softmax_bwd(probs, dprobs, alpha):
+    _dev(probs, dprobs)
+    nz, S, Sp = probs.shape
+    ds = torch.empty(nz, S, Sp, dtype=bf16, device=probs.device)
+    check(L.load().ttsk_softmax_bwd(_ptr(probs), _ptr(dprobs), _ptr(ds), nz, S, Sp, alpha, _stream()), "ttsk_softmax_bwd")
+    return ds
+
+
+def bucketize(values, bins, scale=1.0):
+    _dev(values, bins)
+    values = values.contiguous()
+    idx = torch.empty(values.shape, dtype=torch.int32, device=values.device)
+    check(L.load().ttsk_bucketize(_ptr(values), _ptr(bins), bins.numel(), scale, _ptr(idx), values.numel(), _stream()),
+          "ttsk_bucketize")
+    return idx
+
+
+def gather_add(x, table, idx, idx_div=1, pe=None, pe_mod=1, rows=None, out=None):
+    """out[row] = (x[row] if x is not None) + table[idx[row // idx_div]] + pe[row % pe_mod]; bf16 (rows, D)."""
+    _dev(x, table, idx, pe)
+    D = table.shape[1]
+    if rows is None:
+        rows = x.shape[0]
+    if out is None:
+        out = torch.empty(rows, D, dtype=bf16, device=table.device)
+    check(L.load().ttsk_gather_add(_ptr(x), _ptr(table), _ptr(idx), int(idx.dtype == torch.int64), idx_div, _ptr(pe), pe_mod,
+                                   _ptr(out), rows, D, _stream()), "ttsk_gather_add")
+    return out
+
+
+def scatter_sum(dx, idx, dtable, idx_div=1, skip_row=-1, accumulate=True):
+    _dev(dx, idx, dtable)
+    V, D = dtable.shape
+    check(L.load().ttsk_scatter_sum(_ptr(dx), _ptr(idx), int(idx.dtype == torch.int64), idx_div, idx.numel(), _ptr(dtable), V, D,
+                                    skip_row, int(accumulate), _stream()), "ttsk_scatter_sum")
+    return dtable
+
+
+def cast_bf16(src, dst=None):
+    _dev(src)
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=bf16, device=src.device)
+    check(L.load().ttsk_cast_bf16(_ptr(src), _ptr(dst), src.numel(), _stream()), "ttsk_cast_bf16")
+    return dst
+
+
+def nct_to_ntc_bf16(x):
+    """(B,C,T) fp32 contiguous -> (B,T,C) bf16."""
+    _dev(x)
+    B, Cn, T = x.shape
+    out = torch.empty(B, T, Cn, dtype=bf16, device=x.device)
+    check(L.load().ttsk_nct_to_ntc_bf16(_ptr(x.contiguous()), _ptr(out), B, Cn, T, _stream()), "ttsk_nct_to_ntc_bf16")
+    return out
+
+
+def to_int16(x, scale):
+    _dev(x)
+    out = torch.empty(x.shape, dtype=torch.int16, device=x.device)
+    check(L.load().ttsk_to_int16(_ptr(x.contiguous()), _ptr(out), x.numel(), scale, _stream()), "ttsk_to_int16")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------- batch norm
+
+def bn_train_stats(x, running_mean=None, running_var=None, nbt=None, eps=1e-5, momentum=0.1):
+    """x (rows, C) bf16 -> (mean, rstd) fp32 of the batch; updates the running buffers in place."""
+    _dev(x)
+    rows, Cn = x.shape
+    lib = L.load()
+    nblk = lib.ttsk_bn_nblocks(rows)
+    partials = _f32(nblk, 2 * Cn, device=x.device)
+    mean, rstd = _f32(Cn, device=x.device), _f32(Cn, device=x.device)
+    check(lib.ttsk_bn_stats(_ptr(x), rows, Cn, _ptr(partials), _stream()), "ttsk_bn_stats")
+    check(lib.ttsk_bn_finalize(_ptr(partials), nblk, Cn, rows, eps, momentum, _ptr(mean), _ptr(rstd), _ptr(running_mean),
+                               _ptr(running_var), _ptr(nbt), _stream()), "ttsk_bn_finalize")
+    return mean, rstd
+
+
+def rsqrt_eps(var, eps=1e-5):
+    out = torch.empty_like(var)
+    check(L.load().ttsk_rsqrt_eps(_ptr(var), eps, _ptr(out), var.numel(), _stream()), "ttsk_rsqrt_eps")
+    return out
+
+
+def bn_apply(x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, resid=None, out_f32=False):
+    rows, Cn = x.shape
+    o16 = None if out_f32 else torch.empty(rows, Cn, dtype=bf16, device=x.device)
+    o32 = _f32(rows, Cn, device=x.device) if out_f32 else None
+    check(L.load().ttsk_bn_apply(_ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn, int(use_tanh), p, site,
+                                 _ptr(rng), _ptr(resid), _ptr(o16), _ptr(o32), _stream()), "ttsk_bn_apply")
+    return o32 if out_f32 else o16
+
+
+def bn_bwd(dout, x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, dgamma=None, dbeta=None):
+    """dx (rows,C) bf16; dgamma/dbeta (fp32, accumulated in place when given)."""
+    rows, Cn = x.shape
+    lib = L.load()
+    nblk = lib.ttsk_bn_nblocks(rows)
+    partials = _f32(nblk, 2 * Cn, device=x.device)
+    sums = _f32(2 * Cn, device=x.device)
+    f32 = int(dout.dtype == torch.float32)
+    check(lib.ttsk_bn_bwd_stats(_ptr(dout), f32, _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn,
+                                int(use_tanh), p, site, _ptr(rng), _ptr(partials), _stream()), "ttsk_bn_bwd_stats")
+    colsum_finalize(partials, nblk, 2 * Cn, 2 * Cn, sums, accumulate=False)
+    dx = torch.empty(rows, Cn, dtype=bf16, device=x.device)
+    check(lib.ttsk_bn_bwd_apply(_ptr(dout), f32, _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn,
+                                int(use_tanh), p, site, _ptr(rng), _ptr(sums), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _stream()),
+          "ttsk_bn_bwd_apply")
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------------- loss / optimiser
+
+def fs2_loss(mel, post, mel_t, mel_lens, pitch, energy, logd, pitch_t, energy_t, dur_t, src_lens, grad_scale=1.0):
+    """Returns (losses[8] fp32 device, dmel_sum, dpost, dpitch, denergy, dlogd).  See include/ttsk.h."""
+    _dev(mel, post, mel_t, mel_lens, pitch, energy, logd, pitch_t, energy_t, dur_t, src_lens)
+    B, T, nm = mel.shape
+    Tt = mel_t.shape[1]
+    Lp = pitch.shape[1]
+    dev = mel.device
+    lib = L.load()
+    dmel, dpost = _f32(B, T, nm, device=dev), _f32(B, T, nm, device=dev)
+    dp, de, dd = _f32(B, Lp, device=dev), _f32(B, Lp, device=dev), _f32(B, Lp, device=dev)
+    partials = _f32(lib.ttsk_fs2_loss_nblocks(), 6, device=dev)
+    losses = _f32(8, device=dev)
+    check(lib.ttsk_fs2_loss(_ptr(mel), _ptr(post), _ptr(mel_t), _ptr(mel_lens), _ptr(pitch), _ptr(energy), _ptr(logd),
+                            _ptr(pitch_t), _ptr(energy_t), _ptr(dur_t), _ptr(src_lens), B, T, Tt, nm, Lp, grad_scale,
+                            _ptr(dmel), _ptr(dpost), _ptr(dp), _ptr(de), _ptr(dd), _ptr(partials), _ptr(losses), _stream()),
+          "ttsk_fs2_loss")
+    return losses, dmel, dpost, dp, de, dd
+
+
+def optim_state(device, seed=1234, sched_step=0):
+    """Device state block (see include/ttsk.h): int64[8] view; fields set here, advanced by kernels."""
+    n = L.load().ttsk_optim_state_bytes() // 8
+    st = torch.zeros(n, dtype=torch.int64)
+    st[0] = sched_step
+    st[2] = seed
+    return st.to(device)
+
+
+def rng_of(state):
+    return state[2:4]
+
+
+def optim_advance(state, d_model, warmup, anneal_steps, anneal_rate, beta1, beta2):
+    arr = (C.c_float * 4)(*([float(a) for a in anneal_steps] + [0.0] * (4 - len(anneal_steps))))
+    check(L.load().ttsk_optim_advance(_ptr(state), float(d_model), float(warmup), C.cast(arr, C.c_void_p), len(anneal_steps),
+                                      anneal_rate, beta1, beta2, _stream()), "ttsk_optim_advance")
+
+
+def rng_advance(state):
+    check(L.load().ttsk_rng_advance(_ptr(state), _stream()), "ttsk_rng_advance")
+
+
+def clip_adam_step(params, grads, m, v, shadow, state, partials, max_norm, beta1, beta2, eps, zero_grad=True):
+    _dev(params, grads, m, v, shadow, state, partials)
+    check(L.load().ttsk_clip_adam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(shadow), params.numel(), _ptr(state),
+                                       _ptr(partials), max_norm, beta1, beta2, eps, int(zero_grad), _stream()),
+          "ttsk_clip_adam_step")

@@ -283,7 +283,7 @@ def test_clip_adam_lr(start):
     assert int(stc[0]) == start + 3 and int(stc[1]) == 3
     lr_dev = stc[4:5].view(torch.float32)[0]
     assert abs(float(lr_dev) - ofs2.lr_at(start + 3)) < 1e-9 + 1e-6 * ofs2.lr_at(start + 3)
-    np.testing.assert_allclose((dp.cpu().double() - p.double()).numpy(), (pr - p.double()).numpy(), rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose((dp.cpu().double() - p.double()).numpy(), (pr - p.double()).numpy(), rtol=2e-3, atol=6e-7)  # fp32 ulp of |p| <= 4
     assert torch.equal(shadow.cpu(), dp.cpu().to(BF))
 
 

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
         }
       }
     }
-    dhb += dh;
+    if (lane == 0) dhb += dh;
     c1 = wave_sum(c1) / D;
     c2 = wave_sum(c2) / D;
 #pragma unroll

@@ -150,7 +150,14 @@ int ttsk_softmax_bwd(const void* probs_bf16, const float* dprobs, void* dscores_
  *             reference: Models.py:101-103, fastspeech2.py:72-75 + modules.py:159, modules.py:95-100,134-139
  * scatter_sum: dtable[v] (+)= sum of dx rows whose index is v, ascending row order, no atomics; skip_row = padding_idx
  */
-int ttsk_bucketize(const float* values, const float* bins, int n_bins, float scale, int32_t* idx, int n, void* stream);
+int ttsk_bucketize(const float* values, const float* bins, int n_bins, float scale, int32_t* idx, float* scaled_out,
+                   int n, void* stream);
+/* d = clamp(round(exp(logd) - 1) * d_control, min 0), fp32 — reference: model/modules.py:199-203 */
+int ttsk_duration_round(const float* logd, float d_control, float* out, int n, void* stream);
+/* mask[b][t] = (t >= lens[b]) as bytes (torch.bool storage) — reference: fs_two/utils/tools.py:121-131 */
+int ttsk_length_mask(const int64_t* lens, uint8_t* mask, int B, int T, void* stream);
+/* out = a + scale_b * b */
+int ttsk_add_f32(const float* a, const float* b, float scale_b, float* out, int64_t n, void* stream);
 int ttsk_gather_add(const void* in_bf16, const float* table, const void* idx, int idx_is_i64, int idx_div, const float* pe,
                     int pe_mod, void* out_bf16, int rows, int D, void* stream);
 int ttsk_scatter_sum(const void* dx_bf16, const void* idx, int idx_is_i64, int idx_div, int n_idx, float* dtable,

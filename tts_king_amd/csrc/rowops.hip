@@ -69,10 +69,11 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restri
 // ---------------------------------------------------------------------------------------------- bucketize
 // reference: torch.bucketize(v, bins) (right=False) at model/modules.py:95-100,134-139: index = #{bins < v}
 __global__ __launch_bounds__(256) void bucketize_kernel(const float* __restrict__ v, const float* __restrict__ bins, int nb,
-                                                        float scale, int* __restrict__ idx, int n) {
+                                                        float scale, int* __restrict__ idx, float* __restrict__ scaled, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float x = v[i] * scale;
+  if (scaled) scaled[i] = x;
   int lo = 0, hi = nb;
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (bins[mid] < x) lo = mid + 1; else hi = mid; }
   idx[i] = (x != x) ? nb : lo;   // NaN sorts last, as in torch
@@ -184,6 +185,24 @@ __global__ __launch_bounds__(256) void to_int16_kernel(const float* __restrict__
   }
 }
 
+// out = a + sb * b (fp32)
+__global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float sb,
+                                                      float* __restrict__ o, int64_t n) {
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) o[i] = a[i] + sb * b[i];
+}
+
+// d = clamp(round(exp(logd) - 1) * d_control, min 0)   (reference: model/modules.py:199-203; round = half-to-even)
+__global__ __launch_bounds__(256) void duration_round_kernel(const float* __restrict__ logd, float d_control, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = fmaxf(rintf(expf(logd[i]) - 1.f) * d_control, 0.f);
+}
+
+// mask[b][t] = t >= lens[b]   (True = PAD; reference: fs_two/utils/tools.py:121-131)
+__global__ __launch_bounds__(256) void length_mask_kernel(const long long* __restrict__ lens, unsigned char* __restrict__ mask, int B, int T) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < B * T) { const int b = i / T, t = i - b * T; mask[i] = (float)t >= (float)lens[b] ? 1 : 0; }
+}
+
 }  // namespace
 
 static inline int grid_for(int64_t n, int cap = 2048) {
@@ -213,11 +232,11 @@ extern "C" int ttsk_softmax_bwd(const void* probs_bf16, const float* dprobs, voi
   return TTSK_OK;
 }
 
-extern "C" int ttsk_bucketize(const float* values, const float* bins, int n_bins, float scale, int32_t* idx, int n,
-                              void* stream) {
+extern "C" int ttsk_bucketize(const float* values, const float* bins, int n_bins, float scale, int32_t* idx,
+                              float* scaled_out, int n, void* stream) {
   TTSK_REQUIRE(values && bins && idx && n > 0 && n_bins > 0, "bucketize: bad arguments");
   hipLaunchKernelGGL(bucketize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, values, bins, n_bins, scale,
-                     idx, n);
+                     idx, scaled_out, n);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }
@@ -261,6 +280,27 @@ extern "C" int ttsk_nct_to_ntc_bf16(const float* src, void* dst_bf16, int B, int
 extern "C" int ttsk_to_int16(const float* src, int16_t* dst, int64_t n, float scale, void* stream) {
   TTSK_REQUIRE(src && dst && n > 0, "to_int16: bad arguments");
   hipLaunchKernelGGL(to_int16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, (short*)dst, n, scale);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_add_f32(const float* a, const float* b, float scale_b, float* out, int64_t n, void* stream) {
+  TTSK_REQUIRE(a && b && out && n > 0, "add_f32: bad arguments");
+  hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, scale_b, out, n);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_duration_round(const float* logd, float d_control, float* out, int n, void* stream) {
+  TTSK_REQUIRE(logd && out && n > 0, "duration_round: bad arguments");
+  hipLaunchKernelGGL(duration_round_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, logd, d_control, out, n);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_length_mask(const int64_t* lens, uint8_t* mask, int B, int T, void* stream) {
+  TTSK_REQUIRE(lens && mask && B > 0 && T > 0, "length_mask: bad arguments");
+  hipLaunchKernelGGL(length_mask_kernel, dim3((B * T + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const long long*)lens, mask, B, T);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

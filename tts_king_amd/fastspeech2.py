@@ -1,0 +1,548 @@
+"""FastSpeech2 on MI355X: the reference's module surface (`FastSpeech2(preprocess_config, model_config, n_speakers)`,
+`forward(...) -> 12-tuple`, reference `state_dict` keys) over hand-written gfx950 kernels.
+
+reference: fs_two/model/fastspeech2.py:12-119 (model graph), fs_two/transformer/Models.py (Encoder/Decoder),
+Layers.py (FFTBlock, PostNet), SubLayers.py (MHA, FFN), model/modules.py (VarianceAdaptor, LengthRegulator,
+VariancePredictor).  Every numbered step of `_forward` / `_backward` cites the lines it restates.
+
+Forward AND backward are explicit sequences of kernel launches on the current HIP stream (no autograd graph
+inside): activations are bf16 channels-last [B*T][C], accumulation is fp32, parameters are fp32 masters in one
+flat buffer with a bf16 shadow.  `torch.autograd` only sees one node (`_Bridge`) so that the reference's
+`loss.backward()` call site keeps working.
+"""
+import json
+import os
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from . import params as P
+from .ops import bf16
+
+N_VOCAB = 207  # len(symbols) + 1 — reference: fs_two/transformer/Models.py:40, fs_two/text/symbols.py
+
+
+def sinusoid_table(n_position, d_hid):
+    """reference: fs_two/transformer/Models.py:10-30 (float64, cast to fp32)."""
+    pos = torch.arange(n_position, dtype=torch.float64)[:, None]
+    j = torch.arange(d_hid)[None, :]
+    angle = pos / torch.pow(torch.tensor(10000.0, dtype=torch.float64), 2.0 * (j // 2).double() / d_hid)
+    tab = torch.empty_like(angle)
+    tab[:, 0::2] = torch.sin(angle[:, 0::2])
+    tab[:, 1::2] = torch.cos(angle[:, 1::2])
+    return tab.float()
+
+
+def get_speakers_number(preprocess_config):
+    """reference: fs_two/model/fastspeech2.py:122-137."""
+    path = os.path.join(preprocess_config["path"]["preprocessed_path"], "speakers.json")
+    if not os.path.exists(path):
+        raise Exception("Model is multispeaker but number of speakers was not provided explicitly")
+    with open(path) as f:
+        return len(json.load(f))
+
+
+class _Bridge(torch.autograd.Function):
+    """The single autograd node: forwards the natively computed outputs, routes their gradients into the native
+    backward, which accumulates into the flat gradient buffer (the `.grad` views of the parameters)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, mel, post, pitch, energy, logd):
+        ctx.model = model
+        ctx.step_ctx = model._ctx
+        return mel.view_as(mel), post.view_as(post), pitch.view_as(pitch), energy.view_as(energy), logd.view_as(logd)
+
+    @staticmethod
+    def backward(ctx, dmel, dpost, dpitch, denergy, dlogd):
+        ctx.model._backward_from_autograd(ctx.step_ctx, dmel, dpost, dpitch, denergy, dlogd)
+        return None, None, None, None, None, None, None
+
+
+class _Ctx:
+    """Activations kept for the backward of one step."""
+    pass
+
+
+class FastSpeech2(nn.Module):
+    def __init__(self, preprocess_config, model_config, n_speakers=None, device=None, seed=1234):
+        super().__init__()
+        self.model_config = model_config
+        self.preprocess_config = preprocess_config
+        if not model_config["multi_speaker"]:
+            # reference: fastspeech2.py:72-88 raises NameError on this path; only multi-speaker works there too
+            raise NotImplementedError("multi_speaker: False is not a working path in the reference either")
+        if model_config["use_cwt"]:
+            raise NotImplementedError("use_cwt: True (CWT pitch) is out of scope; shipped config sets False")
+        if n_speakers is None:
+            n_speakers = get_speakers_number(preprocess_config)
+        if device is None or device == "gpu":
+            device = "cuda:0" if torch.cuda.is_available() else "cpu"
+        if isinstance(device, int):
+            device = "cuda:%d" % device
+        device = torch.device(device)
+        tr = model_config["transformer"]
+        self.d = tr["encoder_hidden"]
+        self.d_ff = tr["conv_filter_size"]
+        self.k1, self.k2 = tr["conv_kernel_size"]
+        self.n_head_enc, self.n_head_dec = tr["encoder_head"], tr["decoder_head"]
+        self.n_enc, self.n_dec = tr["encoder_layer"], tr["decoder_layer"]
+        self.p_enc, self.p_dec = float(tr["encoder_dropout"]), float(tr["decoder_dropout"])
+        self.p_var = float(model_config["variance_predictor"]["dropout"])
+        self.k_var = model_config["variance_predictor"]["kernel_size"]
+        self.p_post = 0.5                                                       # hard-coded in Layers.py:137-141
+        self.max_seq_len = model_config["max_seq_len"]
+        self.n_mel = preprocess_config["preprocessing"]["mel"]["n_mel_channels"]
+        self.n_speakers = n_speakers
+        assert self.d == 256 or self.d % 256 == 0, "LayerNorm kernel handles D in {256,512,768,1024}"
+
+        entries = P.build_entries(model_config, self.n_mel, n_speakers, N_VOCAB)
+        self._table, self._n_flat = P.layout(entries)
+        self._flat = torch.zeros(self._n_flat, dtype=torch.float32, device=device)
+        self._flat_grad = torch.zeros(self._n_flat, dtype=torch.float32, device=device)
+        self._shadow = torch.zeros(self._n_flat, dtype=bf16, device=device)
+        self._shadow_version = -1
+        self._anchor = torch.zeros((), requires_grad=True)
+        self._ctx = None
+        self._rng_state = None          # device block shared with the optimizer (ops.optim_state)
+        self._seed = seed
+        self._modules_by_key = {}
+        for en in entries:
+            self._register(en, device)
+        self._init_constants(preprocess_config, model_config)
+        self.reset_parameters(seed)
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _register(self, en, device):
+        mod = self
+        parts = en.key.split(".")
+        for name in parts[:-1]:
+            if name not in mod._modules:
+                mod.add_module(name, nn.Module())
+            mod = mod._modules[name]
+        leaf = parts[-1]
+        if en.kind == P.TRAIN:
+            par = nn.Parameter(self._view(self._flat, en), requires_grad=True)
+            par.grad = self._view(self._flat_grad, en)
+            mod.register_parameter(leaf, par)
+        elif en.kind in (P.FROZEN, P.UNUSED):
+            mod.register_parameter(leaf, nn.Parameter(torch.zeros(en.shape, device=device), requires_grad=en.kind == P.UNUSED))
+        else:
+            dt = torch.int64 if en.dtype == "int64" else torch.float32
+            mod.register_buffer(leaf, torch.zeros(en.shape, dtype=dt, device=device))
+        self._modules_by_key[en.key] = (mod, leaf)
+
+    @staticmethod
+    def _view(flat, en):
+        v = flat[en.offset:en.offset + en.numel].view(en.storage_shape)
+        return v.permute(0, 2, 1) if en.conv else v
+
+    def _rebind(self):
+        for en in self._table.values():
+            if en.kind == P.TRAIN:
+                mod, leaf = self._modules_by_key[en.key]
+                par = mod._parameters[leaf]
+                par.data = self._view(self._flat, en)
+                par.grad = self._view(self._flat_grad, en)
+        self._shadow_version = -1
+
+    def _apply(self, fn, recurse=True):
+        flat, grad, shadow = fn(self._flat), fn(self._flat_grad), fn(self._shadow)
+        if flat.dtype != torch.float32:
+            raise TypeError("FastSpeech2 masters stay fp32 (bf16 shadows are managed internally)")
+        super()._apply(fn, recurse)
+        self._flat, self._flat_grad = flat, grad
+        self._shadow = shadow.to(bf16) if shadow.dtype != bf16 else shadow
+        self._rng_state = None
+        self._rebind()
+        return self
+
+    def get(self, key):
+        mod, leaf = self._modules_by_key[key]
+        return mod._parameters[leaf] if leaf in mod._parameters else mod._buffers[leaf]
+
+    def _init_constants(self, pc, mc):
+        tab = sinusoid_table(mc["max_seq_len"] + 1, self.d)[None]
+        with open(os.path.join(pc["path"]["preprocessed_path"], "stats.json")) as f:     # modules.py:55-60
+            stats = json.load(f)
+        nb = mc["variance_embedding"]["n_bins"]
+        ve = mc["variance_embedding"]
+        with torch.no_grad():
+            self.get("encoder.position_enc").copy_(tab)
+            self.get("decoder.position_enc").copy_(tab)
+            for name, key in (("pitch", "pitch_bins"), ("energy", "energy_bins")):
+                lo, hi = stats[name][:2]
+                if ve[name + "_quantization"] == "log":
+                    import numpy as np
+                    bins = torch.exp(torch.linspace(np.log(lo), np.log(hi), nb - 1))
+                else:
+                    bins = torch.linspace(lo, hi, nb - 1)
+                self.get("variance_adaptor." + key).copy_(bins)
+            for i in range(5):
+                self.get("postnet.convolutions.%d.1.running_var" % i).fill_(1.0)
+
+    def reset_parameters(self, seed=1234):
+        """Seeded random init (weights_path: null).  Statistics follow tts_king_amd.synthetic.seeded_fill;
+        the PAD row of the phoneme embedding is zero as in nn.Embedding(padding_idx=0)."""
+        from .synthetic import seeded_fill
+        sd = {k: v for k, v in self.state_dict().items()}
+        cpu = {k: torch.zeros(v.shape, dtype=v.dtype) for k, v in sd.items()}
+        for k, v in sd.items():
+            if any(s in k for s in ("position_enc", "_bins", "running_", "num_batches")):
+                cpu[k] = v.detach().cpu().clone()
+        seeded_fill(cpu, seed)
+        cpu["encoder.src_word_emb.weight"][0].zero_()
+        with torch.no_grad():
+            for k, v in sd.items():
+                if not any(s in k for s in ("position_enc", "_bins", "running_", "num_batches")):
+                    v.copy_(cpu[k])
+
+    @property
+    def device(self):
+        return self._flat.device
+
+    def flat_buffers(self):
+        """(params fp32, grads fp32, bf16 shadow): the trainable state as three flat tensors."""
+        return self._flat, self._flat_grad, self._shadow
+
+    def grad_buckets(self, bucket_mb=24):
+        return P.buckets(self._table, self._n_flat, int(bucket_mb * (1 << 20) / 4))
+
+    def attach_state(self, state):
+        """Share the optimizer's device state block (dropout counters live in it)."""
+        self._rng_state = state
+
+    def _state(self):
+        if self._rng_state is None:
+            self._rng_state = ops.optim_state(self.device, seed=self._seed)
+        return self._rng_state
+
+    def sync_shadow(self, force=False):
+        """bf16 copies of the masters, refreshed when anything wrote to them through torch (load_state_dict, init)."""
+        if force or self._shadow_version != self._flat._version:
+            ops.cast_bf16(self._flat, self._shadow)
+            self._shadow_version = self._flat._version
+
+    # views into the flat buffers ------------------------------------------------------------------
+    def _w(self, key, rows=None):
+        """bf16 shadow of a weight as a 2-D/3-D tensor in STORAGE layout; `rows` widens it over the following
+        keys (fused q|k|v)."""
+        en = self._table[key]
+        shp = en.storage_shape
+        if rows is not None:
+            return self._shadow[en.offset:en.offset + rows * shp[1]].view(rows, shp[1])
+        return self._shadow[en.offset:en.offset + en.numel].view(shp)
+
+    def _m(self, key, n=None):
+        """fp32 master (vectors / tables) — `n` widens over the following keys."""
+        en = self._table[key]
+        if n is not None:
+            return self._flat[en.offset:en.offset + n]
+        return self._flat[en.offset:en.offset + en.numel].view(en.storage_shape)
+
+    def _g(self, key, n=None):
+        en = self._table[key]
+        if n is not None:
+            return self._flat_grad[en.offset:en.offset + n]
+        return self._flat_grad[en.offset:en.offset + en.numel].view(en.storage_shape)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, speakers, texts, src_lens, max_src_len, mels=None, mel_lens=None, max_mel_len=None,
+                e_targets=None, d_targets=None, pitches_raw=None, pitches_cwt=None, pitches_mean=None,
+                pitches_std=None, p_control=1.0, e_control=1.0, d_control=1.0):
+        """reference: fs_two/model/fastspeech2.py:43-119.  Same arguments, same 12-tuple."""
+        if not self._flat.is_cuda:
+            raise ops.L.TtskError("FastSpeech2.forward needs the model on a HIP device (gpu: 'cuda:0'); there is no CPU path")
+        train = self.training
+        dev = self.device
+        speakers, texts = speakers.to(dev).long().contiguous(), texts.to(dev).long().contiguous()
+        src_lens = src_lens.to(dev).long().contiguous()
+        with torch.no_grad():
+            out, ctx = self._forward(train, speakers, texts, src_lens, int(max_src_len), mel_lens, max_mel_len, e_targets,
+                                     d_targets, pitches_raw, float(p_control), float(e_control), float(d_control))
+        mel, pitch, energy, logd, d_rounded, src_masks, mel_masks, mel_lens_out, post = out
+        self._ctx = ctx
+        if train and torch.is_grad_enabled():
+            mel, post, pitch, energy, logd = _Bridge.apply(self._anchor, self, mel, post, pitch, energy, logd)
+        return (mel, pitch, energy, logd, d_rounded, src_masks, mel_masks, src_lens, mel_lens_out, post, None, None)
+
+    def _fft_fwd(self, pre, x, Bn, S, lens, H, p, site, rng, ctx_list):
+        """One FFTBlock.  reference: Layers.py:25-34, SubLayers.py:31-65 (MHA), :93-101 (FFN), Modules.py:14-24."""
+        d, rows = self.d, Bn * S
+        dk = d // H
+        a, f = pre + "slf_attn.", pre + "pos_ffn."
+        Sp = (S + 7) // 8 * 8
+        dev = x.device
+        # (1) q|k|v projections as one GEMM into a [rows][3d] buffer: SubLayers.py:41-43
+        qkv = ops.linear(x, self._w(a + "w_qs.weight", 3 * d), self._m(a + "w_qs.bias", 3 * d))
+        # (2) scores = Q K^T / sqrt(dk) per (batch, head), head h = columns [h*dk, (h+1)*dk): Modules.py:15-16
+        scores = torch.empty(Bn * H, S, Sp, dtype=torch.float32, device=dev)
+        ops.gemm(qkv, qkv[:, d:], scores, S, S, dk, 3 * d, 3 * d, Sp, alpha=dk ** -0.5, nz1=Bn, nz2=H,
+                 sA=(S * 3 * d, dk), sB=(S * 3 * d, dk), sC=(H * S * Sp, S * Sp))
+        # (3) key-padding mask + softmax: Modules.py:18-21
+        probs = ops.softmax_fwd(scores, lens, H)
+        # (4) O = P V, heads merged back into [rows][d]: Modules.py:22, SubLayers.py:57-60
+        o = torch.empty(rows, d, dtype=bf16, device=dev)
+        ops.gemm(probs, qkv[:, 2 * d:], o, S, dk, S, Sp, 3 * d, d, flags=ops.B_TR, nz1=Bn, nz2=H,
+                 sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * d, dk))
+        # (5) fc, dropout, +residual, LayerNorm, zero PAD rows: SubLayers.py:62-63, Layers.py:29
+        y = ops.linear(o, self._w(a + "fc.weight"), self._m(a + "fc.bias"))
+        x1, z1, mean1, rstd1, _ = ops.layernorm_fwd(y, x, self._m(a + "layer_norm.weight"), self._m(a + "layer_norm.bias"),
+                                                    lens, S, p_pre=p, site_pre=site, rng=rng, save_z=ctx_list is not None)
+        # (6) FFN: Conv1d(k=9)+ReLU, Conv1d(k=1), dropout, +residual, LayerNorm, zero PAD rows: SubLayers.py:96-99, Layers.py:32
+        h = ops.conv1d(x1.view(Bn, S, d), self._w(f + "w_1.weight"), self._m(f + "w_1.bias"), flags=ops.RELU)
+        y2 = ops.conv1d(h, self._w(f + "w_2.weight"), self._m(f + "w_2.bias"))
+        x2, z2, mean2, rstd2, _ = ops.layernorm_fwd(y2.view(rows, d), x1, self._m(f + "layer_norm.weight"),
+                                                    self._m(f + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site + 1,
+                                                    rng=rng, save_z=ctx_list is not None)
+        if ctx_list is not None:
+            ctx_list.append((pre, x, qkv, probs, o, z1, mean1, rstd1, x1, h, z2, mean2, rstd2, Bn, S, lens, H, p, site))
+        return x2
+
+    def _predictor_fwd(self, pre, x, Bn, Lp, lens, p, site, rng, ctx):
+        """VariancePredictor.  reference: model/modules.py:255-309."""
+        d, rows = self.d, Bn * Lp
+        c = pre + "conv_layer."
+        h1 = ops.conv1d(x.view(Bn, Lp, d), self._w(c + "conv1d_1.conv.weight"), self._m(c + "conv1d_1.conv.bias"), flags=ops.RELU)
+        a1, _, m1, r1, _ = ops.layernorm_fwd(h1.view(rows, -1), None, self._m(c + "layer_norm_1.weight"), self._m(c + "layer_norm_1.bias"),
+                                             None, 0, p_post=p, site_post=site, rng=rng, save_z=False)
+        h2 = ops.conv1d(a1.view(Bn, Lp, -1), self._w(c + "conv1d_2.conv.weight"), self._m(c + "conv1d_2.conv.bias"), flags=ops.RELU)
+        _, _, m2, r2, out = ops.layernorm_fwd(h2.view(rows, -1), None, self._m(c + "layer_norm_2.weight"), self._m(c + "layer_norm_2.bias"),
+                                              lens, Lp, p_post=p, site_post=site + 1, rng=rng, save_z=False, want_out=False,
+                                              head=(self._m(pre + "linear_layer.weight").view(-1), self._m(pre + "linear_layer.bias")))
+        if ctx is not None:
+            ctx[pre] = (x, h1, m1, r1, a1, h2, m2, r2, Bn, Lp, lens, p, site)
+        return out.view(Bn, Lp)
+
+    def _forward(self, train, speakers, texts, src_lens, Lp, mel_lens, max_mel_len, e_targets, d_targets, pitches_raw,
+                 p_control, e_control, d_control):
+        self.sync_shadow()
+        dev, d = self.device, self.d
+        Bn = texts.shape[0]
+        ctx = _Ctx() if train else None
+        rng = ops.rng_of(self._state()) if train else None
+        p_enc, p_dec, p_var, p_post = (self.p_enc, self.p_dec, self.p_var, self.p_post) if train else (0.0, 0.0, 0.0, 0.0)
+        blocks = [] if train else None
+        preds = {} if train else None
+
+        # ---- masks: fastspeech2.py:62-69
+        src_masks = ops.length_mask(src_lens, Lp)
+        # ---- encoder: phoneme embedding + position table, 4 FFT blocks: Models.py:79-112
+        if Lp > self.max_seq_len:
+            pe_enc = sinusoid_table(Lp, d).to(dev)        # eval-only long input: Models.py:88-99
+        else:
+            pe_enc = self.get("encoder.position_enc")[0]
+        x = ops.gather_add(None, self._m("encoder.src_word_emb.weight"), texts, pe=pe_enc, pe_mod=Lp, rows=Bn * Lp)
+        x_emb = x
+        for i in range(self.n_enc):
+            x = self._fft_fwd("encoder.layer_stack.%d." % i, x, Bn, Lp, src_lens, self.n_head_enc, p_enc, 2 * i, rng, blocks)
+        # ---- variance adaptor: modules.py:142-217 (duration BEFORE the speaker embedding; energy sees the pitch embedding)
+        va = "variance_adaptor."
+        logd = self._predictor_fwd(va + "duration_predictor.", x, Bn, Lp, src_lens, p_var, 200, rng, preds)
+        x1 = ops.gather_add(x, self._m("speaker_emb.weight"), speakers, idx_div=Lp)          # fastspeech2.py:72-75
+        pitch = self._predictor_fwd(va + "pitch_predictor.", x1, Bn, Lp, src_lens, p_var, 202, rng, preds)
+        if pitches_raw is not None:
+            pidx = ops.bucketize(pitches_raw.to(dev).float(), self.get(va + "pitch_bins"))
+        else:
+            pidx, pitch = ops.bucketize(pitch, self.get(va + "pitch_bins"), p_control, want_scaled=True)
+        x2 = ops.gather_add(x1, self._m(va + "pitch_embedding.weight"), pidx.view(-1))
+        energy = self._predictor_fwd(va + "energy_predictor.", x2, Bn, Lp, src_lens, p_var, 204, rng, preds)
+        if e_targets is not None:
+            eidx = ops.bucketize(e_targets.to(dev).float(), self.get(va + "energy_bins"))
+        else:
+            eidx, energy = ops.bucketize(energy, self.get(va + "energy_bins"), e_control, want_scaled=True)
+        x3 = ops.gather_add(x2, self._m(va + "energy_embedding.weight"), eidx.view(-1))
+        # ---- length regulator (+ decoder position table, fused): modules.py:196-205,225-252; Models.py:172-178
+        if d_targets is not None:
+            dur = d_targets.to(dev).long().contiguous()
+            d_rounded = d_targets
+        else:
+            dur = ops.duration_round(logd, d_control)
+            d_rounded = dur
+        if d_targets is not None and max_mel_len is not None:
+            T_full = int(max_mel_len)
+        else:
+            _, _, _, total = ops.length_regulator_fwd(x3.view(Bn, Lp, d), dur, 1, want_idx=False)
+            T_full = max(int(total.max().item()), 1)       # data-dependent output length: one host read, as in the reference
+        eval_long = (not train) and T_full > self.max_seq_len
+        T = T_full if eval_long else min(T_full, self.max_seq_len)
+        pe_dec = sinusoid_table(T, d).to(dev) if eval_long else self.get("decoder.position_enc")[0]
+        dec_in, _, cs, mel_lens_out = ops.length_regulator_fwd(x3.view(Bn, Lp, d), dur, T, pe=pe_dec, want_idx=False)
+        mlens = mel_lens.to(dev).long().contiguous() if mel_lens is not None else mel_lens_out
+        mel_masks = ops.length_mask(mlens, T)
+        # ---- decoder: Models.py:157-189
+        y = dec_in.view(Bn * T, d)
+        n_enc_blocks = len(blocks) if train else 0
+        for i in range(self.n_dec):
+            y = self._fft_fwd("decoder.layer_stack.%d." % i, y, Bn, T, mlens, self.n_head_dec, p_dec, 100 + 2 * i, rng, blocks)
+        # ---- mel_linear (fp32 output + bf16 copy for the PostNet): fastspeech2.py:102
+        rows = Bn * T
+        mel16 = torch.empty(rows, self.n_mel, dtype=bf16, device=dev)
+        mel = ops.linear(y, self._w("mel_linear.weight"), self._m("mel_linear.bias"), out_dtype=torch.float32, C2=mel16)
+        # ---- PostNet: Layers.py:133-143, + mel: fastspeech2.py:104
+        pn = []
+        xin = mel16.view(Bn, T, self.n_mel)
+        for i in range(5):
+            pp = "postnet.convolutions.%d." % i
+            yc = ops.conv1d(xin, self._w(pp + "0.conv.weight"), self._m(pp + "0.conv.bias"))
+            C = yc.shape[2]
+            if train:
+                mean, rstd = ops.bn_train_stats(yc.view(rows, C), self.get(pp + "1.running_mean"), self.get(pp + "1.running_var"),
+                                                self.get(pp + "1.num_batches_tracked").view(1))
+            else:
+                mean, rstd = self.get(pp + "1.running_mean"), ops.rsqrt_eps(self.get(pp + "1.running_var"))
+            last = i == 4
+            nxt = ops.bn_apply(yc.view(rows, C), mean, rstd, self._m(pp + "1.weight"), self._m(pp + "1.bias"), not last,
+                               p=p_post, site=300 + i, rng=rng, resid=mel if last else None, out_f32=last)
+            pn.append((pp, xin, yc, mean, rstd))
+            xin = nxt.view(Bn, T, C) if not last else nxt
+        post = xin
+        if train:
+            ctx.blocks, ctx.preds, ctx.pn = blocks, preds, pn
+            ctx.n_enc_blocks = n_enc_blocks
+            ctx.dims = (Bn, Lp, T)
+            ctx.texts, ctx.speakers, ctx.pidx, ctx.eidx, ctx.cs = texts, speakers, pidx, eidx, cs
+            ctx.dec_out = y
+            ctx.used = False
+        out = (mel.view(Bn, T, self.n_mel), pitch, energy, logd, d_rounded, src_masks, mel_masks, mel_lens_out,
+               post.view(Bn, T, self.n_mel))
+        return out, ctx
+
+    # ------------------------------------------------------------------ backward
+    def _backward_from_autograd(self, ctx, dmel, dpost, dpitch, denergy, dlogd):
+        dev = self.device
+        Bn, Lp, T = ctx.dims
+
+        def f32(g, shape):
+            if g is None:
+                return torch.zeros(shape, dtype=torch.float32, device=dev)
+            return g.to(torch.float32).contiguous()
+        dmel, dpost = f32(dmel, (Bn, T, self.n_mel)), f32(dpost, (Bn, T, self.n_mel))
+        with torch.no_grad():
+            dmel_sum = ops.add_f32(dmel, dpost)
+            self.backward_native(ctx, dmel_sum, dpost, f32(dpitch, (Bn, Lp)), f32(denergy, (Bn, Lp)), f32(dlogd, (Bn, Lp)))
+
+    def _finalize_ln(self, partials, nblk, D, keys, ncol):
+        """partials [nblk][ncol] -> gradient slots; keys = list of (column offset, grad tensor)."""
+        for off, dst in keys:
+            ops.colsum_finalize(partials[:, off:], nblk, dst.numel(), ncol, dst, accumulate=True)
+
+    def _fft_bwd(self, saved, dx2, rng):
+        (pre, x, qkv, probs, o, z1, mean1, rstd1, x1, h, z2, mean2, rstd2, Bn, S, lens, H, p, site) = saved
+        d, rows = self.d, Bn * S
+        dk = d // H
+        Sp = probs.shape[2]
+        a, f = pre + "slf_attn.", pre + "pos_ffn."
+        dev = dx2.device
+        # ---- FFN tail: LN backward (PAD rows carry no gradient), dropout mask regenerated
+        dz2, dy2, part, nblk = ops.layernorm_bwd(dx2, z2, mean2, rstd2, self._m(f + "layer_norm.weight"), self._m(f + "layer_norm.bias"),
+                                                 lens, S, p_pre=p, site_pre=site + 1, rng=rng)
+        self._finalize_ln(part, nblk, d, [(0, self._g(f + "layer_norm.weight")), (d, self._g(f + "layer_norm.bias")),
+                                          (2 * d, self._g(f + "w_2.bias"))], 3 * d)
+        # ---- w_2 (k=1): dW, dX gated by the ReLU
+        ops.conv1d_dw(dy2.view(Bn, S, d), h, self._g(f + "w_2.weight"), k=self.k2)
+        dh = ops.conv1d_dx(dy2.view(Bn, S, d), self._w(f + "w_2.weight"), G=h)
+        # ---- w_1 (k=9): bias, dW, dX + residual gradient
+        ops.colsum_into(dh.view(rows, -1), self._g(f + "w_1.bias"))
+        ops.conv1d_dw(dh, x1.view(Bn, S, d), self._g(f + "w_1.weight"), k=self.k1)
+        dx1 = ops.conv1d_dx(dh, self._w(f + "w_1.weight"), R=dz2.view(Bn, S, d))
+        # ---- attention tail
+        dz1, dy1, part, nblk = ops.layernorm_bwd(dx1.view(rows, d), z1, mean1, rstd1, self._m(a + "layer_norm.weight"),
+                                                 self._m(a + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site, rng=rng)
+        self._finalize_ln(part, nblk, d, [(0, self._g(a + "layer_norm.weight")), (d, self._g(a + "layer_norm.bias")),
+                                          (2 * d, self._g(a + "fc.bias"))], 3 * d)
+        ops.linear_dw(dy1, o, self._g(a + "fc.weight"))
+        do = ops.linear_dx(dy1, self._w(a + "fc.weight"))
+        # ---- attention core: dP = dO V^T ; dS = softmax'(P, dP)/sqrt(dk) ; dQ = dS K ; dK = dS^T Q ; dV = P^T dO
+        dP = torch.empty(Bn * H, S, Sp, dtype=torch.float32, device=dev)
+        ops.gemm(do, qkv[:, 2 * d:], dP, S, S, dk, d, 3 * d, Sp, nz1=Bn, nz2=H, sA=(S * d, dk), sB=(S * 3 * d, dk),
+                 sC=(H * S * Sp, S * Sp))
+        dS = ops.softmax_bwd(probs, dP, dk ** -0.5)
+        dqkv = torch.empty(rows, 3 * d, dtype=bf16, device=dev)
+        ops.gemm(dS, qkv[:, d:], dqkv, S, dk, S, Sp, 3 * d, 3 * d, flags=ops.B_TR, nz1=Bn, nz2=H,
+                 sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * 3 * d, dk))
+        ops.gemm(dS, qkv, dqkv[:, d:], S, dk, S, Sp, 3 * d, 3 * d, flags=ops.A_TR | ops.B_TR, nz1=Bn, nz2=H,
+                 sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * 3 * d, dk))
+        ops.gemm(probs, do, dqkv[:, 2 * d:], S, dk, S, Sp, d, 3 * d, flags=ops.A_TR | ops.B_TR, nz1=Bn, nz2=H,
+                 sA=(H * S * Sp, S * Sp), sB=(S * d, dk), sC=(S * 3 * d, dk))
+        # ---- q|k|v projections
+        ops.colsum_into(dqkv, self._g(a + "w_qs.bias", 3 * d))
+        ops.linear_dw(dqkv, x, self._g(a + "w_qs.weight", 3 * d * d).view(3 * d, d))
+        return ops.linear_dx(dqkv, self._w(a + "w_qs.weight", 3 * d), R=dz1)
+
+    def _predictor_bwd(self, pre, saved, dout, rng, R):
+        (x, h1, m1, r1, a1, h2, m2, r2, Bn, Lp, lens, p, site) = saved
+        d, rows = self.d, Bn * Lp
+        c = pre + "conv_layer."
+        Fh = h1.shape[-1]
+        hw = self._m(pre + "linear_layer.weight").view(-1)
+        dh2, _, part, nblk = ops.layernorm_bwd(None, h2.view(rows, Fh), m2, r2, self._m(c + "layer_norm_2.weight"),
+                                               self._m(c + "layer_norm_2.bias"), lens, Lp, relu_in=True, p_post=p,
+                                               site_post=site + 1, rng=rng, dhead=dout.contiguous().view(-1), head_w=hw)
+        ncol = 4 * Fh + 1
+        self._finalize_ln(part, nblk, Fh, [(0, self._g(c + "layer_norm_2.weight")), (Fh, self._g(c + "layer_norm_2.bias")),
+                                           (2 * Fh, self._g(c + "conv1d_2.conv.bias")), (3 * Fh, self._g(pre + "linear_layer.weight").view(-1)),
+                                           (4 * Fh, self._g(pre + "linear_layer.bias"))], ncol)
+        ops.conv1d_dw(dh2.view(Bn, Lp, Fh), a1.view(Bn, Lp, Fh), self._g(c + "conv1d_2.conv.weight"), k=self.k_var)
+        da1 = ops.conv1d_dx(dh2.view(Bn, Lp, Fh), self._w(c + "conv1d_2.conv.weight"))
+        dh1, _, part, nblk = ops.layernorm_bwd(da1.view(rows, Fh), h1.view(rows, Fh), m1, r1, self._m(c + "layer_norm_1.weight"),
+                                               self._m(c + "layer_norm_1.bias"), None, 0, relu_in=True, p_post=p,
+                                               site_post=site, rng=rng)
+        self._finalize_ln(part, nblk, Fh, [(0, self._g(c + "layer_norm_1.weight")), (Fh, self._g(c + "layer_norm_1.bias")),
+                                           (2 * Fh, self._g(c + "conv1d_1.conv.bias"))], 3 * Fh)
+        ops.conv1d_dw(dh1.view(Bn, Lp, Fh), x.view(Bn, Lp, d), self._g(c + "conv1d_1.conv.weight"), k=self.k_var)
+        return ops.conv1d_dx(dh1.view(Bn, Lp, Fh), self._w(c + "conv1d_1.conv.weight"), R=R)
+
+    def backward_native(self, ctx, dmel_sum, dpost, dpitch, denergy, dlogd, on_bucket=None):
+        """Accumulate d(loss)/d(params) into the flat gradient buffer.
+        dmel_sum = dL/dmel (direct terms) + dL/dpost, dpost = dL/dpost — fp32 (B,T,n_mel); dpitch/denergy/dlogd fp32 (B,L).
+        `on_bucket(name)` is called when the gradients of a top-level group are complete (data-parallel overlap)."""
+        if ctx is None or ctx.used:
+            raise RuntimeError("backward called without a matching training forward")
+        ctx.used = True
+        rng = ops.rng_of(self._state())
+        Bn, Lp, T = ctx.dims
+        d, rows, nm = self.d, Bn * T, self.n_mel
+        notify = on_bucket or (lambda name: None)
+        # ---- PostNet (last layer first)
+        dout = dpost.view(rows, nm)
+        for i in range(4, -1, -1):
+            pp, xin, yc, mean, rstd = ctx.pn[i]
+            C = yc.shape[2]
+            dy = ops.bn_bwd(dout, yc.view(rows, C), mean, rstd, self._m(pp + "1.weight"), self._m(pp + "1.bias"), i < 4,
+                            p=self.p_post, site=300 + i, rng=rng, dgamma=self._g(pp + "1.weight"), dbeta=self._g(pp + "1.bias"))
+            ops.colsum_into(dy, self._g(pp + "0.conv.bias"))
+            ops.conv1d_dw(dy.view(Bn, T, C), xin, self._g(pp + "0.conv.weight"), k=5)
+            if i > 0:
+                dout = ops.conv1d_dx(dy.view(Bn, T, C), self._w(pp + "0.conv.weight")).view(rows, -1)
+            else:
+                dmel_tot = ops.conv1d_dx(dy.view(Bn, T, C), self._w(pp + "0.conv.weight"), R=dmel_sum.view(Bn, T, nm)).view(rows, nm)
+        notify("postnet")
+        # ---- mel_linear
+        ops.colsum_into(dmel_tot, self._g("mel_linear.bias"))
+        ops.linear_dw(dmel_tot, ctx.dec_out, self._g("mel_linear.weight"))
+        dx = ops.linear_dx(dmel_tot, self._w("mel_linear.weight"))
+        notify("mel_linear")
+        # ---- decoder
+        for i in range(self.n_dec - 1, -1, -1):
+            dx = self._fft_bwd(ctx.blocks[ctx.n_enc_blocks + i], dx, rng)
+            notify("decoder.%d" % i)
+        # ---- length regulator: segment sums (the position table has no parameters)
+        dx3 = ops.length_regulator_bwd(dx.view(Bn, T, d), ctx.cs, Lp).view(Bn * Lp, d)
+        # ---- variance adaptor, reverse order of modules.py:158-193
+        va = "variance_adaptor."
+        ops.scatter_sum(dx3, ctx.eidx.view(-1), self._g(va + "energy_embedding.weight"))
+        dx2 = self._predictor_bwd(va + "energy_predictor.", ctx.preds[va + "energy_predictor."], denergy, rng, dx3.view(Bn, Lp, d))
+        ops.scatter_sum(dx2.view(Bn * Lp, d), ctx.pidx.view(-1), self._g(va + "pitch_embedding.weight"))
+        dx1 = self._predictor_bwd(va + "pitch_predictor.", ctx.preds[va + "pitch_predictor."], dpitch, rng, dx2)
+        ops.scatter_sum(dx1.view(Bn * Lp, d), ctx.speakers, self._g("speaker_emb.weight"), idx_div=Lp)
+        dxe = self._predictor_bwd(va + "duration_predictor.", ctx.preds[va + "duration_predictor."], dlogd, rng, dx1)
+        notify("variance_adaptor")
+        # ---- encoder
+        dx = dxe.view(Bn * Lp, d)
+        for i in range(self.n_enc - 1, -1, -1):
+            dx = self._fft_bwd(ctx.blocks[i], dx, rng)
+            notify("encoder.%d" % i)
+        ops.scatter_sum(dx, ctx.texts.view(-1), self._g("encoder.src_word_emb.weight"), skip_row=0)   # padding_idx=0
+        notify("embedding")
+        self._ctx = None

@@ -281,13 +281,39 @@ def softmax_bwd(probs, dprobs, alpha):
     return ds
 
 
-def bucketize(values, bins, scale=1.0):
+def bucketize(values, bins, scale=1.0, want_scaled=False):
     _dev(values, bins)
     values = values.contiguous()
     idx = torch.empty(values.shape, dtype=torch.int32, device=values.device)
-    check(L.load().ttsk_bucketize(_ptr(values), _ptr(bins), bins.numel(), scale, _ptr(idx), values.numel(), _stream()),
-          "ttsk_bucketize")
-    return idx
+    scaled = torch.empty_like(values) if want_scaled else None
+    check(L.load().ttsk_bucketize(_ptr(values), _ptr(bins), bins.numel(), scale, _ptr(idx), _ptr(scaled), values.numel(),
+                                  _stream()), "ttsk_bucketize")
+    return (idx, scaled) if want_scaled else idx
+
+
+def duration_round(logd, d_control=1.0):
+    _dev(logd)
+    out = torch.empty_like(logd)
+    check(L.load().ttsk_duration_round(_ptr(logd), d_control, _ptr(out), logd.numel(), _stream()), "ttsk_duration_round")
+    return out
+
+
+def length_mask(lens, T):
+    """(B,) int64 -> (B,T) bool, True = PAD.  reference: fs_two/utils/tools.py:121-131."""
+    _dev(lens)
+    B = lens.shape[0]
+    mask = torch.empty(B, T, dtype=torch.bool, device=lens.device)
+    check(L.load().ttsk_length_mask(_ptr(lens), _ptr(mask), B, T, _stream()), "ttsk_length_mask")
+    return mask
+
+
+def add_f32(a, b, out=None, scale_b=1.0):
+    """out = a + scale_b * b (fp32, same shapes)."""
+    _dev(a, b)
+    if out is None:
+        out = torch.empty_like(a)
+    check(L.load().ttsk_add_f32(_ptr(a), _ptr(b), scale_b, _ptr(out), a.numel(), _stream()), "ttsk_add_f32")
+    return out
 
 
 def gather_add(x, table, idx, idx_div=1, pe=None, pe_mod=1, rows=None, out=None):

@@ -173,19 +173,21 @@ int ttsk_to_int16(const float* src, int16_t* dst, int64_t n, float scale, void* 
  * reference: fs_two/transformer/Layers.py:133-143 — training statistics over ALL rows (PAD rows included),
  * eps 1e-5, momentum 0.1, running_var updated with the unbiased variance; tanh (all but the last layer) and
  * F.dropout(0.5) follow; the last layer adds the mel residual (fastspeech2.py:104).
+ * x (the conv output) may be fp32: channels whose batch std is far below their mean amplify a bf16 rounding of x
+ * by mean/std, so the model keeps x in fp32 (x_is_f32 = 1).
  */
 int ttsk_bn_nblocks(int rows);
-int ttsk_bn_stats(const void* x_bf16, int rows, int C, float* partials /* [nblocks][2C] */, void* stream);
+int ttsk_bn_stats(const void* x, int x_is_f32, int rows, int C, float* partials /* [nblocks][2C] */, void* stream);
 int ttsk_bn_finalize(const float* partials, int nblk, int C, int rows, float eps, float momentum, float* mean, float* rstd,
                      float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream);
 int ttsk_rsqrt_eps(const float* var, float eps, float* rstd, int n, void* stream);
-int ttsk_bn_apply(const void* x_bf16, const float* mean, const float* rstd, const float* gamma, const float* beta, int rows,
+int ttsk_bn_apply(const void* x, int x_is_f32, const float* mean, const float* rstd, const float* gamma, const float* beta, int rows,
                   int C, int use_tanh, float p, uint32_t site, const uint64_t* rng, const float* resid_f32, void* out_bf16,
                   float* out_f32, void* stream);
-int ttsk_bn_bwd_stats(const void* dout, int dout_is_f32, const void* x_bf16, const float* mean, const float* rstd,
+int ttsk_bn_bwd_stats(const void* dout, int dout_is_f32, const void* x, int x_is_f32, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
                       const uint64_t* rng, float* partials /* [nblocks][2C]: sum dy | sum dy*xhat */, void* stream);
-int ttsk_bn_bwd_apply(const void* dout, int dout_is_f32, const void* x_bf16, const float* mean, const float* rstd,
+int ttsk_bn_bwd_apply(const void* dout, int dout_is_f32, const void* x, int x_is_f32, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
                       const uint64_t* rng, const float* sums /* [2C] */, void* dx_bf16, float* dgamma, float* dbeta,
                       void* stream);

@@ -190,11 +190,12 @@ def test_gather_add_scatter_sum():
     close_f32(ds, wants.float(), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("xdt", [BF, torch.float32])
 @pytest.mark.parametrize("C,use_tanh", [(512, True), (80, False)])
-def test_batchnorm_train_fwd_bwd(C, use_tanh):
+def test_batchnorm_train_fwd_bwd(C, use_tanh, xdt):
     from tts_king_amd import ops
     rows = 2 * 423
-    x = rnd(rows, C, seed=24, scale=1.5).to(BF)
+    x = rnd(rows, C, seed=24, scale=1.5).to(xdt)
     gamma, beta = 1 + 0.1 * rnd(C, seed=25), 0.1 * rnd(C, seed=26)
     rm, rv = 0.02 * rnd(C, seed=27), 0.5 + torch.rand(C, generator=torch.Generator().manual_seed(28))
     resid = rnd(rows, C, seed=29)

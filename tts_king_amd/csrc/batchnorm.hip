@@ -8,7 +8,7 @@
 namespace {
 
 struct BnCommon {
-  const bf16_t* x;
+  const void* x;          // conv output [rows][C]: fp32 (x_f32) or bf16
   const float* mean;
   const float* rstd;
   const float* gamma;
@@ -17,6 +17,7 @@ struct BnCommon {
   int rows, C, use_tanh;
   float p;
   unsigned site;
+  int x_f32;
 };
 
 __device__ __forceinline__ void ld4(const bf16_t* p, float v[4]) {
@@ -24,13 +25,21 @@ __device__ __forceinline__ void ld4(const bf16_t* p, float v[4]) {
   v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
   v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
 }
+__device__ __forceinline__ void ldx4(const void* x, int x_f32, int64_t off, float v[4]) {
+  if (x_f32) {
+    const f32x4 t = *(const f32x4*)((const float*)x + off);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  } else {
+    ld4((const bf16_t*)x + off, v);
+  }
+}
 __device__ __forceinline__ uint4 bits4(const uint64_t* rng, unsigned site, unsigned e4) {
   const uint64_t seed = rng[0], step = rng[1];
   return Philox::gen(make_uint2((unsigned)seed, (unsigned)(seed >> 32)), make_uint4(e4, site, (unsigned)step, (unsigned)(step >> 32)));
 }
 
 // ---- pass 1: per-column sum and sum of squares -> partials[blk][2C]
-__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict__ x, int rows, int C, float* __restrict__ partials) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const void* __restrict__ x, int x_f32, int rows, int C, float* __restrict__ partials) {
   extern __shared__ float red[];  // [rpi][4*tpr] x 2
   const int tpr = C >> 2, rpi = 256 / tpr;
   const int r0 = threadIdx.x / tpr, c4 = (threadIdx.x % tpr) * 4;
@@ -41,7 +50,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict_
   if (r0 < rpi)
     for (int r = rb + r0; r < re; r += rpi) {
       float v[4];
-      ld4(x + (int64_t)r * C + c4, v);
+      ldx4(x, x_f32, (int64_t)r * C + c4, v);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
     }
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnCommon a, const f
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int r = (int)(i / tpr), c4 = (int)(i - (int64_t)r * tpr) * 4;
     float v[4];
-    ld4(a.x + (int64_t)r * a.C + c4, v);
+    ldx4(a.x, a.x_f32, (int64_t)r * a.C + c4, v);
     const f32x4 m = *(const f32x4*)(a.mean + c4), rs = *(const f32x4*)(a.rstd + c4);
     const f32x4 g = *(const f32x4*)(a.gamma + c4), b = *(const f32x4*)(a.beta + c4);
 #pragma unroll
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnCommon a, const f
 __device__ __forceinline__ void bn_dy(const BnCommon& a, const void* dout, int dout_f32, int r, int c4, int64_t i, unsigned thr,
                                       float scale, float xh[4], float dy[4]) {
   float v[4];
-  ld4(a.x + (int64_t)r * a.C + c4, v);
+  ldx4(a.x, a.x_f32, (int64_t)r * a.C + c4, v);
   const f32x4 m = *(const f32x4*)(a.mean + c4), rs = *(const f32x4*)(a.rstd + c4);
   if (dout_f32) {
     const f32x4 d = *(const f32x4*)((const float*)dout + (int64_t)r * a.C + c4);
@@ -210,12 +219,12 @@ static int bn_check(int rows, int C) {
   return 0;
 }
 
-extern "C" int ttsk_bn_stats(const void* x_bf16, int rows, int C, float* partials, void* stream) {
-  TTSK_REQUIRE(x_bf16 && partials, "bn_stats: null pointer");
+extern "C" int ttsk_bn_stats(const void* x, int x_is_f32, int rows, int C, float* partials, void* stream) {
+  TTSK_REQUIRE(x && partials, "bn_stats: null pointer");
   if (int rc = bn_check(rows, C)) return rc;
   const int rpi = 256 / (C >> 2);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(bn_blocks(rows)), dim3(256), 2 * rpi * C * sizeof(float), (hipStream_t)stream,
-                     (const bf16_t*)x_bf16, rows, C, partials);
+                     x, x_is_f32, rows, C, partials);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }
@@ -238,13 +247,13 @@ extern "C" int ttsk_rsqrt_eps(const float* var, float eps, float* rstd, int n, v
   return TTSK_OK;
 }
 
-extern "C" int ttsk_bn_apply(const void* x_bf16, const float* mean, const float* rstd, const float* gamma, const float* beta,
+extern "C" int ttsk_bn_apply(const void* x, int x_is_f32, const float* mean, const float* rstd, const float* gamma, const float* beta,
                              int rows, int C, int use_tanh, float p, uint32_t site, const uint64_t* rng, const float* resid_f32,
                              void* out_bf16, float* out_f32, void* stream) {
-  TTSK_REQUIRE(x_bf16 && mean && rstd && gamma && beta && (out_bf16 || out_f32), "bn_apply: null pointer");
+  TTSK_REQUIRE(x && mean && rstd && gamma && beta && (out_bf16 || out_f32), "bn_apply: null pointer");
   TTSK_REQUIRE(p == 0.f || rng, "bn_apply: dropout needs rng");
   if (int rc = bn_check(rows, C)) return rc;
-  BnCommon a{(const bf16_t*)x_bf16, mean, rstd, gamma, beta, rng, rows, C, use_tanh, p, site};
+  BnCommon a{x, mean, rstd, gamma, beta, rng, rows, C, use_tanh, p, site, x_is_f32};
   int64_t n = (int64_t)rows * (C >> 2);
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
@@ -253,13 +262,13 @@ extern "C" int ttsk_bn_apply(const void* x_bf16, const float* mean, const float*
   return TTSK_OK;
 }
 
-extern "C" int ttsk_bn_bwd_stats(const void* dout, int dout_is_f32, const void* x_bf16, const float* mean, const float* rstd,
+extern "C" int ttsk_bn_bwd_stats(const void* dout, int dout_is_f32, const void* x, int x_is_f32, const float* mean, const float* rstd,
                                  const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
                                  const uint64_t* rng, float* partials, void* stream) {
-  TTSK_REQUIRE(dout && x_bf16 && mean && rstd && gamma && beta && partials, "bn_bwd_stats: null pointer");
+  TTSK_REQUIRE(dout && x && mean && rstd && gamma && beta && partials, "bn_bwd_stats: null pointer");
   TTSK_REQUIRE(p == 0.f || rng, "bn_bwd_stats: dropout needs rng");
   if (int rc = bn_check(rows, C)) return rc;
-  BnCommon a{(const bf16_t*)x_bf16, mean, rstd, gamma, beta, rng, rows, C, use_tanh, p, site};
+  BnCommon a{x, mean, rstd, gamma, beta, rng, rows, C, use_tanh, p, site, x_is_f32};
   const int rpi = 256 / (C >> 2);
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(bn_blocks(rows)), dim3(256), 2 * rpi * C * sizeof(float), (hipStream_t)stream, a,
                      dout, dout_is_f32, partials);
@@ -267,14 +276,14 @@ extern "C" int ttsk_bn_bwd_stats(const void* dout, int dout_is_f32, const void* 
   return TTSK_OK;
 }
 
-extern "C" int ttsk_bn_bwd_apply(const void* dout, int dout_is_f32, const void* x_bf16, const float* mean, const float* rstd,
+extern "C" int ttsk_bn_bwd_apply(const void* dout, int dout_is_f32, const void* x, int x_is_f32, const float* mean, const float* rstd,
                                  const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
                                  const uint64_t* rng, const float* sums, void* dx_bf16, float* dgamma, float* dbeta,
                                  void* stream) {
-  TTSK_REQUIRE(dout && x_bf16 && mean && rstd && gamma && beta && sums && dx_bf16, "bn_bwd_apply: null pointer");
+  TTSK_REQUIRE(dout && x && mean && rstd && gamma && beta && sums && dx_bf16, "bn_bwd_apply: null pointer");
   TTSK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bn_bwd_apply: dgamma/dbeta come in pairs");
   if (int rc = bn_check(rows, C)) return rc;
-  BnCommon a{(const bf16_t*)x_bf16, mean, rstd, gamma, beta, rng, rows, C, use_tanh, p, site};
+  BnCommon a{x, mean, rstd, gamma, beta, rng, rows, C, use_tanh, p, site, x_is_f32};
   int64_t n = (int64_t)rows * (C >> 2);
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;

@@ -384,7 +384,8 @@ class FastSpeech2(nn.Module):
         xin = mel16.view(Bn, T, self.n_mel)
         for i in range(5):
             pp = "postnet.convolutions.%d." % i
-            yc = ops.conv1d(xin, self._w(pp + "0.conv.weight"), self._m(pp + "0.conv.bias"))
+            # conv output stays fp32: BatchNorm divides by the batch std, which amplifies a bf16 rounding of it
+            yc = ops.conv1d(xin, self._w(pp + "0.conv.weight"), self._m(pp + "0.conv.bias"), out_dtype=torch.float32)
             C = yc.shape[2]
             if train:
                 mean, rstd = ops.bn_train_stats(yc.view(rows, C), self.get(pp + "1.running_mean"), self.get(pp + "1.running_var"),

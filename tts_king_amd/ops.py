@@ -364,14 +364,14 @@ def to_int16(x, scale):
 # ---------------------------------------------------------------------------------------------------- batch norm
 
 def bn_train_stats(x, running_mean=None, running_var=None, nbt=None, eps=1e-5, momentum=0.1):
-    """x (rows, C) bf16 -> (mean, rstd) fp32 of the batch; updates the running buffers in place."""
+    """x (rows, C) bf16 or fp32 -> (mean, rstd) fp32 of the batch; updates the running buffers in place."""
     _dev(x)
     rows, Cn = x.shape
     lib = L.load()
     nblk = lib.ttsk_bn_nblocks(rows)
     partials = _f32(nblk, 2 * Cn, device=x.device)
     mean, rstd = _f32(Cn, device=x.device), _f32(Cn, device=x.device)
-    check(lib.ttsk_bn_stats(_ptr(x), rows, Cn, _ptr(partials), _stream()), "ttsk_bn_stats")
+    check(lib.ttsk_bn_stats(_ptr(x), int(x.dtype == torch.float32), rows, Cn, _ptr(partials), _stream()), "ttsk_bn_stats")
     check(lib.ttsk_bn_finalize(_ptr(partials), nblk, Cn, rows, eps, momentum, _ptr(mean), _ptr(rstd), _ptr(running_mean),
                                _ptr(running_var), _ptr(nbt), _stream()), "ttsk_bn_finalize")
     return mean, rstd
@@ -387,7 +387,7 @@ def bn_apply(x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, resi
     rows, Cn = x.shape
     o16 = None if out_f32 else torch.empty(rows, Cn, dtype=bf16, device=x.device)
     o32 = _f32(rows, Cn, device=x.device) if out_f32 else None
-    check(L.load().ttsk_bn_apply(_ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn, int(use_tanh), p, site,
+    check(L.load().ttsk_bn_apply(_ptr(x), int(x.dtype == torch.float32), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn, int(use_tanh), p, site,
                                  _ptr(rng), _ptr(resid), _ptr(o16), _ptr(o32), _stream()), "ttsk_bn_apply")
     return o32 if out_f32 else o16
 
@@ -400,11 +400,11 @@ def bn_bwd(dout, x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, 
     partials = _f32(nblk, 2 * Cn, device=x.device)
     sums = _f32(2 * Cn, device=x.device)
     f32 = int(dout.dtype == torch.float32)
-    check(lib.ttsk_bn_bwd_stats(_ptr(dout), f32, _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn,
+    check(lib.ttsk_bn_bwd_stats(_ptr(dout), f32, _ptr(x), int(x.dtype == torch.float32), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn,
                                 int(use_tanh), p, site, _ptr(rng), _ptr(partials), _stream()), "ttsk_bn_bwd_stats")
     colsum_finalize(partials, nblk, 2 * Cn, 2 * Cn, sums, accumulate=False)
     dx = torch.empty(rows, Cn, dtype=bf16, device=x.device)
-    check(lib.ttsk_bn_bwd_apply(_ptr(dout), f32, _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn,
+    check(lib.ttsk_bn_bwd_apply(_ptr(dout), f32, _ptr(x), int(x.dtype == torch.float32), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn,
                                 int(use_tanh), p, site, _ptr(rng), _ptr(sums), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _stream()),
           "ttsk_bn_bwd_apply")
     return dx

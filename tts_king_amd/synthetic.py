@@ -11,6 +11,8 @@ test and every benchmark runs on
 Both are pure CPU torch so the same numbers come out in the build container and on the GPU box.
 """
 import math
+import re
+
 import torch
 
 N_VOCAB = 207          # len(symbols) + 1  (reference: fs_two/transformer/Models.py:40)
@@ -40,7 +42,7 @@ def seeded_fill(sd, seed=0, conv_transpose_keys=()):
         g = torch.Generator().manual_seed(seed + idx)
         shape = tuple(t.shape)
         leaf = key.rsplit(".", 1)[-1]
-        is_norm = ("layer_norm" in key) or (".1." in key and "postnet" in key) or (".net.2." in key)
+        is_norm = ("layer_norm" in key) or bool(re.search(r"postnet\.convolutions\.\d+\.1\.", key)) or (".net.2." in key)
         if leaf == "running_var":
             v = 0.5 + torch.rand(shape, generator=g)
         elif leaf == "running_mean":

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — FS2 train-step throughput (BASELINE.json configs[1]) on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one full `main_train_step` (forward, loss, backward, [RCCL gradient all-reduce], global-norm clip, Adam with the
+reference LR schedule, zero_grad; grad_acc_step = 1) on one synthetic batch per GPU: B=16 utterances x L=64 phonemes,
+durations 1..11 frames -> T_max ~423 mel frames, 80-bin mel, 65 speakers, dropout ON, bf16 MFMA compute with fp32
+accumulation and fp32 master weights.  Inputs are resident in HBM before the timed region.  `value` counts VALID
+mel frames (sum of mel_lens) over all ranks per second.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def fs2_flops_per_step(B, L, T):
+    """Exact train-step FLOPs (3 x forward; SURVEY.md §8d, verified with torch.utils.flop_counter on the reference)."""
+    fwd = B * (25429504 * L + 4096 * L * L + 43327488 * T + 6144 * T * T)
+    return 3.0 * fwd
+
+
+def cpu_baseline(cfg, B, L, n_steps=5):
+    """The oracle (CPU fp32 restatement of the reference step) timed on this box's host cores, same workload."""
+    import copy
+    from oracle import fs2 as ofs2
+    from tts_king_amd.fastspeech2 import FastSpeech2
+    from tts_king_amd.synthetic import make_batch
+    c = copy.deepcopy(cfg)
+    c.train_config["optimizer"]["grad_acc_step"] = 1
+    torch.set_num_threads(os.cpu_count() or 1)
+    m = FastSpeech2(c.preprocess_config, c.model_config, 65, device="cpu", seed=1234)
+    sd = {k: v.detach().clone().contiguous() for k, v in m.state_dict().items()}
+    tr = ofs2.OracleTrainer(sd, c.model_config, c.train_config, 0)
+    b = make_batch(B, L, seed=1234)
+    tr.train_step(b, 1)                                  # warm-up
+    t0 = time.perf_counter()
+    for s in range(n_steps):
+        tr.train_step(b, s + 2)
+    dt = (time.perf_counter() - t0) / n_steps
+    frames = int(b[7].sum())
+    return {"value": frames / dt, "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d full train steps (dropout on) of the same B=%d, L=%d batch, fp32, %.2f s/step" % (n_steps, B, L, dt)}
+
+
+def gemm_roofline(enqueue, batch, steps=3):
+    """Bracket every MFMA GEMM launch of `steps` eager train steps with HIP events on the launch stream."""
+    from tts_king_amd import ops
+    enqueue(batch)
+    torch.cuda.synchronize()
+    trace = []
+    ops.GEMM_TRACE = trace
+    try:
+        for _ in range(steps):
+            enqueue(batch)
+        torch.cuda.synchronize()
+    finally:
+        ops.GEMM_TRACE = None
+    tot_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in trace)
+    tot_fl = sum(t[2] for t in trace)
+    by_shape = {}
+    for e0, e1, fl, kind, shape in trace:
+        k = (kind,) + shape
+        d = by_shape.setdefault(k, [0.0, 0.0, 0])
+        d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += 1
+    dom = max(by_shape.items(), key=lambda kv: kv[1][0])
+    n = len(trace)
+    ach = tot_fl / (tot_ms * 1e-3) / 1e12
+    dk, dv = dom
+    return {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_BF16_TFLOPS,
+            "traffic": None,
+            "kernel": "gemm_kernel<A_TR,B_TR> (tts_king_amd/csrc/gemm.hip), all %d launches of a train step" % (n // steps),
+            "avg_launch_us": 1e3 * tot_ms / n, "avg_launch_gflop": tot_fl / n / 1e9, "gemm_ms_per_step": tot_ms / steps,
+            "dominant_shape": {"kind": dk[0], "M,N,K,taps,batch,splits": list(dk[1:]), "launches_per_step": dv[2] // steps,
+                               "avg_us": 1e3 * dv[0] / dv[2], "tflops": dv[1] / (dv[0] * 1e-3) / 1e12}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--phonemes", type=int, default=64)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hifi", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from tts_king_amd.config import default_config
+    from tts_king_amd.fastspeech2 import FastSpeech2
+    from tts_king_amd.graph import GraphedTrainStep, make_enqueue
+    from tts_king_amd.loss import FastSpeech2Loss
+    from tts_king_amd.optimizer import ScheduledOptim
+    from tts_king_amd.parallel import GradReducer, init_distributed
+    from tts_king_amd.synthetic import make_batch
+    from tts_king_amd.train_step import to_device
+
+    rank, world, local = init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dev = "cuda:%d" % local
+    torch.cuda.set_device(local)
+    cfg = default_config()
+    cfg.train_config["optimizer"]["grad_acc_step"] = 1
+    B, L = args.batch, args.phonemes
+    model = FastSpeech2(cfg.preprocess_config, cfg.model_config, 65, device=dev, seed=1234).train()
+    opt = ScheduledOptim(model, cfg.train_config, cfg.model_config, 0)
+    loss_fn = FastSpeech2Loss(cfg.preprocess_config, cfg.model_config)
+    cpu_batch = make_batch(B, L, seed=1234 + rank)
+    batch = to_device(cpu_batch, dev)
+    T = int(batch[8])
+    frames = int(cpu_batch[7].sum())
+
+    reducer = None
+    if world > 1:
+        reducer = GradReducer(model.flat_buffers()[1], model.grad_buckets(cfg.mi355x.dp_bucket_mb), model.group_offsets())
+    enqueue = make_enqueue(model, opt, cfg, loss_fn, reducer=reducer,
+                           grad_scale=reducer.grad_scale(1) if reducer else None)
+    use_graph = (world == 1) and not args.no_graph
+    if use_graph:
+        g = GraphedTrainStep(enqueue, batch)
+        step = lambda: g.run()
+    else:
+        step = lambda: enqueue(batch)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stats = torch.tensor([dt, float(frames)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[0:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tot = stats[1:2].clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt, total_frames = float(tmax), float(tot)
+    else:
+        total_frames = float(frames)
+    losses = out[0].cpu().tolist()
+    ms = 1e3 * dt / args.steps
+    value = total_frames * args.steps / dt
+
+    if rank == 0:
+        flops = fs2_flops_per_step(B, L, T)
+        rec = {
+            "metric": "FS2 train mel-frames/sec/GPU + HiFi-GAN RTF (22.05 kHz), batch=16",
+            "value": value, "unit": "valid mel-frames/s (whole job)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "FS2 train step bf16 on 1xMI355X per rank, 65-speaker embedding, batch=16, 80-bin mel, "
+                                   "256-d FFT blocks (BASELINE.json configs[1]); full step = fwd+loss+bwd+clip+Adam, dropout on",
+                       "global_batch": B * world, "batch_per_gpu": B, "phonemes": L, "T_max": T, "valid_frames_per_gpu": frames,
+                       "padded_frames_per_gpu": B * T, "grad_acc_step": 1, "parallelism": "dp%d" % world,
+                       "launch": "hipGraph replay" if use_graph else "eager (+RCCL bucketed all-reduce on a side stream)"},
+            "mel_frames_per_s_per_gpu": value / world,
+            "model_tflops": flops * world / (ms * 1e-3) / 1e12,
+            "step_mfma_roofline_frac": flops / (ms * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS,
+            "final_losses": {"total": losses[0], "mel": losses[1], "pitch": losses[2], "energy": losses[3], "duration": losses[4]},
+        }
+        if not args.no_roofline:
+            eager = make_enqueue(model, opt, cfg, loss_fn, reducer=None)
+            rec["roofline"] = gemm_roofline(eager, batch)
+        if world == 1 and not args.no_hifi:
+            try:
+                from tts_king_amd.hifi_bench import hifi_rtf
+                rec["hifi_gan"] = hifi_rtf(cfg, dev)
+            except ImportError:
+                rec["hifi_gan"] = None
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(cfg, B, L)
+        print(json.dumps(rec))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -208,6 +208,18 @@ class FastSpeech2(nn.Module):
     def grad_buckets(self, bucket_mb=24):
         return P.buckets(self._table, self._n_flat, int(bucket_mb * (1 << 20) / 4))
 
+    def group_offsets(self):
+        """name -> lowest flat offset of the parameter group announced by backward_native(on_bucket=...)."""
+        def lo(prefixes):
+            return min(en.offset for k, en in self._table.items() if en.kind == P.TRAIN and k.startswith(prefixes))
+        g = {"postnet": lo(("postnet.",)), "mel_linear": lo(("mel_linear.",)),
+             "variance_adaptor": lo(("variance_adaptor.", "speaker_emb.")), "embedding": 0}
+        for i in range(self.n_dec):
+            g["decoder.%d" % i] = lo(("decoder.layer_stack.%d." % i,))
+        for i in range(self.n_enc):
+            g["encoder.%d" % i] = lo(("encoder.layer_stack.%d." % i,))
+        return g
+
     def attach_state(self, state):
         """Share the optimizer's device state block (dropout counters live in it)."""
         self._rng_state = state

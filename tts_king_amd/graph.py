@@ -1,0 +1,68 @@
+"""hipGraph capture of the whole FS2 train step (forward, loss, backward, clip, Adam, counters).
+
+One step is ~450 short kernel launches; launched eagerly from Python the host, not the GPU, sets the pace.
+Everything the step needs that changes from step to step (dropout counters, Adam step, learning rate, BatchNorm
+running statistics) lives in device memory and is advanced by kernels, so a captured graph replays correctly with
+no host work besides copying the next batch into the static input buffers.  Shapes are static per graph: batches
+are bucketed by (B, L, T) and one graph is kept per bucket (T varies per batch in real training).
+"""
+import torch
+
+from . import ops
+
+
+class GraphedTrainStep:
+    """Captures `enqueue(batch)` for one (B, L, T) bucket and replays it.
+
+    `enqueue` must only enqueue device work on the current stream (no host reads); it returns device tensors
+    (e.g. the losses) that are valid after each replay."""
+
+    def __init__(self, enqueue, example_batch, warmup=2):
+        self.static = [t.clone() if torch.is_tensor(t) else t for t in example_batch]
+        self.graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                enqueue(self.static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(self.graph):
+            self.outputs = enqueue(self.static)
+
+    def key(self):
+        return tuple(tuple(t.shape) for t in self.static if torch.is_tensor(t))
+
+    def run(self, batch=None):
+        if batch is not None:
+            for dst, src in zip(self.static, batch):
+                if torch.is_tensor(dst) and src is not dst:
+                    dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.outputs
+
+
+def make_enqueue(model, optimizer, cfg, Loss, step_is_update=True, reducer=None, grad_scale=None):
+    """The device-side part of `main_train_step` (train.py:24-56) as a capturable closure."""
+    grad_acc = cfg.train_config["optimizer"]["grad_acc_step"]
+    gs = (1.0 / grad_acc) if grad_scale is None else grad_scale
+
+    def enqueue(batch):
+        dev = model.device
+        with torch.no_grad():
+            out, ctx = model._forward(True, batch[2], batch[3], batch[4], int(batch[5]), batch[7], batch[8], batch[9],
+                                      batch[10], batch[11], 1.0, 1.0, 1.0)
+            mel, pitch, energy, logd = out[0], out[1], out[2], out[3]
+            post = out[8]
+            losses, dmel_sum, dpost, dp, de, dd = ops.fs2_loss(mel, post, batch[6], batch[7], pitch, energy, logd, batch[11],
+                                                               batch[9], batch[10], batch[4], grad_scale=gs)
+            if reducer is not None and step_is_update:
+                model.backward_native(ctx, dmel_sum, dpost, dp, de, dd, on_bucket=reducer.on_group_done)
+                reducer.finish()
+            else:
+                model.backward_native(ctx, dmel_sum, dpost, dp, de, dd)
+            ops.rng_advance(model._state())
+            if step_is_update:
+                optimizer.step_and_update_lr()
+        return losses, out
+    return enqueue

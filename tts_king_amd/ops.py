@@ -29,6 +29,9 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+GEMM_TRACE = None   # bench.py sets this to a list: every ttsk_gemm launch is then bracketed by HIP events on its stream
+
+
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=None, ldr=0, G=None, ldg=0, C2=None,
          nz1=1, nz2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), taps=0, seg_len=0, tap_shift0=0, tap_dshift=0,
          b_tap_stride=0, bseg_len=0, bshift0=0, bdshift=0, out_seg=0, out_mul=0, out_add=0, splits=1, sCs=0,
@@ -57,6 +60,14 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=No
     d.bseg_len, d.bshift0, d.bdshift = bseg_len, bshift0, bdshift
     d.out_seg, d.out_mul, d.out_add = out_seg, out_mul, out_add
     d.splits, d.sCs = splits, sCs
+    if GEMM_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(L.load().ttsk_gemm(C.byref(d), _stream()), "ttsk_gemm")
+        e1.record()
+        kind = "TT" if flags & A_TR else ("NT_btr" if flags & B_TR else "NT")
+        GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * max(taps, 1) * nz1 * nz2, kind, (M, N, K, max(taps, 1), nz1 * nz2, splits)))
+        return Cout
     check(L.load().ttsk_gemm(C.byref(d), _stream()), "ttsk_gemm")
     return Cout
 

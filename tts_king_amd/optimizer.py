@@ -38,10 +38,11 @@ class ScheduledOptim:
     # -- reference surface ------------------------------------------------------------------------
     @property
     def current_step(self):
-        return self._host_step
+        """Number of optimizer updates so far (device counter: stays right under hipGraph replay)."""
+        return int(self.state[0]) if self.state is not None else self._host_step
 
     def _get_lr_scale(self, step=None):
-        s = self._host_step if step is None else step
+        s = self.current_step if step is None else step
         lr = np.min([np.power(s, -0.5), np.power(self.n_warmup_steps, -1.5) * s])
         for a in self.anneal_steps:
             if s > a:

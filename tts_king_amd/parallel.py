@@ -1,0 +1,69 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, gradients averaged with RCCL all-reduce
+over xGMI on a side HIP stream while backward is still running.
+
+The reference has no distributed code (only a commented-out nn.DataParallel, train.py:104); semantics here are
+"N independent reference micro-batches, gradients averaged" = the reference's own gradient accumulation with
+grad_acc_step = N (train.py:43-47), which is what the gloo test checks.
+
+Design for xGMI (point-to-point links, per-link bound): the gradients live in ONE flat fp32 buffer laid out in
+forward order, so buckets are contiguous slices that complete from the END of the buffer as backward proceeds;
+each bucket is one large all-reduce (default 24 MB) issued as soon as its last gradient is written.  The 1/N
+factor is folded into the loss gradient (grad_scale), so the collective is a plain SUM.
+"""
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run contract).  backend 'nccl' is RCCL."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class GradReducer:
+    """Bucketed all-reduce of a flat gradient buffer.
+
+    `flat_grad`: the fp32 buffer; `buckets`: [(start, end)] from the END of the buffer (FastSpeech2.grad_buckets);
+    `group_offsets`: name -> lowest flat offset of the parameter group whose completion `on_group_done(name)`
+    announces (groups complete in reverse forward order, so everything at or above that offset is final)."""
+
+    def __init__(self, flat_grad, buckets, group_offsets, process_group=None):
+        self.flat_grad = flat_grad
+        self.buckets = list(buckets)
+        self.group_offsets = dict(group_offsets)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._next = 0
+        self._handles = []
+        self.launched = []          # (start, end) in launch order, for tests / tracing
+
+    def _launch_down_to(self, watermark):
+        while self._next < len(self.buckets) and self.buckets[self._next][0] >= watermark:
+            s, e = self.buckets[self._next]
+            if self.world > 1:
+                self._handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self.launched.append((s, e))
+            self._next += 1
+
+    def on_group_done(self, name):
+        self._launch_down_to(self.group_offsets[name])
+
+    def finish(self):
+        """Issue whatever is left and make the current stream wait for every collective (no host block on NCCL)."""
+        self._launch_down_to(0)
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        self._next = 0
+
+    def grad_scale(self, grad_acc_step=1):
+        return 1.0 / (grad_acc_step * self.world)

@@ -24,6 +24,22 @@ struct Args {
   int tiles_m, tiles_n, kchunks, chunks_per_split;
 };
 
+__device__ __forceinline__ unsigned lrelu2(unsigned w, float sl) {
+  float lo = __uint_as_float(w << 16), hi = __uint_as_float(w & 0xFFFF0000u);
+  lo = lo > 0.f ? lo : lo * sl;
+  hi = hi > 0.f ? hi : hi * sl;
+  return pack_bf2(lo, hi);
+}
+__device__ __forceinline__ uint4 lrelu8(uint4 v, float sl) {
+  return make_uint4(lrelu2(v.x, sl), lrelu2(v.y, sl), lrelu2(v.z, sl), lrelu2(v.w, sl));
+}
+__device__ __forceinline__ void add_bf8(float v[8], uint4 r) {
+  v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xFFFF0000u);
+  v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xFFFF0000u);
+  v[4] += __uint_as_float(r.z << 16); v[5] += __uint_as_float(r.z & 0xFFFF0000u);
+  v[6] += __uint_as_float(r.w << 16); v[7] += __uint_as_float(r.w & 0xFFFF0000u);
+}
+
 __device__ __forceinline__ int tr_sw(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
 
 template <bool ATR, bool BTR>
@@ -48,111 +64,109 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 
   const bf16_t* __restrict__ A = (const bf16_t*)d.A + z1 * d.sA1 + z2 * d.sA2;
   const bf16_t* __restrict__ B = (const bf16_t*)d.B + z1 * d.sB1 + z2 * d.sB2;
+  // Buffer descriptors: operands are read with buffer_load_dwordx4 and a 32-bit byte offset; every predicate
+  // (M/N/K tails, conv zero padding outside the utterance) becomes an out-of-range offset, for which the hardware
+  // returns zeros — no branches and no selects in the K loop.
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7FFFFFF0, 0x00020000);
+  constexpr int OOB = 0x7FFFFFFF;
   const int M = d.M, N = d.N, K = d.K;
   const int taps = d.taps > 0 ? d.taps : 1;
   const bool conv_a = d.taps > 0;
   const int bshift = d.bseg_len > 0 ? d.bshift0 + z2 * d.bdshift : 0;
+  const int K8 = (K + 7) & ~7;
 
   // ---- per-thread staging coordinates (4 x 16 B per operand per K tile)
   // normal operand tile [128 rows][64 k]: chunk c = tid + 256 i -> row = c >> 3, slot = c & 7
   // transposed operand tile [64 k][128 m]: chunk c -> krow = c >> 4, slot16 = c & 15
   const int nrow = tid >> 3, nslot = tid & 7;      // + 32 i rows
   const int trow = tid >> 4, tslot = tid & 15;     // + 16 i krows
+  int a_off[4], b_off[4];                          // byte offsets of this thread's 4 chunks at k = 0, tap 0 (OOB if never valid)
   int a_t[4];                                      // conv-A: position of row inside its segment
-  if (conv_a) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a_t[i] = (m0 + nrow + 32 * i) % d.seg_len;
+  for (int i = 0; i < 4; ++i) {
+    if (!ATR) {
+      const int gm = m0 + nrow + 32 * i;
+      a_off[i] = gm < M ? (gm * d.lda + nslot * 8) * 2 : OOB;
+      a_t[i] = conv_a ? gm % d.seg_len : 0;
+    } else {
+      const int mcol = m0 + tslot * 8;
+      a_off[i] = mcol < M ? ((trow + 16 * i) * d.lda + mcol) * 2 : OOB;
+      a_t[i] = 0;
+    }
+    if (!BTR) {
+      const int gn = n0 + nrow + 32 * i;
+      b_off[i] = gn < N ? (gn * d.ldb + nslot * 8) * 2 : OOB;
+    } else {
+      const int ncol = n0 + tslot * 8;
+      b_off[i] = ncol < N ? ((trow + 16 * i) * d.ldb + ncol) * 2 : OOB;
+    }
   }
 
   const int kc_begin = split * g.chunks_per_split;
   int kc_end = kc_begin + g.chunks_per_split;
   if (kc_end > g.kchunks) kc_end = g.kchunks;
-  const int nk = (kc_end > kc_begin ? (kc_end - kc_begin) : 0) * taps;
+  const int per = kc_end > kc_begin ? kc_end - kc_begin : 0;
+  const int nk = per * taps;
 
-  uint4 ra[4], rb[4];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
-  const int K8 = (K + 7) & ~7;
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  const float in_slope = d.in_slope;
+  const bool lrelu_in = d.flags & TTSK_GEMM_LRELU_IN;
 
-  auto load_tile = [&](int kt) {
-    const int per = kc_end - kc_begin;
+#define TTSK_LD(rs, off) __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0))
+  auto load_tile = [&](int kt) __attribute__((always_inline)) {
     const int tap = kt / per;
     const int kbase = (kc_begin + (kt - tap * per)) * BK;
-    // ---------------- A
+    int oa[4], ob[4];
     if (!ATR) {
       const int shift = conv_a ? d.tap_shift0 + tap * d.tap_dshift : 0;
-      const int k = kbase + nslot * 8;
+      const int add = (shift * d.lda + kbase) * 2;
+      const bool kok = kbase + nslot * 8 < K8;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int gm = m0 + nrow + 32 * i;
-        bool ok = gm < M && k < K8;
-        if (conv_a) { const int tt = a_t[i] + shift; ok = ok && tt >= 0 && tt < d.seg_len; }
-        ra[i] = ok ? *(const uint4*)(A + (int64_t)(gm + shift) * d.lda + k) : zero4;
-      }
-      if (d.flags & TTSK_GEMM_LRELU_IN) {
-        const float sl = d.in_slope;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          unsigned* w = (unsigned*)&ra[i];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xFFFF0000u);
-            lo = lo > 0.f ? lo : lo * sl;
-            hi = hi > 0.f ? hi : hi * sl;
-            w[j] = pack_bf2(lo, hi);
-          }
-        }
+        const int tt = a_t[i] + shift;
+        const bool ok = kok && (!conv_a || (tt >= 0 && tt < d.seg_len));
+        oa[i] = (ok && a_off[i] != OOB) ? a_off[i] + add : OOB;
       }
     } else {
-      const int mcol = m0 + tslot * 8;
+      const int add = kbase * d.lda * 2;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int kk = kbase + trow + 16 * i;
-        const bool ok = kk < K && mcol < M;
-        ra[i] = ok ? *(const uint4*)(A + (int64_t)kk * d.lda + mcol) : zero4;
-      }
+      for (int i = 0; i < 4; ++i) oa[i] = (kbase + trow + 16 * i < K && a_off[i] != OOB) ? a_off[i] + add : OOB;
     }
-    // ---------------- B
-    const int64_t tapoff = (int64_t)tap * d.b_tap_stride;
+    const int tapoff = tap * (int)d.b_tap_stride;
     if (!BTR) {
-      const int k = kbase + nslot * 8;
+      const bool kok = kbase + nslot * 8 < K8;
+      const int add = (tapoff + kbase) * 2;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gn = n0 + nrow + 32 * i;
-        const bool ok = gn < N && k < K8;
-        rb[i] = ok ? *(const uint4*)(B + (int64_t)gn * d.ldb + tapoff + k) : zero4;
-      }
+      for (int i = 0; i < 4; ++i) ob[i] = (kok && b_off[i] != OOB) ? b_off[i] + add : OOB;
     } else {
-      const int ncol = n0 + tslot * 8;
+      const int add = ((kbase + bshift) * d.ldb + tapoff) * 2;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int kk = kbase + trow + 16 * i;
-        bool ok = kk < K && ncol < N;
+        bool ok = kk < K && b_off[i] != OOB;
         if (d.bseg_len > 0) { const int tt = kk % d.bseg_len + bshift; ok = ok && tt >= 0 && tt < d.bseg_len; }
-        rb[i] = ok ? *(const uint4*)(B + (int64_t)(kk + bshift) * d.ldb + tapoff + ncol) : zero4;
+        ob[i] = ok ? b_off[i] + add : OOB;
       }
     }
+    ra0 = TTSK_LD(rsA, oa[0]); ra1 = TTSK_LD(rsA, oa[1]); ra2 = TTSK_LD(rsA, oa[2]); ra3 = TTSK_LD(rsA, oa[3]);
+    rb0 = TTSK_LD(rsB, ob[0]); rb1 = TTSK_LD(rsB, ob[1]); rb2 = TTSK_LD(rsB, ob[2]); rb3 = TTSK_LD(rsB, ob[3]);
   };
+#undef TTSK_LD
 
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
     unsigned char* sa = smem + buf * STAGE_BYTES;
     unsigned char* sb = sa + BM * BK * 2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (!ATR) {
-        const int row = nrow + 32 * i;
-        *(uint4*)(sa + row * 128 + ((nslot ^ (row & 7)) << 4)) = ra[i];
-      } else {
-        const int kr = trow + 16 * i;
-        *(uint4*)(sa + kr * 256 + ((((tslot >> 1) ^ tr_sw(kr))) << 5) + ((tslot & 1) << 4)) = ra[i];
-      }
-      if (!BTR) {
-        const int row = nrow + 32 * i;
-        *(uint4*)(sb + row * 128 + ((nslot ^ (row & 7)) << 4)) = rb[i];
-      } else {
-        const int kr = trow + 16 * i;
-        *(uint4*)(sb + kr * 256 + ((((tslot >> 1) ^ tr_sw(kr))) << 5) + ((tslot & 1) << 4)) = rb[i];
-      }
+    if (lrelu_in && !ATR) { ra0 = lrelu8(ra0, in_slope); ra1 = lrelu8(ra1, in_slope); ra2 = lrelu8(ra2, in_slope); ra3 = lrelu8(ra3, in_slope); }
+#define TTSK_ST(i, RA, RB)                                                                                        \
+    {                                                                                                             \
+      if (!ATR) { const int row = nrow + 32 * i; *(uint4*)(sa + row * 128 + ((nslot ^ (row & 7)) << 4)) = RA; }     \
+      else { const int kr = trow + 16 * i; *(uint4*)(sa + kr * 256 + (((tslot >> 1) ^ tr_sw(kr)) << 5) + ((tslot & 1) << 4)) = RA; } \
+      if (!BTR) { const int row = nrow + 32 * i; *(uint4*)(sb + row * 128 + ((nslot ^ (row & 7)) << 4)) = RB; }     \
+      else { const int kr = trow + 16 * i; *(uint4*)(sb + kr * 256 + (((tslot >> 1) ^ tr_sw(kr)) << 5) + ((tslot & 1) << 4)) = RB; } \
     }
+    TTSK_ST(0, ra0, rb0) TTSK_ST(1, ra1, rb1) TTSK_ST(2, ra2, rb2) TTSK_ST(3, ra3, rb3)
+#undef TTSK_ST
   };
 
   f32x4 acc[4][4];
@@ -272,13 +286,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
       } else {
         const bf16_t* rp = (const bf16_t*)d.R + roff + orow * d.ldr + gn;
         if (nvalid == 8 && ((d.ldr & 7) == 0)) {
-          const uint4 rv = *(const uint4*)rp;
-          const unsigned* w = (const unsigned*)&rv;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[2 * e] += __uint_as_float(w[e] << 16);
-            v[2 * e + 1] += __uint_as_float(w[e] & 0xFFFF0000u);
-          }
+          add_bf8(v, *(const uint4*)rp);
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += bf2f(rp[e]);

@@ -230,44 +230,58 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
   }
 }
 
-// dst[c] (+)= sum_b partials[b][c]   (fixed order: deterministic)
+// dst[c] (+)= scale * sum_b partials[b][c].  32 columns x 8 row-groups per workgroup; every thread adds its rows in
+// ascending order and the 8 group sums are combined in a fixed order: deterministic.
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partials, int nblk, int ncols,
                                                               int ld, float* __restrict__ dst, int accumulate, float scale) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= ncols) return;
+  __shared__ float red[8][33];
+  const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partials[(int64_t)b * ld + c];
-  s *= scale;
-  dst[c] = accumulate ? dst[c] + s : s;
+  if (c < ncols)
+    for (int b = gy; b < nblk; b += 8) s += partials[(int64_t)b * ld + c];
+  red[gy][cx] = s;
+  __syncthreads();
+  if (gy == 0 && c < ncols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    t *= scale;
+    dst[c] = accumulate ? dst[c] + t : t;
+  }
 }
 
-// column sums of a [rows][C] matrix (bf16 or fp32) -> partials[nblk][C]
+// column sums of a [rows][C] matrix (bf16 or fp32) -> partials[nblk][C]; a thread owns 4 contiguous columns
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int rows, int C, int ld, float* __restrict__ partials) {
-  __shared__ float red[256];
-  const int tpr = C < 256 ? C : 256;            // threads per row pass
+  extern __shared__ float red[];                // [rpi][C]
+  const int tpr = (C + 3) >> 2;                 // threads per row (C % 4 == 0 or C < 4 handled by the host)
   const int rpi = 256 / tpr;                    // rows per iteration
-  const int r0 = threadIdx.x / tpr, c0 = threadIdx.x % tpr;
-  const int rows_per_blk = (rows + gridDim.x - 1) / gridDim.x;
-  const int rb = blockIdx.x * rows_per_blk;
-  int re = rb + rows_per_blk;
-  if (re > rows) re = rows;
-  for (int cb = 0; cb < C; cb += tpr) {
-    const int c = cb + c0;
-    float s = 0.f;
-    if (r0 < rpi && c < C)
-      for (int r = rb + r0; r < re; r += rpi) {
-        if constexpr (sizeof(T) == 2) s += bf2f(((const bf16_t*)x)[(int64_t)r * ld + c]);
-        else s += ((const float*)x)[(int64_t)r * ld + c];
+  const int r0 = threadIdx.x / tpr, c4 = (threadIdx.x % tpr) * 4;
+  const int per = (rows + gridDim.x - 1) / gridDim.x;
+  const int rb = blockIdx.x * per;
+  const int re = min(rb + per, rows);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (r0 < rpi)
+    for (int r = rb + r0; r < re; r += rpi) {
+      if constexpr (sizeof(T) == 2) {
+        const uint2 u = *(const uint2*)((const bf16_t*)x + (int64_t)r * ld + c4);
+        s[0] += __uint_as_float(u.x << 16); s[1] += __uint_as_float(u.x & 0xFFFF0000u);
+        s[2] += __uint_as_float(u.y << 16); s[3] += __uint_as_float(u.y & 0xFFFF0000u);
+      } else {
+        const f32x4 u = *(const f32x4*)((const float*)x + (int64_t)r * ld + c4);
+        s[0] += u[0]; s[1] += u[1]; s[2] += u[2]; s[3] += u[3];
       }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x < tpr && c < C) {
-      float t = 0.f;
-      for (int k = 0; k < rpi; ++k) t += red[k * tpr + threadIdx.x];
-      partials[(int64_t)blockIdx.x * C + c] = t;
     }
-    __syncthreads();
+  if (r0 < rpi) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[r0 * C + c4 + e] = s[e];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int k = 0; k < rpi; ++k) t += red[k * C + c];
+    partials[(int64_t)blockIdx.x * C + c] = t;
   }
 }
 
@@ -316,24 +330,27 @@ extern "C" int ttsk_layernorm_bwd(const void* dout, const float* dhead, const fl
 extern "C" int ttsk_colsum_finalize(const float* partials, int nblk, int ncols, int ld, float* dst, int accumulate,
                                     float scale, void* stream) {
   TTSK_REQUIRE(partials && dst && nblk > 0 && ncols > 0 && ld >= ncols, "colsum_finalize: bad arguments");
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, nblk,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, nblk,
                      ncols, ld, dst, accumulate, scale);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }
 
 extern "C" int ttsk_colsum_nblocks(int rows) {
-  int n = (rows + 63) / 64;
+  int n = (rows + 15) / 16;
   return n > 256 ? 256 : (n < 1 ? 1 : n);
 }
 
 extern "C" int ttsk_colsum(const void* x, int is_f32, int rows, int C, int ld, float* partials, void* stream) {
   TTSK_REQUIRE(x && partials && rows > 0 && C > 0 && ld >= C, "colsum: bad arguments");
+  TTSK_REQUIRE((C & 3) == 0 && C <= 1024 && (ld & 3) == 0, "colsum: C must be a multiple of 4 and <= 1024 (got %d)", C);
   const int nblk = ttsk_colsum_nblocks(rows);
+  const int rpi = 256 / (C >> 2);
+  const size_t shm = (size_t)rpi * C * sizeof(float);
   if (is_f32)
-    hipLaunchKernelGGL(colsum_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, C, ld, partials);
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3(nblk), dim3(256), shm, (hipStream_t)stream, (const float*)x, rows, C, ld, partials);
   else
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, rows, C, ld, partials);
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nblk), dim3(256), shm, (hipStream_t)stream, (const bf16_t*)x, rows, C, ld, partials);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -55,6 +55,28 @@ def cpu_baseline(cfg, B, L, n_steps=5):
             "sample": "%d full train steps (dropout on) of the same B=%d, L=%d batch, fp32, %.2f s/step" % (n_steps, B, L, dt)}
 
 
+def hifi_cpu_baseline(cfg, B=8, T=384, runs=1):
+    """The oracle (CPU fp32 restatement of the reference generator) timed on this box's host cores."""
+    import os
+    from oracle import hifigan as ohifi
+    torch.set_num_threads(os.cpu_count() or 1)
+    from tts_king_amd.hifigan import Generator
+    from tts_king_amd.synthetic import make_mel
+    g = Generator(cfg.hifi)
+    g.reset_parameters(1234)
+    sd = ohifi.fold_weight_norm({k: v.detach().clone() for k, v in g.state_dict().items()})
+    mel = make_mel(B, T, seed=1234)
+    with torch.no_grad():
+        ohifi.generator(sd, cfg.hifi, mel[:1, :, :32])          # warm-up
+        t0 = time.perf_counter()
+        for _ in range(runs):
+            ohifi.generator(sd, cfg.hifi, mel)
+        dt = (time.perf_counter() - t0) / runs
+    audio_s = B * T * 256 / float(cfg.hifi.sampling_rate)
+    return {"rtf": dt / audio_s, "seconds_per_batch": dt, "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d run(s) of the same B=%d, T=%d batch, fp32" % (runs, B, T)}
+
+
 def gemm_roofline(enqueue, batch, steps=3):
     """Bracket every MFMA GEMM launch of `steps` eager train steps with HIP events on the launch stream."""
     from tts_king_amd import ops
@@ -192,6 +214,8 @@ def main():
                 rec["hifi_gan"] = None
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(cfg, B, L)
+            if rec.get("hifi_gan"):
+                rec["hifi_gan"]["cpu_baseline"] = hifi_cpu_baseline(cfg)
         print(json.dumps(rec))
     if world > 1:
         dist.barrier()

@@ -169,6 +169,20 @@ int ttsk_nct_to_ntc_bf16(const float* src, void* dst_bf16, int B, int C, int T, 
 /* (x * scale) truncated toward zero to int16 — reference: hifiapi.py:50-51 */
 int ttsk_to_int16(const float* src, int16_t* dst, int64_t n, float scale, void* stream);
 
+/* ------------------------------------------------------------------------------------ HiFi-GAN generator
+ * reference: hifi/models.py:146-210 (Generator), :12-95 (ResBlock1), hifi/vocoder/utils.py:24-37.
+ * The convolutions themselves run on ttsk_gemm (conv-A mode: dilation = tap_dshift, LeakyReLU fused into the
+ * operand staging, ConvTranspose1d as `stride` polyphase launches with the output-row remap).
+ * weight_norm_fold: w[r][:] = v[r][:] * g[r] / ||v[r][:]||  (remove_weight_norm, dim 0 — for ConvTranspose1d rows are
+ *                   IN-channels, hifi/models.py:203-210).
+ * pack_conv_weight: mode 0: Conv1d (Cout,Cin,k) fp32 -> (Cout,k,Cin) bf16; mode 1: ConvTranspose1d (Cin,Cout,k) fp32 ->
+ *                   (k,Cout,Cin) bf16.  (d0,d1,d2) = the source shape.
+ * avg3_bf16:        out = (a + b + c) * scale — the multi-receptive-field average, hifi/models.py:190-196.
+ */
+int ttsk_weight_norm_fold(const float* v, const float* g, float* w, int rows, int cols, void* stream);
+int ttsk_pack_conv_weight(const float* src, void* dst_bf16, int d0, int d1, int d2, int mode, void* stream);
+int ttsk_avg3_bf16(const void* a, const void* b, const void* c, void* out, int64_t n, float scale, void* stream);
+
 /* ------------------------------------------------------------------------------------- PostNet BatchNorm1d
  * reference: fs_two/transformer/Layers.py:133-143 — training statistics over ALL rows (PAD rows included),
  * eps 1e-5, momentum 0.1, running_var updated with the unbiased variance; tanh (all but the last layer) and

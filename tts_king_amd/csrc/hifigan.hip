@@ -1,0 +1,96 @@
+// hifigan.hip — HiFi-GAN V1 generator support kernels: weight-norm folding, weight repacking for the implicit-GEMM
+// conv kernels, and the MRF average.  reference: hifi/models.py:146-210 (Generator), :12-95 (ResBlock1).
+#include "common.h"
+
+namespace {
+
+// w[r][:] = v[r][:] * g[r] / ||v[r][:]||   — torch.nn.utils.remove_weight_norm with dim=0 (hifi/models.py:203-210):
+// the norm runs over every dim but 0; for ConvTranspose1d dim 0 is the IN-channel axis.  One workgroup per row.
+__global__ __launch_bounds__(256) void wn_fold_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                      float* __restrict__ w, int cols) {
+  __shared__ float part[4];
+  const int r = blockIdx.x;
+  const float* vr = v + (int64_t)r * cols;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) s += vr[c] * vr[c];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float norm = sqrtf(part[0] + part[1] + part[2] + part[3]);
+  const float sc = g[r] / norm;
+  float* wr = w + (int64_t)r * cols;
+  for (int c = threadIdx.x; c < cols; c += 256) wr[c] = vr[c] * sc;
+}
+
+// mode 0: Conv1d weight (Cout, Cin, k) fp32 -> (Cout, k, Cin) bf16   (input channels contiguous per tap)
+// mode 1: ConvTranspose1d weight (Cin, Cout, k) fp32 -> (k, Cout, Cin) bf16
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int d0,
+                                                          int d1, int d2, int mode, int64_t n) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    // i indexes dst
+    int64_t s;
+    if (mode == 0) {  // dst (d0, d2, d1)
+      const int ci = (int)(i % d1);
+      const int j = (int)((i / d1) % d2);
+      const int co = (int)(i / ((int64_t)d1 * d2));
+      s = ((int64_t)co * d1 + ci) * d2 + j;
+    } else {          // dst (d2, d1, d0)
+      const int ci = (int)(i % d0);
+      const int co = (int)((i / d0) % d1);
+      const int j = (int)(i / ((int64_t)d0 * d1));
+      s = ((int64_t)ci * d1 + co) * d2 + j;
+    }
+    dst[i] = f2bf(src[s]);
+  }
+}
+
+// out = (a + b + c) * scale, bf16, 8 elements per lane  — the MRF average (hifi/models.py:190-196)
+__global__ __launch_bounds__(256) void avg3_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b,
+                                                   const uint4* __restrict__ c, uint4* __restrict__ out, int64_t n8,
+                                                   float scale) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const uint4 va = a[i], vb = b[i], vc = c[i];
+    const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w}, wc[4] = {vc.x, vc.y, vc.z, vc.w};
+    unsigned o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = __uint_as_float(wa[e] << 16) + __uint_as_float(wb[e] << 16) + __uint_as_float(wc[e] << 16);
+      const float hi = __uint_as_float(wa[e] & 0xFFFF0000u) + __uint_as_float(wb[e] & 0xFFFF0000u) +
+                       __uint_as_float(wc[e] & 0xFFFF0000u);
+      o[e] = pack_bf2(lo * scale, hi * scale);
+    }
+    out[i] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+}  // namespace
+
+extern "C" int ttsk_weight_norm_fold(const float* v, const float* g, float* w, int rows, int cols, void* stream) {
+  TTSK_REQUIRE(v && g && w && rows > 0 && cols > 0, "ttsk_weight_norm_fold: bad arguments");
+  hipLaunchKernelGGL(wn_fold_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, v, g, w, cols);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_pack_conv_weight(const float* src, void* dst_bf16, int d0, int d1, int d2, int mode, void* stream) {
+  TTSK_REQUIRE(src && dst_bf16 && d0 > 0 && d1 > 0 && d2 > 0 && (mode == 0 || mode == 1), "ttsk_pack_conv_weight: bad arguments");
+  const int64_t n = (int64_t)d0 * d1 * d2;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst_bf16, d0, d1, d2,
+                     mode, n);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_avg3_bf16(const void* a, const void* b, const void* c, void* out, int64_t n, float scale, void* stream) {
+  TTSK_REQUIRE(a && b && c && out && n > 0 && (n & 7) == 0, "ttsk_avg3_bf16: n must be a positive multiple of 8");
+  TTSK_REQUIRE(((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)out)) & 15) == 0, "ttsk_avg3_bf16: 16-byte alignment");
+  const int64_t n8 = n / 8;
+  int blocks = (int)((n8 + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(avg3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b,
+                     (const uint4*)c, (uint4*)out, n8, scale);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}

@@ -1,0 +1,184 @@
+"""HiFi-GAN V1 generator inference on MI355X: the reference's `Generator(h)` surface (constructor, weight-normed
+`state_dict` keys, `remove_weight_norm()`, `forward((B,80,T)) -> (B,1,T*prod(upsample_rates))`) over hand-written
+gfx950 kernels.
+
+reference: hifi/models.py:146-210 (Generator), :12-95 (ResBlock1), :98-143 (ResBlock2), hifiapi.py:11-52.
+
+Activations are bf16 channels-last [B*len][C] (each conv is an implicit GEMM whose contraction index — the input
+channel — is contiguous in memory), accumulation is fp32, weights are folded (weight-norm removed), repacked tap-major
+and cast to bf16 once.  Forward only: the reference's generator is used for inference (hifiapi.py:32-33 `train`
+raises).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import bf16
+
+LRELU_SLOPE = 0.1          # reference: hifi/models.py:9
+
+
+def get_padding(kernel_size, dilation=1):
+    """reference: hifi/vocoder/utils.py:36-37."""
+    return int((kernel_size * dilation - dilation) / 2)
+
+
+class _WNConv(nn.Module):
+    """Parameter holder for one weight-normed Conv1d / ConvTranspose1d with the reference's key names:
+    `weight_g`, `weight_v`, `bias` before `remove_weight_norm()`, `weight`, `bias` after."""
+
+    def __init__(self, shape, n_bias):
+        super().__init__()
+        self.weight_g = nn.Parameter(torch.ones(shape[0], 1, 1), requires_grad=False)
+        self.weight_v = nn.Parameter(torch.zeros(shape), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(n_bias), requires_grad=False)
+
+    def fold(self):
+        if "weight_g" not in self._parameters:
+            return
+        g, v = self.weight_g, self.weight_v
+        if v.is_cuda:
+            w = ops.weight_norm_fold(v.data, g.data.view(-1))
+        else:   # folding before .to(device): plain tensor math on the host (load-time only, not the hot path)
+            w = v.data * (g.data / v.data.reshape(v.shape[0], -1).norm(dim=1).view(-1, 1, 1))
+        del self._parameters["weight_g"], self._parameters["weight_v"]
+        self.weight = nn.Parameter(w, requires_grad=False)
+
+    def folded_weight(self):
+        if "weight" in self._parameters:
+            return self.weight.data
+        if not self.weight_v.is_cuda:
+            raise ops.L.TtskError("HiFi-GAN generator needs its weights on a HIP device")
+        return ops.weight_norm_fold(self.weight_v.data, self.weight_g.data.view(-1))
+
+
+class _ResBlock(nn.Module):
+    """ResBlock1 (three (dilated, plain) conv pairs) or ResBlock2 (two dilated convs).
+    reference: hifi/models.py:12-95, :98-143."""
+
+    def __init__(self, channels, kernel_size, dilation, kind):
+        super().__init__()
+        self.kind, self.k, self.dilation = kind, kernel_size, tuple(dilation)
+        mk = lambda: _WNConv((channels, channels, kernel_size), channels)
+        if kind == "1":
+            self.convs1 = nn.ModuleList([mk() for _ in self.dilation])
+            self.convs2 = nn.ModuleList([mk() for _ in self.dilation])
+        else:
+            self.convs = nn.ModuleList([mk() for _ in self.dilation])
+
+    def all_convs(self):
+        return (list(self.convs1) + list(self.convs2)) if self.kind == "1" else list(self.convs)
+
+    def remove_weight_norm(self):
+        for c in self.all_convs():
+            c.fold()
+
+
+class Generator(nn.Module):
+    def __init__(self, h):
+        super().__init__()
+        self.h = h
+        self.num_kernels = len(h.resblock_kernel_sizes)
+        self.num_upsamples = len(h.upsample_rates)
+        c0 = h.upsample_initial_channel
+        self.conv_pre = _WNConv((c0, 80, 7), c0)                       # 80 is hard-coded in the reference (:152)
+        self.ups = nn.ModuleList()
+        for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
+            self.ups.append(_WNConv((c0 // (2 ** i), c0 // (2 ** (i + 1)), k), c0 // (2 ** (i + 1))))
+        self.resblocks = nn.ModuleList()
+        ch = c0
+        for i in range(self.num_upsamples):
+            ch = c0 // (2 ** (i + 1))
+            for k, d in zip(h.resblock_kernel_sizes, h.resblock_dilation_sizes):
+                self.resblocks.append(_ResBlock(ch, k, d, str(h.resblock)))
+        self.conv_post = _WNConv((1, ch, 7), 1)
+        self._packed = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------ reference surface
+    def remove_weight_norm(self):
+        """reference: hifi/models.py:203-210 — fold g*v/||v|| into `weight`; keys lose `_g/_v`."""
+        for l in self.ups:
+            l.fold()
+        for l in self.resblocks:
+            l.remove_weight_norm()
+        self.conv_pre.fold()
+        self.conv_post.fold()
+        self._packed = None
+
+    def reset_parameters(self, seed=1234):
+        """Seeded random init (weights_path: null): tts_king_amd.synthetic.seeded_fill statistics."""
+        from .synthetic import seeded_fill
+        sd = self.state_dict()
+        cpu = {k: torch.zeros(v.shape, dtype=v.dtype) for k, v in sd.items()}
+        seeded_fill(cpu, seed)
+        with torch.no_grad():
+            for k, v in sd.items():
+                v.copy_(cpu[k])
+        self._packed = None
+
+    def _all_convs(self):
+        out = [self.conv_pre] + list(self.ups)
+        for rb in self.resblocks:
+            out += rb.all_convs()
+        return out + [self.conv_post]
+
+    def _weights_key(self):
+        return tuple((id(p), p._version) for c in self._all_convs() for p in c._parameters.values())
+
+    def _prepare(self):
+        """bf16 tap-major copies of the folded weights, rebuilt when any parameter was written."""
+        key = self._weights_key()
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        pk = {}
+        pk["pre"] = (ops.pack_conv_weight(self.conv_pre.folded_weight()), self.conv_pre.bias.data)
+        pk["ups"] = [(ops.pack_conv_weight(u.folded_weight(), transposed=True), u.bias.data) for u in self.ups]
+        pk["rb"] = [[(ops.pack_conv_weight(c.folded_weight()), c.bias.data) for c in rb.all_convs()] for rb in self.resblocks]
+        wp = self.conv_post.folded_weight()                               # (1, C, 7)
+        pk["post"] = (ops.pack_conv_weight(wp), self.conv_post.bias.data)
+        self._packed, self._packed_key = pk, key
+        return pk
+
+    # ------------------------------------------------------------------ forward
+    def _resblock(self, rb, packed, x):
+        """reference: hifi/models.py:88-95 (ResBlock1) / :136-140 (ResBlock2); LeakyReLU(0.1) is applied while the
+        conv stages its input tile, the residual add happens in the conv epilogue."""
+        if rb.kind == "1":
+            n = len(rb.dilation)
+            for m, d in enumerate(rb.dilation):
+                w1, b1 = packed[m]
+                w2, b2 = packed[n + m]
+                t = ops.conv1d(x, w1, b1, dilation=d, flags=ops.LRELU_IN, in_slope=LRELU_SLOPE)
+                x = ops.conv1d(t, w2, b2, flags=ops.LRELU_IN, in_slope=LRELU_SLOPE, R=x)
+            return x
+        for m, d in enumerate(rb.dilation):
+            w, b = packed[m]
+            x = ops.conv1d(x, w, b, dilation=d, flags=ops.LRELU_IN, in_slope=LRELU_SLOPE, R=x)
+        return x
+
+    def forward(self, x):
+        """x (B, 80, T) mel on a HIP device -> (B, 1, T*prod(upsample_rates)) fp32.  reference: hifi/models.py:185-201."""
+        if not x.is_cuda:
+            raise ops.L.TtskError("HiFi-GAN Generator.forward needs a HIP device tensor (gpu: 'cuda:0'); there is no CPU path")
+        pk = self._prepare()
+        h = self.h
+        with torch.no_grad():
+            Bn, _, T = x.shape
+            a = ops.nct_to_ntc_bf16(x.float())                                            # (B, T, 80) bf16
+            a = ops.conv1d(a, pk["pre"][0], pk["pre"][1])                                 # conv_pre
+            for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
+                wu, bu = pk["ups"][i]
+                a = ops.conv_transpose1d(a, wu, bu, u, k, in_slope=LRELU_SLOPE)           # lrelu(0.1) -> ConvTranspose1d
+                outs = [self._resblock(self.resblocks[i * self.num_kernels + j], pk["rb"][i * self.num_kernels + j], a)
+                        for j in range(self.num_kernels)]
+                if self.num_kernels == 3:
+                    a = ops.avg3(outs[0], outs[1], outs[2], 1.0 / 3.0)                    # xs / num_kernels
+                else:
+                    raise NotImplementedError("MRF average is written for 3 resblock kernels per stage")
+            Bn, Tout, C = a.shape
+            wp, bp = pk["post"]
+            y = torch.empty(Bn * Tout, 1, dtype=torch.float32, device=a.device)
+            # F.leaky_relu default slope 0.01 (hifi/models.py:197) -> conv_post -> tanh
+            ops.conv1d(a, wp, bp, out=y.view(Bn, Tout, 1), flags=ops.LRELU_IN | ops.TANH, in_slope=0.01)
+        return y.view(Bn, 1, Tout)

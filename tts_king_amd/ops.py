@@ -470,3 +470,35 @@ def clip_adam_step(params, grads, m, v, shadow, state, partials, max_norm, beta1
     check(L.load().ttsk_clip_adam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(shadow), params.numel(), _ptr(state),
                                        _ptr(partials), max_norm, beta1, beta2, eps, int(zero_grad), _stream()),
           "ttsk_clip_adam_step")
+
+
+# ---------------------------------------------------------------------------------------------------- HiFi-GAN helpers
+
+def weight_norm_fold(v, g):
+    """w = g * v / ||v|| with the norm over every dim but 0 (reference: hifi/models.py:203-210)."""
+    _dev(v, g)
+    v = v.contiguous()
+    rows = v.shape[0]
+    w = torch.empty_like(v)
+    check(L.load().ttsk_weight_norm_fold(_ptr(v), _ptr(g.contiguous()), _ptr(w), rows, v.numel() // rows, _stream()),
+          "ttsk_weight_norm_fold")
+    return w
+
+
+def pack_conv_weight(w, transposed=False):
+    """Conv1d (Cout,Cin,k) fp32 -> (Cout,k,Cin) bf16, or ConvTranspose1d (Cin,Cout,k) fp32 -> (k,Cout,Cin) bf16."""
+    _dev(w)
+    d0, d1, d2 = w.shape
+    shape = (d2, d1, d0) if transposed else (d0, d2, d1)
+    out = torch.empty(shape, dtype=bf16, device=w.device)
+    check(L.load().ttsk_pack_conv_weight(_ptr(w.contiguous()), _ptr(out), d0, d1, d2, int(transposed), _stream()),
+          "ttsk_pack_conv_weight")
+    return out
+
+
+def avg3(a, b, c, scale, out=None):
+    _dev(a, b, c)
+    if out is None:
+        out = torch.empty_like(a)
+    check(L.load().ttsk_avg3_bf16(_ptr(a), _ptr(b), _ptr(c), _ptr(out), a.numel(), scale, _stream()), "ttsk_avg3_bf16")
+    return out

@@ -183,6 +183,15 @@ int ttsk_weight_norm_fold(const float* v, const float* g, float* w, int rows, in
 int ttsk_pack_conv_weight(const float* src, void* dst_bf16, int d0, int d1, int d2, int mode, void* stream);
 int ttsk_avg3_bf16(const void* a, const void* b, const void* c, void* out, int64_t n, float scale, void* stream);
 
+/* Fused ResBlock1 (hifi/models.py:88-95): all six convs of one block for C in {32,64}, K in {3,7,11}; x/out bf16
+ * channels-last (B, len, C); weights/biases in the order convs1[0], convs2[0], convs1[1], convs2[1], convs1[2],
+ * convs2[2], each weight packed (C, K, C) bf16 (ttsk_pack_conv_weight mode 0).  mode 0: out = y; 1: out += y;
+ * 2: out = (out + y) * scale  — the MRF sum / average over the three blocks of a stage (hifi/models.py:190-196). */
+int ttsk_hifi_resblock1(const void* x_bf16, void* out_bf16, const void* const* weights, const float* const* biases,
+                        const int32_t* dilations, int B, int len, int C, int K, int mode, float scale, float slope,
+                        void* stream);
+int ttsk_hifi_resblock1_supported(int C, int K);
+
 /* ------------------------------------------------------------------------------------- PostNet BatchNorm1d
  * reference: fs_two/transformer/Layers.py:133-143 — training statistics over ALL rows (PAD rows included),
  * eps 1e-5, momentum 0.1, running_var updated with the unbiased variance; tanh (all but the last layer) and

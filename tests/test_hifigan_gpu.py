@@ -113,3 +113,49 @@ def test_batch_independence_and_determinism(cfg):
     assert w1.shape == (8, 1, 98304) and float(w1.abs().max()) <= 1.0 and bool(torch.isfinite(w1).all())
     single = gen(mel[5:6])
     assert torch.equal(single, w1[5:6])
+
+
+@pytest.mark.parametrize("C,K,B,ln", [(32, 3, 2, 700), (32, 7, 1, 256), (32, 11, 2, 1000), (64, 3, 1, 130), (64, 7, 2, 515),
+                                      (64, 11, 3, 300), (32, 11, 1, 5), (64, 11, 1, 1)])
+def test_fused_resblock1_vs_oracle(C, K, B, ln):
+    """The fused six-conv ResBlock1 kernel against the oracle's res_block1 on the same bf16-rounded input and
+    weights: only fp32 summation order and the bf16 rounding of the two LDS-resident intermediates differ.
+    Lengths that are not tile multiples, shorter than the halo, and a single frame are covered; mode 1/2 = MRF sum."""
+    from tts_king_amd import ops
+    g = torch.Generator().manual_seed(C * K + ln)
+    bf = lambda t: t.to(torch.bfloat16)
+    x = bf(torch.randn(B, ln, C, generator=g))
+    ws = [bf(torch.randn(C, C, K, generator=g) * (C * K) ** -0.5) for _ in range(6)]
+    bs = [0.1 * torch.randn(C, generator=g) for _ in range(6)]
+    sd = {}
+    for m in range(3):
+        sd["r.convs1.%d.weight" % m], sd["r.convs1.%d.bias" % m] = ws[2 * m].float(), bs[2 * m]
+        sd["r.convs2.%d.weight" % m], sd["r.convs2.%d.bias" % m] = ws[2 * m + 1].float(), bs[2 * m + 1]
+    with torch.no_grad():
+        want = ohifi.res_block1(sd, "r.", x.float().transpose(1, 2), K, (1, 3, 5)).transpose(1, 2)
+    wk = [w.permute(0, 2, 1).contiguous().to(DEV) for w in ws]          # (Cout, K, Cin)
+    bd = [b.to(DEV) for b in bs]
+    out = torch.full((B, ln, C), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.hifi_resblock1(x.to(DEV), wk, bd, (1, 3, 5), out, mode=0)
+    got = out.float().cpu()
+    r = rel_rms(got, want)
+    print("C=%d K=%d len=%d rel-RMS %.3f%% max-abs %.4f" % (C, K, ln, 100 * r, float((got - want).abs().max())))
+    assert r <= 0.008 and float((got - want).abs().max()) <= 0.05 * float(want.abs().max())
+    # MRF accumulation modes: out2 = (out + y) / 3 computed in fp32 from the bf16 values, rounded once
+    out2 = out.clone()
+    ops.hifi_resblock1(x.to(DEV), wk, bd, (1, 3, 5), out2, mode=1)
+    assert torch.equal(out2.cpu(), (got + got).to(torch.bfloat16))
+    ops.hifi_resblock1(x.to(DEV), wk, bd, (1, 3, 5), out2, mode=2, scale=1.0 / 3.0)
+    assert torch.equal(out2.cpu(), (((got + got).to(torch.bfloat16).float() + got) * (1.0 / 3.0)).to(torch.bfloat16))
+
+
+def test_fused_and_unfused_generators_agree(cfg):
+    gen = build(cfg, 5)
+    mel = make_mel(2, 40, seed=9).to(DEV)
+    gen.fused = True
+    wf = gen(mel)
+    gen.fused = False
+    wu = gen(mel)
+    r = rel_rms(wf.cpu(), wu.cpu())
+    print("fused vs conv-by-conv generator: rel-RMS %.3f%%" % (100 * r))
+    assert r <= 0.01

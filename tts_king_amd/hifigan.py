@@ -94,6 +94,7 @@ class Generator(nn.Module):
         self.conv_post = _WNConv((1, ch, 7), 1)
         self._packed = None
         self._packed_key = None
+        self.fused = True            # fused ResBlock1 kernel where an instance exists (C in {32,64}); False = conv-by-conv
 
     # ------------------------------------------------------------------ reference surface
     def remove_weight_norm(self):
@@ -170,8 +171,20 @@ class Generator(nn.Module):
             for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
                 wu, bu = pk["ups"][i]
                 a = ops.conv_transpose1d(a, wu, bu, u, k, in_slope=LRELU_SLOPE)           # lrelu(0.1) -> ConvTranspose1d
-                outs = [self._resblock(self.resblocks[i * self.num_kernels + j], pk["rb"][i * self.num_kernels + j], a)
-                        for j in range(self.num_kernels)]
+                rbs = [self.resblocks[i * self.num_kernels + j] for j in range(self.num_kernels)]
+                if self.fused and all(rb.kind == "1" and ops.hifi_resblock1_supported(a.shape[2], rb.k) for rb in rbs):
+                    # fused path: one kernel per ResBlock (six convs), MRF sum/average folded into the copy-out
+                    nxt = torch.empty_like(a)
+                    for j, rb in enumerate(rbs):
+                        pr = pk["rb"][i * self.num_kernels + j]
+                        n = len(rb.dilation)
+                        order = [pr[m // 2 + (n if m % 2 else 0)] for m in range(2 * n)]     # c1_0, c2_0, c1_1, c2_1, ...
+                        mode = 0 if j == 0 else (2 if j == self.num_kernels - 1 else 1)
+                        ops.hifi_resblock1(a, [w for w, _ in order], [b for _, b in order], rb.dilation, nxt, mode=mode,
+                                           scale=1.0 / self.num_kernels, slope=LRELU_SLOPE)
+                    a = nxt
+                    continue
+                outs = [self._resblock(rb, pk["rb"][i * self.num_kernels + j], a) for j, rb in enumerate(rbs)]
                 if self.num_kernels == 3:
                     a = ops.avg3(outs[0], outs[1], outs[2], 1.0 / 3.0)                    # xs / num_kernels
                 else:

@@ -502,3 +502,22 @@ def avg3(a, b, c, scale, out=None):
         out = torch.empty_like(a)
     check(L.load().ttsk_avg3_bf16(_ptr(a), _ptr(b), _ptr(c), _ptr(out), a.numel(), scale, _stream()), "ttsk_avg3_bf16")
     return out
+
+
+def hifi_resblock1_supported(C_, K):
+    return bool(L.load().ttsk_hifi_resblock1_supported(C_, K))
+
+
+def hifi_resblock1(x, weights, biases, dilations, out, mode=0, scale=1.0, slope=0.1):
+    """Fused ResBlock1 (reference: hifi/models.py:88-95).  x/out (B, len, C) bf16; weights: six (C, K, C) bf16 tensors and
+    biases six fp32 (C,) in the order convs1[0], convs2[0], convs1[1], convs2[1], convs1[2], convs2[2].
+    mode 0: out = y, 1: out += y, 2: out = (out + y) * scale."""
+    _dev(x, out, *weights, *biases)
+    Bn, ln, Cn = x.shape
+    K = weights[0].shape[1]
+    wp = (C.c_void_p * 6)(*[w.data_ptr() for w in weights])
+    bp = (C.c_void_p * 6)(*[b.data_ptr() for b in biases])
+    dl = (C.c_int32 * 3)(*[int(d) for d in dilations])
+    check(L.load().ttsk_hifi_resblock1(_ptr(x), _ptr(out), C.cast(wp, C.c_void_p), C.cast(bp, C.c_void_p), C.cast(dl, C.c_void_p),
+                                       Bn, ln, Cn, K, mode, scale, slope, _stream()), "ttsk_hifi_resblock1")
+    return out

@@ -32,6 +32,16 @@ def fs2_flops_per_step(B, L, T):
     return 3.0 * fwd
 
 
+def host_threads():
+    """Threads for the CPU baseline: the cores this process may actually use (a 1-GPU box gives a 16-core share of a much
+    larger host; os.cpu_count() would oversubscribe it)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("TTSK_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(cfg, B, L, n_steps=5):
     """The oracle (CPU fp32 restatement of the reference step) timed on this box's host cores, same workload."""
     import copy
@@ -40,12 +50,15 @@ def cpu_baseline(cfg, B, L, n_steps=5):
     from tts_king_amd.synthetic import make_batch
     c = copy.deepcopy(cfg)
     c.train_config["optimizer"]["grad_acc_step"] = 1
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_threads())
     m = FastSpeech2(c.preprocess_config, c.model_config, 65, device="cpu", seed=1234)
     sd = {k: v.detach().clone().contiguous() for k, v in m.state_dict().items()}
     tr = ofs2.OracleTrainer(sd, c.model_config, c.train_config, 0)
     b = make_batch(B, L, seed=1234)
+    t0 = time.perf_counter()
     tr.train_step(b, 1)                                  # warm-up
+    warm = time.perf_counter() - t0
+    n_steps = max(1, min(n_steps, int(20.0 / max(warm, 1e-3))))      # bounded sample: ~20 s of CPU work
     t0 = time.perf_counter()
     for s in range(n_steps):
         tr.train_step(b, s + 2)
@@ -59,7 +72,7 @@ def hifi_cpu_baseline(cfg, B=8, T=384, runs=1):
     """The oracle (CPU fp32 restatement of the reference generator) timed on this box's host cores."""
     import os
     from oracle import hifigan as ohifi
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_threads())
     from tts_king_amd.hifigan import Generator
     from tts_king_amd.synthetic import make_mel
     g = Generator(cfg.hifi)

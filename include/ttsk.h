@@ -53,7 +53,8 @@ enum {
   TTSK_GEMM_LRELU_IN  = 1 << 7,  /* A := leaky_relu(A, in_slope) while staging (conv-A mode, HiFi-GAN)     */
   TTSK_GEMM_TANH      = 1 << 8,  /* v = tanh(v) last                                                       */
   TTSK_GEMM_ACCUM_C   = 1 << 9,  /* C_F32 only: C += v  (plain read-modify-write, one writer per element)   */
-  TTSK_GEMM_LRELU_OUT = 1 << 10  /* v = leaky_relu(v, out_slope) before the store                           */
+  TTSK_GEMM_LRELU_OUT = 1 << 10, /* v = leaky_relu(v, out_slope) before the store                           */
+  TTSK_GEMM_F16       = 1 << 11  /* 16-bit operands (A, B, C, C2, R, G) are IEEE fp16 instead of bf16           */
 };
 
 typedef struct ttsk_gemm_desc {
@@ -82,16 +83,20 @@ typedef struct ttsk_gemm_desc {
   /* output row remap (polyphase ConvTranspose1d): C row for A row (s, t) is s*out_seg + t*out_mul + out_add,
    * skipped when outside [0, out_seg).  out_mul == 0 means identity. */
   int32_t out_seg, out_mul, out_add;
-  /* split-K: `splits` > 1 writes fp32 partial slabs C + split*sCs (C_F32 required, no epilogue except alpha) */
-  int32_t splits;
-  int64_t sCs;
+  /* split-K: `splits` > 1 cuts the K chunks into `splits` ranges whose fp32 partial tiles go to `workspace`
+   * ([splits][nz][M][N] floats); a second kernel sums them in fixed order and applies the epilogue (deterministic). */
+  int32_t splits;      /* 0 = let the library choose (ttsk_gemm_plan) */
+  void* workspace;
+  int64_t workspace_bytes;
+  /* tile configuration: 0 = let the library choose, 1 = 128x128x64 (4 waves, register staging; required by LRELU_IN),
+   * 2 = 256x128x64 (8 waves, 3-stage LDS-DMA ring) */
+  int32_t kernel;
 } ttsk_gemm_desc;
 
 int ttsk_gemm(const ttsk_gemm_desc* d, void* stream);
+/* what ttsk_gemm will run for `d` (with d->kernel / d->splits as constraints when non-zero) and the workspace it needs */
+int ttsk_gemm_plan(const ttsk_gemm_desc* d, int32_t* kernel, int32_t* splits, int64_t* workspace_bytes);
 
-/* sum `n_slabs` fp32 slabs of `numel` elements (stride `slab_stride`) into dst; accumulate != 0: dst += sum */
-int ttsk_reduce_slabs(const float* slabs, int n_slabs, int64_t slab_stride, float* dst, int64_t numel,
-                      int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------ LengthRegulator
  * reference: fs_two/model/modules.py:220-252 (LengthRegulator.LR/expand) + fs_two/utils/tools.py:369-387 (pad)
@@ -122,7 +127,8 @@ int ttsk_layernorm_fwd(const void* y_bf16, const void* res_bf16, const float* ga
                        float eps, float p_pre, uint32_t site_pre, float p_post, uint32_t site_post, const uint64_t* rng,
                        const float* head_w, const float* head_b, float* head_out, void* stream);
 int ttsk_layernorm_bwd_nblocks(int rows);
-/* partials: [nblocks][3*D] = dgamma | dbeta | dbias(sum of dy), or [nblocks][4*D + 1] with the head (| dhead_w | dhead_b).
+/* partials: [nblocks][3*D] = dbias(sum of dy) | dgamma | dbeta, or [nblocks][4*D + 1] with the head (| dhead_w | dhead_b)
+ * — the order in which these parameters sit in the flat gradient buffer, so one ttsk_colsum_finalize call lands them all.
  * dz = grad wrt the LN input (bf16; times (z > 0) when relu_in); dy = dz through the pre-dropout mask (only if p_pre > 0). */
 int ttsk_layernorm_bwd(const void* dout_bf16, const float* dhead, const float* head_w, const void* z_bf16, const float* mean,
                        const float* rstd, const float* gamma, const float* beta, const int64_t* lens, int seg_len, int rows,
@@ -165,29 +171,31 @@ int ttsk_scatter_sum(const void* dx_bf16, const void* idx, int idx_is_i64, int i
 
 /* ------------------------------------------------------------------------------------------------ conversions */
 int ttsk_cast_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
-int ttsk_nct_to_ntc_bf16(const float* src, void* dst_bf16, int B, int C, int T, void* stream);
+int ttsk_nct_to_ntc(const float* src, void* dst16, int f16, int B, int C, int T, void* stream);  /* f16: 0 = bf16, 1 = fp16 */
 /* (x * scale) truncated toward zero to int16 — reference: hifiapi.py:50-51 */
 int ttsk_to_int16(const float* src, int16_t* dst, int64_t n, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------ HiFi-GAN generator
  * reference: hifi/models.py:146-210 (Generator), :12-95 (ResBlock1), hifi/vocoder/utils.py:24-37.
- * The convolutions themselves run on ttsk_gemm (conv-A mode: dilation = tap_dshift, LeakyReLU fused into the
+ * 16-bit tensors of this family are bf16 (f16 = 0) or IEEE fp16 (f16 = 1; what hifigan.py uses: the generator is
+ * inference-only, fp16 has 3 more mantissa bits than bf16 at the same MFMA rate and its activations stay far inside
+ * fp16's range).  The convolutions themselves run on ttsk_gemm (conv-A mode: dilation = tap_dshift, LeakyReLU fused into the
  * operand staging, ConvTranspose1d as `stride` polyphase launches with the output-row remap).
  * weight_norm_fold: w[r][:] = v[r][:] * g[r] / ||v[r][:]||  (remove_weight_norm, dim 0 — for ConvTranspose1d rows are
  *                   IN-channels, hifi/models.py:203-210).
  * pack_conv_weight: mode 0: Conv1d (Cout,Cin,k) fp32 -> (Cout,k,Cin) bf16; mode 1: ConvTranspose1d (Cin,Cout,k) fp32 ->
  *                   (k,Cout,Cin) bf16.  (d0,d1,d2) = the source shape.
- * avg3_bf16:        out = (a + b + c) * scale — the multi-receptive-field average, hifi/models.py:190-196.
+ * avg3:             out = (a + b + c) * scale — the multi-receptive-field average, hifi/models.py:190-196.
  */
 int ttsk_weight_norm_fold(const float* v, const float* g, float* w, int rows, int cols, void* stream);
-int ttsk_pack_conv_weight(const float* src, void* dst_bf16, int d0, int d1, int d2, int mode, void* stream);
-int ttsk_avg3_bf16(const void* a, const void* b, const void* c, void* out, int64_t n, float scale, void* stream);
+int ttsk_pack_conv_weight(const float* src, void* dst16, int f16, int d0, int d1, int d2, int mode, void* stream);
+int ttsk_avg3(const void* a, const void* b, const void* c, void* out, int f16, int64_t n, float scale, void* stream);
 
 /* Fused ResBlock1 (hifi/models.py:88-95): all six convs of one block for C in {32,64}, K in {3,7,11}; x/out bf16
  * channels-last (B, len, C); weights/biases in the order convs1[0], convs2[0], convs1[1], convs2[1], convs1[2],
  * convs2[2], each weight packed (C, K, C) bf16 (ttsk_pack_conv_weight mode 0).  mode 0: out = y; 1: out += y;
  * 2: out = (out + y) * scale  — the MRF sum / average over the three blocks of a stage (hifi/models.py:190-196). */
-int ttsk_hifi_resblock1(const void* x_bf16, void* out_bf16, const void* const* weights, const float* const* biases,
+int ttsk_hifi_resblock1(const void* x16, void* out16, int f16, const void* const* weights, const float* const* biases,
                         const int32_t* dilations, int B, int len, int C, int K, int mode, float scale, float slope,
                         void* stream);
 int ttsk_hifi_resblock1_supported(int C, int K);

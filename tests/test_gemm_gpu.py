@@ -155,3 +155,121 @@ def test_conv_transpose_polyphase(Cin, Cout, k, s, T, ints):
     out = ops.conv_transpose1d(x.to(DEV), wp, b.to(DEV), s, k, in_slope=0.0 if ints else 0.1)
     assert out.shape == (Bsz, T * s, Cout)
     check(out, bf(ref.float()).double() if ints else ref, Cin * k // s, exact=ints)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("splits", [1, 3, 16])
+def test_split_k_with_fused_epilogue(splits, dtype):
+    """Split-K through the workspace: the reducer applies bias + residual + ReLU gate + second output exactly like the
+    single-pass epilogue (conv taps included), for bf16 and fp16 operands."""
+    from tts_king_amd import ops
+    Bsz, T, Cin, Cout, k = 2, 96, 1024, 256, 9
+    x = rnd(Bsz, T, Cin, seed=30).to(dtype)
+    w = (rnd(Cout, Cin, k, seed=31) * (Cin * k) ** -0.5).to(dtype)
+    b = rnd(Cout, seed=32)
+    r = rnd(Bsz, T, Cout, seed=33).to(dtype)
+    ref = torch.relu(F.conv1d(x.double().transpose(1, 2), w.double(), b.double(), padding=4).transpose(1, 2) + r.double())
+    wk = w.permute(0, 2, 1).contiguous().to(DEV)
+    out = torch.empty(Bsz, T, Cout, dtype=torch.float32, device=DEV)
+    c2 = torch.empty(Bsz, T, Cout, dtype=dtype, device=DEV)
+    ops.gemm(x.to(DEV), wk, out, Bsz * T, Cout, Cin, Cin, k * Cin, Cout, flags=ops.RELU, bias=b.to(DEV), R=r.to(DEV), ldr=Cout,
+             C2=c2, taps=k, seg_len=T, tap_shift0=-4, tap_dshift=1, b_tap_stride=Cin, splits=splits)
+    check(out, ref, Cin * k, out_bf16=False)
+    assert float((c2.float().cpu() - out.cpu()).abs().max()) <= float(ref.abs().max()) * 2 ** -8
+
+
+def test_plan_fills_the_chip():
+    """ttsk_gemm_plan: small problems are split along K, LRELU_IN forces the register-staged kernel."""
+    from tts_king_amd import ops
+    from tts_king_amd.lib import GemmDesc
+    def mk(M, N, K, taps=0, flags=0, nz2=1):
+        d = GemmDesc()
+        d.A = d.B = d.C = 256
+        d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.taps, d.flags, d.nz1, d.nz2 = M, N, K, K, K, N, taps, flags, 1, nz2
+        d.seg_len = M
+        return d
+    k, sp, ws = ops.plan(mk(1024, 256, 1024, 9))
+    assert sp >= 4 and ws == sp * 1024 * 256 * 4
+    k, sp, ws = ops.plan(mk(196608, 128, 128, 11, flags=ops.LRELU_IN))
+    assert k == 1 and sp == 1 and ws == 0
+    k, sp, ws = ops.plan(mk(196608, 128, 128, 11))
+    assert sp == 1
+
+
+# ---- the 256x128 LDS-DMA kernel (kernel=2) on every operand layout, with tails in M, N and K
+@pytest.mark.parametrize("ints", [True, False])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 200, 264), (1024, 768, 256), (77, 80, 256), (513, 129, 1000)])
+def test_k2_nt_bias_relu(M, N, K, ints):
+    from tts_king_amd import ops
+    a, w, b = bf(rnd(M, K, seed=1, ints=ints)), bf(rnd(N, K, seed=2, ints=ints)), rnd(N, seed=3, ints=ints)
+    ref = torch.relu(a.double() @ w.double().t() + b.double())
+    out32 = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV), flags=ops.RELU, out_dtype=torch.float32, kernel=2, splits=1)
+    check(out32, ref, K, exact=ints, out_bf16=False)
+    out16 = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV), flags=ops.RELU, kernel=2)
+    check(out16, bf(ref.float()).double() if ints else ref, K, exact=ints)
+
+
+@pytest.mark.parametrize("ints", [True, False])
+@pytest.mark.parametrize("M,N,K", [(423, 128, 423), (200, 256, 768), (600, 80, 64)])
+def test_k2_b_transposed(M, N, K, ints):
+    from tts_king_amd import ops
+    Kp = (K + 7) // 8 * 8
+    a = torch.zeros(M, Kp)
+    a[:, :K] = rnd(M, K, seed=5, ints=ints)
+    a, b = bf(a), bf(rnd(K, N, seed=6, ints=ints))
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(a.to(DEV), b.to(DEV), out, M, N, K, Kp, N, N, flags=ops.B_TR, kernel=2, splits=1)
+    check(out, a[:, :K].double() @ b.double(), K, exact=ints, out_bf16=False)
+
+
+@pytest.mark.parametrize("ints", [True, False])
+@pytest.mark.parametrize("M,N,K,splits", [(256, 256, 1000, 1), (768, 256, 6768, 5), (423, 128, 423, 1), (80, 512, 300, 2), (1024, 256, 2000, 0)])
+def test_k2_both_transposed(M, N, K, splits, ints):
+    from tts_king_amd import ops
+    Mp = (M + 7) // 8 * 8
+    a = torch.zeros(K, Mp)
+    a[:, :M] = rnd(K, M, seed=7, ints=ints)
+    a, b = bf(a), bf(rnd(K, N, seed=8, ints=ints))
+    ref = a[:, :M].double().t() @ b.double()
+    out = torch.ones(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(a.to(DEV), b.to(DEV), out, M, N, K, Mp, N, N, flags=ops.A_TR | ops.B_TR | ops.ACCUM_C, kernel=2, splits=splits)
+    check(out, ref + 1, K, exact=ints, out_bf16=False)
+
+
+@pytest.mark.parametrize("ints", [True, False])
+@pytest.mark.parametrize("Bsz,T,Cin,Cout,k,dil", [(3, 50, 256, 1024, 9, 1), (2, 423, 80, 512, 5, 1), (2, 131, 128, 128, 7, 3),
+                                                  (2, 300, 256, 256, 11, 5), (2, 40, 1024, 256, 1, 1)])
+def test_k2_conv1d_fwd_dx_dw(Bsz, T, Cin, Cout, k, dil, ints):
+    from tts_king_amd import ops
+    x = bf(rnd(Bsz, T, Cin, seed=9, ints=ints))
+    w = bf(rnd(Cout, Cin, k, seed=10, ints=ints) * (1.0 if ints else (Cin * k) ** -0.5))
+    b = rnd(Cout, seed=11, ints=ints)
+    dy = bf(rnd(Bsz, T, Cout, seed=12, ints=ints))
+    pad = dil * (k - 1) // 2
+    xd = x.double().transpose(1, 2).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    y = F.conv1d(xd, wd, b.double(), dilation=dil, padding=pad)
+    y.backward(dy.double().transpose(1, 2))
+    wk = w.permute(0, 2, 1).contiguous().to(DEV)
+    out = ops.conv1d(x.to(DEV), wk, b.to(DEV), dilation=dil, out_dtype=torch.float32, kernel=2)
+    check(out, y.detach().transpose(1, 2), Cin * k, exact=ints, out_bf16=False)
+    dx = torch.empty(Bsz, T, Cin, dtype=torch.float32, device=DEV)
+    ops.conv1d_dx(dy.to(DEV), wk, dilation=dil, out=dx, kernel=2)
+    check(dx, xd.grad.transpose(1, 2), Cout * k, exact=ints, out_bf16=False)
+    dw = torch.zeros(Cout, k, Cin, dtype=torch.float32, device=DEV)
+    ops.conv1d_dw(dy.to(DEV), x.to(DEV), dw, dilation=dil, k=k, accumulate=True, kernel=2)
+    check(dw, wd.grad.permute(0, 2, 1), Bsz * T, exact=ints, out_bf16=False)
+
+
+def test_k2_fp16_and_polyphase():
+    from tts_king_amd import ops
+    Cin, Cout, k, s, T, Bsz = 256, 128, 16, 8, 70, 2
+    x = rnd(Bsz, T, Cin, seed=18).half()
+    w = (rnd(Cin, Cout, k, seed=19) * (Cin * k / s) ** -0.5).half()
+    b = rnd(Cout, seed=20)
+    ref = F.conv_transpose1d(x.double().transpose(1, 2), w.double(), b.double(), stride=s, padding=(k - s) // 2).transpose(1, 2)
+    wp = w.permute(2, 1, 0).contiguous().to(DEV)
+    out = ops.conv_transpose1d(x.to(DEV), wp, b.to(DEV), s, k, kernel=2)
+    assert out.dtype == torch.float16
+    err = float((out.float().cpu().double() - ref).abs().max())
+    assert err <= 2e-6 * (Cin * k // s) ** 0.5 * float(ref.abs().max() + 1) + float(ref.abs().max()) * 2 ** -10, err

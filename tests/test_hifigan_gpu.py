@@ -2,10 +2,12 @@
 hifi_b2_t32.npz) and (b) the oracle on the same inputs, through the reference's surface (weight-normed
 state_dict -> remove_weight_norm -> forward; HIFIapi.generate -> int16).
 
-Stated tolerance (bf16 activations/weights, fp32 accumulate, vs the reference's fp32; the reference itself under
-bf16 autocast measured rel-RMS 0.35 %): waveform rel-RMS <= 1 %, max-abs <= 0.02 of full
-scale; int16 samples within 1 % of full scale of the reference's; weight-norm folding fp32-exact (rtol 1e-5);
-the int16 cast of an identical float input: bit-exact."""
+Stated tolerance (fp16 activations/weights — the generator is inference-only, so the product path stores fp16, which
+has 3 more mantissa bits than bf16 at the same MFMA rate — fp32 accumulate, vs the reference's fp32): waveform
+rel-RMS <= 0.5 %, max-abs <= 0.01 of full scale; int16 samples within 0.5 % of full scale of the reference's;
+weight-norm folding fp32-exact (rtol 1e-5 per element); the int16 cast of an identical float input: bit-exact.
+(With bf16 storage the same path measures 0.7-1.1 % rel-RMS: 0.58 % from the weights' and 0.58 % from the MFMA
+operands' 8-bit mantissas alone — `test_bf16_storage_variant` keeps that variant under a 1.5 % bar.)"""
 import copy
 import os
 
@@ -49,7 +51,8 @@ def test_state_dict_keys_and_fold(cfg):
         if name.startswith("fold/"):
             np.testing.assert_allclose(sd[name[5:]].cpu().reshape(-1)[:64].numpy(), g[name], rtol=1e-5, atol=1e-7)
         if name.startswith("foldnorm/"):
-            np.testing.assert_allclose(float(sd[name[9:]].double().norm()), float(g[name]), rtol=1e-5)
+            # the golden norm itself was accumulated in fp32 by torch (3e-5 off the fp64 value for the largest tensor)
+            np.testing.assert_allclose(float(sd[name[9:]].double().norm()), float(g[name]), rtol=1e-4)
 
 
 @pytest.mark.parametrize("fold_on_device", [True, False])
@@ -62,7 +65,18 @@ def test_waveform_vs_reference_golden(cfg, fold_on_device):
     assert wav.shape == (2, 1, 8192) and wav.dtype == torch.float32
     r, a = rel_rms(wav.cpu(), g["wav"]), float((wav.cpu() - torch.from_numpy(g["wav"])).abs().max())
     print("waveform vs reference: rel-RMS %.3f%%  max-abs %.5f (rms of the reference %.4f)" % (100 * r, a, float(np.sqrt((g["wav"] ** 2).mean()))))
-    assert r <= 0.01 and a <= 0.02
+    assert r <= 0.005 and a <= 0.01
+
+
+def test_bf16_storage_variant(cfg):
+    from tts_king_amd.ops import bf16
+    g = np.load(os.path.join(GOLDEN, "hifi_b2_t32.npz"))
+    gen = build(cfg, int(g["weight_seed"]))
+    gen.act_dtype = bf16
+    wav = gen(make_mel(int(g["B"]), int(g["T"]), seed=int(g["seed"])).to(DEV)).cpu()
+    r = rel_rms(wav, g["wav"])
+    print("bf16 storage variant vs reference: rel-RMS %.3f%%" % (100 * r))
+    assert r <= 0.015
 
 
 def test_hifiapi_generate_int16(cfg):
@@ -75,7 +89,7 @@ def test_hifiapi_generate_int16(cfg):
     mel = make_mel(int(g["B"]), int(g["T"]), seed=int(g["seed"]))
     i16 = api.generate(mel)
     assert i16.dtype == np.int16 and i16.shape == (2, 1, 8192)
-    assert np.abs(i16.astype(np.int32) - g["int16"].astype(np.int32)).max() <= 328          # 1 % of full scale
+    assert np.abs(i16.astype(np.int32) - g["int16"].astype(np.int32)).max() <= 164          # 0.5 % of full scale
     # the cast itself is exact: same float input -> same int16 as numpy astype (truncation toward zero)
     wav = api(mel)
     assert np.array_equal(ohifi.to_int16(wav.cpu(), c.hifi.MAX_WAV_VALUE), api.generate(mel))
@@ -99,7 +113,7 @@ def test_waveform_vs_oracle_shapes(cfg, B, T):
     assert got.shape == want.shape == (B, 1, 256 * T)
     r = rel_rms(got, want)
     print("B=%d T=%d rel-RMS %.3f%% max-abs %.5f" % (B, T, 100 * r, float((got - want).abs().max())))
-    assert r <= 0.01 and float((got - want).abs().max()) <= 0.02
+    assert r <= 0.005 and float((got - want).abs().max()) <= 0.01
 
 
 def test_batch_independence_and_determinism(cfg):
@@ -112,18 +126,20 @@ def test_batch_independence_and_determinism(cfg):
     assert torch.equal(w1, w2)
     assert w1.shape == (8, 1, 98304) and float(w1.abs().max()) <= 1.0 and bool(torch.isfinite(w1).all())
     single = gen(mel[5:6])
-    assert torch.equal(single, w1[5:6])
+    # same utterance alone: the split-K plan may differ with the row count, so only fp32 summation order changes
+    assert rel_rms(single.cpu(), w1[5:6].cpu()) <= 1e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("C,K,B,ln", [(32, 3, 2, 700), (32, 7, 1, 256), (32, 11, 2, 1000), (64, 3, 1, 130), (64, 7, 2, 515),
                                       (64, 11, 3, 300), (32, 11, 1, 5), (64, 11, 1, 1)])
-def test_fused_resblock1_vs_oracle(C, K, B, ln):
+def test_fused_resblock1_vs_oracle(C, K, B, ln, dtype):
     """The fused six-conv ResBlock1 kernel against the oracle's res_block1 on the same bf16-rounded input and
     weights: only fp32 summation order and the bf16 rounding of the two LDS-resident intermediates differ.
     Lengths that are not tile multiples, shorter than the halo, and a single frame are covered; mode 1/2 = MRF sum."""
     from tts_king_amd import ops
     g = torch.Generator().manual_seed(C * K + ln)
-    bf = lambda t: t.to(torch.bfloat16)
+    bf = lambda t: t.to(dtype)
     x = bf(torch.randn(B, ln, C, generator=g))
     ws = [bf(torch.randn(C, C, K, generator=g) * (C * K) ** -0.5) for _ in range(6)]
     bs = [0.1 * torch.randn(C, generator=g) for _ in range(6)]
@@ -135,18 +151,19 @@ def test_fused_resblock1_vs_oracle(C, K, B, ln):
         want = ohifi.res_block1(sd, "r.", x.float().transpose(1, 2), K, (1, 3, 5)).transpose(1, 2)
     wk = [w.permute(0, 2, 1).contiguous().to(DEV) for w in ws]          # (Cout, K, Cin)
     bd = [b.to(DEV) for b in bs]
-    out = torch.full((B, ln, C), 7.0, dtype=torch.bfloat16, device=DEV)
+    out = torch.full((B, ln, C), 7.0, dtype=dtype, device=DEV)
     ops.hifi_resblock1(x.to(DEV), wk, bd, (1, 3, 5), out, mode=0)
     got = out.float().cpu()
     r = rel_rms(got, want)
     print("C=%d K=%d len=%d rel-RMS %.3f%% max-abs %.4f" % (C, K, ln, 100 * r, float((got - want).abs().max())))
-    assert r <= 0.008 and float((got - want).abs().max()) <= 0.05 * float(want.abs().max())
+    tol = 0.008 if dtype == torch.bfloat16 else 0.001
+    assert r <= tol and float((got - want).abs().max()) <= 6 * tol * float(want.abs().max())
     # MRF accumulation modes: out2 = (out + y) / 3 computed in fp32 from the bf16 values, rounded once
     out2 = out.clone()
     ops.hifi_resblock1(x.to(DEV), wk, bd, (1, 3, 5), out2, mode=1)
-    assert torch.equal(out2.cpu(), (got + got).to(torch.bfloat16))
+    assert torch.equal(out2.cpu(), (got + got).to(dtype))
     ops.hifi_resblock1(x.to(DEV), wk, bd, (1, 3, 5), out2, mode=2, scale=1.0 / 3.0)
-    assert torch.equal(out2.cpu(), (((got + got).to(torch.bfloat16).float() + got) * (1.0 / 3.0)).to(torch.bfloat16))
+    assert torch.equal(out2.cpu(), (((got + got).to(dtype).float() + got) * (1.0 / 3.0)).to(dtype))
 
 
 def test_fused_and_unfused_generators_agree(cfg):
@@ -158,4 +175,4 @@ def test_fused_and_unfused_generators_agree(cfg):
     wu = gen(mel)
     r = rel_rms(wf.cpu(), wu.cpu())
     print("fused vs conv-by-conv generator: rel-RMS %.3f%%" % (100 * r))
-    assert r <= 0.01
+    assert r <= 0.002

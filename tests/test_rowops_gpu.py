@@ -56,9 +56,9 @@ def test_layernorm_residual_mask_fwd_bwd(rows_seg):
     assert dy is dz
     close_bf16(dz, zf.grad, extra=1e-3)
     sums = partials.sum(0).cpu()
-    close_f32(sums[:D], g2.grad, rtol=2e-3, atol=2e-2)
-    close_f32(sums[D:2 * D], b2.grad, rtol=2e-3, atol=2e-2)
-    close_f32(sums[2 * D:], zf.grad.to(BF).float().sum(0), rtol=2e-2, atol=0.1)
+    close_f32(sums[D:2 * D], g2.grad, rtol=2e-3, atol=2e-2)             # layout: dbias | dgamma | dbeta
+    close_f32(sums[2 * D:3 * D], b2.grad, rtol=2e-3, atol=2e-2)
+    close_f32(sums[:D], zf.grad.to(BF).float().sum(0), rtol=2e-2, atol=0.1)
 
 
 def test_layernorm_predictor_tail_head_relu():
@@ -85,8 +85,8 @@ def test_layernorm_predictor_tail_head_relu():
     want = hf.grad * (h.float() > 0)
     close_bf16(dz, want, extra=1e-3)
     sums = partials.sum(0).cpu()
-    close_f32(sums[:D], g2.grad, rtol=2e-3, atol=2e-2)
-    close_f32(sums[D:2 * D], b2.grad, rtol=2e-3, atol=2e-2)
+    close_f32(sums[D:2 * D], g2.grad, rtol=2e-3, atol=2e-2)
+    close_f32(sums[2 * D:3 * D], b2.grad, rtol=2e-3, atol=2e-2)
     close_f32(sums[3 * D:4 * D], w2.grad, rtol=2e-3, atol=2e-2)
     close_f32(sums[4 * D:], bb2.grad, rtol=1e-3, atol=1e-3)
 

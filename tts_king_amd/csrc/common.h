@@ -30,6 +30,48 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// 16-bit element codecs: bf16 (FS2 training) or IEEE fp16 (HiFi-GAN inference: 3 more mantissa bits at the same MFMA rate)
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+template <bool F16> __device__ __forceinline__ void unpack2(unsigned w, float& lo, float& hi) {
+  if constexpr (F16) {
+    const half2v h = __builtin_bit_cast(half2v, w);
+    lo = (float)h[0]; hi = (float)h[1];
+  } else {
+    lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xFFFF0000u);
+  }
+}
+template <bool F16> __device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  if constexpr (F16) {
+    half2v h; h[0] = (_Float16)lo; h[1] = (_Float16)hi;      // v_cvt_f16_f32: round to nearest even
+    return __builtin_bit_cast(unsigned, h);
+  } else {
+    return pack_bf2(lo, hi);
+  }
+}
+template <bool F16> __device__ __forceinline__ float unpack1(bf16_t v) {
+  if constexpr (F16) return (float)__builtin_bit_cast(_Float16, v);
+  else return bf2f(v);
+}
+template <bool F16> __device__ __forceinline__ bf16_t pack1(float f) {
+  if constexpr (F16) return __builtin_bit_cast(bf16_t, (_Float16)f);
+  else return f2bf(f);
+}
+template <bool F16> __device__ __forceinline__ unsigned lrelu2(unsigned w, float sl) {
+  float lo, hi;
+  unpack2<F16>(w, lo, hi);
+  lo = lo > 0.f ? lo : lo * sl;
+  hi = hi > 0.f ? hi : hi * sl;
+  return pack2<F16>(lo, hi);
+}
+template <bool F16> __device__ __forceinline__ uint4 lrelu8(uint4 v, float sl) {
+  return make_uint4(lrelu2<F16>(v.x, sl), lrelu2<F16>(v.y, sl), lrelu2<F16>(v.z, sl), lrelu2<F16>(v.w, sl));
+}
+template <bool F16> __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // Philox4x32-10 counter RNG: dropout masks are regenerated in backward from (seed, site, element index),
 // never stored (reference dropout sites: SubLayers.py:62,99; modules.py:286,298; Layers.py:137-141).
 struct Philox {

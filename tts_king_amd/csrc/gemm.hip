@@ -9,7 +9,7 @@
 // Conv1d is an implicit GEMM: the K loop walks (tap, channel-chunk) and a tap only shifts the A row index
 // (channels-last activations), with zero fill outside the utterance.  The epilogue goes through LDS so that
 // C (and the residual / gate operands) move as full 16-byte rows.
-#include "common.h"
+#include "gemm_common.h"
 
 namespace {
 
@@ -19,30 +19,10 @@ constexpr int STAGE_BYTES = (BM * BK + BN * BK) * 2;     // 32 KiB
 constexpr int CS_LD = 132;                               // fp32 epilogue tile leading dim (floats)
 constexpr int SMEM_BYTES = BM * CS_LD * 4;               // 67,584 B >= 2 stages (65,536 B)
 
-struct Args {
-  ttsk_gemm_desc d;
-  int tiles_m, tiles_n, kchunks, chunks_per_split;
-};
+typedef GemmArgs Args;
 
-__device__ __forceinline__ unsigned lrelu2(unsigned w, float sl) {
-  float lo = __uint_as_float(w << 16), hi = __uint_as_float(w & 0xFFFF0000u);
-  lo = lo > 0.f ? lo : lo * sl;
-  hi = hi > 0.f ? hi : hi * sl;
-  return pack_bf2(lo, hi);
-}
-__device__ __forceinline__ uint4 lrelu8(uint4 v, float sl) {
-  return make_uint4(lrelu2(v.x, sl), lrelu2(v.y, sl), lrelu2(v.z, sl), lrelu2(v.w, sl));
-}
-__device__ __forceinline__ void add_bf8(float v[8], uint4 r) {
-  v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xFFFF0000u);
-  v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xFFFF0000u);
-  v[4] += __uint_as_float(r.z << 16); v[5] += __uint_as_float(r.z & 0xFFFF0000u);
-  v[6] += __uint_as_float(r.w << 16); v[7] += __uint_as_float(r.w & 0xFFFF0000u);
-}
 
-__device__ __forceinline__ int tr_sw(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
-
-template <bool ATR, bool BTR>
+template <bool ATR, bool BTR, bool F16>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
   const ttsk_gemm_desc& d = g.d;
@@ -157,7 +137,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   auto store_tile = [&](int buf) __attribute__((always_inline)) {
     unsigned char* sa = smem + buf * STAGE_BYTES;
     unsigned char* sb = sa + BM * BK * 2;
-    if (lrelu_in && !ATR) { ra0 = lrelu8(ra0, in_slope); ra1 = lrelu8(ra1, in_slope); ra2 = lrelu8(ra2, in_slope); ra3 = lrelu8(ra3, in_slope); }
+    if (lrelu_in && !ATR) { ra0 = lrelu8<F16>(ra0, in_slope); ra1 = lrelu8<F16>(ra1, in_slope); ra2 = lrelu8<F16>(ra2, in_slope); ra3 = lrelu8<F16>(ra3, in_slope); }
 #define TTSK_ST(i, RA, RB)                                                                                        \
     {                                                                                                             \
       if (!ATR) { const int row = nrow + 32 * i; *(uint4*)(sa + row * 128 + ((nslot ^ (row & 7)) << 4)) = RA; }     \
@@ -218,7 +198,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
     }
   };
 
@@ -246,29 +226,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
         cs[(wm * 64 + i * 16 + lg * 4 + r) * CS_LD + wn * 64 + j * 16 + l15] = acc[i][j][r];
   __syncthreads();
 
-  const int flags = d.flags;
-  const bool c32 = flags & TTSK_GEMM_C_F32;
-  const int64_t coff = z1 * d.sC1 + z2 * d.sC2 + (d.splits > 1 ? split * d.sCs : 0);
+  const int64_t coff = z1 * d.sC1 + z2 * d.sC2;
   const int64_t roff = z1 * d.sR1 + z2 * d.sR2;
   const int cg = tid & 15;
   const int gn = n0 + cg * 8;
   if (gn >= N) return;
   const int nvalid = (N - gn) < 8 ? (N - gn) : 8;
+  if (d.splits > 1) {
+    // split-K: raw fp32 partial sums into the workspace slab [split][z][M][N]; the reducer applies the epilogue
+    float* ws = (float*)d.workspace + ((int64_t)split * gridDim.y + z) * ((int64_t)M * N);
+    for (int p = 0; p < 8; ++p) {
+      const int row = p * 16 + (tid >> 4);
+      const int gm = m0 + row;
+      if (gm >= M) continue;
+      float* wp = ws + (int64_t)gm * N + gn;
+      const f32x4 lo = *(const f32x4*)(cs + row * CS_LD + cg * 8);
+      const f32x4 hi = *(const f32x4*)(cs + row * CS_LD + cg * 8 + 4);
+      if (nvalid == 8 && (N & 3) == 0) {
+        *(f32x4*)wp = lo;
+        *(f32x4*)(wp + 4) = hi;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { if (e < nvalid) wp[e] = lo[e]; if (e + 4 < nvalid) wp[e + 4] = hi[e]; }
+      }
+    }
+    return;
+  }
   float bias[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias[e] = (d.bias && e < nvalid) ? d.bias[gn + e] : 0.f;
-
   for (int p = 0; p < 8; ++p) {
     const int row = p * 16 + (tid >> 4);
     const int gm = m0 + row;
     if (gm >= M) continue;
-    int64_t orow = gm;
-    if (d.out_mul != 0) {
-      const int s = gm / d.seg_len, t = gm - s * d.seg_len;
-      const int o = t * d.out_mul + d.out_add;
-      if (o < 0 || o >= d.out_seg) continue;
-      orow = (int64_t)s * d.out_seg + o;
-    }
     float v[8];
     {
       const f32x4 lo = *(const f32x4*)(cs + row * CS_LD + cg * 8);
@@ -276,103 +266,59 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[e + 4] = hi[e]; }
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = v[e] * d.alpha + bias[e];
-    if (flags & TTSK_GEMM_ADD_R) {
-      if (flags & TTSK_GEMM_R_F32) {
-        const float* rp = (const float*)d.R + roff + orow * d.ldr + gn;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += rp[e];
-      } else {
-        const bf16_t* rp = (const bf16_t*)d.R + roff + orow * d.ldr + gn;
-        if (nvalid == 8 && ((d.ldr & 7) == 0)) {
-          add_bf8(v, *(const uint4*)rp);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += bf2f(rp[e]);
-        }
-      }
-    }
-    if (flags & TTSK_GEMM_RELU) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-    }
-    if (flags & TTSK_GEMM_MASK_G) {
-      const bf16_t* gp = (const bf16_t*)d.G + roff + orow * d.ldg + gn;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] = bf2f(gp[e]) > 0.f ? v[e] : 0.f;
-    }
-    if (flags & TTSK_GEMM_LRELU_OUT) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * d.out_slope;
-    }
-    if (flags & TTSK_GEMM_TANH) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
-    }
-    if (c32) {
-      float* cp = (float*)d.C + coff + orow * d.ldc + gn;
-      if (flags & TTSK_GEMM_ACCUM_C) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) if (e < nvalid) cp[e] += v[e];
-      } else if (nvalid == 8 && ((d.ldc & 3) == 0) && ((coff & 3) == 0)) {
-        *(f32x4*)cp = f32x4{v[0], v[1], v[2], v[3]};
-        *(f32x4*)(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) if (e < nvalid) cp[e] = v[e];
-      }
-    } else {
-      bf16_t* cp = (bf16_t*)d.C + coff + orow * d.ldc + gn;
-      if (nvalid == 8 && ((d.ldc & 7) == 0) && ((coff & 7) == 0)) {
-        *(uint4*)cp = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) if (e < nvalid) cp[e] = f2bf(v[e]);
-      }
-    }
-    if (d.C2) {
-      bf16_t* cp = (bf16_t*)d.C2 + coff + orow * d.ldc + gn;
-      if (nvalid == 8 && ((d.ldc & 7) == 0) && ((coff & 7) == 0)) {
-        *(uint4*)cp = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) if (e < nvalid) cp[e] = f2bf(v[e]);
-      }
-    }
+    epilogue_store<F16>(d, coff, roff, gm, gn, nvalid, v, bias);
   }
 }
 
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs,
-                                                           int64_t stride, float* __restrict__ dst, int64_t n4,
-                                                           int64_t numel, int accumulate) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t e = i * 4;
-    if (e + 4 <= numel) {
-      f32x4 s = accumulate ? *(const f32x4*)(dst + e) : f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int k = 0; k < n_slabs; ++k) s += *(const f32x4*)(slabs + k * stride + e);
-      *(f32x4*)(dst + e) = s;
-    } else {
-      for (int64_t j = e; j < numel; ++j) {
-        float s = accumulate ? dst[j] : 0.f;
-        for (int k = 0; k < n_slabs; ++k) s += slabs[k * stride + j];
-        dst[j] = s;
+// split-K reducer: sums the `splits` workspace slabs in fixed order and applies the epilogue (deterministic)
+template <bool F16>
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const Args g) {
+  const ttsk_gemm_desc& d = g.d;
+  const int M = d.M, N = d.N;
+  const int ngrp = (N + 7) >> 3;
+  const int z = blockIdx.y;
+  const int z1 = z / d.nz2, z2 = z - z1 * d.nz2;
+  const int64_t coff = z1 * d.sC1 + z2 * d.sC2;
+  const int64_t roff = z1 * d.sR1 + z2 * d.sR2;
+  const int64_t mn = (int64_t)M * N;
+  const float* ws = (const float*)d.workspace + (int64_t)z * mn;
+  const int64_t sstride = (int64_t)gridDim.y * mn;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < (int64_t)M * ngrp; i += (int64_t)gridDim.x * 256) {
+    const int gm = (int)(i / ngrp);
+    const int gn = (int)(i - (int64_t)gm * ngrp) * 8;
+    const int nvalid = (N - gn) < 8 ? (N - gn) : 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* p = ws + (int64_t)gm * N + gn;
+    if (nvalid == 8 && (N & 3) == 0) {
+      for (int s = 0; s < d.splits; ++s) {
+        const f32x4 lo = *(const f32x4*)(p + s * sstride), hi = *(const f32x4*)(p + s * sstride + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += lo[e]; v[e + 4] += hi[e]; }
       }
+    } else {
+      for (int s = 0; s < d.splits; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += p[s * sstride + e];
     }
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = (d.bias && e < nvalid) ? d.bias[gn + e] : 0.f;
+    epilogue_store<F16>(d, coff, roff, gm, gn, nvalid, v, bias);
   }
 }
 
 }  // namespace
 
-extern "C" int ttsk_gemm(const ttsk_gemm_desc* dp, void* stream) {
-  TTSK_REQUIRE(dp != nullptr, "ttsk_gemm: null descriptor");
-  Args g;
-  g.d = *dp;
-  ttsk_gemm_desc& d = g.d;
+// ---- planning: which tile configuration, how many K splits
+namespace {
+struct Plan { int kernel, splits, tiles_m, tiles_n, kchunks, chunks_per_split; int64_t ws_bytes; };
+
+int validate(ttsk_gemm_desc& d) {
   TTSK_REQUIRE(d.A && d.B && d.C, "ttsk_gemm: null operand");
   TTSK_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "ttsk_gemm: empty problem M=%d N=%d K=%d", d.M, d.N, d.K);
-  const bool atr = d.flags & TTSK_GEMM_A_TR, btr = d.flags & TTSK_GEMM_B_TR;
+  const bool atr = d.flags & TTSK_GEMM_A_TR, btr = d.flags & TTSK_GEMM_B_TR, f16 = d.flags & TTSK_GEMM_F16;
   TTSK_REQUIRE(!(atr && !btr), "ttsk_gemm: A_TR without B_TR is not instantiated");
+  TTSK_REQUIRE(!(f16 && atr), "ttsk_gemm: fp16 operands are instantiated for the inference shapes only (A untransposed)");
   TTSK_REQUIRE((d.lda & 7) == 0 && (d.ldb & 7) == 0, "ttsk_gemm: lda/ldb must be multiples of 8 (16-byte rows)");
   TTSK_REQUIRE((((uintptr_t)d.A) & 15) == 0 && (((uintptr_t)d.B) & 15) == 0, "ttsk_gemm: A/B must be 16-byte aligned");
   TTSK_REQUIRE(((d.sA1 | d.sA2 | d.sB1 | d.sB2) & 7) == 0, "ttsk_gemm: batch strides of A/B must be multiples of 8");
@@ -380,39 +326,121 @@ extern "C" int ttsk_gemm(const ttsk_gemm_desc* dp, void* stream) {
   TTSK_REQUIRE(d.taps == 0 || (d.b_tap_stride & 7) == 0, "ttsk_gemm: b_tap_stride must be a multiple of 8");
   TTSK_REQUIRE(d.bseg_len == 0 || btr, "ttsk_gemm: B row shift needs B_TR");
   TTSK_REQUIRE(d.out_mul == 0 || (d.seg_len > 0 && d.out_seg > 0), "ttsk_gemm: output remap needs seg_len/out_seg");
+  TTSK_REQUIRE(d.kernel >= 0 && d.kernel <= 2 && d.splits >= 0, "ttsk_gemm: kernel must be 0 (auto), 1 or 2; splits >= 0");
+  TTSK_REQUIRE(!(d.kernel == 2 && (d.flags & TTSK_GEMM_LRELU_IN)), "ttsk_gemm: LRELU_IN needs the register-staged kernel (kernel = 1)");
   if (d.nz1 < 1) d.nz1 = 1;
   if (d.nz2 < 1) d.nz2 = 1;
-  if (d.splits < 1) d.splits = 1;
-  TTSK_REQUIRE(d.splits == 1 || ((d.flags & TTSK_GEMM_C_F32) && d.taps <= 1), "ttsk_gemm: split-K needs fp32 C and no taps");
   TTSK_REQUIRE(!(d.flags & TTSK_GEMM_ADD_R) || d.R, "ttsk_gemm: ADD_R without R");
   TTSK_REQUIRE(!(d.flags & TTSK_GEMM_MASK_G) || d.G, "ttsk_gemm: MASK_G without G");
-  g.tiles_m = (d.M + BM - 1) / BM;
-  g.tiles_n = (d.N + BN - 1) / BN;
-  g.kchunks = (d.K + BK - 1) / BK;
-  g.chunks_per_split = (g.kchunks + d.splits - 1) / d.splits;
-  dim3 grid(g.tiles_m * g.tiles_n, d.nz1 * d.nz2, d.splits), block(NTHREADS);
-  TTSK_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "ttsk_gemm: batch/splits too large");
-  hipStream_t s = (hipStream_t)stream;
-  if (atr)
-    hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, s, g);
-  else if (btr)
-    hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, s, g);
-  else
-    hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, s, g);
-  TTSK_CHECK_LAUNCH();
+  TTSK_REQUIRE(!(d.flags & TTSK_GEMM_ACCUM_C) || (d.flags & TTSK_GEMM_C_F32), "ttsk_gemm: ACCUM_C needs fp32 C");
   return TTSK_OK;
 }
 
-extern "C" int ttsk_reduce_slabs(const float* slabs, int n_slabs, int64_t slab_stride, float* dst, int64_t numel,
-                                 int accumulate, void* stream) {
-  TTSK_REQUIRE(slabs && dst && n_slabs > 0 && numel > 0, "ttsk_reduce_slabs: bad arguments");
-  TTSK_REQUIRE((slab_stride & 3) == 0 && (((uintptr_t)slabs | (uintptr_t)dst) & 15) == 0,
-               "ttsk_reduce_slabs: slabs/dst must be 16-byte aligned");
-  const int64_t n4 = (numel + 3) / 4;
-  int blocks = (int)((n4 + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs, slab_stride,
-                     dst, n4, numel, accumulate);
+// Cost model in microseconds, calibrated on MI355X with tools/debug/gemm_tune.py: a K step of a 128^2 workgroup takes
+// 1.1 us alone on its CU and 1.5 us when two share it, a K step of the 256x128 ring 1.3 us; SLOTS workgroups run at once;
+// a split-K reducer costs a launch plus its slab traffic.  Small problems (the encoder's 1024 rows) gain most from
+// splitting K (16 tiles -> 256 workgroups: 164 us -> 26 us for the k=9 conv dX), large ones take the big tile.
+constexpr float T_ITER1 = 1.5f, T_ITER1_ALONE = 1.1f, T_ITER2 = 1.3f, T_LAUNCH = 4.f, T_REDUCE = 7.f;
+constexpr int SLOTS1 = 512, SLOTS2 = 256;
+
+Plan make_plan(const ttsk_gemm_desc& d) {
+  const int nz = d.nz1 * d.nz2;
+  const int taps = d.taps > 0 ? d.taps : 1;
+  const int kchunks = (d.K + BK - 1) / BK;
+  Plan best{};
+  float best_t = -1.f;
+  for (int kernel = 1; kernel <= 2; ++kernel) {
+    if (d.kernel != 0 && d.kernel != kernel) continue;
+    if (kernel == 2 && (d.flags & TTSK_GEMM_LRELU_IN)) continue;
+    const int bm = kernel == 1 ? 128 : 256;
+    const int tm = (d.M + bm - 1) / bm, tn = (d.N + 127) / 128;
+    const int64_t tiles = (int64_t)tm * tn * nz;
+    static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
+    for (int ci = 0; ci < 12; ++ci) {
+      int sp = cand[ci];
+      if (d.splits != 0) sp = d.splits;
+      if (sp > kchunks) sp = kchunks;
+      const int per = (kchunks + sp - 1) / sp;
+      sp = (kchunks + per - 1) / per;
+      const int64_t wgs = tiles * sp;
+      const int slots = kernel == 1 ? SLOTS1 : SLOTS2;
+      const int64_t rounds = (wgs + slots - 1) / slots;
+      const float t_iter = kernel == 2 ? T_ITER2 : (wgs <= 256 ? T_ITER1_ALONE : T_ITER1);   // one workgroup per CU runs faster
+      float t = (float)rounds * per * taps * t_iter + T_LAUNCH;
+      const int64_t ws = sp > 1 ? (int64_t)sp * nz * d.M * d.N * 4 : 0;
+      if (ws > ((int64_t)512 << 20)) { if (d.splits != 0) {} else break; }
+      if (sp > 1) t += T_REDUCE + (float)ws * 1.25f / 4.0e6f;
+      if (best_t < 0.f || t < best_t - 0.25f) {
+        best_t = t;
+        best = Plan{kernel, sp, tm, tn, kchunks, per, ws};
+      }
+      if (d.splits != 0 || sp >= kchunks) break;
+    }
+  }
+  return best;
+}
+}  // namespace
+
+extern "C" int ttsk_gemm_plan(const ttsk_gemm_desc* dp, int32_t* kernel, int32_t* splits, int64_t* workspace_bytes) {
+  TTSK_REQUIRE(dp && kernel && splits && workspace_bytes, "ttsk_gemm_plan: null pointer");
+  ttsk_gemm_desc d = *dp;
+  const int rc = validate(d);
+  if (rc != TTSK_OK) return rc;
+  const Plan p = make_plan(d);
+  *kernel = p.kernel;
+  *splits = p.splits;
+  *workspace_bytes = p.ws_bytes;
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_gemm(const ttsk_gemm_desc* dp, void* stream) {
+  TTSK_REQUIRE(dp != nullptr, "ttsk_gemm: null descriptor");
+  Args g;
+  g.d = *dp;
+  ttsk_gemm_desc& d = g.d;
+  const int rc = validate(d);
+  if (rc != TTSK_OK) return rc;
+  const bool atr = d.flags & TTSK_GEMM_A_TR, btr = d.flags & TTSK_GEMM_B_TR, f16 = d.flags & TTSK_GEMM_F16;
+  Plan p = make_plan(d);
+  if (p.splits > 1 && !(d.workspace && d.workspace_bytes >= p.ws_bytes && (((uintptr_t)d.workspace) & 15) == 0)) {
+    // auto mode without (enough) workspace: fall back to a single pass; an explicit split request is an error
+    TTSK_REQUIRE(d.splits == 0, "ttsk_gemm: split-K needs a 16-byte aligned workspace of %lld bytes (got %lld)",
+                 (long long)p.ws_bytes, (long long)d.workspace_bytes);
+    d.splits = 1;
+    p = make_plan(d);
+  }
+  d.kernel = p.kernel;
+  d.splits = p.splits;
+  g.tiles_m = p.tiles_m;
+  g.tiles_n = p.tiles_n;
+  g.kchunks = p.kchunks;
+  g.chunks_per_split = p.chunks_per_split;
+  const int nz = d.nz1 * d.nz2;
+  TTSK_REQUIRE(nz <= 65535 && d.splits <= 65535, "ttsk_gemm: batch/splits too large");
+  hipStream_t s = (hipStream_t)stream;
+  if (d.kernel == 2) {
+    ttsk_launch_gemm2(g, atr, btr, f16, s);
+  } else {
+    dim3 grid(g.tiles_m * g.tiles_n, nz, d.splits), block(NTHREADS);
+    if (atr)
+      hipLaunchKernelGGL((gemm_kernel<true, true, false>), grid, block, 0, s, g);
+    else if (btr) {
+      if (f16) hipLaunchKernelGGL((gemm_kernel<false, true, true>), grid, block, 0, s, g);
+      else hipLaunchKernelGGL((gemm_kernel<false, true, false>), grid, block, 0, s, g);
+    } else {
+      if (f16) hipLaunchKernelGGL((gemm_kernel<false, false, true>), grid, block, 0, s, g);
+      else hipLaunchKernelGGL((gemm_kernel<false, false, false>), grid, block, 0, s, g);
+    }
+  }
   TTSK_CHECK_LAUNCH();
+  if (d.splits > 1) {
+    const int64_t work = (int64_t)d.M * ((d.N + 7) / 8);
+    int blocks = (int)((work + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    dim3 rgrid(blocks, nz);
+    if (f16) hipLaunchKernelGGL((gemm_reduce_kernel<true>), rgrid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_reduce_kernel<false>), rgrid, dim3(256), 0, s, g);
+    TTSK_CHECK_LAUNCH();
+  }
   return TTSK_OK;
 }

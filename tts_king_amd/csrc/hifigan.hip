@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void wn_fold_kernel(const float* __restrict__ 
 
 // mode 0: Conv1d weight (Cout, Cin, k) fp32 -> (Cout, k, Cin) bf16   (input channels contiguous per tap)
 // mode 1: ConvTranspose1d weight (Cin, Cout, k) fp32 -> (k, Cout, Cin) bf16
+template <bool F16>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int d0,
                                                           int d1, int d2, int mode, int64_t n) {
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -40,11 +41,12 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
       const int j = (int)(i / ((int64_t)d0 * d1));
       s = ((int64_t)ci * d1 + co) * d2 + j;
     }
-    dst[i] = f2bf(src[s]);
+    dst[i] = pack1<F16>(src[s]);
   }
 }
 
 // out = (a + b + c) * scale, bf16, 8 elements per lane  — the MRF average (hifi/models.py:190-196)
+template <bool F16>
 __global__ __launch_bounds__(256) void avg3_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b,
                                                    const uint4* __restrict__ c, uint4* __restrict__ out, int64_t n8,
                                                    float scale) {
@@ -54,10 +56,9 @@ __global__ __launch_bounds__(256) void avg3_kernel(const uint4* __restrict__ a, 
     unsigned o[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float lo = __uint_as_float(wa[e] << 16) + __uint_as_float(wb[e] << 16) + __uint_as_float(wc[e] << 16);
-      const float hi = __uint_as_float(wa[e] & 0xFFFF0000u) + __uint_as_float(wb[e] & 0xFFFF0000u) +
-                       __uint_as_float(wc[e] & 0xFFFF0000u);
-      o[e] = pack_bf2(lo * scale, hi * scale);
+      float al, ah, bl, bh, cl, ch;
+      unpack2<F16>(wa[e], al, ah); unpack2<F16>(wb[e], bl, bh); unpack2<F16>(wc[e], cl, ch);
+      o[e] = pack2<F16>((al + bl + cl) * scale, (ah + bh + ch) * scale);
     }
     out[i] = make_uint4(o[0], o[1], o[2], o[3]);
   }
@@ -72,25 +73,31 @@ extern "C" int ttsk_weight_norm_fold(const float* v, const float* g, float* w, i
   return TTSK_OK;
 }
 
-extern "C" int ttsk_pack_conv_weight(const float* src, void* dst_bf16, int d0, int d1, int d2, int mode, void* stream) {
-  TTSK_REQUIRE(src && dst_bf16 && d0 > 0 && d1 > 0 && d2 > 0 && (mode == 0 || mode == 1), "ttsk_pack_conv_weight: bad arguments");
+extern "C" int ttsk_pack_conv_weight(const float* src, void* dst16, int f16, int d0, int d1, int d2, int mode, void* stream) {
+  TTSK_REQUIRE(src && dst16 && d0 > 0 && d1 > 0 && d2 > 0 && (mode == 0 || mode == 1), "ttsk_pack_conv_weight: bad arguments");
   const int64_t n = (int64_t)d0 * d1 * d2;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst_bf16, d0, d1, d2,
-                     mode, n);
+  if (f16)
+    hipLaunchKernelGGL(pack_weight_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst16, d0, d1, d2, mode, n);
+  else
+    hipLaunchKernelGGL(pack_weight_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst16, d0, d1, d2, mode, n);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }
 
-extern "C" int ttsk_avg3_bf16(const void* a, const void* b, const void* c, void* out, int64_t n, float scale, void* stream) {
-  TTSK_REQUIRE(a && b && c && out && n > 0 && (n & 7) == 0, "ttsk_avg3_bf16: n must be a positive multiple of 8");
-  TTSK_REQUIRE(((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)out)) & 15) == 0, "ttsk_avg3_bf16: 16-byte alignment");
+extern "C" int ttsk_avg3(const void* a, const void* b, const void* c, void* out, int f16, int64_t n, float scale, void* stream) {
+  TTSK_REQUIRE(a && b && c && out && n > 0 && (n & 7) == 0, "ttsk_avg3: n must be a positive multiple of 8");
+  TTSK_REQUIRE(((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)out)) & 15) == 0, "ttsk_avg3: 16-byte alignment");
   const int64_t n8 = n / 8;
   int blocks = (int)((n8 + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(avg3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b,
-                     (const uint4*)c, (uint4*)out, n8, scale);
+  if (f16)
+    hipLaunchKernelGGL(avg3_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b,
+                       (const uint4*)c, (uint4*)out, n8, scale);
+  else
+    hipLaunchKernelGGL(avg3_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b,
+                       (const uint4*)c, (uint4*)out, n8, scale);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

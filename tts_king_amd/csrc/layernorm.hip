@@ -120,7 +120,7 @@ struct LnBwdArgs {
   const uint64_t* rng;
   bf16_t* dz;             // [rows][D] grad wrt LN input (the residual branch's grad)
   bf16_t* dy;             // [rows][D] grad wrt the sub-layer output (dz with the pre-dropout mask); null if p_pre == 0
-  float* partials;        // [nblk][nq*D (+1)]: dgamma | dbeta | dbias (| dhead_w | dhead_b)
+  float* partials;        // [nblk][nq*D (+1)]: dbias | dgamma | dbeta (| dhead_w | dhead_b): the order of the flat gradient buffer
   int rows, D, seg_len, relu_in;
   float p_pre, p_post;
   unsigned site_pre, site_post;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
       if (j < nj)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = qn == 0 ? dg[j][e] : qn == 1 ? db[j][e] : qn == 2 ? dbias[j][e] : dhw[j][e];
+          const float v = qn == 0 ? dbias[j][e] : qn == 1 ? dg[j][e] : qn == 2 ? db[j][e] : dhw[j][e];
           red[wave][j * 256 + lane * 4 + e] = v;
         }
     __syncthreads();
@@ -234,18 +234,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
 // ascending order and the 8 group sums are combined in a fixed order: deterministic.
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partials, int nblk, int ncols,
                                                               int ld, float* __restrict__ dst, int accumulate, float scale) {
-  __shared__ float red[8][33];
-  const int cx = threadIdx.x & 31, gy = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
-  float s = 0.f;
-  if (c < ncols)
-    for (int b = gy; b < nblk; b += 8) s += partials[(int64_t)b * ld + c];
-  red[gy][cx] = s;
+  __shared__ float red[16][17];
+  const int cx = threadIdx.x & 15, gy = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < ncols) {
+    int b = gy;
+    for (; b + 48 < nblk; b += 64) {       // 4 loads in flight per thread; summation order is fixed
+      s0 += partials[(int64_t)b * ld + c];
+      s1 += partials[(int64_t)(b + 16) * ld + c];
+      s2 += partials[(int64_t)(b + 32) * ld + c];
+      s3 += partials[(int64_t)(b + 48) * ld + c];
+    }
+    for (; b < nblk; b += 16) s0 += partials[(int64_t)b * ld + c];
+  }
+  red[gy][cx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (gy == 0 && c < ncols) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    for (int k = 0; k < 16; ++k) t += red[k][cx];
     t *= scale;
     dst[c] = accumulate ? dst[c] + t : t;
   }
@@ -330,7 +338,7 @@ extern "C" int ttsk_layernorm_bwd(const void* dout, const float* dhead, const fl
 extern "C" int ttsk_colsum_finalize(const float* partials, int nblk, int ncols, int ld, float* dst, int accumulate,
                                     float scale, void* stream) {
   TTSK_REQUIRE(partials && dst && nblk > 0 && ncols > 0 && ld >= ncols, "colsum_finalize: bad arguments");
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, nblk,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, nblk,
                      ncols, ld, dst, accumulate, scale);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;

@@ -31,13 +31,6 @@ struct RbArgs {
   float slope;
 };
 
-__device__ __forceinline__ unsigned lrelu_pk(unsigned w, float sl) {
-  float lo = __uint_as_float(w << 16), hi = __uint_as_float(w & 0xFFFF0000u);
-  lo = lo > 0.f ? lo : lo * sl;
-  hi = hi > 0.f ? hi : hi * sl;
-  return pack_bf2(lo, hi);
-}
-
 template <int C, int K, int TT>
 struct RbGeom {
   static constexpr int HK = (K - 1) / 2;
@@ -53,7 +46,7 @@ struct RbGeom {
   static constexpr int SMEM = 2 * LROWS * RS;
 };
 
-template <int C, int K, int TT>
+template <int C, int K, int TT, bool F16>
 __global__ __launch_bounds__(256, 1) void resblock1_kernel(const RbArgs a) {
   using Gm = RbGeom<C, K, TT>;
   constexpr int HK = Gm::HK, H = Gm::H, NTILE = Gm::NTILE, NSLOT = Gm::NSLOT, G = Gm::G, LROWS = Gm::LROWS, RS = Gm::RS,
@@ -79,7 +72,7 @@ __global__ __launch_bounds__(256, 1) void resblock1_kernel(const RbArgs a) {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (r >= 0 && r < NTILE * 16 && t >= 0 && t < len) v = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
     *(uint4*)(TL + row * RS + ch * 16) = v;
-    *(uint4*)(XL + row * RS + ch * 16) = make_uint4(lrelu_pk(v.x, slope), lrelu_pk(v.y, slope), lrelu_pk(v.z, slope), lrelu_pk(v.w, slope));
+    *(uint4*)(XL + row * RS + ch * 16) = lrelu8<F16>(v, slope);
   }
   __syncthreads();
 
@@ -92,8 +85,9 @@ __global__ __launch_bounds__(256, 1) void resblock1_kernel(const RbArgs a) {
     for (int c = 0; c < NC; ++c) {
       uint2 v = make_uint2(0, 0);
       if (i < NTILE) v = *(const uint2*)(TL + (i * 16 + l15 + G) * RS + (c * 16 + q * 4) * 2);
-      xr[c][s] = f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u), __uint_as_float(v.y << 16),
-                       __uint_as_float(v.y & 0xFFFF0000u)};
+      float x0, x1, x2, x3;
+      unpack2<F16>(v.x, x0, x1); unpack2<F16>(v.y, x2, x3);
+      xr[c][s] = f32x4{x0, x1, x2, x3};
     }
   }
   __syncthreads();
@@ -145,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void resblock1_kernel(const RbArgs a) {
               const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
 #pragma unroll
               for (int c = 0; c < NC; ++c)
-                acc[c][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[tap & 1][c * KS + ks], Bf, acc[c][s], 0, 0, 0);
+                acc[c][s] = mfma16<F16>(Af[tap & 1][c * KS + ks], Bf, acc[c][s]);
             }
           }
         }
@@ -179,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void resblock1_kernel(const RbArgs a) {
                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
               }
             }
-            *(uint2*)(dst + (i * 16 + l15 + G) * RS + (c * 16 + q * 4) * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            *(uint2*)(dst + (i * 16 + l15 + G) * RS + (c * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
           }
         }
       }
@@ -201,9 +195,11 @@ __global__ __launch_bounds__(256, 1) void resblock1_kernel(const RbArgs a) {
       unsigned rw[4];
       const float sc = a.mode == 2 ? a.scale : 1.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        rw[e] = pack_bf2((__uint_as_float(vw[e] << 16) + __uint_as_float(ow[e] << 16)) * sc,
-                         (__uint_as_float(vw[e] & 0xFFFF0000u) + __uint_as_float(ow[e] & 0xFFFF0000u)) * sc);
+      for (int e = 0; e < 4; ++e) {
+        float vl, vh, ol, oh;
+        unpack2<F16>(vw[e], vl, vh); unpack2<F16>(ow[e], ol, oh);
+        rw[e] = pack2<F16>((vl + ol) * sc, (vh + oh) * sc);
+      }
       v = make_uint4(rw[0], rw[1], rw[2], rw[3]);
     }
     *op = v;
@@ -211,15 +207,16 @@ __global__ __launch_bounds__(256, 1) void resblock1_kernel(const RbArgs a) {
 }
 
 template <int C, int K, int TT>
-int launch_rb(const RbArgs& a, int B, hipStream_t s) {
+int launch_rb(const RbArgs& a, int B, int f16, hipStream_t s) {
   dim3 grid((a.len + TT - 1) / TT, B);
-  hipLaunchKernelGGL((resblock1_kernel<C, K, TT>), grid, dim3(256), 0, s, a);
+  if (f16) hipLaunchKernelGGL((resblock1_kernel<C, K, TT, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((resblock1_kernel<C, K, TT, false>), grid, dim3(256), 0, s, a);
   return 0;
 }
 
 }  // namespace
 
-extern "C" int ttsk_hifi_resblock1(const void* x_bf16, void* out_bf16, const void* const* weights /* 6 x (C,K,C) bf16 */,
+extern "C" int ttsk_hifi_resblock1(const void* x_bf16, void* out_bf16, int f16, const void* const* weights /* 6 x (C,K,C) */,
                                    const float* const* biases /* 6 x [C] */, const int32_t* dilations /* 3 */, int B, int len,
                                    int C, int K, int mode, float scale, float slope, void* stream) {
   TTSK_REQUIRE(x_bf16 && out_bf16 && weights && biases && dilations, "ttsk_hifi_resblock1: null pointer");
@@ -243,12 +240,12 @@ extern "C" int ttsk_hifi_resblock1(const void* x_bf16, void* out_bf16, const voi
   hipStream_t s = (hipStream_t)stream;
   const int key = C * 100 + K;
   switch (key) {
-    case 3203: launch_rb<32, 3, 256>(a, B, s); break;
-    case 3207: launch_rb<32, 7, 256>(a, B, s); break;
-    case 3211: launch_rb<32, 11, 256>(a, B, s); break;
-    case 6403: launch_rb<64, 3, 128>(a, B, s); break;
-    case 6407: launch_rb<64, 7, 128>(a, B, s); break;
-    case 6411: launch_rb<64, 11, 128>(a, B, s); break;
+    case 3203: launch_rb<32, 3, 256>(a, B, f16, s); break;
+    case 3207: launch_rb<32, 7, 256>(a, B, f16, s); break;
+    case 3211: launch_rb<32, 11, 256>(a, B, f16, s); break;
+    case 6403: launch_rb<64, 3, 128>(a, B, f16, s); break;
+    case 6407: launch_rb<64, 7, 128>(a, B, f16, s); break;
+    case 6411: launch_rb<64, 11, 128>(a, B, f16, s); break;
     default:
       ttsk_set_error("ttsk_hifi_resblock1: no fused instance for C=%d K=%d (C in {32,64}, K in {3,7,11})", C, K);
       return TTSK_EINVAL;

@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 }
 
 // (B,C,T) fp32 -> (B,T,C) bf16 through a 32x33 LDS tile (HiFi-GAN takes mel as (B,80,T); kernels are channels-last)
+template <bool F16>
 __global__ __launch_bounds__(256) void nct_to_ntc_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int C, int T) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void nct_to_ntc_kernel(const float* __restrict
   __syncthreads();
   for (int r = ty; r < 32; r += 8) {
     const int t = t0 + r, c = c0 + tx;
-    if (t < T && c < C) dst[((int64_t)b * T + t) * C + c] = f2bf(tile[tx][r]);
+    if (t < T && c < C) dst[((int64_t)b * T + t) * C + c] = pack1<F16>(tile[tx][r]);
   }
 }
 
@@ -269,10 +270,14 @@ extern "C" int ttsk_cast_bf16(const float* src, void* dst_bf16, int64_t n, void*
   return TTSK_OK;
 }
 
-extern "C" int ttsk_nct_to_ntc_bf16(const float* src, void* dst_bf16, int B, int C, int T, void* stream) {
-  TTSK_REQUIRE(src && dst_bf16 && B > 0 && C > 0 && T > 0 && B <= 65535, "nct_to_ntc: bad arguments");
-  hipLaunchKernelGGL(nct_to_ntc_kernel, dim3((T + 31) / 32, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, src,
-                     (bf16_t*)dst_bf16, C, T);
+extern "C" int ttsk_nct_to_ntc(const float* src, void* dst16, int f16, int B, int C, int T, void* stream) {
+  TTSK_REQUIRE(src && dst16 && B > 0 && C > 0 && T > 0 && B <= 65535, "nct_to_ntc: bad arguments");
+  if (f16)
+    hipLaunchKernelGGL(nct_to_ntc_kernel<true>, dim3((T + 31) / 32, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, src,
+                       (bf16_t*)dst16, C, T);
+  else
+    hipLaunchKernelGGL(nct_to_ntc_kernel<false>, dim3((T + 31) / 32, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, src,
+                       (bf16_t*)dst16, C, T);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -435,10 +435,12 @@ class FastSpeech2(nn.Module):
             dmel_sum = ops.add_f32(dmel, dpost)
             self.backward_native(ctx, dmel_sum, dpost, f32(dpitch, (Bn, Lp)), f32(denergy, (Bn, Lp)), f32(dlogd, (Bn, Lp)))
 
-    def _finalize_ln(self, partials, nblk, D, keys, ncol):
-        """partials [nblk][ncol] -> gradient slots; keys = list of (column offset, grad tensor)."""
-        for off, dst in keys:
-            ops.colsum_finalize(partials[:, off:], nblk, dst.numel(), ncol, dst, accumulate=True)
+    def _finalize_ln(self, partials, nblk, ncol, first_key):
+        """partials [nblk][ncol] = dbias | dgamma | dbeta (| dhead_w | dhead_b) -> the flat gradient buffer, where the
+        sub-layer bias, LayerNorm weight and LayerNorm bias (and the predictor head) sit back to back in that order
+        starting at `first_key` (params.py builds them so): ONE finalize launch per LayerNorm."""
+        off = self._table[first_key].offset
+        ops.colsum_finalize(partials, nblk, ncol, ncol, self._flat_grad[off:off + ncol], accumulate=True)
 
     def _fft_bwd(self, saved, dx2, rng):
         (pre, x, qkv, probs, o, z1, mean1, rstd1, x1, h, z2, mean2, rstd2, Bn, S, lens, H, p, site) = saved
@@ -450,8 +452,7 @@ class FastSpeech2(nn.Module):
         # ---- FFN tail: LN backward (PAD rows carry no gradient), dropout mask regenerated
         dz2, dy2, part, nblk = ops.layernorm_bwd(dx2, z2, mean2, rstd2, self._m(f + "layer_norm.weight"), self._m(f + "layer_norm.bias"),
                                                  lens, S, p_pre=p, site_pre=site + 1, rng=rng)
-        self._finalize_ln(part, nblk, d, [(0, self._g(f + "layer_norm.weight")), (d, self._g(f + "layer_norm.bias")),
-                                          (2 * d, self._g(f + "w_2.bias"))], 3 * d)
+        self._finalize_ln(part, nblk, 3 * d, f + "w_2.bias")
         # ---- w_2 (k=1): dW, dX gated by the ReLU
         ops.conv1d_dw(dy2.view(Bn, S, d), h, self._g(f + "w_2.weight"), k=self.k2)
         dh = ops.conv1d_dx(dy2.view(Bn, S, d), self._w(f + "w_2.weight"), G=h)
@@ -462,8 +463,7 @@ class FastSpeech2(nn.Module):
         # ---- attention tail
         dz1, dy1, part, nblk = ops.layernorm_bwd(dx1.view(rows, d), z1, mean1, rstd1, self._m(a + "layer_norm.weight"),
                                                  self._m(a + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site, rng=rng)
-        self._finalize_ln(part, nblk, d, [(0, self._g(a + "layer_norm.weight")), (d, self._g(a + "layer_norm.bias")),
-                                          (2 * d, self._g(a + "fc.bias"))], 3 * d)
+        self._finalize_ln(part, nblk, 3 * d, a + "fc.bias")
         ops.linear_dw(dy1, o, self._g(a + "fc.weight"))
         do = ops.linear_dx(dy1, self._w(a + "fc.weight"))
         # ---- attention core: dP = dO V^T ; dS = softmax'(P, dP)/sqrt(dk) ; dQ = dS K ; dK = dS^T Q ; dV = P^T dO
@@ -492,17 +492,13 @@ class FastSpeech2(nn.Module):
         dh2, _, part, nblk = ops.layernorm_bwd(None, h2.view(rows, Fh), m2, r2, self._m(c + "layer_norm_2.weight"),
                                                self._m(c + "layer_norm_2.bias"), lens, Lp, relu_in=True, p_post=p,
                                                site_post=site + 1, rng=rng, dhead=dout.contiguous().view(-1), head_w=hw)
-        ncol = 4 * Fh + 1
-        self._finalize_ln(part, nblk, Fh, [(0, self._g(c + "layer_norm_2.weight")), (Fh, self._g(c + "layer_norm_2.bias")),
-                                           (2 * Fh, self._g(c + "conv1d_2.conv.bias")), (3 * Fh, self._g(pre + "linear_layer.weight").view(-1)),
-                                           (4 * Fh, self._g(pre + "linear_layer.bias"))], ncol)
+        self._finalize_ln(part, nblk, 4 * Fh + 1, c + "conv1d_2.conv.bias")
         ops.conv1d_dw(dh2.view(Bn, Lp, Fh), a1.view(Bn, Lp, Fh), self._g(c + "conv1d_2.conv.weight"), k=self.k_var)
         da1 = ops.conv1d_dx(dh2.view(Bn, Lp, Fh), self._w(c + "conv1d_2.conv.weight"))
         dh1, _, part, nblk = ops.layernorm_bwd(da1.view(rows, Fh), h1.view(rows, Fh), m1, r1, self._m(c + "layer_norm_1.weight"),
                                                self._m(c + "layer_norm_1.bias"), None, 0, relu_in=True, p_post=p,
                                                site_post=site, rng=rng)
-        self._finalize_ln(part, nblk, Fh, [(0, self._g(c + "layer_norm_1.weight")), (Fh, self._g(c + "layer_norm_1.bias")),
-                                           (2 * Fh, self._g(c + "conv1d_1.conv.bias"))], 3 * Fh)
+        self._finalize_ln(part, nblk, 3 * Fh, c + "conv1d_1.conv.bias")
         ops.conv1d_dw(dh1.view(Bn, Lp, Fh), x.view(Bn, Lp, d), self._g(c + "conv1d_1.conv.weight"), k=self.k_var)
         return ops.conv1d_dx(dh1.view(Bn, Lp, Fh), self._w(c + "conv1d_1.conv.weight"), R=R)
 

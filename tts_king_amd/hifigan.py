@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .ops import bf16
+from .ops import bf16, f16
 
 LRELU_SLOPE = 0.1          # reference: hifi/models.py:9
 
@@ -29,9 +29,9 @@ class _WNConv(nn.Module):
 
     def __init__(self, shape, n_bias):
         super().__init__()
+        self.bias = nn.Parameter(torch.zeros(n_bias), requires_grad=False)          # reference key order: bias, weight_g, weight_v
         self.weight_g = nn.Parameter(torch.ones(shape[0], 1, 1), requires_grad=False)
         self.weight_v = nn.Parameter(torch.zeros(shape), requires_grad=False)
-        self.bias = nn.Parameter(torch.zeros(n_bias), requires_grad=False)
 
     def fold(self):
         if "weight_g" not in self._parameters:
@@ -94,6 +94,7 @@ class Generator(nn.Module):
         self.conv_post = _WNConv((1, ch, 7), 1)
         self._packed = None
         self._packed_key = None
+        self.act_dtype = f16         # storage type of activations and packed weights (fp32 accumulate); bf16 also works
         self.fused = True            # fused ResBlock1 kernel where an instance exists (C in {32,64}); False = conv-by-conv
 
     # ------------------------------------------------------------------ reference surface
@@ -129,15 +130,16 @@ class Generator(nn.Module):
 
     def _prepare(self):
         """bf16 tap-major copies of the folded weights, rebuilt when any parameter was written."""
-        key = self._weights_key()
+        dt = self.act_dtype
+        key = self._weights_key() + (dt,)
         if self._packed is not None and self._packed_key == key:
             return self._packed
         pk = {}
-        pk["pre"] = (ops.pack_conv_weight(self.conv_pre.folded_weight()), self.conv_pre.bias.data)
-        pk["ups"] = [(ops.pack_conv_weight(u.folded_weight(), transposed=True), u.bias.data) for u in self.ups]
-        pk["rb"] = [[(ops.pack_conv_weight(c.folded_weight()), c.bias.data) for c in rb.all_convs()] for rb in self.resblocks]
+        pk["pre"] = (ops.pack_conv_weight(self.conv_pre.folded_weight(), dtype=dt), self.conv_pre.bias.data)
+        pk["ups"] = [(ops.pack_conv_weight(u.folded_weight(), transposed=True, dtype=dt), u.bias.data) for u in self.ups]
+        pk["rb"] = [[(ops.pack_conv_weight(c.folded_weight(), dtype=dt), c.bias.data) for c in rb.all_convs()] for rb in self.resblocks]
         wp = self.conv_post.folded_weight()                               # (1, C, 7)
-        pk["post"] = (ops.pack_conv_weight(wp), self.conv_post.bias.data)
+        pk["post"] = (ops.pack_conv_weight(wp, dtype=dt), self.conv_post.bias.data)
         self._packed, self._packed_key = pk, key
         return pk
 
@@ -166,7 +168,7 @@ class Generator(nn.Module):
         h = self.h
         with torch.no_grad():
             Bn, _, T = x.shape
-            a = ops.nct_to_ntc_bf16(x.float())                                            # (B, T, 80) bf16
+            a = ops.nct_to_ntc(x.float(), self.act_dtype)                                 # (B, T, 80) 16-bit
             a = ops.conv1d(a, pk["pre"][0], pk["pre"][1])                                 # conv_pre
             for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
                 wu, bu = pk["ups"][i]

@@ -31,12 +31,12 @@ class GemmDesc(C.Structure):
         ("b_tap_stride", C.c_int64),
         ("bseg_len", C.c_int32), ("bshift0", C.c_int32), ("bdshift", C.c_int32),
         ("out_seg", C.c_int32), ("out_mul", C.c_int32), ("out_add", C.c_int32),
-        ("splits", C.c_int32), ("sCs", C.c_int64),
+        ("splits", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("kernel", C.c_int32),
     ]
 
 
 # flags (include/ttsk.h)
-A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT = [1 << i for i in range(11)]
+A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT, F16 = [1 << i for i in range(12)]
 
 
 def declared_symbols(header_path=HEADER_PATH):
@@ -93,6 +93,7 @@ def load(path=LIB_PATH):
             fn.restype = C.c_int
         fn.argtypes = argtypes
     lib.ttsk_gemm.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
+    lib.ttsk_gemm_plan.argtypes = [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     _lib = lib
     return lib
 

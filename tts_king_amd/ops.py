@@ -9,10 +9,11 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import (A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT,  # noqa: F401
+from .lib import (A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT, F16,  # noqa: F401
                   GemmDesc, check)
 
 bf16 = torch.bfloat16
+f16 = torch.float16
 
 
 def _stream():
@@ -32,18 +33,28 @@ def _ptr(t):
 GEMM_TRACE = None   # bench.py sets this to a list: every ttsk_gemm launch is then bracketed by HIP events on its stream
 
 
+def plan(d):
+    """(kernel, splits, workspace_bytes) the library will use for descriptor `d` (ttsk_gemm_plan)."""
+    k, sp, ws = C.c_int32(0), C.c_int32(0), C.c_int64(0)
+    check(L.load().ttsk_gemm_plan(C.byref(d), C.byref(k), C.byref(sp), C.byref(ws)), "ttsk_gemm_plan")
+    return k.value, sp.value, ws.value
+
+
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=None, ldr=0, G=None, ldg=0, C2=None,
          nz1=1, nz2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), taps=0, seg_len=0, tap_shift0=0, tap_dshift=0,
-         b_tap_stride=0, bseg_len=0, bshift0=0, bdshift=0, out_seg=0, out_mul=0, out_add=0, splits=1, sCs=0,
+         b_tap_stride=0, bseg_len=0, bshift0=0, bdshift=0, out_seg=0, out_mul=0, out_add=0, splits=0, kernel=0,
          in_slope=0.0, out_slope=0.0):
     """Raw descriptor-level call of ttsk_gemm (see include/ttsk.h).  A/B/Cout may be views: the data pointer of
-    the view is the operand origin."""
+    the view is the operand origin.  splits / kernel = 0 let the library plan (tile configuration, split-K factor);
+    the split-K workspace is allocated here (the C library never allocates)."""
     _dev(A, B, Cout, bias, R, G, C2)
     d = GemmDesc()
     d.A, d.B, d.C, d.C2 = _ptr(A), _ptr(B), _ptr(Cout), _ptr(C2)
     d.bias, d.R, d.G = _ptr(bias), _ptr(R), _ptr(G)
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldb, d.ldc, d.ldr, d.ldg = lda, ldb, ldc, ldr, ldg
+    if A.dtype == f16:
+        flags |= F16
     if Cout.dtype == torch.float32:
         flags |= C_F32
     if R is not None:
@@ -59,24 +70,23 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=No
     d.taps, d.seg_len, d.tap_shift0, d.tap_dshift, d.b_tap_stride = taps, seg_len, tap_shift0, tap_dshift, b_tap_stride
     d.bseg_len, d.bshift0, d.bdshift = bseg_len, bshift0, bdshift
     d.out_seg, d.out_mul, d.out_add = out_seg, out_mul, out_add
-    d.splits, d.sCs = splits, sCs
+    d.splits, d.kernel = splits, kernel
+    kernel, splits, ws_bytes = plan(d)
+    d.splits, d.kernel = splits, kernel
+    ws = None
+    if ws_bytes > 0:
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=A.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws_bytes
     if GEMM_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(L.load().ttsk_gemm(C.byref(d), _stream()), "ttsk_gemm")
         e1.record()
         kind = "TT" if flags & A_TR else ("NT_btr" if flags & B_TR else "NT")
-        GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * max(taps, 1) * nz1 * nz2, kind, (M, N, K, max(taps, 1), nz1 * nz2, splits)))
+        GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * max(taps, 1) * nz1 * nz2, kind + str(kernel), (M, N, K, max(taps, 1), nz1 * nz2, splits)))
         return Cout
     check(L.load().ttsk_gemm(C.byref(d), _stream()), "ttsk_gemm")
     return Cout
-
-
-def reduce_slabs(slabs, n_slabs, slab_stride, dst, numel, accumulate=False):
-    _dev(slabs, dst)
-    check(L.load().ttsk_reduce_slabs(_ptr(slabs), n_slabs, slab_stride, _ptr(dst), numel, int(accumulate), _stream()),
-          "ttsk_reduce_slabs")
-    return dst
 
 
 _DUR_DTYPE = {torch.int64: 0, torch.float32: 1, torch.int32: 2}
@@ -111,61 +121,50 @@ def length_regulator_bwd(dout, cs, L_src):
 # GEMM-shaped ops expressed on the one kernel.  Activations are channels-last bf16 [rows][C], rows = B*T.
 # Weights are the bf16 shadows: Linear (out,in); Conv1d (out, k, in)  [the fp32 masters use the same layout].
 
-def _splits_for(M, N, K, nz=1):
-    tiles = ((M + 127) // 128) * ((N + 127) // 128) * nz
-    kchunks = (K + 63) // 64
-    return max(1, min(512 // max(tiles, 1), kchunks // 4))
-
-
-def linear(x, W, bias=None, out=None, flags=0, out_dtype=bf16, R=None, G=None, C2=None, alpha=1.0, out_slope=0.0):
+def linear(x, W, bias=None, out=None, flags=0, out_dtype=None, R=None, G=None, C2=None, alpha=1.0, out_slope=0.0, **kw):
     """y[M,N] = x[M,K] @ W[N,K]^T (+bias, epilogue).  reference: nn.Linear sites SubLayers.py:41-43,62; fastspeech2.py:102."""
     M, K = x.shape
     N = W.shape[0]
     if out is None:
-        out = torch.empty(M, N, dtype=out_dtype, device=x.device)
+        out = torch.empty(M, N, dtype=out_dtype or x.dtype, device=x.device)
     return gemm(x, W, out, M, N, K, x.stride(0), W.stride(0), out.stride(0), flags=flags, alpha=alpha, bias=bias,
                 R=R, ldr=0 if R is None else R.stride(0), G=G, ldg=0 if G is None else G.stride(0), C2=C2,
-                out_slope=out_slope)
+                out_slope=out_slope, **kw)
 
 
-def linear_dx(dy, W, out=None, R=None, G=None, out_dtype=bf16):
+def linear_dx(dy, W, out=None, R=None, G=None, out_dtype=bf16, **kw):
     """dx[M,K] = dy[M,N] @ W[N,K]   (W read in place through the transposing LDS read)."""
     M, N = dy.shape
     K = W.shape[1]
     if out is None:
         out = torch.empty(M, K, dtype=out_dtype, device=dy.device)
     return gemm(dy, W, out, M, K, N, dy.stride(0), W.stride(0), out.stride(0), flags=B_TR, R=R,
-                ldr=0 if R is None else R.stride(0), G=G, ldg=0 if G is None else G.stride(0))
+                ldr=0 if R is None else R.stride(0), G=G, ldg=0 if G is None else G.stride(0), **kw)
 
 
-def linear_dw(dy, x, dst, accumulate=True):
-    """dst[N,K] (fp32) (+)= dy[M,N]^T @ x[M,K]: contraction over rows, split-K slabs + deterministic reduce."""
+def linear_dw(dy, x, dst, accumulate=True, **kw):
+    """dst[N,K] (fp32) (+)= dy[M,N]^T @ x[M,K]: contraction over rows (split-K over the rows, deterministic reduce)."""
     M, N = dy.shape
     K = x.shape[1]
-    splits = _splits_for(N, K, M)
-    if splits == 1 and not accumulate:
-        return gemm(dy, x, dst, N, K, M, dy.stride(0), x.stride(0), K, flags=A_TR | B_TR)
-    slabs = torch.empty(splits, N * K, dtype=torch.float32, device=dy.device)
-    gemm(dy, x, slabs, N, K, M, dy.stride(0), x.stride(0), K, flags=A_TR | B_TR, splits=splits, sCs=N * K)
-    return reduce_slabs(slabs, splits, N * K, dst, N * K, accumulate)
+    return gemm(dy, x, dst, N, K, M, dy.stride(0), x.stride(0), K, flags=A_TR | B_TR | (ACCUM_C if accumulate else 0), **kw)
 
 
-def conv1d(x, W, bias, dilation=1, out=None, flags=0, out_dtype=bf16, R=None, C2=None, in_slope=0.0, out_slope=0.0,
-           alpha=1.0):
+def conv1d(x, W, bias, dilation=1, out=None, flags=0, out_dtype=None, R=None, C2=None, in_slope=0.0, out_slope=0.0,
+           alpha=1.0, **kw):
     """'same' Conv1d on channels-last activations.  x (B,T,Cin) bf16, W (Cout,k,Cin) bf16 -> (B,T,Cout).
     reference: SubLayers.py:96 (k=9/1), modules.py:337-355 (k=3), Layers.py:59-67 (k=5), hifi/models.py:88-95."""
     Bsz, T, Cin = x.shape
     Cout, k, _ = W.shape
     pad = dilation * (k - 1) // 2
     if out is None:
-        out = torch.empty(Bsz, T, Cout, dtype=out_dtype, device=x.device)
+        out = torch.empty(Bsz, T, Cout, dtype=out_dtype or x.dtype, device=x.device)
     gemm(x, W, out, Bsz * T, Cout, Cin, Cin, k * Cin, Cout, flags=flags, bias=bias, R=R, ldr=Cout, C2=C2, taps=k,
          seg_len=T, tap_shift0=-pad, tap_dshift=dilation, b_tap_stride=Cin, in_slope=in_slope, out_slope=out_slope,
-         alpha=alpha)
+         alpha=alpha, **kw)
     return out
 
 
-def conv1d_dx(dy, W, dilation=1, out=None, R=None, G=None):
+def conv1d_dx(dy, W, dilation=1, out=None, R=None, G=None, **kw):
     """dx (B,T,Cin) = sum_j dy[t + pad - j*dil] @ W[:, j, :]."""
     Bsz, T, Cout = dy.shape
     _, k, Cin = W.shape
@@ -173,30 +172,22 @@ def conv1d_dx(dy, W, dilation=1, out=None, R=None, G=None):
     if out is None:
         out = torch.empty(Bsz, T, Cin, dtype=bf16, device=dy.device)
     gemm(dy, W, out, Bsz * T, Cin, Cout, Cout, k * Cin, Cin, flags=B_TR, R=R, ldr=Cin, G=G, ldg=Cin, taps=k, seg_len=T,
-         tap_shift0=pad, tap_dshift=-dilation, b_tap_stride=Cin)
+         tap_shift0=pad, tap_dshift=-dilation, b_tap_stride=Cin, **kw)
     return out
 
 
-def conv1d_dw(dy, x, dst, dilation=1, k=1, accumulate=True):
-    """dst (Cout,k,Cin) fp32 (+)= sum_rows dy[r, co] * x[r + j*dil - pad, ci]."""
+def conv1d_dw(dy, x, dst, dilation=1, k=1, accumulate=True, **kw):
+    """dst (Cout,k,Cin) fp32 (+)= sum_rows dy[r, co] * x[r + j*dil - pad, ci]  (taps as the second batch index)."""
     Bsz, T, Cout = dy.shape
     Cin = x.shape[2]
     pad = dilation * (k - 1) // 2
     rows = Bsz * T
-    splits = _splits_for(Cout, Cin, rows, k)
-    n = Cout * k * Cin
-    if splits == 1 and not accumulate:
-        slabs = dst
-    else:
-        slabs = torch.empty(splits, n, dtype=torch.float32, device=dy.device)
-    gemm(dy, x, slabs, Cout, Cin, rows, Cout, Cin, k * Cin, flags=A_TR | B_TR, nz2=k, sC=(0, Cin), bseg_len=T,
-         bshift0=-pad, bdshift=dilation, splits=splits, sCs=n)
-    if slabs is not dst:
-        reduce_slabs(slabs, splits, n, dst, n, accumulate)
+    gemm(dy, x, dst, Cout, Cin, rows, Cout, Cin, k * Cin, flags=A_TR | B_TR | (ACCUM_C if accumulate else 0), nz2=k,
+         sC=(0, Cin), bseg_len=T, bshift0=-pad, bdshift=dilation, **kw)
     return dst
 
 
-def conv_transpose1d(x, Wp, bias, stride, k, out=None, in_slope=0.0, flags=0):
+def conv_transpose1d(x, Wp, bias, stride, k, out=None, in_slope=0.0, flags=0, **kw):
     """ConvTranspose1d(padding=(k-stride)//2) as `stride` polyphase implicit GEMMs.
     x (B,T,Cin) bf16, Wp (k, Cout, Cin) bf16 (tap-major repack of torch's (Cin,Cout,k)) -> (B,T*stride,Cout).
     reference: hifi/models.py:166-176,189."""
@@ -204,13 +195,13 @@ def conv_transpose1d(x, Wp, bias, stride, k, out=None, in_slope=0.0, flags=0):
     Cout = Wp.shape[1]
     p = (k - stride) // 2
     if out is None:
-        out = torch.empty(Bsz, T * stride, Cout, dtype=bf16, device=x.device)
+        out = torch.empty(Bsz, T * stride, Cout, dtype=x.dtype, device=x.device)
     taps = k // stride
     for r in range(stride):
         qoff = max(0, -((r - p) // stride))          # ceil((p - r)/stride) clipped at 0
         gemm(x, Wp[r], out, Bsz * T, Cout, Cin, Cin, Cin, Cout, flags=flags | (LRELU_IN if in_slope else 0),
              bias=bias, taps=taps, seg_len=T, tap_shift0=qoff, tap_dshift=-1, b_tap_stride=stride * Cout * Cin,
-             out_seg=T * stride, out_mul=stride, out_add=qoff * stride + r - p, in_slope=in_slope)
+             out_seg=T * stride, out_mul=stride, out_add=qoff * stride + r - p, in_slope=in_slope, **kw)
     return out
 
 
@@ -356,12 +347,12 @@ def cast_bf16(src, dst=None):
     return dst
 
 
-def nct_to_ntc_bf16(x):
-    """(B,C,T) fp32 contiguous -> (B,T,C) bf16."""
+def nct_to_ntc(x, dtype=bf16):
+    """(B,C,T) fp32 contiguous -> (B,T,C) bf16 / fp16."""
     _dev(x)
     B, Cn, T = x.shape
-    out = torch.empty(B, T, Cn, dtype=bf16, device=x.device)
-    check(L.load().ttsk_nct_to_ntc_bf16(_ptr(x.contiguous()), _ptr(out), B, Cn, T, _stream()), "ttsk_nct_to_ntc_bf16")
+    out = torch.empty(B, T, Cn, dtype=dtype, device=x.device)
+    check(L.load().ttsk_nct_to_ntc(_ptr(x.contiguous()), _ptr(out), int(dtype == f16), B, Cn, T, _stream()), "ttsk_nct_to_ntc")
     return out
 
 
@@ -485,13 +476,13 @@ def weight_norm_fold(v, g):
     return w
 
 
-def pack_conv_weight(w, transposed=False):
-    """Conv1d (Cout,Cin,k) fp32 -> (Cout,k,Cin) bf16, or ConvTranspose1d (Cin,Cout,k) fp32 -> (k,Cout,Cin) bf16."""
+def pack_conv_weight(w, transposed=False, dtype=bf16):
+    """Conv1d (Cout,Cin,k) fp32 -> (Cout,k,Cin) 16-bit, or ConvTranspose1d (Cin,Cout,k) fp32 -> (k,Cout,Cin) 16-bit."""
     _dev(w)
     d0, d1, d2 = w.shape
     shape = (d2, d1, d0) if transposed else (d0, d2, d1)
-    out = torch.empty(shape, dtype=bf16, device=w.device)
-    check(L.load().ttsk_pack_conv_weight(_ptr(w.contiguous()), _ptr(out), d0, d1, d2, int(transposed), _stream()),
+    out = torch.empty(shape, dtype=dtype, device=w.device)
+    check(L.load().ttsk_pack_conv_weight(_ptr(w.contiguous()), _ptr(out), int(dtype == f16), d0, d1, d2, int(transposed), _stream()),
           "ttsk_pack_conv_weight")
     return out
 
@@ -500,7 +491,7 @@ def avg3(a, b, c, scale, out=None):
     _dev(a, b, c)
     if out is None:
         out = torch.empty_like(a)
-    check(L.load().ttsk_avg3_bf16(_ptr(a), _ptr(b), _ptr(c), _ptr(out), a.numel(), scale, _stream()), "ttsk_avg3_bf16")
+    check(L.load().ttsk_avg3(_ptr(a), _ptr(b), _ptr(c), _ptr(out), int(a.dtype == f16), a.numel(), scale, _stream()), "ttsk_avg3")
     return out
 
 
@@ -518,6 +509,6 @@ def hifi_resblock1(x, weights, biases, dilations, out, mode=0, scale=1.0, slope=
     wp = (C.c_void_p * 6)(*[w.data_ptr() for w in weights])
     bp = (C.c_void_p * 6)(*[b.data_ptr() for b in biases])
     dl = (C.c_int32 * 3)(*[int(d) for d in dilations])
-    check(L.load().ttsk_hifi_resblock1(_ptr(x), _ptr(out), C.cast(wp, C.c_void_p), C.cast(bp, C.c_void_p), C.cast(dl, C.c_void_p),
+    check(L.load().ttsk_hifi_resblock1(_ptr(x), _ptr(out), int(x.dtype == f16), C.cast(wp, C.c_void_p), C.cast(bp, C.c_void_p), C.cast(dl, C.c_void_p),
                                        Bn, ln, Cn, K, mode, scale, slope, _stream()), "ttsk_hifi_resblock1")
     return out

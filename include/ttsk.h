@@ -54,7 +54,9 @@ enum {
   TTSK_GEMM_TANH      = 1 << 8,  /* v = tanh(v) last                                                       */
   TTSK_GEMM_ACCUM_C   = 1 << 9,  /* C_F32 only: C += v  (plain read-modify-write, one writer per element)   */
   TTSK_GEMM_LRELU_OUT = 1 << 10, /* v = leaky_relu(v, out_slope) before the store                           */
-  TTSK_GEMM_F16       = 1 << 11  /* 16-bit operands (A, B, C, C2, R, G) are IEEE fp16 instead of bf16           */
+  TTSK_GEMM_F16       = 1 << 11, /* 16-bit operands (A, B, C, C2, R, G) are IEEE fp16 instead of bf16           */
+  TTSK_GEMM_C2_LRELU  = 1 << 12  /* the second output is leaky_relu(v, out_slope) (C keeps v): the next conv's   */
+                                 /* activation is produced by this conv's epilogue instead of its operand staging */
 };
 
 typedef struct ttsk_gemm_desc {
@@ -185,19 +187,24 @@ int ttsk_to_int16(const float* src, int16_t* dst, int64_t n, float scale, void* 
  *                   IN-channels, hifi/models.py:203-210).
  * pack_conv_weight: mode 0: Conv1d (Cout,Cin,k) fp32 -> (Cout,k,Cin) bf16; mode 1: ConvTranspose1d (Cin,Cout,k) fp32 ->
  *                   (k,Cout,Cin) bf16.  (d0,d1,d2) = the source shape.
- * avg3:             out = (a + b + c) * scale — the multi-receptive-field average, hifi/models.py:190-196.
+ * avg3:             out = leaky_relu((a + b + c) * scale, slope) — the multi-receptive-field average, hifi/models.py:190-196,
+ *                   with the consumer's LeakyReLU fused (slope 1.0 = none).
  */
 int ttsk_weight_norm_fold(const float* v, const float* g, float* w, int rows, int cols, void* stream);
 int ttsk_pack_conv_weight(const float* src, void* dst16, int f16, int d0, int d1, int d2, int mode, void* stream);
-int ttsk_avg3(const void* a, const void* b, const void* c, void* out, int f16, int64_t n, float scale, void* stream);
+int ttsk_avg3(const void* a, const void* b, const void* c, void* out, int f16, int64_t n, float scale, float slope, void* stream);
 
-/* Fused ResBlock1 (hifi/models.py:88-95): all six convs of one block for C in {32,64}, K in {3,7,11}; x/out bf16
+/* Fused ResBlock1 (hifi/models.py:88-95): all six convs of one block for C in {32,64}, K in {3,7,11}; x/out 16-bit
  * channels-last (B, len, C); weights/biases in the order convs1[0], convs2[0], convs1[1], convs2[1], convs1[2],
- * convs2[2], each weight packed (C, K, C) bf16 (ttsk_pack_conv_weight mode 0).  mode 0: out = y; 1: out += y;
- * 2: out = (out + y) * scale  — the MRF sum / average over the three blocks of a stage (hifi/models.py:190-196). */
+ * convs2[2], each weight a fragment-major pack made by ttsk_pack_resblock_weight from the folded (C, C, K) fp32 tensor.
+ * mode 0: out = y; 1: out += y; 2: out = (out + y) * scale — the MRF sum / average over the three blocks of a stage
+ * (hifi/models.py:190-196); final_slope != 1 applies LeakyReLU(final_slope) to the stored value (the consumer's
+ * activation, hifi/models.py:188,197, fused into the last block of the stage). */
+int64_t ttsk_resblock_pack_elems(int C, int K);   /* elements of one pack (K padded to the kernel's weight stage) */
+int ttsk_pack_resblock_weight(const float* src, void* dst16, int f16, int C, int K, void* stream);
 int ttsk_hifi_resblock1(const void* x16, void* out16, int f16, const void* const* weights, const float* const* biases,
                         const int32_t* dilations, int B, int len, int C, int K, int mode, float scale, float slope,
-                        void* stream);
+                        float final_slope, void* stream);
 int ttsk_hifi_resblock1_supported(int C, int K);
 
 /* ------------------------------------------------------------------------------------- PostNet BatchNorm1d

@@ -149,10 +149,10 @@ def test_fused_resblock1_vs_oracle(C, K, B, ln, dtype):
         sd["r.convs2.%d.weight" % m], sd["r.convs2.%d.bias" % m] = ws[2 * m + 1].float(), bs[2 * m + 1]
     with torch.no_grad():
         want = ohifi.res_block1(sd, "r.", x.float().transpose(1, 2), K, (1, 3, 5)).transpose(1, 2)
-    wk = [w.permute(0, 2, 1).contiguous().to(DEV) for w in ws]          # (Cout, K, Cin)
+    wk = [ops.pack_resblock_weight(w.float().to(DEV), dtype=dtype) for w in ws]      # fragment-major packs
     bd = [b.to(DEV) for b in bs]
     out = torch.full((B, ln, C), 7.0, dtype=dtype, device=DEV)
-    ops.hifi_resblock1(x.to(DEV), wk, bd, (1, 3, 5), out, mode=0)
+    ops.hifi_resblock1(x.to(DEV), wk, bd, (1, 3, 5), out, K, mode=0)
     got = out.float().cpu()
     r = rel_rms(got, want)
     print("C=%d K=%d len=%d rel-RMS %.3f%% max-abs %.4f" % (C, K, ln, 100 * r, float((got - want).abs().max())))
@@ -160,10 +160,11 @@ def test_fused_resblock1_vs_oracle(C, K, B, ln, dtype):
     assert r <= tol and float((got - want).abs().max()) <= 6 * tol * float(want.abs().max())
     # MRF accumulation modes: out2 = (out + y) / 3 computed in fp32 from the bf16 values, rounded once
     out2 = out.clone()
-    ops.hifi_resblock1(x.to(DEV), wk, bd, (1, 3, 5), out2, mode=1)
+    ops.hifi_resblock1(x.to(DEV), wk, bd, (1, 3, 5), out2, K, mode=1)
     assert torch.equal(out2.cpu(), (got + got).to(dtype))
-    ops.hifi_resblock1(x.to(DEV), wk, bd, (1, 3, 5), out2, mode=2, scale=1.0 / 3.0)
-    assert torch.equal(out2.cpu(), (((got + got).to(dtype).float() + got) * (1.0 / 3.0)).to(dtype))
+    ops.hifi_resblock1(x.to(DEV), wk, bd, (1, 3, 5), out2, K, mode=2, scale=1.0 / 3.0, final_slope=0.01)
+    want2 = ((got + got).to(dtype).float() + got) * (1.0 / 3.0)
+    assert torch.equal(out2.cpu(), torch.where(want2 > 0, want2, want2 * 0.01).to(dtype))
 
 
 def test_fused_and_unfused_generators_agree(cfg):

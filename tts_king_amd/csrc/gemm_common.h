@@ -88,6 +88,10 @@ __device__ __forceinline__ void epilogue_store(const ttsk_gemm_desc& d, int64_t 
     }
   }
   if (d.C2) {
+    if (flags & TTSK_GEMM_C2_LRELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * d.out_slope;
+    }
     bf16_t* cp = (bf16_t*)d.C2 + coff + orow * d.ldc + gn;
     if (nvalid == 8 && ((d.ldc & 7) == 0) && ((coff & 7) == 0)) {
       *(uint4*)cp = pack8<F16>(v);

@@ -45,11 +45,12 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
   }
 }
 
-// out = (a + b + c) * scale, bf16, 8 elements per lane  — the MRF average (hifi/models.py:190-196)
+// out = lrelu((a + b + c) * scale, slope), 8 elements per lane — the MRF average (hifi/models.py:190-196) with the
+// consumer's LeakyReLU (hifi/models.py:188,197) fused
 template <bool F16>
 __global__ __launch_bounds__(256) void avg3_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b,
                                                    const uint4* __restrict__ c, uint4* __restrict__ out, int64_t n8,
-                                                   float scale) {
+                                                   float scale, float slope) {
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
     const uint4 va = a[i], vb = b[i], vc = c[i];
     const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w}, wc[4] = {vc.x, vc.y, vc.z, vc.w};
@@ -58,7 +59,10 @@ __global__ __launch_bounds__(256) void avg3_kernel(const uint4* __restrict__ a, 
     for (int e = 0; e < 4; ++e) {
       float al, ah, bl, bh, cl, ch;
       unpack2<F16>(wa[e], al, ah); unpack2<F16>(wb[e], bl, bh); unpack2<F16>(wc[e], cl, ch);
-      o[e] = pack2<F16>((al + bl + cl) * scale, (ah + bh + ch) * scale);
+      float lo = (al + bl + cl) * scale, hi = (ah + bh + ch) * scale;
+      lo = lo > 0.f ? lo : lo * slope;      // slope 1.0 = identity
+      hi = hi > 0.f ? hi : hi * slope;
+      o[e] = pack2<F16>(lo, hi);
     }
     out[i] = make_uint4(o[0], o[1], o[2], o[3]);
   }
@@ -86,7 +90,7 @@ extern "C" int ttsk_pack_conv_weight(const float* src, void* dst16, int f16, int
   return TTSK_OK;
 }
 
-extern "C" int ttsk_avg3(const void* a, const void* b, const void* c, void* out, int f16, int64_t n, float scale, void* stream) {
+extern "C" int ttsk_avg3(const void* a, const void* b, const void* c, void* out, int f16, int64_t n, float scale, float slope, void* stream) {
   TTSK_REQUIRE(a && b && c && out && n > 0 && (n & 7) == 0, "ttsk_avg3: n must be a positive multiple of 8");
   TTSK_REQUIRE(((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)out)) & 15) == 0, "ttsk_avg3: 16-byte alignment");
   const int64_t n8 = n / 8;
@@ -94,10 +98,10 @@ extern "C" int ttsk_avg3(const void* a, const void* b, const void* c, void* out,
   if (blocks > 4096) blocks = 4096;
   if (f16)
     hipLaunchKernelGGL(avg3_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b,
-                       (const uint4*)c, (uint4*)out, n8, scale);
+                       (const uint4*)c, (uint4*)out, n8, scale, slope);
   else
     hipLaunchKernelGGL(avg3_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b,
-                       (const uint4*)c, (uint4*)out, n8, scale);
+                       (const uint4*)c, (uint4*)out, n8, scale, slope);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -129,7 +129,8 @@ class Generator(nn.Module):
         return tuple((id(p), p._version) for c in self._all_convs() for p in c._parameters.values())
 
     def _prepare(self):
-        """bf16 tap-major copies of the folded weights, rebuilt when any parameter was written."""
+        """16-bit copies of the folded weights in kernel layouts (tap-major for the implicit-GEMM convs, MFMA-fragment-
+        major for the fused ResBlock kernel), rebuilt when any parameter was written."""
         dt = self.act_dtype
         key = self._weights_key() + (dt,)
         if self._packed is not None and self._packed_key == key:
@@ -137,63 +138,80 @@ class Generator(nn.Module):
         pk = {}
         pk["pre"] = (ops.pack_conv_weight(self.conv_pre.folded_weight(), dtype=dt), self.conv_pre.bias.data)
         pk["ups"] = [(ops.pack_conv_weight(u.folded_weight(), transposed=True, dtype=dt), u.bias.data) for u in self.ups]
-        pk["rb"] = [[(ops.pack_conv_weight(c.folded_weight(), dtype=dt), c.bias.data) for c in rb.all_convs()] for rb in self.resblocks]
-        wp = self.conv_post.folded_weight()                               # (1, C, 7)
-        pk["post"] = (ops.pack_conv_weight(wp, dtype=dt), self.conv_post.bias.data)
+        pk["rb"], pk["rbf"] = [], []
+        for rb in self.resblocks:
+            convs = rb.all_convs()
+            ch = convs[0].bias.shape[0]
+            if rb.kind == "1" and ops.hifi_resblock1_supported(ch, rb.k):
+                n = len(rb.dilation)
+                order = [convs[m // 2 + (n if m % 2 else 0)] for m in range(2 * n)]          # c1_0, c2_0, c1_1, c2_1, ...
+                pk["rbf"].append(([ops.pack_resblock_weight(c.folded_weight(), dtype=dt) for c in order], [c.bias.data for c in order]))
+            else:
+                pk["rbf"].append(None)
+            pk["rb"].append([(ops.pack_conv_weight(c.folded_weight(), dtype=dt), c.bias.data) for c in convs])
+        pk["post"] = (ops.pack_conv_weight(self.conv_post.folded_weight(), dtype=dt), self.conv_post.bias.data)
         self._packed, self._packed_key = pk, key
         return pk
 
     # ------------------------------------------------------------------ forward
-    def _resblock(self, rb, packed, x):
-        """reference: hifi/models.py:88-95 (ResBlock1) / :136-140 (ResBlock2); LeakyReLU(0.1) is applied while the
-        conv stages its input tile, the residual add happens in the conv epilogue."""
-        if rb.kind == "1":
-            n = len(rb.dilation)
-            for m, d in enumerate(rb.dilation):
-                w1, b1 = packed[m]
-                w2, b2 = packed[n + m]
-                t = ops.conv1d(x, w1, b1, dilation=d, flags=ops.LRELU_IN, in_slope=LRELU_SLOPE)
-                x = ops.conv1d(t, w2, b2, flags=ops.LRELU_IN, in_slope=LRELU_SLOPE, R=x)
-            return x
+    def _resblock(self, rb, packed, x, xl):
+        """reference: hifi/models.py:88-95 (ResBlock1) / :136-140 (ResBlock2), conv by conv on the implicit-GEMM kernel.
+        x = block input, xl = lrelu(x).  Every LeakyReLU is applied by the PRODUCING conv's epilogue (LRELU_OUT, or a
+        second output C2 = lrelu(v) next to the raw v the residual path needs), the residual add is an epilogue too."""
+        nd = len(rb.dilation)
         for m, d in enumerate(rb.dilation):
-            w, b = packed[m]
-            x = ops.conv1d(x, w, b, dilation=d, flags=ops.LRELU_IN, in_slope=LRELU_SLOPE, R=x)
+            lastp = m == nd - 1
+            xl_next = None if lastp else torch.empty_like(x)
+            if rb.kind == "1":
+                w1, b1 = packed[m]
+                w2, b2 = packed[nd + m]
+                tl = ops.conv1d(xl, w1, b1, dilation=d, flags=ops.LRELU_OUT, out_slope=LRELU_SLOPE)
+                x = ops.conv1d(tl, w2, b2, R=x, C2=xl_next, flags=0 if lastp else ops.C2_LRELU, out_slope=LRELU_SLOPE)
+            else:
+                w, b = packed[m]
+                x = ops.conv1d(xl, w, b, dilation=d, R=x, C2=xl_next, flags=0 if lastp else ops.C2_LRELU, out_slope=LRELU_SLOPE)
+            xl = xl_next
         return x
 
     def forward(self, x):
-        """x (B, 80, T) mel on a HIP device -> (B, 1, T*prod(upsample_rates)) fp32.  reference: hifi/models.py:185-201."""
+        """x (B, 80, T) mel on a HIP device -> (B, 1, T*prod(upsample_rates)) fp32.  reference: hifi/models.py:185-201.
+
+        Dataflow: `al` always holds LeakyReLU(stage output) — the only thing the next ConvTranspose1d / conv_post reads
+        (hifi/models.py:188,197) — produced by conv_pre's epilogue, then by the MRF average of each stage."""
         if not x.is_cuda:
             raise ops.L.TtskError("HiFi-GAN Generator.forward needs a HIP device tensor (gpu: 'cuda:0'); there is no CPU path")
         pk = self._prepare()
         h = self.h
+        nk = self.num_kernels
         with torch.no_grad():
-            Bn, _, T = x.shape
-            a = ops.nct_to_ntc(x.float(), self.act_dtype)                                 # (B, T, 80) 16-bit
-            a = ops.conv1d(a, pk["pre"][0], pk["pre"][1])                                 # conv_pre
+            a0 = ops.nct_to_ntc(x.float(), self.act_dtype)                                 # (B, T, 80) 16-bit
+            al = ops.conv1d(a0, pk["pre"][0], pk["pre"][1], flags=ops.LRELU_OUT, out_slope=LRELU_SLOPE)   # lrelu(conv_pre(x))
             for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
                 wu, bu = pk["ups"][i]
-                a = ops.conv_transpose1d(a, wu, bu, u, k, in_slope=LRELU_SLOPE)           # lrelu(0.1) -> ConvTranspose1d
-                rbs = [self.resblocks[i * self.num_kernels + j] for j in range(self.num_kernels)]
-                if self.fused and all(rb.kind == "1" and ops.hifi_resblock1_supported(a.shape[2], rb.k) for rb in rbs):
-                    # fused path: one kernel per ResBlock (six convs), MRF sum/average folded into the copy-out
-                    nxt = torch.empty_like(a)
+                # slope of the activation that consumes this stage's output: 0.1 before the next upsampler,
+                # F.leaky_relu's default 0.01 before conv_post (hifi/models.py:197)
+                nxt_slope = LRELU_SLOPE if i + 1 < self.num_upsamples else 0.01
+                rbs = [self.resblocks[i * nk + j] for j in range(nk)]
+                fused = self.fused and all(pk["rbf"][i * nk + j] is not None for j in range(nk)) and nk >= 2
+                if fused:
+                    a = ops.conv_transpose1d(al, wu, bu, u, k)                             # raw x: the fused blocks activate it themselves
+                    out = torch.empty_like(a)
                     for j, rb in enumerate(rbs):
-                        pr = pk["rb"][i * self.num_kernels + j]
-                        n = len(rb.dilation)
-                        order = [pr[m // 2 + (n if m % 2 else 0)] for m in range(2 * n)]     # c1_0, c2_0, c1_1, c2_1, ...
-                        mode = 0 if j == 0 else (2 if j == self.num_kernels - 1 else 1)
-                        ops.hifi_resblock1(a, [w for w, _ in order], [b for _, b in order], rb.dilation, nxt, mode=mode,
-                                           scale=1.0 / self.num_kernels, slope=LRELU_SLOPE)
-                    a = nxt
+                        ws, bs = pk["rbf"][i * nk + j]
+                        lastb = j == nk - 1
+                        ops.hifi_resblock1(a, ws, bs, rb.dilation, out, rb.k, mode=0 if j == 0 else (2 if lastb else 1),
+                                           scale=1.0 / nk, slope=LRELU_SLOPE, final_slope=nxt_slope if lastb else 1.0)
+                    al = out
                     continue
-                outs = [self._resblock(rb, pk["rb"][i * self.num_kernels + j], a) for j, rb in enumerate(rbs)]
-                if self.num_kernels == 3:
-                    a = ops.avg3(outs[0], outs[1], outs[2], 1.0 / 3.0)                    # xs / num_kernels
+                axl = torch.empty(al.shape[0], al.shape[1] * u, wu.shape[1], dtype=al.dtype, device=al.device)
+                a = ops.conv_transpose1d(al, wu, bu, u, k, C2=axl, flags=ops.C2_LRELU, out_slope=LRELU_SLOPE)   # x and lrelu(x)
+                outs = [self._resblock(rb, pk["rb"][i * nk + j], a, axl) for j, rb in enumerate(rbs)]
+                if nk == 3:
+                    al = ops.avg3(outs[0], outs[1], outs[2], 1.0 / 3.0, slope=nxt_slope)   # lrelu(xs / num_kernels)
                 else:
                     raise NotImplementedError("MRF average is written for 3 resblock kernels per stage")
-            Bn, Tout, C = a.shape
+            Bn, Tout, C = al.shape
             wp, bp = pk["post"]
-            y = torch.empty(Bn * Tout, 1, dtype=torch.float32, device=a.device)
-            # F.leaky_relu default slope 0.01 (hifi/models.py:197) -> conv_post -> tanh
-            ops.conv1d(a, wp, bp, out=y.view(Bn, Tout, 1), flags=ops.LRELU_IN | ops.TANH, in_slope=0.01)
+            y = torch.empty(Bn * Tout, 1, dtype=torch.float32, device=al.device)
+            ops.conv1d(al, wp, bp, out=y.view(Bn, Tout, 1), flags=ops.TANH)                 # conv_post -> tanh
         return y.view(Bn, 1, Tout)

@@ -36,7 +36,7 @@ class GemmDesc(C.Structure):
 
 
 # flags (include/ttsk.h)
-A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT, F16 = [1 << i for i in range(12)]
+A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT, F16, C2_LRELU = [1 << i for i in range(13)]
 
 
 def declared_symbols(header_path=HEADER_PATH):
@@ -89,7 +89,9 @@ def load(path=LIB_PATH):
     lib.ttsk_last_error.restype = C.c_char_p
     for name, argtypes in declared_prototypes().items():
         fn = getattr(lib, name)
-        if name != "ttsk_last_error":
+        if name == "ttsk_resblock_pack_elems":
+            fn.restype = C.c_int64
+        elif name != "ttsk_last_error":
             fn.restype = C.c_int
         fn.argtypes = argtypes
     lib.ttsk_gemm.argtypes = [C.POINTER(GemmDesc), C.c_void_p]

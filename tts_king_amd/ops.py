@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import (A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT, F16,  # noqa: F401
+from .lib import (A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT, F16, C2_LRELU,  # noqa: F401
                   GemmDesc, check)
 
 bf16 = torch.bfloat16
@@ -187,7 +187,7 @@ def conv1d_dw(dy, x, dst, dilation=1, k=1, accumulate=True, **kw):
     return dst
 
 
-def conv_transpose1d(x, Wp, bias, stride, k, out=None, in_slope=0.0, flags=0, **kw):
+def conv_transpose1d(x, Wp, bias, stride, k, out=None, in_slope=0.0, flags=0, C2=None, out_slope=0.0, **kw):
     """ConvTranspose1d(padding=(k-stride)//2) as `stride` polyphase implicit GEMMs.
     x (B,T,Cin) bf16, Wp (k, Cout, Cin) bf16 (tap-major repack of torch's (Cin,Cout,k)) -> (B,T*stride,Cout).
     reference: hifi/models.py:166-176,189."""
@@ -201,7 +201,7 @@ def conv_transpose1d(x, Wp, bias, stride, k, out=None, in_slope=0.0, flags=0, **
         qoff = max(0, -((r - p) // stride))          # ceil((p - r)/stride) clipped at 0
         gemm(x, Wp[r], out, Bsz * T, Cout, Cin, Cin, Cin, Cout, flags=flags | (LRELU_IN if in_slope else 0),
              bias=bias, taps=taps, seg_len=T, tap_shift0=qoff, tap_dshift=-1, b_tap_stride=stride * Cout * Cin,
-             out_seg=T * stride, out_mul=stride, out_add=qoff * stride + r - p, in_slope=in_slope, **kw)
+             out_seg=T * stride, out_mul=stride, out_add=qoff * stride + r - p, in_slope=in_slope, C2=C2, out_slope=out_slope, **kw)
     return out
 
 
@@ -487,11 +487,12 @@ def pack_conv_weight(w, transposed=False, dtype=bf16):
     return out
 
 
-def avg3(a, b, c, scale, out=None):
+def avg3(a, b, c, scale, out=None, slope=1.0):
+    """out = leaky_relu((a + b + c) * scale, slope)  (slope 1.0 = no activation)."""
     _dev(a, b, c)
     if out is None:
         out = torch.empty_like(a)
-    check(L.load().ttsk_avg3(_ptr(a), _ptr(b), _ptr(c), _ptr(out), int(a.dtype == f16), a.numel(), scale, _stream()), "ttsk_avg3")
+    check(L.load().ttsk_avg3(_ptr(a), _ptr(b), _ptr(c), _ptr(out), int(a.dtype == f16), a.numel(), scale, slope, _stream()), "ttsk_avg3")
     return out
 
 
@@ -499,16 +500,26 @@ def hifi_resblock1_supported(C_, K):
     return bool(L.load().ttsk_hifi_resblock1_supported(C_, K))
 
 
-def hifi_resblock1(x, weights, biases, dilations, out, mode=0, scale=1.0, slope=0.1):
-    """Fused ResBlock1 (reference: hifi/models.py:88-95).  x/out (B, len, C) bf16; weights: six (C, K, C) bf16 tensors and
-    biases six fp32 (C,) in the order convs1[0], convs2[0], convs1[1], convs2[1], convs1[2], convs2[2].
-    mode 0: out = y, 1: out += y, 2: out = (out + y) * scale."""
+def pack_resblock_weight(w, dtype=f16):
+    """Folded Conv1d weight (C, C, K) fp32 -> MFMA-fragment-major 16-bit pack for ttsk_hifi_resblock1."""
+    _dev(w)
+    Cn, _, K = w.shape
+    out = torch.empty(L.load().ttsk_resblock_pack_elems(Cn, K), dtype=dtype, device=w.device)
+    check(L.load().ttsk_pack_resblock_weight(_ptr(w.contiguous()), _ptr(out), int(dtype == f16), Cn, K, _stream()),
+          "ttsk_pack_resblock_weight")
+    return out
+
+
+def hifi_resblock1(x, weights, biases, dilations, out, K, mode=0, scale=1.0, slope=0.1, final_slope=1.0):
+    """Fused ResBlock1 (reference: hifi/models.py:88-95).  x/out (B, len, C) 16-bit; weights: six fragment-major packs
+    (pack_resblock_weight) and biases six fp32 (C,) in the order convs1[0], convs2[0], convs1[1], convs2[1], convs1[2],
+    convs2[2].  mode 0: out = y, 1: out += y, 2: out = (out + y) * scale; final_slope: LeakyReLU on the stored value."""
     _dev(x, out, *weights, *biases)
     Bn, ln, Cn = x.shape
-    K = weights[0].shape[1]
     wp = (C.c_void_p * 6)(*[w.data_ptr() for w in weights])
     bp = (C.c_void_p * 6)(*[b.data_ptr() for b in biases])
     dl = (C.c_int32 * 3)(*[int(d) for d in dilations])
-    check(L.load().ttsk_hifi_resblock1(_ptr(x), _ptr(out), int(x.dtype == f16), C.cast(wp, C.c_void_p), C.cast(bp, C.c_void_p), C.cast(dl, C.c_void_p),
-                                       Bn, ln, Cn, K, mode, scale, slope, _stream()), "ttsk_hifi_resblock1")
+    check(L.load().ttsk_hifi_resblock1(_ptr(x), _ptr(out), int(x.dtype == f16), C.cast(wp, C.c_void_p), C.cast(bp, C.c_void_p),
+                                       C.cast(dl, C.c_void_p), Bn, ln, Cn, K, mode, scale, slope, final_slope, _stream()),
+          "ttsk_hifi_resblock1")
     return out

@@ -91,7 +91,11 @@ def hifi_cpu_baseline(cfg, B=8, T=384, runs=1):
 
 
 def gemm_roofline(enqueue, batch, steps=3):
-    """Bracket every MFMA GEMM launch of `steps` eager train steps with HIP events on the launch stream."""
+    """Roofline of the dominant kernel of the step.  Every ttsk_gemm launch of `steps` eager train steps is bracketed by
+    HIP events on its launch stream (tts_king_amd/ops.py:GEMM_TRACE); launches are grouped by kernel symbol (tile
+    configuration x operand layout, the names rocprofv3 reports) and the symbol that carries the most algorithmic FLOPs is
+    reported (under hipGraph replay no single symbol dominates the step's time): achieved = its algorithmic FLOPs (2*M*N*K*taps*batch per launch) / its measured time.  A split-K launch includes
+    its reducer kernel in the bracket."""
     from tts_king_amd import ops
     enqueue(batch)
     torch.cuda.synchronize()
@@ -103,23 +107,26 @@ def gemm_roofline(enqueue, batch, steps=3):
         torch.cuda.synchronize()
     finally:
         ops.GEMM_TRACE = None
-    tot_ms = sum(e0.elapsed_time(e1) for e0, e1, *_ in trace)
-    tot_fl = sum(t[2] for t in trace)
-    by_shape = {}
+    sym = {"NT1": "gemm_kernel<false, false, false>", "NT_btr1": "gemm_kernel<false, true, false>", "TT1": "gemm_kernel<true, true, false>",
+           "NT2": "gemm2_kernel<false, false, false>", "NT_btr2": "gemm2_kernel<false, true, false>", "TT2": "gemm2_kernel<true, true, false>"}
+    by_sym, by_shape = {}, {}
     for e0, e1, fl, kind, shape in trace:
-        k = (kind,) + shape
-        d = by_shape.setdefault(k, [0.0, 0.0, 0])
-        d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += 1
-    dom = max(by_shape.items(), key=lambda kv: kv[1][0])
-    n = len(trace)
-    ach = tot_fl / (tot_ms * 1e-3) / 1e12
-    dk, dv = dom
+        ms = e0.elapsed_time(e1)
+        d = by_sym.setdefault(kind, [0.0, 0.0, 0]); d[0] += ms; d[1] += fl; d[2] += 1
+        d = by_shape.setdefault((kind,) + shape, [0.0, 0.0, 0]); d[0] += ms; d[1] += fl; d[2] += 1
+    tot_ms = sum(v[0] for v in by_sym.values())
+    tot_fl = sum(v[1] for v in by_sym.values())
+    dk, dv = max(by_sym.items(), key=lambda kv: kv[1][1])      # dominant = most algorithmic FLOPs (decoder FFN / PostNet convs)
+    sk, sv = max(((k, v) for k, v in by_shape.items() if k[0] == dk), key=lambda kv: kv[1][0])
+    ach = dv[1] / (dv[0] * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_BF16_TFLOPS,
             "traffic": None,
-            "kernel": "gemm_kernel<A_TR,B_TR> (tts_king_amd/csrc/gemm.hip), all %d launches of a train step" % (n // steps),
-            "avg_launch_us": 1e3 * tot_ms / n, "avg_launch_gflop": tot_fl / n / 1e9, "gemm_ms_per_step": tot_ms / steps,
-            "dominant_shape": {"kind": dk[0], "M,N,K,taps,batch,splits": list(dk[1:]), "launches_per_step": dv[2] // steps,
-                               "avg_us": 1e3 * dv[0] / dv[2], "tflops": dv[1] / (dv[0] * 1e-3) / 1e12}}
+            "kernel": "%s (tts_king_amd/csrc/gemm%s.hip)" % (sym.get(dk, dk), "2" if dk.endswith("2") else ""),
+            "launches_per_step": dv[2] // steps, "avg_launch_us": 1e3 * dv[0] / dv[2], "avg_launch_gflop": dv[1] / dv[2] / 1e9,
+            "kernel_ms_per_step": dv[0] / steps,
+            "all_gemm": {"launches_per_step": len(trace) // steps, "ms_per_step": tot_ms / steps, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12},
+            "largest_shape": {"M,N,K,taps,batch,splits": list(sk[1:]), "launches_per_step": sv[2] // steps,
+                              "avg_us": 1e3 * sv[0] / sv[2], "tflops": sv[1] / (sv[0] * 1e-3) / 1e12}}
 
 
 def main():

@@ -54,5 +54,5 @@ def hifi_rtf(cfg, dev, B=8, T=384, iters=20, warmup=3, use_graph=True):
     return {"workload": "HiFi-GAN V1 generator, B=%d, T=%d mel frames -> %d samples @ %d Hz (BASELINE.json configs[2])" % (B, T, samples, int(sr)),
             "rtf": wall / audio_s, "ms_per_batch": 1e3 * wall, "device_ms_per_batch": 1e3 * dev_s, "samples_per_s": samples / wall,
             "audio_seconds_per_batch": audio_s, "tflops": flops / wall / 1e12, "mfma_roofline_frac": flops / wall / 2.5e15,
-            "int16_d2h_ms": 1e3 * d2h, "launch": "hipGraph replay" if use_graph else "eager", "dtype": "bf16",
+            "int16_d2h_ms": 1e3 * d2h, "launch": "hipGraph replay" if use_graph else "eager", "dtype": "f16 (fp32 accumulate)",
             "iters": iters}

@@ -32,6 +32,11 @@ class FSTWOapi:
         self.cfg = config
         self.device = device
         self.restore_step = 0
+        mi = config.get("mi355x", {}) if hasattr(config, "get") else {}
+        self._synth = None
+        if mi and mi.get("hip_graph", False) and str(device).startswith("cuda"):
+            from tts_king_amd.synth import GraphedSynthesizer
+            self._synth = GraphedSynthesizer(self.model)
 
     def generate(self, phonemes, duration_control=1.0, pitch_control=1.0, energy_control=1.0, speaker_name=None):
         """phonemes: int ndarray (1, L) -> postnet mel (1, T, 80) fp32 on the device.  reference: fsapi.py:38-82."""
@@ -44,6 +49,10 @@ class FSTWOapi:
         speaker = torch.tensor(speaker_id).long().unsqueeze(0).to(self.device)
         self.model.eval()
         phonemes = np.asarray(phonemes)
+        if self._synth is not None:      # hipGraph-replayed path (tts_king_amd/synth.py): same kernels, no launch overhead
+            post, _ = self._synth.mel(speaker, torch.from_numpy(phonemes).long().to(self.device), pitch_control, energy_control,
+                                      duration_control)
+            return post
         src_len = np.array([len(phonemes[0])])
         result = self.model(speaker, torch.from_numpy(phonemes).long().to(self.device), torch.from_numpy(src_len).to(self.device),
                             max(src_len), d_control=duration_control, p_control=pitch_control, e_control=energy_control)

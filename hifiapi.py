@@ -46,6 +46,11 @@ class HIFIapi:
         self.model.to(device)
         self.model.remove_weight_norm()
         self.model.eval()
+        mi = config.get("mi355x", {}) if hasattr(config, "get") else {}
+        self._synth = None
+        if mi and mi.get("hip_graph", False):
+            from tts_king_amd.synth import GraphedSynthesizer
+            self._synth = GraphedSynthesizer(None, self.model)
 
     def train(self):
         """reference: hifiapi.py:32-33 raises (`NotImplemented(...)` is not callable -> TypeError there)."""
@@ -59,7 +64,8 @@ class HIFIapi:
         """mel (B,80,T) -> int16 ndarray (B,1,256T) on the host.  reference: hifiapi.py:40-52."""
         self.model.eval()
         with torch.no_grad():
-            audio = self.model(mel_specs.to(self.device))
+            mel_specs = mel_specs.to(self.device)
+            audio = self._synth.wav(mel_specs.float()) if self._synth is not None else self.model(mel_specs)
             audio = ops.to_int16(audio, float(self.cfg.hifi.MAX_WAV_VALUE))     # scale + truncate toward zero on device
             audio = audio.cpu().numpy()
         return audio

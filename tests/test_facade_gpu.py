@@ -1,0 +1,87 @@
+"""GPU: the reference's synthesis surface end to end (BASELINE.json configs[4]): TTSKing(config) -> generate_mel ->
+mel_to_wav, eager and hipGraph-replayed, against the oracle on the same weights.
+
+reference: tts_king.py:18-49, fsapi.py:38-82, hifiapi.py:40-52.  Free-running durations come from a bf16-accurate
+log-duration, so a few may land on the other side of a rounding boundary than the fp32 oracle's, and a pitch/energy
+prediction next to a bin edge may select the neighbouring embedding row (same rule as tests/test_fs2_gpu.py::
+test_eval_free_running); the mel is therefore compared with the oracle run teacher-forced on the durations, pitch and
+energy values the HIP path produced (stated tolerance: rel-RMS <= 1 %), the waveform with the oracle vocoder on the
+HIP path's own mel (rel-RMS <= 0.5 %).  Graph replay must reproduce the eager result bit for bit."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fs2 as ofs2
+from oracle import hifigan as ohifi
+from tests.oracle_util import rel_rms
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_tts(tmp_path, hip_graph):
+    import yaml
+    import tts_king
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config.yaml")))
+    cfg["preprocess_config"]["path"]["preprocessed_path"] = os.path.join(ROOT, "pretrained")
+    cfg["mi355x"]["hip_graph"] = hip_graph
+    p = tmp_path / ("config_%d.yaml" % hip_graph)
+    p.write_text(yaml.safe_dump(cfg))
+    t = tts_king.TTSKing(str(p))
+    with torch.no_grad():       # random-init duration head predicts ~0 frames: shift it so utterances have a few frames per phoneme
+        t.tts.model.get("variance_adaptor.duration_predictor.linear_layer.bias").fill_(1.3)
+    return t
+
+
+def test_ttsking_surface_and_parity(tmp_path):
+    tts = make_tts(tmp_path, False)
+    assert len(tts.speakers) == 66 and tts.speakers == tts.tts.speaker_names           # pretrained/speakers.json
+    g = torch.Generator().manual_seed(3)
+    phon = torch.randint(1, 207, (1, 48), generator=g).numpy()
+    mel = tts.generate_mel(phon, duration_control=1.0, pitch_control=1.2, energy_control=0.9, speaker=5)
+    assert mel.dim() == 3 and mel.shape[0] == 1 and mel.shape[2] == 80 and mel.dtype == torch.float32
+    T = mel.shape[1]
+    assert T > 48
+    wav = tts.mel_to_wav(mel)
+    assert wav.dtype == np.int16 and wav.shape == (1, 1, 256 * T)
+    with pytest.raises(Exception):
+        tts.tts.generate(phon, speaker_name="no such speaker")
+    # ---- oracle on the same weights, teacher-forced on the durations the HIP path predicted
+    sd = {k: v.detach().float().cpu() for k, v in tts.tts.model.state_dict().items()}
+    m = tts.tts.model
+    out = m(torch.tensor([5]), torch.from_numpy(phon), torch.tensor([48]), 48, p_control=1.2, e_control=0.9)
+    d_rounded = out[4].cpu()
+    assert int(d_rounded.clamp(min=0).trunc().sum()) == T
+    cfg = tts.cfg
+    with torch.no_grad():
+        ref = ofs2.fs2_forward(sd, cfg.model_config, torch.tensor([5]), torch.from_numpy(phon).long(), torch.tensor([48]), 48,
+                               d_targets=d_rounded, max_mel_len=T, mel_lens=torch.tensor([T]),
+                               pitches_raw=out[1].detach().float().cpu(), e_targets=out[2].detach().float().cpu())
+    r = rel_rms(mel.cpu(), ref[9])
+    print("facade mel vs oracle (HIP durations, pitch, energy): rel-RMS %.3f%%" % (100 * r))
+    assert r <= 0.01
+    gsd = {k: v.detach().float().cpu() for k, v in tts.vocoder.model.state_dict().items()}
+    with torch.no_grad():
+        wref = ohifi.generator(gsd, cfg.hifi, mel.cpu().transpose(1, 2))
+    got = wav.astype(np.float32) / 32768.0
+    r = rel_rms(torch.from_numpy(got), wref)
+    print("facade waveform vs oracle vocoder on the same mel: rel-RMS %.3f%%" % (100 * r))
+    assert r <= 0.005 + 2e-5 / float(wref.pow(2).mean().sqrt())          # + int16 quantisation
+
+
+def test_graph_replay_is_bit_identical_to_eager(tmp_path):
+    eager = make_tts(tmp_path, False)
+    graphed = make_tts(tmp_path, True)
+    g = torch.Generator().manual_seed(4)
+    phons = [torch.randint(1, 207, (1, L), generator=g).numpy() for L in (40, 40, 40, 56)]
+    for i, ph in enumerate(phons):          # 1st call of a shape: eager warm-up, 2nd: capture + replay, 3rd: replay
+        ph = phons[0] if i < 3 else ph
+        a = eager.generate_mel(ph, speaker=2)
+        b = graphed.generate_mel(ph, speaker=2)
+        assert torch.equal(a, b), i
+        wa, wb = eager.mel_to_wav(a), graphed.mel_to_wav(b)
+        assert np.array_equal(wa, wb), i
+    assert len(graphed.tts._synth._front) >= 1 and len(graphed.tts._synth._back) >= 1 and len(graphed.vocoder._synth._voc) >= 1

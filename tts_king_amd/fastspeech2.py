@@ -421,6 +421,58 @@ class FastSpeech2(nn.Module):
                post.view(Bn, T, self.n_mel))
         return out, ctx
 
+    # ------------------------------------------------------------------ inference in two capturable halves
+    def eval_front(self, speakers, texts, src_lens, Lp, p_control=1.0, e_control=1.0, d_control=1.0):
+        """Encoder + variance adaptor of the free-running inference path (reference: fastspeech2.py:62-99 with no
+        targets, modules.py:142-205) up to the per-utterance frame totals.  Only enqueues kernels (hipGraph-capturable);
+        the caller reads `total.max()` on the host — the one data-dependent shape of the path — and calls `eval_back`."""
+        self.sync_shadow()
+        d = self.d
+        Bn = texts.shape[0]
+        va = "variance_adaptor."
+        src_masks = ops.length_mask(src_lens, Lp)
+        pe_enc = sinusoid_table(Lp, d).to(self.device) if Lp > self.max_seq_len else self.get("encoder.position_enc")[0]
+        x = ops.gather_add(None, self._m("encoder.src_word_emb.weight"), texts, pe=pe_enc, pe_mod=Lp, rows=Bn * Lp)
+        for i in range(self.n_enc):
+            x = self._fft_fwd("encoder.layer_stack.%d." % i, x, Bn, Lp, src_lens, self.n_head_enc, 0.0, 0, None, None)
+        logd = self._predictor_fwd(va + "duration_predictor.", x, Bn, Lp, src_lens, 0.0, 0, None, None)
+        x1 = ops.gather_add(x, self._m("speaker_emb.weight"), speakers, idx_div=Lp)
+        pitch = self._predictor_fwd(va + "pitch_predictor.", x1, Bn, Lp, src_lens, 0.0, 0, None, None)
+        pidx, pitch = ops.bucketize(pitch, self.get(va + "pitch_bins"), p_control, want_scaled=True)
+        x2 = ops.gather_add(x1, self._m(va + "pitch_embedding.weight"), pidx.view(-1))
+        energy = self._predictor_fwd(va + "energy_predictor.", x2, Bn, Lp, src_lens, 0.0, 0, None, None)
+        eidx, energy = ops.bucketize(energy, self.get(va + "energy_bins"), e_control, want_scaled=True)
+        x3 = ops.gather_add(x2, self._m(va + "energy_embedding.weight"), eidx.view(-1))
+        dur = ops.duration_round(logd, d_control)
+        _, _, _, total = ops.length_regulator_fwd(x3.view(Bn, Lp, d), dur, 1, want_idx=False)
+        return x3, dur, total, (pitch, energy, logd, src_masks)
+
+    def eval_back(self, x3, dur, Lp, T):
+        """LengthRegulator + decoder + mel_linear + PostNet for a known frame count T (reference: modules.py:199-205,
+        Models.py:157-189, fastspeech2.py:101-104).  Capturable; returns (mel, postnet mel, mel_lens, mel_masks)."""
+        d = self.d
+        Bn = x3.shape[0] // Lp
+        dev = self.device
+        pe_dec = sinusoid_table(T, d).to(dev) if T > self.max_seq_len else self.get("decoder.position_enc")[0]
+        dec_in, _, _, mel_lens = ops.length_regulator_fwd(x3.view(Bn, Lp, d), dur, T, pe=pe_dec, want_idx=False)
+        mel_masks = ops.length_mask(mel_lens, T)
+        y = dec_in.view(Bn * T, d)
+        for i in range(self.n_dec):
+            y = self._fft_fwd("decoder.layer_stack.%d." % i, y, Bn, T, mel_lens, self.n_head_dec, 0.0, 0, None, None)
+        rows = Bn * T
+        mel16 = torch.empty(rows, self.n_mel, dtype=bf16, device=dev)
+        mel = ops.linear(y, self._w("mel_linear.weight"), self._m("mel_linear.bias"), out_dtype=torch.float32, C2=mel16)
+        xin = mel16.view(Bn, T, self.n_mel)
+        for i in range(5):
+            pp = "postnet.convolutions.%d." % i
+            yc = ops.conv1d(xin, self._w(pp + "0.conv.weight"), self._m(pp + "0.conv.bias"), out_dtype=torch.float32)
+            C = yc.shape[2]
+            last = i == 4
+            nxt = ops.bn_apply(yc.view(rows, C), self.get(pp + "1.running_mean"), ops.rsqrt_eps(self.get(pp + "1.running_var")),
+                               self._m(pp + "1.weight"), self._m(pp + "1.bias"), not last, resid=mel if last else None, out_f32=last)
+            xin = nxt.view(Bn, T, C) if not last else nxt
+        return mel.view(Bn, T, self.n_mel), xin.view(Bn, T, self.n_mel), mel_lens, mel_masks
+
     # ------------------------------------------------------------------ backward
     def _backward_from_autograd(self, ctx, dmel, dpost, dpitch, denergy, dlogd):
         dev = self.device

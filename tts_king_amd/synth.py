@@ -1,0 +1,74 @@
+"""hipGraph-captured synthesis: text ids -> mel -> waveform with two host-visible steps.
+
+reference path: tts_king.py:25-49 (`generate_mel` -> `mel_to_wav`), fsapi.py:38-82, hifiapi.py:40-52.  The reference
+launches ~400 small ATen ops per utterance and syncs per phoneme in the LengthRegulator; here the path is three replayed
+graphs: A = encoder + variance adaptor + duration totals (shape key: phonemes L, controls), then ONE host read of the
+frame count T (the only data-dependent shape), B = LengthRegulator + decoder + PostNet (key: L, T), C = HiFi-GAN
+generator (key: T).  Graphs are cached per key (utterances of equal L and T replay the same graphs); a key's first call
+runs eagerly once (warm-up: lazy allocations, weight packing) and is captured on the second.
+"""
+import torch
+
+from . import ops
+
+
+class _Graph:
+    def __init__(self, fn, static_inputs):
+        self.static = static_inputs
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = fn(*self.static)
+
+    def run(self, *inputs):
+        for dst, src in zip(self.static, inputs):
+            if torch.is_tensor(dst):
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+
+class GraphedSynthesizer:
+    def __init__(self, fs2, vocoder=None, max_graphs=32):
+        self.fs2, self.vocoder, self.max_graphs = fs2, vocoder, max_graphs
+        self._front, self._back, self._voc = {}, {}, {}
+        self._seen = set()
+
+    def _get(self, cache, key, fn, inputs):
+        """Eager on first sight of `key`, captured on the second, replayed afterwards."""
+        if key is None:                 # not capturable (host-side position table for > max_seq_len): plain launches
+            return fn(*inputs)
+        g = cache.get(key)
+        if g is not None:
+            return g.run(*inputs)
+        if key not in self._seen:
+            self._seen.add(key)
+            return fn(*inputs)
+        if len(cache) >= self.max_graphs:
+            cache.pop(next(iter(cache)))
+        static = [t.clone() if torch.is_tensor(t) else t for t in inputs]
+        torch.cuda.synchronize()
+        g = cache[key] = _Graph(fn, static)
+        return g.run(*inputs)
+
+    @torch.no_grad()
+    def mel(self, speaker, texts, p_control=1.0, e_control=1.0, d_control=1.0):
+        """speaker (B,) int64, texts (B, L) int64 on the device -> (postnet mel (B, T, 80) fp32, mel_lens (B,))."""
+        m = self.fs2
+        m.eval()
+        Bn, Lp = texts.shape
+        src_lens = torch.full((Bn,), Lp, dtype=torch.int64, device=texts.device)
+        ctl = (float(p_control), float(e_control), float(d_control))
+        front = lambda spk, txt, sl: m.eval_front(spk, txt, sl, Lp, *ctl)
+        kf = ("front", Bn, Lp) + ctl if Lp <= m.max_seq_len else None
+        x3, dur, total, _ = self._get(self._front, kf, front, (speaker, texts, src_lens))
+        T = max(int(total.max().item()), 1)                 # the path's one host read
+        back = lambda x, dd: m.eval_back(x, dd, Lp, T)
+        kb = ("back", Bn, Lp, T) if T <= m.max_seq_len else None
+        mel, post, mel_lens, _ = self._get(self._back, kb, back, (x3, dur))
+        return post, mel_lens
+
+    @torch.no_grad()
+    def wav(self, mel_bct):
+        """mel (B, 80, T) fp32 on the device -> waveform (B, 1, 256 T) fp32."""
+        Bn, _, T = mel_bct.shape
+        return self._get(self._voc, ("voc", Bn, T), lambda x: self.vocoder(x), (mel_bct.contiguous(),))

@@ -55,8 +55,10 @@ enum {
   TTSK_GEMM_ACCUM_C   = 1 << 9,  /* C_F32 only: C += v  (plain read-modify-write, one writer per element)   */
   TTSK_GEMM_LRELU_OUT = 1 << 10, /* v = leaky_relu(v, out_slope) before the store                           */
   TTSK_GEMM_F16       = 1 << 11, /* 16-bit operands (A, B, C, C2, R, G) are IEEE fp16 instead of bf16           */
-  TTSK_GEMM_C2_LRELU  = 1 << 12  /* the second output is leaky_relu(v, out_slope) (C keeps v): the next conv's   */
+  TTSK_GEMM_C2_LRELU  = 1 << 12, /* the second output is leaky_relu(v, out_slope) (C keeps v): the next conv's   */
                                  /* activation is produced by this conv's epilogue instead of its operand staging */
+  TTSK_GEMM_DEFER_REDUCE = 1 << 13 /* split-K: write the partial slabs only; the caller sums many GEMMs' slabs later */
+                                 /* with ONE ttsk_gemm_reduce_batch launch (weight gradients: needed only by Adam)  */
 };
 
 typedef struct ttsk_gemm_desc {
@@ -96,6 +98,18 @@ typedef struct ttsk_gemm_desc {
 } ttsk_gemm_desc;
 
 int ttsk_gemm(const ttsk_gemm_desc* d, void* stream);
+/* Deferred split-K reduction.  A GEMM launched with TTSK_GEMM_DEFER_REDUCE (fp32 C, no epilogue beyond alpha / ACCUM_C,
+ * nz1 == 1) leaves `splits` slabs [split][nz2][M][N] in its workspace; ttsk_gemm_reduce_batch sums the slabs of `n` such
+ * GEMMs in fixed order (deterministic) into their C (C[z2*sC2 + m*ldc + n] (+)= alpha * sum) with one kernel per 64 items. */
+typedef struct ttsk_reduce_item {
+  const float* ws;
+  float* C;
+  int32_t M, N, ldc, nz, splits, accumulate;
+  int64_t sC2;
+  float alpha;
+} ttsk_reduce_item;
+int ttsk_gemm_reduce_batch(const ttsk_reduce_item* items, int n, void* stream);
+
 /* what ttsk_gemm will run for `d` (with d->kernel / d->splits as constraints when non-zero) and the workspace it needs */
 int ttsk_gemm_plan(const ttsk_gemm_desc* d, int32_t* kernel, int32_t* splits, int64_t* workspace_bytes);
 

@@ -7,7 +7,7 @@ mkdir -p $O
 cd $R
 export TMPDIR=/tmp
 ARGS=${@:-tests}
-timeout 900 python -m pytest $ARGS -m gpu -x -q -s > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
+timeout 900 python -m pytest $ARGS -m gpu -q -s > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
 grep -E "rel-RMS|passed|failed|Error|error" $O/pytest_gpu.log | tail -40
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/smoke.log
 tail -2 $O/smoke.log

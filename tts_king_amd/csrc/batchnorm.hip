@@ -72,11 +72,22 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float momentum, float* __restrict__ mean, float* __restrict__ rstd,
                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
                                                           long long* __restrict__ nbt) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c == 0 && nbt) nbt[0] += 1;
-  if (c >= C) return;
+  // 16 channels x 16 row-groups per workgroup; every thread adds its partial rows in ascending order (double), the 16
+  // group sums are combined in fixed order: deterministic
+  __shared__ double rs[16][17], rq[16][17];
+  const int cx = threadIdx.x & 15, gy = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
   double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) { s += partials[(int64_t)b * 2 * C + c]; q += partials[(int64_t)b * 2 * C + C + c]; }
+  if (c < C)
+    for (int b = gy; b < nblk; b += 16) { s += partials[(int64_t)b * 2 * C + c]; q += partials[(int64_t)b * 2 * C + C + c]; }
+  rs[gy][cx] = s;
+  rq[gy][cx] = q;
+  __syncthreads();
+  if (gy != 0 || c >= C) return;
+  s = 0.0; q = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { s += rs[k][cx]; q += rq[k][cx]; }
   const double m = s / rows;
   double var = q / rows - m * m;
   if (var < 0.0) var = 0.0;
@@ -208,7 +219,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnCommon a, con
   }
 }
 
-inline int bn_blocks(int rows) { int n = (rows + 63) / 64; return n > 256 ? 256 : (n < 1 ? 1 : n); }
+// enough workgroups to cover the chip twice with few sequential (latency-bound) row iterations each
+inline int bn_blocks(int rows) { int n = (rows + 15) / 16; return n > 1024 ? 1024 : (n < 1 ? 1 : n); }
 
 }  // namespace
 
@@ -234,7 +246,7 @@ extern "C" int ttsk_bn_finalize(const float* partials, int nblk, int C, int rows
                                 void* stream) {
   TTSK_REQUIRE(partials && mean && rstd && nblk > 0, "bn_finalize: null pointer");
   TTSK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats come in pairs");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, nblk, C, rows, eps,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, nblk, C, rows, eps,
                      momentum, mean, rstd, running_mean, running_var, (long long*)num_batches_tracked);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;

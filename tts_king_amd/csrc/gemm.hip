@@ -309,6 +309,67 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const Args g) {
 
 }  // namespace
 
+// ---- deferred split-K reduction of weight-gradient GEMMs: one launch sums the slabs of up to 64 GEMMs
+struct ReduceBatch {
+  ttsk_reduce_item it[64];
+  int n;
+};
+
+namespace {
+__global__ __launch_bounds__(256) void gemm_reduce_batch_kernel(const ReduceBatch rb) {
+  const ttsk_reduce_item& it = rb.it[blockIdx.y];
+  const int M = it.M, N = it.N;
+  const int ngrp = (N + 7) >> 3;
+  const int64_t mn = (int64_t)M * N;
+  const int64_t sstride = (int64_t)it.nz * mn;
+  const bool vec = (N & 3) == 0 && (it.ldc & 3) == 0 && (it.sC2 & 3) == 0;
+  const int64_t total = (int64_t)it.nz * M * ngrp;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int z = (int)(i / ((int64_t)M * ngrp));
+    const int64_t r = i - (int64_t)z * M * ngrp;
+    const int gm = (int)(r / ngrp);
+    const int gn = (int)(r - (int64_t)gm * ngrp) * 8;
+    const int nvalid = (N - gn) < 8 ? (N - gn) : 8;
+    const float* p = it.ws + (int64_t)z * mn + (int64_t)gm * N + gn;
+    float* cp = it.C + (int64_t)z * it.sC2 + (int64_t)gm * it.ldc + gn;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (nvalid == 8 && vec) {
+      for (int s = 0; s < it.splits; ++s) {
+        const f32x4 lo = *(const f32x4*)(p + s * sstride), hi = *(const f32x4*)(p + s * sstride + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += lo[e]; v[e + 4] += hi[e]; }
+      }
+      f32x4 lo = f32x4{v[0], v[1], v[2], v[3]} * it.alpha, hi = f32x4{v[4], v[5], v[6], v[7]} * it.alpha;
+      if (it.accumulate) { lo += *(const f32x4*)cp; hi += *(const f32x4*)(cp + 4); }
+      *(f32x4*)cp = lo;
+      *(f32x4*)(cp + 4) = hi;
+    } else {
+      for (int s = 0; s < it.splits; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += p[s * sstride + e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (e < nvalid) cp[e] = (it.accumulate ? cp[e] : 0.f) + v[e] * it.alpha;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int ttsk_gemm_reduce_batch(const ttsk_reduce_item* items, int n, void* stream) {
+  TTSK_REQUIRE(items && n > 0, "ttsk_gemm_reduce_batch: bad arguments");
+  for (int base = 0; base < n; base += 64) {
+    ReduceBatch rb;
+    rb.n = n - base < 64 ? n - base : 64;
+    for (int i = 0; i < rb.n; ++i) {
+      rb.it[i] = items[base + i];
+      TTSK_REQUIRE(rb.it[i].ws && rb.it[i].C && rb.it[i].M > 0 && rb.it[i].N > 0 && rb.it[i].splits > 0 && rb.it[i].nz > 0,
+                   "ttsk_gemm_reduce_batch: bad item %d", base + i);
+    }
+    hipLaunchKernelGGL(gemm_reduce_batch_kernel, dim3(96, rb.n), dim3(256), 0, (hipStream_t)stream, rb);
+    TTSK_CHECK_LAUNCH();
+  }
+  return TTSK_OK;
+}
+
 // ---- planning: which tile configuration, how many K splits
 namespace {
 struct Plan { int kernel, splits, tiles_m, tiles_n, kchunks, chunks_per_split; int64_t ws_bytes; };
@@ -333,6 +394,10 @@ int validate(ttsk_gemm_desc& d) {
   TTSK_REQUIRE(!(d.flags & TTSK_GEMM_ADD_R) || d.R, "ttsk_gemm: ADD_R without R");
   TTSK_REQUIRE(!(d.flags & TTSK_GEMM_MASK_G) || d.G, "ttsk_gemm: MASK_G without G");
   TTSK_REQUIRE(!(d.flags & TTSK_GEMM_ACCUM_C) || (d.flags & TTSK_GEMM_C_F32), "ttsk_gemm: ACCUM_C needs fp32 C");
+  TTSK_REQUIRE(!(d.flags & TTSK_GEMM_DEFER_REDUCE) ||
+                   ((d.flags & TTSK_GEMM_C_F32) && !d.bias && !d.R && !d.G && !d.C2 && d.out_mul == 0 && d.nz1 <= 1 &&
+                    !(d.flags & (TTSK_GEMM_RELU | TTSK_GEMM_TANH | TTSK_GEMM_LRELU_OUT))),
+               "ttsk_gemm: DEFER_REDUCE is for plain fp32 outputs (weight gradients) only");
   return TTSK_OK;
 }
 
@@ -433,7 +498,7 @@ extern "C" int ttsk_gemm(const ttsk_gemm_desc* dp, void* stream) {
     }
   }
   TTSK_CHECK_LAUNCH();
-  if (d.splits > 1) {
+  if (d.splits > 1 && !(d.flags & TTSK_GEMM_DEFER_REDUCE)) {
     const int64_t work = (int64_t)d.M * ((d.N + 7) / 8);
     int blocks = (int)((work + 255) / 256);
     if (blocks > 1024) blocks = 1024;

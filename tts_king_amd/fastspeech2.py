@@ -104,6 +104,7 @@ class FastSpeech2(nn.Module):
         self._shadow_version = -1
         self._anchor = torch.zeros((), requires_grad=True)
         self._ctx = None
+        self._deferred = None           # split-K slabs awaiting the batched reducer (backward only)
         self._rng_state = None          # device block shared with the optimizer (ops.optim_state)
         self._seed = seed
         self._modules_by_key = {}
@@ -506,17 +507,17 @@ class FastSpeech2(nn.Module):
                                                  lens, S, p_pre=p, site_pre=site + 1, rng=rng)
         self._finalize_ln(part, nblk, 3 * d, f + "w_2.bias")
         # ---- w_2 (k=1): dW, dX gated by the ReLU
-        ops.conv1d_dw(dy2.view(Bn, S, d), h, self._g(f + "w_2.weight"), k=self.k2)
+        ops.conv1d_dw(dy2.view(Bn, S, d), h, self._g(f + "w_2.weight"), k=self.k2, defer=self._deferred)
         dh = ops.conv1d_dx(dy2.view(Bn, S, d), self._w(f + "w_2.weight"), G=h)
         # ---- w_1 (k=9): bias, dW, dX + residual gradient
         ops.colsum_into(dh.view(rows, -1), self._g(f + "w_1.bias"))
-        ops.conv1d_dw(dh, x1.view(Bn, S, d), self._g(f + "w_1.weight"), k=self.k1)
+        ops.conv1d_dw(dh, x1.view(Bn, S, d), self._g(f + "w_1.weight"), k=self.k1, defer=self._deferred)
         dx1 = ops.conv1d_dx(dh, self._w(f + "w_1.weight"), R=dz2.view(Bn, S, d))
         # ---- attention tail
         dz1, dy1, part, nblk = ops.layernorm_bwd(dx1.view(rows, d), z1, mean1, rstd1, self._m(a + "layer_norm.weight"),
                                                  self._m(a + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site, rng=rng)
         self._finalize_ln(part, nblk, 3 * d, a + "fc.bias")
-        ops.linear_dw(dy1, o, self._g(a + "fc.weight"))
+        ops.linear_dw(dy1, o, self._g(a + "fc.weight"), defer=self._deferred)
         do = ops.linear_dx(dy1, self._w(a + "fc.weight"))
         # ---- attention core: dP = dO V^T ; dS = softmax'(P, dP)/sqrt(dk) ; dQ = dS K ; dK = dS^T Q ; dV = P^T dO
         dP = torch.empty(Bn * H, S, Sp, dtype=torch.float32, device=dev)
@@ -532,7 +533,7 @@ class FastSpeech2(nn.Module):
                  sA=(H * S * Sp, S * Sp), sB=(S * d, dk), sC=(S * 3 * d, dk))
         # ---- q|k|v projections
         ops.colsum_into(dqkv, self._g(a + "w_qs.bias", 3 * d))
-        ops.linear_dw(dqkv, x, self._g(a + "w_qs.weight", 3 * d * d).view(3 * d, d))
+        ops.linear_dw(dqkv, x, self._g(a + "w_qs.weight", 3 * d * d).view(3 * d, d), defer=self._deferred)
         return ops.linear_dx(dqkv, self._w(a + "w_qs.weight", 3 * d), R=dz1)
 
     def _predictor_bwd(self, pre, saved, dout, rng, R):
@@ -545,13 +546,13 @@ class FastSpeech2(nn.Module):
                                                self._m(c + "layer_norm_2.bias"), lens, Lp, relu_in=True, p_post=p,
                                                site_post=site + 1, rng=rng, dhead=dout.contiguous().view(-1), head_w=hw)
         self._finalize_ln(part, nblk, 4 * Fh + 1, c + "conv1d_2.conv.bias")
-        ops.conv1d_dw(dh2.view(Bn, Lp, Fh), a1.view(Bn, Lp, Fh), self._g(c + "conv1d_2.conv.weight"), k=self.k_var)
+        ops.conv1d_dw(dh2.view(Bn, Lp, Fh), a1.view(Bn, Lp, Fh), self._g(c + "conv1d_2.conv.weight"), k=self.k_var, defer=self._deferred)
         da1 = ops.conv1d_dx(dh2.view(Bn, Lp, Fh), self._w(c + "conv1d_2.conv.weight"))
         dh1, _, part, nblk = ops.layernorm_bwd(da1.view(rows, Fh), h1.view(rows, Fh), m1, r1, self._m(c + "layer_norm_1.weight"),
                                                self._m(c + "layer_norm_1.bias"), None, 0, relu_in=True, p_post=p,
                                                site_post=site, rng=rng)
         self._finalize_ln(part, nblk, 3 * Fh, c + "conv1d_1.conv.bias")
-        ops.conv1d_dw(dh1.view(Bn, Lp, Fh), x.view(Bn, Lp, d), self._g(c + "conv1d_1.conv.weight"), k=self.k_var)
+        ops.conv1d_dw(dh1.view(Bn, Lp, Fh), x.view(Bn, Lp, d), self._g(c + "conv1d_1.conv.weight"), k=self.k_var, defer=self._deferred)
         return ops.conv1d_dx(dh1.view(Bn, Lp, Fh), self._w(c + "conv1d_1.conv.weight"), R=R)
 
     def backward_native(self, ctx, dmel_sum, dpost, dpitch, denergy, dlogd, on_bucket=None):
@@ -564,7 +565,15 @@ class FastSpeech2(nn.Module):
         rng = ops.rng_of(self._state())
         Bn, Lp, T = ctx.dims
         d, rows, nm = self.d, Bn * T, self.n_mel
-        notify = on_bucket or (lambda name: None)
+        # split-K slabs of the weight-gradient GEMMs are summed by ONE batched reducer launch per parameter group when a
+        # data-parallel reducer is waiting for finished buckets, otherwise once at the end (only Adam reads them)
+        self._deferred = []
+        if on_bucket is not None:
+            def notify(name):
+                ops.flush_deferred(self._deferred)
+                on_bucket(name)
+        else:
+            notify = lambda name: None
         # ---- PostNet (last layer first)
         dout = dpost.view(rows, nm)
         for i in range(4, -1, -1):
@@ -573,7 +582,7 @@ class FastSpeech2(nn.Module):
             dy = ops.bn_bwd(dout, yc.view(rows, C), mean, rstd, self._m(pp + "1.weight"), self._m(pp + "1.bias"), i < 4,
                             p=self.p_post, site=300 + i, rng=rng, dgamma=self._g(pp + "1.weight"), dbeta=self._g(pp + "1.bias"))
             ops.colsum_into(dy, self._g(pp + "0.conv.bias"))
-            ops.conv1d_dw(dy.view(Bn, T, C), xin, self._g(pp + "0.conv.weight"), k=5)
+            ops.conv1d_dw(dy.view(Bn, T, C), xin, self._g(pp + "0.conv.weight"), k=5, defer=self._deferred)
             if i > 0:
                 dout = ops.conv1d_dx(dy.view(Bn, T, C), self._w(pp + "0.conv.weight")).view(rows, -1)
             else:
@@ -581,7 +590,7 @@ class FastSpeech2(nn.Module):
         notify("postnet")
         # ---- mel_linear
         ops.colsum_into(dmel_tot, self._g("mel_linear.bias"))
-        ops.linear_dw(dmel_tot, ctx.dec_out, self._g("mel_linear.weight"))
+        ops.linear_dw(dmel_tot, ctx.dec_out, self._g("mel_linear.weight"), defer=self._deferred)
         dx = ops.linear_dx(dmel_tot, self._w("mel_linear.weight"))
         notify("mel_linear")
         # ---- decoder
@@ -606,4 +615,5 @@ class FastSpeech2(nn.Module):
             notify("encoder.%d" % i)
         ops.scatter_sum(dx, ctx.texts.view(-1), self._g("encoder.src_word_emb.weight"), skip_row=0)   # padding_idx=0
         notify("embedding")
+        ops.flush_deferred(self._deferred)
         self._ctx = None

@@ -35,8 +35,14 @@ class GemmDesc(C.Structure):
     ]
 
 
+class ReduceItem(C.Structure):
+    """Mirror of `ttsk_reduce_item` (include/ttsk.h)."""
+    _fields_ = [("ws", C.c_void_p), ("C", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("ldc", C.c_int32), ("nz", C.c_int32),
+                ("splits", C.c_int32), ("accumulate", C.c_int32), ("sC2", C.c_int64), ("alpha", C.c_float)]
+
+
 # flags (include/ttsk.h)
-A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT, F16, C2_LRELU = [1 << i for i in range(13)]
+A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT, F16, C2_LRELU, DEFER_REDUCE = [1 << i for i in range(14)]
 
 
 def declared_symbols(header_path=HEADER_PATH):
@@ -95,6 +101,7 @@ def load(path=LIB_PATH):
             fn.restype = C.c_int
         fn.argtypes = argtypes
     lib.ttsk_gemm.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
+    lib.ttsk_gemm_reduce_batch.argtypes = [C.POINTER(ReduceItem), C.c_int, C.c_void_p]
     lib.ttsk_gemm_plan.argtypes = [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     _lib = lib
     return lib

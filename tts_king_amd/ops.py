@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import (A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT, F16, C2_LRELU,  # noqa: F401
+from .lib import (A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT, F16, C2_LRELU, DEFER_REDUCE,  # noqa: F401
                   GemmDesc, check)
 
 bf16 = torch.bfloat16
@@ -33,6 +33,15 @@ def _ptr(t):
 GEMM_TRACE = None   # bench.py sets this to a list: every ttsk_gemm launch is then bracketed by HIP events on its stream
 
 
+def flush_deferred(items):
+    """One ttsk_gemm_reduce_batch launch (per 64 items) for the split-K slabs collected in `items` (see gemm(defer=...))."""
+    if not items:
+        return
+    arr = (L.ReduceItem * len(items))(*[it for it, _ in items])
+    check(L.load().ttsk_gemm_reduce_batch(arr, len(items), _stream()), "ttsk_gemm_reduce_batch")
+    items.clear()
+
+
 def plan(d):
     """(kernel, splits, workspace_bytes) the library will use for descriptor `d` (ttsk_gemm_plan)."""
     k, sp, ws = C.c_int32(0), C.c_int32(0), C.c_int64(0)
@@ -43,10 +52,11 @@ def plan(d):
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=None, ldr=0, G=None, ldg=0, C2=None,
          nz1=1, nz2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), taps=0, seg_len=0, tap_shift0=0, tap_dshift=0,
          b_tap_stride=0, bseg_len=0, bshift0=0, bdshift=0, out_seg=0, out_mul=0, out_add=0, splits=0, kernel=0,
-         in_slope=0.0, out_slope=0.0):
+         in_slope=0.0, out_slope=0.0, defer=None):
     """Raw descriptor-level call of ttsk_gemm (see include/ttsk.h).  A/B/Cout may be views: the data pointer of
     the view is the operand origin.  splits / kernel = 0 let the library plan (tile configuration, split-K factor);
-    the split-K workspace is allocated here (the C library never allocates)."""
+    the split-K workspace is allocated here (the C library never allocates).  `defer`: a list — a split-K weight-
+    gradient GEMM then leaves its slabs un-reduced and appends a reduce item to it (see flush_deferred)."""
     _dev(A, B, Cout, bias, R, G, C2)
     d = GemmDesc()
     d.A, d.B, d.C, d.C2 = _ptr(A), _ptr(B), _ptr(Cout), _ptr(C2)
@@ -77,6 +87,12 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=No
     if ws_bytes > 0:
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=A.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws_bytes
+        if defer is not None and nz1 == 1 and (flags & C_F32) and not (flags & ~(A_TR | B_TR | C_F32 | ACCUM_C)) and bias is None:
+            d.flags = flags | DEFER_REDUCE
+            it = L.ReduceItem()
+            it.ws, it.C, it.M, it.N, it.ldc, it.nz, it.splits = ws.data_ptr(), Cout.data_ptr(), M, N, ldc, nz2, splits
+            it.accumulate, it.sC2, it.alpha = int(bool(flags & ACCUM_C)), sC[1], alpha
+            defer.append((it, ws))
     if GEMM_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -87,6 +87,7 @@ typedef struct ttsk_gemm_desc {
   /* output row remap (polyphase ConvTranspose1d): C row for A row (s, t) is s*out_seg + t*out_mul + out_add,
    * skipped when outside [0, out_seg).  out_mul == 0 means identity. */
   int32_t out_seg, out_mul, out_add;
+  int32_t out_add_dz;   /* out_add += z2 * out_add_dz: several polyphase phases batched into one launch */
   /* split-K: `splits` > 1 cuts the K chunks into `splits` ranges whose fp32 partial tiles go to `workspace`
    * ([splits][nz][M][N] floats); a second kernel sums them in fixed order and applies the epilogue (deterministic). */
   int32_t splits;      /* 0 = let the library choose (ttsk_gemm_plan) */
@@ -206,6 +207,10 @@ int ttsk_to_int16(const float* src, int16_t* dst, int64_t n, float scale, void* 
  */
 int ttsk_weight_norm_fold(const float* v, const float* g, float* w, int rows, int cols, void* stream);
 int ttsk_pack_conv_weight(const float* src, void* dst16, int f16, int d0, int d1, int d2, int mode, void* stream);
+/* conv_post + tanh (hifi/models.py:198-199): x (B, len, C) 16-bit (already activated), w (1, k, C) tap-major 16-bit,
+ * out (B, 1, len) fp32.  A streaming kernel: one output sample per thread. */
+int ttsk_hifi_conv_post(const void* x16, const void* w16, const float* bias, float* out, int f16, int B, int len, int C, int K,
+                        void* stream);
 int ttsk_avg3(const void* a, const void* b, const void* c, void* out, int f16, int64_t n, float scale, float slope, void* stream);
 
 /* Fused ResBlock1 (hifi/models.py:88-95): all six convs of one block for C in {32,64}, K in {3,7,11}; x/out 16-bit

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[e + 4] = hi[e]; }
     }
-    epilogue_store<F16>(d, coff, roff, gm, gn, nvalid, v, bias);
+    epilogue_store<F16>(d, coff, roff, gm, gn, nvalid, v, bias, z2);
   }
 }
 
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const Args g) {
     float bias[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[e] = (d.bias && e < nvalid) ? d.bias[gn + e] : 0.f;
-    epilogue_store<F16>(d, coff, roff, gm, gn, nvalid, v, bias);
+    epilogue_store<F16>(d, coff, roff, gm, gn, nvalid, v, bias, z2);
   }
 }
 

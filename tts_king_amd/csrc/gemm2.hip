@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm2_kernel(const GemmArgs g) {
           float v[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[e + 4] = hi[e]; }
-          epilogue_store<F16>(d, coff, roff, gm, gn, nvalid, v, bias);
+          epilogue_store<F16>(d, coff, roff, gm, gn, nvalid, v, bias, z2);
         }
       }
     }

@@ -23,12 +23,12 @@ template <bool F16> __device__ __forceinline__ uint4 pack8(const float v[8]) {
 // store(s).  Shared by the GEMM kernel (splits == 1) and by the split-K reducer.
 template <bool F16>
 __device__ __forceinline__ void epilogue_store(const ttsk_gemm_desc& d, int64_t coff, int64_t roff, int gm, int gn, int nvalid,
-                                               float v[8], const float bias[8]) {
+                                               float v[8], const float bias[8], int z2 = 0) {
   const int flags = d.flags;
   int64_t orow = gm;
   if (d.out_mul != 0) {
     const int s = gm / d.seg_len, t = gm - s * d.seg_len;
-    const int o = t * d.out_mul + d.out_add;
+    const int o = t * d.out_mul + d.out_add + z2 * d.out_add_dz;
     if (o < 0 || o >= d.out_seg) return;
     orow = (int64_t)s * d.out_seg + o;
   }

@@ -68,6 +68,45 @@ __global__ __launch_bounds__(256) void avg3_kernel(const uint4* __restrict__ a, 
   }
 }
 
+// conv_post: Conv1d(C -> 1, k, pad (k-1)/2) + tanh on channels-last 16-bit activations (hifi/models.py:198-199; the
+// LeakyReLU(0.01) of :197 is produced by the previous stage's epilogue).  One output sample per thread: a GEMM tile
+// would spend 127/128 of its MFMA columns on padding (205 us on the 128x128 kernel); this is a 50 MB streaming read.
+// A workgroup stages 256 + k - 1 frames in LDS (16-byte rows chunks, zero outside the utterance), weights as fp32.
+template <bool F16>
+__global__ __launch_bounds__(256) void conv_post_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w /* [k][C] */,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int len, int C, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  const int HK = (K - 1) / 2, CH8 = C >> 3, rows = 256 + K - 1;
+  const int RS = C * 2 + 16;                        // padded row stride: consecutive lanes hit different banks
+  float* wf = (float*)(sm + rows * RS);             // [K][C] fp32
+  const int b = blockIdx.y, t0 = blockIdx.x * 256;
+  const bf16_t* xb = x + (int64_t)b * len * C;
+  for (int i = threadIdx.x; i < rows * CH8; i += 256) {
+    const int r = i / CH8, ch = i - r * CH8;
+    const int t = t0 - HK + r;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (t >= 0 && t < len) v = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
+    *(uint4*)(sm + r * RS + ch * 16) = v;
+  }
+  for (int i = threadIdx.x; i < K * C; i += 256) wf[i] = unpack1<F16>(w[i]);
+  __syncthreads();
+  const int t = t0 + threadIdx.x;
+  if (t >= len) return;
+  float acc = bias[0];
+  for (int j = 0; j < K; ++j) {
+    const unsigned char* row = sm + (threadIdx.x + j) * RS;
+    const float* wj = wf + j * C;
+    for (int ch = 0; ch < CH8; ++ch) {
+      const uint4 v = *(const uint4*)(row + ch * 16);
+      float a0, a1, a2, a3, a4, a5, a6, a7;
+      unpack2<F16>(v.x, a0, a1); unpack2<F16>(v.y, a2, a3); unpack2<F16>(v.z, a4, a5); unpack2<F16>(v.w, a6, a7);
+      const f32x4 w0 = *(const f32x4*)(wj + ch * 8), w1 = *(const f32x4*)(wj + ch * 8 + 4);
+      acc += a0 * w0[0] + a1 * w0[1] + a2 * w0[2] + a3 * w0[3] + a4 * w1[0] + a5 * w1[1] + a6 * w1[2] + a7 * w1[3];
+    }
+  }
+  out[(int64_t)b * len + t] = tanhf(acc);
+}
+
 }  // namespace
 
 extern "C" int ttsk_weight_norm_fold(const float* v, const float* g, float* w, int rows, int cols, void* stream) {
@@ -102,6 +141,20 @@ extern "C" int ttsk_avg3(const void* a, const void* b, const void* c, void* out,
   else
     hipLaunchKernelGGL(avg3_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b,
                        (const uint4*)c, (uint4*)out, n8, scale, slope);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_hifi_conv_post(const void* x16, const void* w16 /* (1, k, C) tap-major */, const float* bias, float* out,
+                                   int f16, int B, int len, int C, int K, void* stream) {
+  TTSK_REQUIRE(x16 && w16 && bias && out && B > 0 && len > 0 && B <= 65535, "ttsk_hifi_conv_post: bad arguments");
+  TTSK_REQUIRE(C >= 8 && C <= 128 && (C & 7) == 0 && (K & 1) == 1 && K <= 15, "ttsk_hifi_conv_post: C in 8..128 step 8, odd K <= 15");
+  const size_t shm = (size_t)(256 + K - 1) * (C * 2 + 16) + (size_t)K * C * 4;
+  dim3 grid((len + 255) / 256, B);
+  if (f16)
+    hipLaunchKernelGGL(conv_post_kernel<true>, grid, dim3(256), shm, (hipStream_t)stream, (const bf16_t*)x16, (const bf16_t*)w16, bias, out, len, C, K);
+  else
+    hipLaunchKernelGGL(conv_post_kernel<false>, grid, dim3(256), shm, (hipStream_t)stream, (const bf16_t*)x16, (const bf16_t*)w16, bias, out, len, C, K);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

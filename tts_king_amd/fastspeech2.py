@@ -105,6 +105,9 @@ class FastSpeech2(nn.Module):
         self._anchor = torch.zeros((), requires_grad=True)
         self._ctx = None
         self._deferred = None           # split-K slabs awaiting the batched reducer (backward only)
+        self._side = None               # second HIP stream for parameter-gradient work (see _SideWork)
+        self.overlap_param_grads = False   # measured on MI355X: the branches do overlap under graph replay, but the concurrent
+                                           # kernels slow each other by as much (6.39 vs 6.47 ms/step): off by default
         self._rng_state = None          # device block shared with the optimizer (ops.optim_state)
         self._seed = seed
         self._modules_by_key = {}
@@ -155,6 +158,7 @@ class FastSpeech2(nn.Module):
         self._flat, self._flat_grad = flat, grad
         self._shadow = shadow.to(bf16) if shadow.dtype != bf16 else shadow
         self._rng_state = None
+        self._side = None
         self._rebind()
         return self
 
@@ -495,6 +499,42 @@ class FastSpeech2(nn.Module):
         off = self._table[first_key].offset
         ops.colsum_finalize(partials, nblk, ncol, ncol, self._flat_grad[off:off + ncol], accumulate=True)
 
+    class _SideWork:
+        """Parameter-gradient work (dW GEMMs, bias / LayerNorm column sums) runs on a second HIP stream: nothing on the
+        dX critical path reads it, and most backward kernels fill a fraction of the 256 CUs, so the two chains overlap
+        (captured as parallel branches of the step's hipGraph).  Entering makes the side stream wait for everything the
+        main stream has enqueued (the producers of the tensors about to be read); leaving marks those tensors as in use
+        on the side stream so the caching allocator does not hand their memory to a later main-stream kernel."""
+
+        def __init__(self, model, tensors):
+            self.m, self.tensors = model, tensors
+
+        def __enter__(self):
+            m = self.m
+            if m._side is None:
+                return self
+            m._side.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(m._side)
+            self.ctx.__enter__()
+            return self
+
+        def __exit__(self, *exc):
+            m = self.m
+            if m._side is None:
+                return False
+            for t in self.tensors:
+                if t is not None:
+                    t.record_stream(m._side)
+            self.ctx.__exit__(*exc)
+            return False
+
+    def _side_work(self, *tensors):
+        return FastSpeech2._SideWork(self, tensors)
+
+    def _join_side(self):
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
     def _fft_bwd(self, saved, dx2, rng):
         (pre, x, qkv, probs, o, z1, mean1, rstd1, x1, h, z2, mean2, rstd2, Bn, S, lens, H, p, site) = saved
         d, rows = self.d, Bn * S
@@ -505,19 +545,22 @@ class FastSpeech2(nn.Module):
         # ---- FFN tail: LN backward (PAD rows carry no gradient), dropout mask regenerated
         dz2, dy2, part, nblk = ops.layernorm_bwd(dx2, z2, mean2, rstd2, self._m(f + "layer_norm.weight"), self._m(f + "layer_norm.bias"),
                                                  lens, S, p_pre=p, site_pre=site + 1, rng=rng)
-        self._finalize_ln(part, nblk, 3 * d, f + "w_2.bias")
         # ---- w_2 (k=1): dW, dX gated by the ReLU
-        ops.conv1d_dw(dy2.view(Bn, S, d), h, self._g(f + "w_2.weight"), k=self.k2, defer=self._deferred)
+        with self._side_work(dy2, part, h):
+            self._finalize_ln(part, nblk, 3 * d, f + "w_2.bias")
+            ops.conv1d_dw(dy2.view(Bn, S, d), h, self._g(f + "w_2.weight"), k=self.k2, defer=self._deferred)
         dh = ops.conv1d_dx(dy2.view(Bn, S, d), self._w(f + "w_2.weight"), G=h)
         # ---- w_1 (k=9): bias, dW, dX + residual gradient
-        ops.colsum_into(dh.view(rows, -1), self._g(f + "w_1.bias"))
-        ops.conv1d_dw(dh, x1.view(Bn, S, d), self._g(f + "w_1.weight"), k=self.k1, defer=self._deferred)
+        with self._side_work(dh, x1):
+            ops.colsum_into(dh.view(rows, -1), self._g(f + "w_1.bias"))
+            ops.conv1d_dw(dh, x1.view(Bn, S, d), self._g(f + "w_1.weight"), k=self.k1, defer=self._deferred)
         dx1 = ops.conv1d_dx(dh, self._w(f + "w_1.weight"), R=dz2.view(Bn, S, d))
         # ---- attention tail
         dz1, dy1, part, nblk = ops.layernorm_bwd(dx1.view(rows, d), z1, mean1, rstd1, self._m(a + "layer_norm.weight"),
                                                  self._m(a + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site, rng=rng)
-        self._finalize_ln(part, nblk, 3 * d, a + "fc.bias")
-        ops.linear_dw(dy1, o, self._g(a + "fc.weight"), defer=self._deferred)
+        with self._side_work(dy1, part, o):
+            self._finalize_ln(part, nblk, 3 * d, a + "fc.bias")
+            ops.linear_dw(dy1, o, self._g(a + "fc.weight"), defer=self._deferred)
         do = ops.linear_dx(dy1, self._w(a + "fc.weight"))
         # ---- attention core: dP = dO V^T ; dS = softmax'(P, dP)/sqrt(dk) ; dQ = dS K ; dK = dS^T Q ; dV = P^T dO
         dP = torch.empty(Bn * H, S, Sp, dtype=torch.float32, device=dev)
@@ -532,8 +575,9 @@ class FastSpeech2(nn.Module):
         ops.gemm(probs, do, dqkv[:, 2 * d:], S, dk, S, Sp, d, 3 * d, flags=ops.A_TR | ops.B_TR, nz1=Bn, nz2=H,
                  sA=(H * S * Sp, S * Sp), sB=(S * d, dk), sC=(S * 3 * d, dk))
         # ---- q|k|v projections
-        ops.colsum_into(dqkv, self._g(a + "w_qs.bias", 3 * d))
-        ops.linear_dw(dqkv, x, self._g(a + "w_qs.weight", 3 * d * d).view(3 * d, d), defer=self._deferred)
+        with self._side_work(dqkv, x):
+            ops.colsum_into(dqkv, self._g(a + "w_qs.bias", 3 * d))
+            ops.linear_dw(dqkv, x, self._g(a + "w_qs.weight", 3 * d * d).view(3 * d, d), defer=self._deferred)
         return ops.linear_dx(dqkv, self._w(a + "w_qs.weight", 3 * d), R=dz1)
 
     def _predictor_bwd(self, pre, saved, dout, rng, R):
@@ -545,14 +589,16 @@ class FastSpeech2(nn.Module):
         dh2, _, part, nblk = ops.layernorm_bwd(None, h2.view(rows, Fh), m2, r2, self._m(c + "layer_norm_2.weight"),
                                                self._m(c + "layer_norm_2.bias"), lens, Lp, relu_in=True, p_post=p,
                                                site_post=site + 1, rng=rng, dhead=dout.contiguous().view(-1), head_w=hw)
-        self._finalize_ln(part, nblk, 4 * Fh + 1, c + "conv1d_2.conv.bias")
-        ops.conv1d_dw(dh2.view(Bn, Lp, Fh), a1.view(Bn, Lp, Fh), self._g(c + "conv1d_2.conv.weight"), k=self.k_var, defer=self._deferred)
+        with self._side_work(dh2, part, a1):
+            self._finalize_ln(part, nblk, 4 * Fh + 1, c + "conv1d_2.conv.bias")
+            ops.conv1d_dw(dh2.view(Bn, Lp, Fh), a1.view(Bn, Lp, Fh), self._g(c + "conv1d_2.conv.weight"), k=self.k_var, defer=self._deferred)
         da1 = ops.conv1d_dx(dh2.view(Bn, Lp, Fh), self._w(c + "conv1d_2.conv.weight"))
         dh1, _, part, nblk = ops.layernorm_bwd(da1.view(rows, Fh), h1.view(rows, Fh), m1, r1, self._m(c + "layer_norm_1.weight"),
                                                self._m(c + "layer_norm_1.bias"), None, 0, relu_in=True, p_post=p,
                                                site_post=site, rng=rng)
-        self._finalize_ln(part, nblk, 3 * Fh, c + "conv1d_1.conv.bias")
-        ops.conv1d_dw(dh1.view(Bn, Lp, Fh), x.view(Bn, Lp, d), self._g(c + "conv1d_1.conv.weight"), k=self.k_var, defer=self._deferred)
+        with self._side_work(dh1, part, x):
+            self._finalize_ln(part, nblk, 3 * Fh, c + "conv1d_1.conv.bias")
+            ops.conv1d_dw(dh1.view(Bn, Lp, Fh), x.view(Bn, Lp, d), self._g(c + "conv1d_1.conv.weight"), k=self.k_var, defer=self._deferred)
         return ops.conv1d_dx(dh1.view(Bn, Lp, Fh), self._w(c + "conv1d_1.conv.weight"), R=R)
 
     def backward_native(self, ctx, dmel_sum, dpost, dpitch, denergy, dlogd, on_bucket=None):
@@ -568,8 +614,11 @@ class FastSpeech2(nn.Module):
         # split-K slabs of the weight-gradient GEMMs are summed by ONE batched reducer launch per parameter group when a
         # data-parallel reducer is waiting for finished buckets, otherwise once at the end (only Adam reads them)
         self._deferred = []
+        if self.overlap_param_grads and self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
         if on_bucket is not None:
             def notify(name):
+                self._join_side()
                 ops.flush_deferred(self._deferred)
                 on_bucket(name)
         else:
@@ -581,16 +630,18 @@ class FastSpeech2(nn.Module):
             C = yc.shape[2]
             dy = ops.bn_bwd(dout, yc.view(rows, C), mean, rstd, self._m(pp + "1.weight"), self._m(pp + "1.bias"), i < 4,
                             p=self.p_post, site=300 + i, rng=rng, dgamma=self._g(pp + "1.weight"), dbeta=self._g(pp + "1.bias"))
-            ops.colsum_into(dy, self._g(pp + "0.conv.bias"))
-            ops.conv1d_dw(dy.view(Bn, T, C), xin, self._g(pp + "0.conv.weight"), k=5, defer=self._deferred)
+            with self._side_work(dy, xin):
+                ops.colsum_into(dy, self._g(pp + "0.conv.bias"))
+                ops.conv1d_dw(dy.view(Bn, T, C), xin, self._g(pp + "0.conv.weight"), k=5, defer=self._deferred)
             if i > 0:
                 dout = ops.conv1d_dx(dy.view(Bn, T, C), self._w(pp + "0.conv.weight")).view(rows, -1)
             else:
                 dmel_tot = ops.conv1d_dx(dy.view(Bn, T, C), self._w(pp + "0.conv.weight"), R=dmel_sum.view(Bn, T, nm)).view(rows, nm)
         notify("postnet")
         # ---- mel_linear
-        ops.colsum_into(dmel_tot, self._g("mel_linear.bias"))
-        ops.linear_dw(dmel_tot, ctx.dec_out, self._g("mel_linear.weight"), defer=self._deferred)
+        with self._side_work(dmel_tot, ctx.dec_out):
+            ops.colsum_into(dmel_tot, self._g("mel_linear.bias"))
+            ops.linear_dw(dmel_tot, ctx.dec_out, self._g("mel_linear.weight"), defer=self._deferred)
         dx = ops.linear_dx(dmel_tot, self._w("mel_linear.weight"))
         notify("mel_linear")
         # ---- decoder
@@ -601,11 +652,14 @@ class FastSpeech2(nn.Module):
         dx3 = ops.length_regulator_bwd(dx.view(Bn, T, d), ctx.cs, Lp).view(Bn * Lp, d)
         # ---- variance adaptor, reverse order of modules.py:158-193
         va = "variance_adaptor."
-        ops.scatter_sum(dx3, ctx.eidx.view(-1), self._g(va + "energy_embedding.weight"))
+        with self._side_work(dx3):
+            ops.scatter_sum(dx3, ctx.eidx.view(-1), self._g(va + "energy_embedding.weight"))
         dx2 = self._predictor_bwd(va + "energy_predictor.", ctx.preds[va + "energy_predictor."], denergy, rng, dx3.view(Bn, Lp, d))
-        ops.scatter_sum(dx2.view(Bn * Lp, d), ctx.pidx.view(-1), self._g(va + "pitch_embedding.weight"))
+        with self._side_work(dx2):
+            ops.scatter_sum(dx2.view(Bn * Lp, d), ctx.pidx.view(-1), self._g(va + "pitch_embedding.weight"))
         dx1 = self._predictor_bwd(va + "pitch_predictor.", ctx.preds[va + "pitch_predictor."], dpitch, rng, dx2)
-        ops.scatter_sum(dx1.view(Bn * Lp, d), ctx.speakers, self._g("speaker_emb.weight"), idx_div=Lp)
+        with self._side_work(dx1):
+            ops.scatter_sum(dx1.view(Bn * Lp, d), ctx.speakers, self._g("speaker_emb.weight"), idx_div=Lp)
         dxe = self._predictor_bwd(va + "duration_predictor.", ctx.preds[va + "duration_predictor."], dlogd, rng, dx1)
         notify("variance_adaptor")
         # ---- encoder
@@ -613,7 +667,9 @@ class FastSpeech2(nn.Module):
         for i in range(self.n_enc - 1, -1, -1):
             dx = self._fft_bwd(ctx.blocks[i], dx, rng)
             notify("encoder.%d" % i)
-        ops.scatter_sum(dx, ctx.texts.view(-1), self._g("encoder.src_word_emb.weight"), skip_row=0)   # padding_idx=0
+        with self._side_work(dx):
+            ops.scatter_sum(dx, ctx.texts.view(-1), self._g("encoder.src_word_emb.weight"), skip_row=0)   # padding_idx=0
         notify("embedding")
+        self._join_side()
         ops.flush_deferred(self._deferred)
         self._ctx = None

@@ -210,8 +210,10 @@ class Generator(nn.Module):
                     al = ops.avg3(outs[0], outs[1], outs[2], 1.0 / 3.0, slope=nxt_slope)   # lrelu(xs / num_kernels)
                 else:
                     raise NotImplementedError("MRF average is written for 3 resblock kernels per stage")
-            Bn, Tout, C = al.shape
             wp, bp = pk["post"]
+            if al.shape[2] <= 128:
+                return ops.hifi_conv_post(al, wp, bp)                                      # conv_post -> tanh, streaming kernel
+            Bn, Tout, C = al.shape
             y = torch.empty(Bn * Tout, 1, dtype=torch.float32, device=al.device)
-            ops.conv1d(al, wp, bp, out=y.view(Bn, Tout, 1), flags=ops.TANH)                 # conv_post -> tanh
+            ops.conv1d(al, wp, bp, out=y.view(Bn, Tout, 1), flags=ops.TANH)
         return y.view(Bn, 1, Tout)

@@ -51,7 +51,7 @@ def plan(d):
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=None, ldr=0, G=None, ldg=0, C2=None,
          nz1=1, nz2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), taps=0, seg_len=0, tap_shift0=0, tap_dshift=0,
-         b_tap_stride=0, bseg_len=0, bshift0=0, bdshift=0, out_seg=0, out_mul=0, out_add=0, splits=0, kernel=0,
+         b_tap_stride=0, bseg_len=0, bshift0=0, bdshift=0, out_seg=0, out_mul=0, out_add=0, out_add_dz=0, splits=0, kernel=0,
          in_slope=0.0, out_slope=0.0, defer=None):
     """Raw descriptor-level call of ttsk_gemm (see include/ttsk.h).  A/B/Cout may be views: the data pointer of
     the view is the operand origin.  splits / kernel = 0 let the library plan (tile configuration, split-K factor);
@@ -79,7 +79,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=No
     d.sR1, d.sR2 = sR
     d.taps, d.seg_len, d.tap_shift0, d.tap_dshift, d.b_tap_stride = taps, seg_len, tap_shift0, tap_dshift, b_tap_stride
     d.bseg_len, d.bshift0, d.bdshift = bseg_len, bshift0, bdshift
-    d.out_seg, d.out_mul, d.out_add = out_seg, out_mul, out_add
+    d.out_seg, d.out_mul, d.out_add, d.out_add_dz = out_seg, out_mul, out_add, out_add_dz
     d.splits, d.kernel = splits, kernel
     kernel, splits, ws_bytes = plan(d)
     d.splits, d.kernel = splits, kernel
@@ -213,11 +213,20 @@ def conv_transpose1d(x, Wp, bias, stride, k, out=None, in_slope=0.0, flags=0, C2
     if out is None:
         out = torch.empty(Bsz, T * stride, Cout, dtype=x.dtype, device=x.device)
     taps = k // stride
+    # phases r = 0..stride-1; phases with the same first tap offset qoff share one launch (batch index z2 = phase):
+    # their weights Wp[r] are consecutive, their output rows differ by one (out_add_dz = 1)
+    groups = []
     for r in range(stride):
         qoff = max(0, -((r - p) // stride))          # ceil((p - r)/stride) clipped at 0
-        gemm(x, Wp[r], out, Bsz * T, Cout, Cin, Cin, Cin, Cout, flags=flags | (LRELU_IN if in_slope else 0),
+        if groups and groups[-1][1] == qoff:
+            groups[-1][2] += 1
+        else:
+            groups.append([r, qoff, 1])
+    for r0, qoff, n in groups:
+        gemm(x, Wp[r0], out, Bsz * T, Cout, Cin, Cin, Cin, Cout, flags=flags | (LRELU_IN if in_slope else 0),
              bias=bias, taps=taps, seg_len=T, tap_shift0=qoff, tap_dshift=-1, b_tap_stride=stride * Cout * Cin,
-             out_seg=T * stride, out_mul=stride, out_add=qoff * stride + r - p, in_slope=in_slope, C2=C2, out_slope=out_slope, **kw)
+             out_seg=T * stride, out_mul=stride, out_add=qoff * stride + r0 - p, out_add_dz=1, nz2=n, sB=(0, Cout * Cin),
+             in_slope=in_slope, C2=C2, out_slope=out_slope, **kw)
     return out
 
 
@@ -538,4 +547,15 @@ def hifi_resblock1(x, weights, biases, dilations, out, K, mode=0, scale=1.0, slo
     check(L.load().ttsk_hifi_resblock1(_ptr(x), _ptr(out), int(x.dtype == f16), C.cast(wp, C.c_void_p), C.cast(bp, C.c_void_p),
                                        C.cast(dl, C.c_void_p), Bn, ln, Cn, K, mode, scale, slope, final_slope, _stream()),
           "ttsk_hifi_resblock1")
+    return out
+
+
+def hifi_conv_post(x, w, bias):
+    """tanh(Conv1d(C -> 1, k)(x)): x (B, len, C) 16-bit already activated, w (1, k, C) 16-bit -> (B, 1, len) fp32.
+    reference: hifi/models.py:198-199."""
+    _dev(x, w, bias)
+    Bn, ln, Cn = x.shape
+    out = torch.empty(Bn, 1, ln, dtype=torch.float32, device=x.device)
+    check(L.load().ttsk_hifi_conv_post(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), int(x.dtype == f16), Bn, ln, Cn, w.shape[1], _stream()),
+          "ttsk_hifi_conv_post")
     return out

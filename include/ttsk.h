@@ -207,6 +207,12 @@ int ttsk_to_int16(const float* src, int16_t* dst, int64_t n, float scale, void* 
  */
 int ttsk_weight_norm_fold(const float* v, const float* g, float* w, int rows, int cols, void* stream);
 int ttsk_pack_conv_weight(const float* src, void* dst16, int f16, int d0, int d1, int d2, int mode, void* stream);
+/* "Window" Conv1d for the C = 128 stage (one conv per launch, activation window resident in LDS, weights streamed from a
+ * ttsk_pack_resblock_weight pack): out = [lrelu](conv_{K,dil}(x) + bias [+ R]); out2 (optional) = lrelu(out, slope).
+ * x must already be activated (zeros outside the utterance are the conv padding).  reference: hifi/models.py:88-95. */
+int ttsk_hifi_conv_window_supported(int C, int K, int dil);
+int ttsk_hifi_conv_window(const void* x16, const void* w_pack, const float* bias, const void* R16, void* out16, void* out2_16,
+                          int f16, int B, int len, int C, int K, int dil, int lrelu_out, float slope, void* stream);
 /* conv_post + tanh (hifi/models.py:198-199): x (B, len, C) 16-bit (already activated), w (1, k, C) tap-major 16-bit,
  * out (B, 1, len) fp32.  A streaming kernel: one output sample per thread. */
 int ttsk_hifi_conv_post(const void* x16, const void* w16, const float* bias, float* out, int f16, int B, int len, int C, int K,

@@ -177,3 +177,42 @@ def test_fused_and_unfused_generators_agree(cfg):
     r = rel_rms(wf.cpu(), wu.cpu())
     print("fused vs conv-by-conv generator: rel-RMS %.3f%%" % (100 * r))
     assert r <= 0.002
+
+
+@pytest.mark.parametrize("K,dil,B,ln,res", [(3, 1, 2, 700, False), (7, 3, 1, 256, True), (11, 5, 2, 1000, True), (11, 1, 1, 5, False), (7, 5, 3, 257, True)])
+def test_window_conv_vs_fp64(K, dil, B, ln, res):
+    """The C = 128 window-conv kernel against fp64 conv1d on the same fp16-rounded operands (K-scaled summation bound),
+    with the residual and the second (activated) output."""
+    from tts_king_amd import ops
+    import torch.nn.functional as F
+    C = 128
+    g = torch.Generator().manual_seed(K * 100 + ln)
+    x = torch.randn(B, ln, C, generator=g).half()
+    w = (torch.randn(C, C, K, generator=g) * (C * K) ** -0.5).half()
+    b = 0.1 * torch.randn(C, generator=g)
+    r = torch.randn(B, ln, C, generator=g).half() if res else None
+    ref = F.conv1d(x.double().transpose(1, 2), w.double(), b.double(), dilation=dil, padding=dil * (K - 1) // 2).transpose(1, 2)
+    if res:
+        ref = ref + r.double()
+    pack = ops.pack_resblock_weight(w.float().to(DEV), dtype=torch.float16)
+    out2 = torch.empty(B, ln, C, dtype=torch.float16, device=DEV) if res else None
+    out = ops.hifi_conv_window(x.to(DEV), pack, b.to(DEV), K, dil, R=r.to(DEV) if res else None, out2=out2, lrelu_out=not res)
+    want = ref if res else torch.where(ref > 0, ref, 0.1 * ref)
+    err = float((out.float().cpu().double() - want).abs().max())
+    tol = 2e-6 * (C * K) ** 0.5 * float(want.abs().max() + 1) + float(want.abs().max()) * 2 ** -10
+    assert err <= tol, (err, tol)
+    if res:
+        o = out.float().cpu()
+        assert torch.equal(out2.cpu(), torch.where(o > 0, o, 0.1 * o).half())
+
+
+def test_window_and_gemm_generators_agree(cfg):
+    gen = build(cfg, 5)
+    mel = make_mel(2, 40, seed=9).to(DEV)
+    gen.window_conv = True
+    a = gen(mel)
+    gen.window_conv = False
+    b = gen(mel)
+    r = rel_rms(a.cpu(), b.cpu())
+    print("window-conv vs implicit-GEMM generator: rel-RMS %.3f%%" % (100 * r))
+    assert r <= 0.002

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void pack_rb_weight_kernel(const float* __rest
 }
 
 int rb_kpad(int C, int K) {
-  const int gt = C == 32 ? K : 2;
+  const int gt = C == 32 ? K : (C == 64 ? 2 : 1);      // taps per weight stage of the consuming kernel
   return (K + gt - 1) / gt * gt;
 }
 
@@ -325,7 +325,7 @@ int launch_rb(const RbArgs& a, int B, int f16, hipStream_t s) {
 extern "C" int64_t ttsk_resblock_pack_elems(int C, int K) { return (int64_t)C * C * rb_kpad(C, K); }
 
 extern "C" int ttsk_pack_resblock_weight(const float* src, void* dst16, int f16, int C, int K, void* stream) {
-  TTSK_REQUIRE(src && dst16 && (C == 32 || C == 64) && K >= 1, "ttsk_pack_resblock_weight: C must be 32 or 64");
+  TTSK_REQUIRE(src && dst16 && (C == 32 || C == 64 || C == 128) && K >= 1, "ttsk_pack_resblock_weight: C must be 32, 64 or 128");
   const int Kpad = rb_kpad(C, K);
   const int64_t n = (int64_t)C * C * Kpad;
   int blocks = (int)((n + 255) / 256);

@@ -95,6 +95,7 @@ class Generator(nn.Module):
         self._packed = None
         self._packed_key = None
         self.act_dtype = f16         # storage type of activations and packed weights (fp32 accumulate); bf16 also works
+        self.window_conv = True      # window-conv kernel at the C = 128 stage; False = implicit-GEMM convs
         self.fused = True            # fused ResBlock1 kernel where an instance exists (C in {32,64}); False = conv-by-conv
 
     # ------------------------------------------------------------------ reference surface
@@ -138,7 +139,7 @@ class Generator(nn.Module):
         pk = {}
         pk["pre"] = (ops.pack_conv_weight(self.conv_pre.folded_weight(), dtype=dt), self.conv_pre.bias.data)
         pk["ups"] = [(ops.pack_conv_weight(u.folded_weight(), transposed=True, dtype=dt), u.bias.data) for u in self.ups]
-        pk["rb"], pk["rbf"] = [], []
+        pk["rb"], pk["rbf"], pk["rbw"] = [], [], []
         for rb in self.resblocks:
             convs = rb.all_convs()
             ch = convs[0].bias.shape[0]
@@ -148,13 +149,17 @@ class Generator(nn.Module):
                 pk["rbf"].append(([ops.pack_resblock_weight(c.folded_weight(), dtype=dt) for c in order], [c.bias.data for c in order]))
             else:
                 pk["rbf"].append(None)
+            if rb.kind == "1" and pk["rbf"][-1] is None and all(ops.hifi_conv_window_supported(ch, rb.k, dd) for dd in rb.dilation):
+                pk["rbw"].append([ops.pack_resblock_weight(c.folded_weight(), dtype=dt) for c in convs])     # window-conv packs
+            else:
+                pk["rbw"].append(None)
             pk["rb"].append([(ops.pack_conv_weight(c.folded_weight(), dtype=dt), c.bias.data) for c in convs])
         pk["post"] = (ops.pack_conv_weight(self.conv_post.folded_weight(), dtype=dt), self.conv_post.bias.data)
         self._packed, self._packed_key = pk, key
         return pk
 
     # ------------------------------------------------------------------ forward
-    def _resblock(self, rb, packed, x, xl):
+    def _resblock(self, rb, packed, x, xl, wpacks=None):
         """reference: hifi/models.py:88-95 (ResBlock1) / :136-140 (ResBlock2), conv by conv on the implicit-GEMM kernel.
         x = block input, xl = lrelu(x).  Every LeakyReLU is applied by the PRODUCING conv's epilogue (LRELU_OUT, or a
         second output C2 = lrelu(v) next to the raw v the residual path needs), the residual add is an epilogue too."""
@@ -162,7 +167,11 @@ class Generator(nn.Module):
         for m, d in enumerate(rb.dilation):
             lastp = m == nd - 1
             xl_next = None if lastp else torch.empty_like(x)
-            if rb.kind == "1":
+            if rb.kind == "1" and wpacks is not None and self.window_conv:
+                # C = 128: one window-conv launch per conv (activation window in LDS, weights streamed)
+                tl = ops.hifi_conv_window(xl, wpacks[m], packed[m][1], rb.k, d, lrelu_out=True, slope=LRELU_SLOPE)
+                x = ops.hifi_conv_window(tl, wpacks[nd + m], packed[nd + m][1], rb.k, 1, R=x, out2=xl_next, slope=LRELU_SLOPE)
+            elif rb.kind == "1":
                 w1, b1 = packed[m]
                 w2, b2 = packed[nd + m]
                 tl = ops.conv1d(xl, w1, b1, dilation=d, flags=ops.LRELU_OUT, out_slope=LRELU_SLOPE)
@@ -205,7 +214,7 @@ class Generator(nn.Module):
                     continue
                 axl = torch.empty(al.shape[0], al.shape[1] * u, wu.shape[1], dtype=al.dtype, device=al.device)
                 a = ops.conv_transpose1d(al, wu, bu, u, k, C2=axl, flags=ops.C2_LRELU, out_slope=LRELU_SLOPE)   # x and lrelu(x)
-                outs = [self._resblock(rb, pk["rb"][i * nk + j], a, axl) for j, rb in enumerate(rbs)]
+                outs = [self._resblock(rb, pk["rb"][i * nk + j], a, axl, pk["rbw"][i * nk + j]) for j, rb in enumerate(rbs)]
                 if nk == 3:
                     al = ops.avg3(outs[0], outs[1], outs[2], 1.0 / 3.0, slope=nxt_slope)   # lrelu(xs / num_kernels)
                 else:

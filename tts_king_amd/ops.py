@@ -559,3 +559,17 @@ def hifi_conv_post(x, w, bias):
     check(L.load().ttsk_hifi_conv_post(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), int(x.dtype == f16), Bn, ln, Cn, w.shape[1], _stream()),
           "ttsk_hifi_conv_post")
     return out
+
+
+def hifi_conv_window_supported(Cn, K, dil):
+    return bool(L.load().ttsk_hifi_conv_window_supported(Cn, K, dil))
+
+
+def hifi_conv_window(x, w_pack, bias, K, dilation=1, R=None, out2=None, lrelu_out=False, slope=0.1):
+    """out = [lrelu](conv_{K,dil}(x) + bias [+ R]) on the window kernel (C = 128); out2 (optional tensor) = lrelu(out)."""
+    _dev(x, w_pack, bias, R, out2)
+    Bn, ln, Cn = x.shape
+    out = torch.empty_like(x)
+    check(L.load().ttsk_hifi_conv_window(_ptr(x), _ptr(w_pack), _ptr(bias), _ptr(R), _ptr(out), _ptr(out2), int(x.dtype == f16), Bn, ln,
+                                         Cn, K, dilation, int(lrelu_out), slope, _stream()), "ttsk_hifi_conv_window")
+    return out

@@ -50,6 +50,10 @@ def test_ttsking_surface_and_parity(tmp_path):
     assert wav.dtype == np.int16 and wav.shape == (1, 1, 256 * T)
     with pytest.raises(Exception):
         tts.tts.generate(phon, speaker_name="no such speaker")
+    # phoneme-string input (the notation of examples.ipynb cell 2) goes through the text frontend
+    ids = tts.text_preprocess("{R A B O0 T A T0 sp}")
+    assert ids.shape == (1, 8) and ids[0, 0] == 184
+    assert tts.generate_mel("{R A B O0 T A T0 sp}", speaker=1).shape[2] == 80
     # ---- oracle on the same weights, teacher-forced on the durations the HIP path predicted
     sd = {k: v.detach().float().cpu() for k, v in tts.tts.model.state_dict().items()}
     m = tts.tts.model

@@ -220,7 +220,29 @@ def g8_shapes():
     print("G8 fs2 keys", len(sd), "hifi", len(sdw), len(sdf))
 
 
+def g9_text():
+    """Symbol inventory (data asset pretrained/symbols.json: the id of a symbol is its position + the model's vocabulary
+    is len + 1, Models.py:40) and known-answer vectors of `text_to_sequence` (examples.ipynb cell 2 plus a few more)."""
+    import json
+    from fs_two.text import text_to_sequence
+    from fs_two.text.symbols import symbols
+    with open(os.path.join(REPO, "pretrained", "symbols.json"), "w") as f:
+        json.dump(list(symbols), f, ensure_ascii=False)
+    cases = ["{R A B O0 T A T0 I R A B O0 T A T0 sp S K A Z A0 L O0 N sp}",
+             "{P R I0 V E0 T sp M I0 R sp}",
+             "Turn left on {HH AW1 S S T AH0 N} Street.",
+             "{sil} {spn} a-b, c!",
+             "{NOSUCH R A} ~_x"]
+    out = {c: text_to_sequence(c, []) for c in cases}
+    with open(os.path.join(OUT, "text_to_sequence.json"), "w") as f:
+        json.dump({"n_symbols": len(symbols), "cases": out}, f, ensure_ascii=False, indent=1)
+    print("G9 symbols", len(symbols), {k: len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "text":
+        g9_text()
+        sys.exit(0)
     g1_eval_teacher_forced()
     g2_eval_free_running()
     g3_train_no_dropout()
@@ -228,3 +250,4 @@ if __name__ == "__main__":
     g6_adam_steps()
     g7_hifigan()
     g8_shapes()
+    g9_text()

@@ -2,8 +2,9 @@
 
 `TTSKing(config_path)`, `.generate_mel(text, d, p, e, speaker)`, `.mel_to_wav(mel)`, `.speakers`, `.text_preprocess`,
 `.to_torch_device` keep the reference signatures.  The text frontend (russian_g2p / g2p_en, fs_two/text) is outside this
-build's scope: `text` may be a phoneme-id array (1, L) (what `text_preprocess` returns in the
-reference) and, when the optional frontend packages are importable, a string.
+build's G2P dependency list: `text` may be a phoneme-id array (1, L) (what `text_preprocess` returns in the reference), a
+phoneme string "{R A B O0 T ...}" (tts_king_amd/text.py, pinned by the notebook's known-answer vector), or — when the
+optional `russian_g2p` package is importable — plain Russian text.
 """
 import numpy as np
 import torch
@@ -36,13 +37,18 @@ class TTSKing:
         return self.vocoder(mel.transpose(1, 2))
 
     def text_preprocess(self, text):
-        """reference: tts_king.py:59-60 -> input_process.preprocess_rus (needs russian_g2p)."""
-        try:
-            from input_process import preprocess_rus
-        except ImportError as e:
-            raise ImportError("the text frontend (russian_g2p + fs_two.text) is not part of this build; pass a phoneme-id "
-                              "array (1, L) instead of a string") from e
+        """reference: tts_king.py:59-60 -> input_process.preprocess_rus (needs russian_g2p).  A string that already is in
+        the phoneme notation of the reference's frontend, "{R A B O0 T ...}", is converted directly."""
+        from input_process import preprocess_rus
+        from tts_king_amd.text import text_to_sequence
+        if "{" in text:
+            return np.array([text_to_sequence(text, [])])
         return np.array([preprocess_rus(text)])
+
+    def text_preprocess_eng(self, text):
+        """reference: tts_king.py:62-63."""
+        from input_process import preprocess_eng
+        return np.array([preprocess_eng(text, self.cfg.preprocess_config)])
 
     def to_torch_device(self, items):
         return [torch.tensor(t).to(self.cfg.gpu) for t in items]

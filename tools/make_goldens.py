@@ -239,9 +239,45 @@ def g9_text():
     print("G9 symbols", len(symbols), {k: len(v) for k, v in out.items()})
 
 
+def synthetic_samples(n, seed):
+    """Seeded per-utterance sample dicts with the fields Dataset.__getitem__ returns (fs_two/dataset.py:117-131)."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        L = int(rng.randint(5, 40))
+        dur = rng.randint(1, 6, size=L)
+        T = int(dur.sum())
+        out.append({"id": "utt%03d" % i, "speaker": int(rng.randint(0, 65)), "text": rng.randint(1, 207, size=L),
+                    "raw_text": "raw %d" % i, "mel": rng.randn(T, 80).astype(np.float32), "energy": rng.randn(L).astype(np.float32),
+                    "duration": dur, "pitch_raw": rng.randn(L).astype(np.float32), "pitch_mean": np.float32(rng.randn()),
+                    "pitch_std": np.float32(abs(rng.randn()) + 0.1), "pitch_cwt": rng.randn(L, 11).astype(np.float32)})
+    return out
+
+
+def g10_collate():
+    """Reference collate (sort by phoneme count, cut into batches, pad) on seeded samples: fs_two/dataset.py:158-225."""
+    from fs_two.dataset import Dataset as RefDataset
+    res = {}
+    for tag, (n, bs, sort, drop) in {"a": (11, 4, True, True), "b": (11, 4, True, False), "c": (8, 4, False, True)}.items():
+        dummy = types.SimpleNamespace(sort=sort, batch_size=bs, drop_last=drop)
+        dummy.reprocess = lambda data, idxs: RefDataset.reprocess(dummy, data, idxs)
+        batches = RefDataset.collate_fn(dummy, synthetic_samples(n, 77))
+        res[tag + "/n"] = len(batches)
+        for bi, b in enumerate(batches):
+            res["%s/%d/ids" % (tag, bi)] = np.array(b[0])
+            for fi in (2, 3, 4, 6, 7, 9, 10, 11, 12, 13, 14):
+                res["%s/%d/%d" % (tag, bi, fi)] = np.asarray(b[fi])
+            res["%s/%d/max" % (tag, bi)] = np.array([b[5], b[8]])
+    np.savez_compressed(os.path.join(OUT, "collate.npz"), **res)
+    print("G10 collate", {k: int(v) for k, v in res.items() if k.endswith("/n")})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "text":
         g9_text()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "collate":
+        g10_collate()
         sys.exit(0)
     g1_eval_teacher_forced()
     g2_eval_free_running()
@@ -251,3 +287,4 @@ if __name__ == "__main__":
     g7_hifigan()
     g8_shapes()
     g9_text()
+    g10_collate()

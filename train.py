@@ -1,0 +1,108 @@
+"""FS2 trainer with the reference's entry points (reference: train.py:24-56 `main_train_step`, :78-235 `main`,
+fs_two/evaluate.py:18-101 `evaluate`), running the MI355X train step.
+
+Kept from the reference: the step function and its return value, the loop structure (DataLoader over groups of
+batch_size*4 utterances sorted by phoneme count and cut into batches, `grad_acc_step`, log / val / save cadence from
+`train_config.step`), the validation message, the checkpoint layout `{"model", "embedding", "optimizer"}`
+(train.py:212-227).  Different: batches reach the GPU through a pinned-memory prefetcher (tts_king_amd/dataset.py),
+wandb / matplotlib logging is replaced by a plain print (no network on the GPU box), and resuming also
+restores the optimizer state the reference saves but never reloads.
+"""
+import os
+
+import torch
+from torch.utils.data import DataLoader
+
+from tts_king_amd.config import load_config
+from tts_king_amd.dataset import Dataset, DeviceFeeder
+from tts_king_amd.loss import FastSpeech2Loss
+from tts_king_amd.train_step import get_model, main_train_step, save_checkpoint, to_device  # noqa: F401  (reference names)
+
+
+def get_param_num(model):
+    """reference: fs_two/utils/model.py:41-43."""
+    return sum(p.numel() for p in model.parameters())
+
+
+def evaluate(model, step, cfg, logger=None, train_val="val", vocoder=None, device=0):
+    """reference: fs_two/evaluate.py:18-101 — teacher-forced forward in eval mode over `val.txt`, loss means weighted by
+    batch size over len(dataset); returns the reference's message string (logger output is not reproduced)."""
+    dataset = Dataset("%s.txt" % train_val, cfg.preprocess_config, cfg.train_config, sort=False, drop_last=False)
+    batch_size = cfg.train_config["optimizer"]["batch_size"]
+    loader = DataLoader(dataset, batch_size=batch_size, shuffle=False, collate_fn=dataset.collate_fn)
+    Loss = FastSpeech2Loss(cfg.preprocess_config, cfg.model_config)
+    dev = model.device
+    was_training = model.training
+    model.eval()
+    loss_sums = [0.0 for _ in range(6)]
+    with torch.no_grad():
+        for batchs in loader:
+            for batch in DeviceFeeder(batchs, dev):
+                output = model(*(batch[2:]))
+                losses = Loss(batch, output)
+                vals = torch.stack([l.reshape(-1)[0].float() for l in losses[1:]]).cpu().tolist()   # one host read per batch
+                for i, v in enumerate(vals):
+                    loss_sums[i] += v * len(batch[0])
+    model.train(was_training)
+    loss_means = [s / len(dataset) for s in loss_sums]
+    loss_means = [sum(loss_means)] + loss_means
+    return """Validation Step {}, 
+                 Total Loss: {:.4f}, 
+                 Mel Loss: {:.4f}, 
+                 Pitch Loss: {:.4f}, 
+                 Mean pitch {:.4f},
+                 Std pitch {:.4f}""".format(step, *loss_means[:5])
+
+
+def load_training_state(model, optimizer, path):
+    """Resume from a checkpoint written by save_checkpoint: weights, speaker embedding (re-inserted as in fsapi.py:28-30)
+    and — unlike the reference, which saves it but has no caller for ScheduledOptim.load_state_dict — the Adam state."""
+    ckpt = torch.load(path, map_location="cpu")
+    state = dict(ckpt["model"])
+    state["speaker_emb.weight"] = ckpt["embedding"]
+    model.load_state_dict(state)
+    if optimizer is not None and ckpt.get("optimizer") is not None:
+        optimizer.load_state_dict(ckpt["optimizer"])
+
+
+def main(cfg, max_steps=None):
+    """reference: train.py:78-235.  `max_steps` (extra) stops early instead of the reference's `quit()` at total_step."""
+    print("Prepare training ...")
+    device = cfg.gpu
+    dataset = Dataset("train.txt", cfg.preprocess_config, cfg.train_config, sort=True, drop_last=True)
+    batch_size = cfg.train_config["optimizer"]["batch_size"]
+    group_size = 4                                    # sorting happens inside groups of 4 batches (train.py:91)
+    assert batch_size * group_size < len(dataset)
+    mi = cfg.get("mi355x", {}) if hasattr(cfg, "get") else {}
+    workers = int(mi.get("loader_workers", 4)) if mi else 4          # reference: num_workers=4 (train.py:98)
+    loader = DataLoader(dataset, batch_size=batch_size * group_size, shuffle=True, collate_fn=dataset.collate_fn, num_workers=workers)
+    model, optimizer = get_model(cfg, device, train=True)
+    Loss = FastSpeech2Loss(cfg.preprocess_config, cfg.model_config)
+    print("Number of FastSpeech2 Parameters:", get_param_num(model))
+    for p in cfg.train_config["path"].values():
+        os.makedirs(p, exist_ok=True)
+    step = cfg.tts.restore_step + 1
+    total_step = cfg.train_config["step"]["total_step"]
+    if max_steps is not None:
+        total_step = min(total_step, cfg.tts.restore_step + max_steps)
+    st = cfg.train_config["step"]
+    epoch = 1
+    while True:
+        for batchs in loader:
+            for batch in DeviceFeeder(batchs, model.device):
+                losses, output = main_train_step(model, batch, step, optimizer, cfg, Loss)
+                if step % st["log_step"] == 0:
+                    print("Step {}/{}, Total Loss: {:.4f}, Mel Loss: {:.4f}, Pitch Loss: {:.4f}, Energy Loss: {:.4f}, "
+                          "Duration Loss: {:.4f}".format(step, total_step, sum(losses[:4]), *losses[:4]))
+                if step % st["val_step"] == 0:
+                    print(evaluate(model, step, cfg, None, "val", None, device))
+                if step % st["save_step"] == 0:
+                    save_checkpoint(model, optimizer, os.path.join(cfg.train_config["path"]["ckpt_path"], "{}.pth.tar".format(step)))
+                if step == total_step:
+                    return model, optimizer
+                step += 1
+        epoch += 1
+
+
+if __name__ == "__main__":
+    main(load_config("./config.yaml"))

@@ -1,0 +1,134 @@
+"""Dataset, collate and device feeder of the FS2 trainer (host-side, no kernels).
+
+reference: fs_two/dataset.py:32-225 (`Dataset`: metadata file `name|speaker|phonemes|raw text`, per-utterance .npy files
+`{kind}/{speaker}-{kind}-{basename}.npy`, `collate_fn` = sort a group of batch_size*group_size utterances by phoneme
+count, cut it into batch_size batches, `reprocess` = pad and emit the 15-tuple), fs_two/utils/tools.py:330-366 (pad_1D,
+pad_2D), train.py:83-99,139-141 (DataLoader with group_size 4, `to_device`).
+
+What is MI355X-specific: `DeviceFeeder` — the reference moves each batch with blocking `.to(device)` calls from the
+training loop; here batches are staged in pinned host memory and copied on a side HIP stream one batch ahead, so the
+H2D transfer (2.2 MB per batch) overlaps the previous step's graph replay.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from .text import text_to_sequence
+
+
+def pad_1D(inputs, PAD=0):
+    """reference: fs_two/utils/tools.py:330-341."""
+    n = max(len(x) for x in inputs)
+    return np.stack([np.pad(x, (0, n - x.shape[0]), mode="constant", constant_values=PAD) for x in inputs])
+
+
+def pad_2D(inputs, maxlen=None):
+    """reference: fs_two/utils/tools.py:344-366 (rows padded with zeros; a longer input is an error)."""
+    n = maxlen if maxlen else max(np.shape(x)[0] for x in inputs)
+    out = []
+    for x in inputs:
+        if np.shape(x)[0] > n:
+            raise ValueError("not max_len")
+        out.append(np.pad(x, ((0, n - np.shape(x)[0]), (0, 0)), mode="constant", constant_values=0))
+    return np.stack(out)
+
+
+def reprocess(data, idxs):
+    """Samples -> the 15-tuple batch (reference: fs_two/dataset.py:158-204)."""
+    g = lambda k: [data[i][k] for i in idxs]
+    texts, mels = g("text"), g("mel")
+    text_lens = np.array([t.shape[0] for t in texts])
+    mel_lens = np.array([m.shape[0] for m in mels])
+    return (g("id"), g("raw_text"), np.array(g("speaker")), pad_1D(texts), text_lens, max(text_lens), pad_2D(mels), mel_lens,
+            max(mel_lens), pad_1D(g("energy")), pad_1D(g("duration")), pad_1D(g("pitch_raw")), pad_2D(g("pitch_cwt")),
+            np.array(g("pitch_mean")), np.array(g("pitch_std")))
+
+
+def collate(data, batch_size, sort=True, drop_last=True):
+    """A group of samples -> list of batches (reference: fs_two/dataset.py:206-225): descending phoneme count (stable
+    argsort of the negated lengths), full batches first, the remainder only when drop_last is False."""
+    n = len(data)
+    idx = np.argsort(-np.array([d["text"].shape[0] for d in data])) if sort else np.arange(n)
+    full = n - n % batch_size
+    groups = idx[:full].reshape((-1, batch_size)).tolist()
+    if not drop_last and n % batch_size:
+        groups.append(idx[full:].tolist())
+    return [reprocess(data, g) for g in groups]
+
+
+class Dataset(torch.utils.data.Dataset):
+    """reference: fs_two/dataset.py:32-156.  `random_mask` never triggers in the reference (max_masks_per_sentence 0.15
+    is not > 1) and is not reproduced."""
+
+    def __init__(self, filename, preprocess_config, train_config, sort=False, drop_last=True):
+        self.preprocessed_path = preprocess_config["path"]["preprocessed_path"]
+        self.cleaners = preprocess_config["preprocessing"]["text"]["text_cleaners"]
+        self.batch_size = train_config["optimizer"]["batch_size"]
+        self.sort, self.drop_last = sort, drop_last
+        self.basename, self.speaker, self.text, self.raw_text = [], [], [], []
+        with open(os.path.join(self.preprocessed_path, filename), encoding="utf-8") as f:
+            for line in f:
+                n, s, t, r = line.strip("\n").split("|")
+                self.basename.append(n); self.speaker.append(s); self.text.append(t); self.raw_text.append(r)
+        with open(os.path.join(self.preprocessed_path, "speakers.json")) as f:
+            self.speaker_map = json.load(f)
+
+    def __len__(self):
+        return len(self.text)
+
+    def _load(self, kind, sub, speaker, basename):
+        return np.load(os.path.join(self.preprocessed_path, kind, "%s-%s-%s.npy" % (speaker, sub, basename)))
+
+    def __getitem__(self, idx):
+        b, s = self.basename[idx], self.speaker[idx]
+        return {"id": b, "speaker": self.speaker_map[s], "raw_text": self.raw_text[idx],
+                "text": np.array(text_to_sequence(self.text[idx], self.cleaners)),
+                "mel": self._load("mel", "mel", s, b), "energy": self._load("energy", "energy", s, b),
+                "duration": self._load("duration", "duration", s, b), "pitch_raw": self._load("pitch", "pitch", s, b),
+                "pitch_cwt": self._load("pitch", "cwt-pitch", s, b), "pitch_mean": self._load("pitch", "pitch-mean", s, b),
+                "pitch_std": self._load("pitch", "pitch-std", s, b)}
+
+    def collate_fn(self, data):
+        return collate(data, self.batch_size, self.sort, self.drop_last)
+
+
+class DeviceFeeder:
+    """Iterates device batches (the tuple `to_device` returns) over an iterable of numpy 15-tuples, copying one batch
+    ahead on a side stream from pinned memory."""
+
+    def __init__(self, batches, device):
+        self.it, self.device = iter(batches), torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._next = None
+        self._preload()
+
+    def _preload(self):
+        from .train_step import to_device
+        try:
+            b = next(self.it)
+        except StopIteration:
+            self._next = None
+            return
+        if self.stream is None:
+            self._next = to_device(b, self.device)
+            return
+        pinned = tuple(torch.as_tensor(x).pin_memory() if isinstance(x, np.ndarray) and x.dtype != object else x for x in b)
+        with torch.cuda.stream(self.stream):
+            self._next = to_device(pinned, self.device, non_blocking=True)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._next is None:
+            raise StopIteration
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        batch = self._next
+        for t in batch:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(torch.cuda.current_stream())
+        self._preload()
+        return batch

@@ -18,17 +18,17 @@ def _t(x):
     return torch.from_numpy(x) if isinstance(x, np.ndarray) else torch.as_tensor(x)
 
 
-def to_device(data, device="cuda:0"):
+def to_device(data, device="cuda:0", non_blocking=False):
     """reference: fs_two/utils/tools.py:15-83 — numpy/CPU batch tuple -> device tensors with the reference dtypes
     (speakers/texts/durations long, mels/pitches float, lens as stored; NaNs in pitches_cwt -> 0)."""
+    nb = non_blocking
     if len(data) == 15:
         (ids, raw_texts, speakers, texts, src_lens, max_src_len, mels, mel_lens, max_mel_len, energies, durations,
          pitches_raw, pitches_cwt, pitches_mean, pitches_std) = data
-        return (ids, raw_texts, _t(speakers).long().to(device), _t(texts).long().to(device), _t(src_lens).to(device),
-                max_src_len, _t(mels).float().to(device), _t(mel_lens).to(device), max_mel_len, _t(energies).to(device),
-                _t(durations).long().to(device), _t(pitches_raw).float().to(device),
-                torch.nan_to_num(_t(pitches_cwt).float(), nan=0.0).to(device), _t(pitches_mean).float().to(device),
-                _t(pitches_std).float().to(device))
+        mv = lambda t: t.to(device, non_blocking=nb)
+        return (ids, raw_texts, mv(_t(speakers).long()), mv(_t(texts).long()), mv(_t(src_lens)), max_src_len, mv(_t(mels).float()),
+                mv(_t(mel_lens)), max_mel_len, mv(_t(energies)), mv(_t(durations).long()), mv(_t(pitches_raw).float()),
+                mv(torch.nan_to_num(_t(pitches_cwt).float(), nan=0.0)), mv(_t(pitches_mean).float()), mv(_t(pitches_std).float()))
     if len(data) == 6:
         ids, raw_texts, speakers, texts, src_lens, max_src_len = data
         return (ids, raw_texts, _t(speakers).long().to(device), _t(texts).long().to(device), _t(src_lens).to(device), max_src_len)
@@ -42,6 +42,7 @@ def get_model(cfg, device, train=False):
     model = FastSpeech2(cfg.preprocess_config, cfg.model_config, device=device,
                         seed=int(cfg.get("mi355x", {}).get("seed", 1234)) if hasattr(cfg, "get") else 1234)
     load_path = cfg.tts.get("load_path") if hasattr(cfg.tts, "get") else None
+    ckpt = None
     if load_path:
         ckpt = torch.load(load_path, map_location="cpu")
         state = dict(ckpt["model"])
@@ -50,7 +51,10 @@ def get_model(cfg, device, train=False):
         model.load_state_dict(state, strict=False)
     if train:
         model.train()
-        return model, ScheduledOptim(model, cfg.train_config, cfg.model_config, cfg.tts.restore_step)
+        optim = ScheduledOptim(model, cfg.train_config, cfg.model_config, cfg.tts.restore_step)
+        if ckpt is not None and isinstance(ckpt.get("optimizer"), dict) and "exp_avg" in ckpt["optimizer"]:
+            optim.load_state_dict(ckpt["optimizer"])       # the reference saves this state but never restores it (row f-4)
+        return model, optim
     model.eval()
     return model
 

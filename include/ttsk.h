@@ -167,6 +167,19 @@ int ttsk_softmax_fwd(const float* scores, void* probs_bf16, const int64_t* lens,
 int ttsk_softmax_bwd(const void* probs_bf16, const float* dprobs, void* dscores_bf16, int nz, int S, int Sp, float alpha,
                      void* stream);
 
+/* ------------------------------------------------------------------------------------- fused attention (d_k = 128)
+ * reference: fs_two/transformer/Modules.py:14-24 + SubLayers.py:44-60.  qkv is the fused projection output
+ * [B*S][3*d] (q | k | v, head h = columns h*128.. of each part), o [B*S][d] has the heads merged back.
+ * fwd: o = softmax(q k^T * scale, keys >= lens[b] masked) v; probs (optional, [B*H][S][Sp] bf16, Sp % 8 == 0) receives P;
+ *      o_f32 (optional, [B*S][d]) the un-rounded sum_k P v, from which the backward forms rowsum(P o dP) = dO . o_f32
+ *      consistently with the bf16 P it multiplies by.
+ * bwd_q: dS = scale * P o (dO V^T - dO . o_f32) -> ds [B*H][S][Sp]; dQ = dS K -> columns h*128.. of dqkv [B*S][3*d].
+ *        (dK = dS^T Q and dV = P^T dO are batched ttsk_gemm launches.) */
+int ttsk_attention_fwd(const void* qkv_bf16, void* o_bf16, float* o_f32, void* probs_bf16, const int64_t* lens, int B, int H, int S,
+                       int Sp, int d, float scale, void* stream);
+int ttsk_attention_bwd_q(const void* qkv_bf16, const float* o_f32, const void* dout_bf16, const void* probs_bf16, void* ds_bf16,
+                         void* dqkv_bf16, int B, int H, int S, int Sp, int d, float scale, void* stream);
+
 /* ------------------------------------------------------------------------------- embeddings / variance adaptor
  * bucketize: idx = #{bins < v*scale} (torch.bucketize right=False; reference: model/modules.py:95-100,134-139)
  * gather_add: out[row] = (in ? in[row] : 0) + table[idx[row / idx_div]] + (pe ? pe[row % pe_mod] : 0)

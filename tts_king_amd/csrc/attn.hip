@@ -1,0 +1,393 @@
+// attn.hip — fused multi-head self-attention for the FFT blocks (d_k = 128), forward and the query-side backward.
+// reference: fs_two/transformer/Modules.py:14-24 (softmax(Q K^T / sqrt(d_k) masked on PAD keys) V) and
+// fs_two/transformer/SubLayers.py:44-60 (head split / merge), autograd for the backward.
+//
+// Forward: one 256-thread workgroup per (utterance, head, 64 queries).  Q stays in LDS; K and V stream through LDS in
+// 64-key tiles.  Each wave owns 16 query rows: S = Q K^T on v_mfma_f32_16x16x32_bf16 (keys on the MFMA columns), a
+// first sweep over the keys accumulates the row maxima and sums, a second sweep recomputes S, normalises, rounds P to
+// bf16 (the same rounding point as the unfused path), optionally stores P for the backward, and multiplies P V with V
+// read through the transposing LDS read.  The S x S score matrix never exists in HBM in fp32 and three launches
+// (scores GEMM, softmax, P.V GEMM) become one.
+//
+// Backward (query side): dP = dO V^T per key tile, dS = P o (dP - rowsum(dO o O)) / sqrt(d_k) with P from the forward,
+// dS stored (bf16) for the key-side products dK = dS^T Q, dV = P^T dO (batched GEMMs), and dQ = dS K accumulated over the
+// key tiles — one launch instead of dP GEMM + softmax backward + dQ GEMM.
+#include "common.h"
+
+namespace {
+
+constexpr int DK = 128;
+constexpr int TQ = 64, TK = 64;
+constexpr int QS_BYTES = TQ * DK * 2;      // 16 KiB: two [64][64] row-major sub-tiles (k chunks of 64), chunk ^= row & 7
+constexpr int KS_BYTES = TK * DK * 2;      // same layout, rows = keys
+constexpr int VS_BYTES = TK * DK * 2;      // [64 k][128 n] contraction-major tile (ds_read_b64_tr_b16 layout)
+constexpr int PS_RS = 144;                 // per-wave P / dS tile [16][64] bf16, padded rows
+constexpr int PS_BYTES = 4 * 16 * PS_RS;   // 9 KiB
+constexpr int OS_RS = 272;                 // output staging [64][128] bf16, padded rows
+
+__device__ __forceinline__ int tr_sw(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
+
+// A 64 x 128 bf16 tile travels global -> 4 x uint4 per thread -> LDS; loads and stores are separate so that the next
+// tile's loads are in flight while the current tile is multiplied.
+__device__ __forceinline__ void load_tile(uint4 (&r)[4], const bf16_t* __restrict__ src, int ld, int row0, int nrows_valid, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid;
+    const int row = c >> 4, kc = c & 15;
+    r[i] = make_uint4(0, 0, 0, 0);
+    if (row0 + row < nrows_valid) r[i] = *(const uint4*)(src + (int64_t)(row0 + row) * ld + kc * 8);
+  }
+}
+// row-major image: two swizzled [64][64] sub-tiles (k chunks of 64), 16-byte chunk ^= row & 7
+__device__ __forceinline__ void store_rows(unsigned char* dst, const uint4 (&r)[4], int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid;
+    const int row = c >> 4, kc = c & 15;
+    *(uint4*)(dst + (kc >> 3) * 8192 + row * 128 + (((kc & 7) ^ (row & 7)) << 4)) = r[i];
+  }
+}
+// contraction-major image [64 k][128 n] for ds_read_b64_tr_b16
+__device__ __forceinline__ void store_tr(unsigned char* dst, const uint4 (&r)[4], int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid;
+    const int kr = c >> 4, ts = c & 15;
+    *(uint4*)(dst + kr * 256 + (((ts >> 1) ^ tr_sw(kr)) << 5) + ((ts & 1) << 4)) = r[i];
+  }
+}
+__device__ __forceinline__ void stage_rows(unsigned char* dst, const bf16_t* __restrict__ src, int ld, int row0, int nrows_valid,
+                                           int tid) {
+  uint4 r[4];
+  load_tile(r, src, ld, row0, nrows_valid, tid);
+  store_rows(dst, r, tid);
+}
+// fragment of a row-major tile: rows r0 + l15, k step (sub-tile ks >> 1, half ks & 1)
+__device__ __forceinline__ bf16x8 frag_rows(const unsigned char* base, int r0, int ks, int l15, int lg) {
+  const int row = r0 + l15;
+  return *(const bf16x8*)(base + (ks >> 1) * 8192 + row * 128 + ((((ks & 1) * 4 + lg) ^ (row & 7)) << 4));
+}
+// fragment of a contraction-major tile: n tile nblk, k step ks (32 k rows)
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* base, int nblk, int ks, int l15, int lg) {
+  const int k0 = ks * 32 + 8 * lg + (l15 >> 2), k1 = k0 + 4;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) bf16x4*)(base + k0 * 256 + ((nblk ^ tr_sw(k0)) << 5) + ((l15 & 3) << 3)));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) bf16x4*)(base + k1 * 256 + ((nblk ^ tr_sw(k1)) << 5) + ((l15 & 3) << 3)));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ float quad16_max(float v) {      // reduce over the 16 lanes that share lane >> 4
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float quad16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct AttnArgs {
+  const bf16_t* qkv;     // [B*S][3*d]: q | k | v, head h = columns h*128 .. of each part
+  bf16_t* o;             // [B*S][d]
+  float* o32;            // optional fp32 copy of o (un-rounded sum_k P V): lets the backward form rowsum(P o dP) = dO . o32
+  bf16_t* probs;         // [B*H][S][Sp] or null
+  const long long* lens; // [B] valid keys per utterance (null = S)
+  int S, Sp, H, d;
+  float scale;
+};
+
+constexpr int KBLK = 7;                         // key tiles resident in LDS at once (448 keys = 112 KiB)
+
+__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[QS_BYTES + KBLK * KS_BYTES + VS_BYTES + PS_BYTES];
+  unsigned char* Qs = smem;
+  unsigned char* Kb = smem + QS_BYTES;                 // KBLK key tiles, row-major images
+  unsigned char* Vs = Kb + KBLK * KS_BYTES;
+  unsigned char* Ps = Vs + VS_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
+  const int q0 = blockIdx.x * TQ;
+  const int S = a.S, ld = 3 * a.d;
+  const int len = a.lens ? (int)a.lens[b] : S;
+  const bf16_t* base = a.qkv + (int64_t)b * S * ld + h * DK;
+  const int ntile = (S + TK - 1) / TK;
+  const int nblk = (ntile + KBLK - 1) / KBLK;
+  unsigned char* Pw = Ps + wave * 16 * PS_RS;
+
+  // scores of this wave's 16 queries against key tile `jt` of the resident block (already scaled, PAD keys -inf)
+  auto scores = [&](int j, int jt, f32x4 (&s)[4]) __attribute__((always_inline)) {
+    const unsigned char* Ks = Kb + jt * KS_BYTES;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 qa = frag_rows(Qs, wave * 16, ks, l15, lg);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, frag_rows(Ks, nt * 16, ks, l15, lg), s[nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int key = j * TK + nt * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[nt][r] = key < len ? s[nt][r] * a.scale : -INFINITY;
+    }
+  };
+  // all tiles of key block kb: loads issued together (one memory latency per block, not per tile)
+  auto stage_kblock = [&](int kb) __attribute__((always_inline)) {
+    uint4 r[KBLK][4];
+#pragma unroll
+    for (int jt = 0; jt < KBLK; ++jt)
+      if (kb * KBLK + jt < ntile) load_tile(r[jt], base + a.d, ld, (kb * KBLK + jt) * TK, S, tid);
+#pragma unroll
+    for (int jt = 0; jt < KBLK; ++jt)
+      if (kb * KBLK + jt < ntile) store_rows(Kb + jt * KS_BYTES, r[jt], tid);
+  };
+
+  stage_rows(Qs, base, ld, q0, S, tid);
+  float m[4], l[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
+
+  // ---- sweep 1: row maxima and sums
+  for (int kb = 0; kb < nblk; ++kb) {
+    if (kb > 0) __syncthreads();
+    stage_kblock(kb);
+    __syncthreads();
+    for (int jt = 0; jt < KBLK && kb * KBLK + jt < ntile; ++jt) {
+      f32x4 s[4];
+      scores(kb * KBLK + jt, jt, s);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float tm = fmaxf(fmaxf(s[0][r], s[1][r]), fmaxf(s[2][r], s[3][r]));
+        tm = quad16_max(tm);
+        const float mn = fmaxf(m[r], tm);
+        float ts = 0.f;
+        if (mn > -INFINITY) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) ts += __expf(s[nt][r] - mn);
+        }
+        ts = quad16_sum(ts);
+        l[r] = (m[r] > -INFINITY ? l[r] * __expf(m[r] - mn) : 0.f) + ts;
+        m[r] = mn;
+      }
+    }
+  }
+  float inv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) inv[r] = 1.f / l[r];
+
+  // ---- sweep 2: P = exp(S - m) / l  ->  bf16  ->  O += P V, V tiles one ahead in registers
+  f32x4 oacc[8];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) oacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint4 vr[4];
+  load_tile(vr, base + 2 * a.d, ld, 0, S, tid);
+  for (int kb = 0; kb < nblk; ++kb) {
+    if (nblk > 1) {                          // more than 448 keys: the block has to be staged again
+      __syncthreads();
+      stage_kblock(kb);
+    }
+    for (int jt = 0; jt < KBLK && kb * KBLK + jt < ntile; ++jt) {
+      const int j = kb * KBLK + jt;
+      __syncthreads();                       // previous tile's V reads are done
+      store_tr(Vs, vr, tid);
+      if (j + 1 < ntile) load_tile(vr, base + 2 * a.d, ld, (j + 1) * TK, S, tid);
+      __syncthreads();
+      f32x4 s[4];
+      scores(j, jt, s);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(s[nt][r] - m[r]) * inv[r];                  // exp(-inf) = 0 on PAD keys
+          *(bf16_t*)(Pw + (lg * 4 + r) * PS_RS + (nt * 16 + l15) * 2) = f2bf(p);
+        }
+      // the P tile is private to the wave; the wait orders its LDS writes before its reads (and pins the compiler)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (a.probs) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int cid = i * 64 + lane, row = cid >> 3, ch = cid & 7;
+          const int q = q0 + wave * 16 + row, key = j * TK + ch * 8;
+          if (q < S && key < a.Sp) *(uint4*)(a.probs + ((int64_t)z * S + q) * a.Sp + key) = *(const uint4*)(Pw + row * PS_RS + ch * 16);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pa = *(const bf16x8*)(Pw + l15 * PS_RS + (ks * 32 + lg * 8) * 2);
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) oacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, frag_tr(Vs, nb, ks, l15, lg), oacc[nb], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- O tile -> LDS -> full-row stores (heads merged: column h*128); fp32 copy straight from the accumulators
+  if (a.o32) {
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = q0 + wave * 16 + lg * 4 + r;
+        if (q < S) a.o32[((int64_t)b * S + q) * a.d + h * DK + nb * 16 + l15] = oacc[nb][r];
+      }
+  }
+  __syncthreads();
+  unsigned char* Os = smem;   // 64 x 272 B = 17 KiB over Qs / the first key tile
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *(bf16_t*)(Os + (wave * 16 + lg * 4 + r) * OS_RS + (nb * 16 + l15) * 2) = f2bf(oacc[nb][r]);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid, row = c >> 4, ch = c & 15;
+    if (q0 + row < S) *(uint4*)(a.o + ((int64_t)b * S + q0 + row) * a.d + h * DK + ch * 8) = *(const uint4*)(Os + row * OS_RS + ch * 16);
+  }
+}
+
+struct AttnBwdArgs {
+  const bf16_t* qkv;     // forward input
+  const float* o32;      // forward output, fp32 (sum_k P V before rounding)
+  const bf16_t* dout;    // dO [B*S][d]
+  const bf16_t* probs;   // P [B*H][S][Sp]
+  bf16_t* ds;            // dS [B*H][S][Sp] out
+  bf16_t* dq;            // dqkv base: dQ written at columns h*128 of a [B*S][3*d] buffer
+  int S, Sp, H, d;
+  float scale;
+};
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[QS_BYTES + KS_BYTES + VS_BYTES + 2 * PS_BYTES];
+  unsigned char* Ds = smem;                 // dO tile (row-major, like Q)
+  unsigned char* Vs = smem + QS_BYTES;      // V tile row-major [key][d]   (B operand of dP = dO V^T)
+  unsigned char* Kt = Vs + KS_BYTES;        // K tile contraction-major [key k][d n] (B operand of dQ = dS K)
+  unsigned char* Ps = Kt + VS_BYTES;        // per-wave P tile
+  unsigned char* Ss = Ps + PS_BYTES;        // per-wave dS tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
+  const int q0 = blockIdx.x * TQ;
+  const int S = a.S, ld = 3 * a.d;
+  const bf16_t* base = a.qkv + (int64_t)b * S * ld + h * DK;
+  const bf16_t* dob = a.dout + (int64_t)b * S * a.d + h * DK;
+  const float* ob = a.o32 + (int64_t)b * S * a.d + h * DK;
+  const int ntile = (S + TK - 1) / TK;
+  unsigned char* Pw = Ps + wave * 16 * PS_RS;
+  unsigned char* Sw = Ss + wave * 16 * PS_RS;
+
+  // tile j = {V tile, K tile, this wave's 16 x 64 slice of P}, requested one tile ahead
+  uint4 vr[4], kr[4], pr[2];
+  auto load_j = [&](int j) __attribute__((always_inline)) {
+    load_tile(vr, base + 2 * a.d, ld, j * TK, S, tid);
+    load_tile(kr, base + a.d, ld, j * TK, S, tid);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int cid = i * 64 + lane, row = cid >> 3, ch = cid & 7;
+      const int q = q0 + wave * 16 + row, key = j * TK + ch * 8;
+      pr[i] = make_uint4(0, 0, 0, 0);
+      if (q < S && key < a.Sp) pr[i] = *(const uint4*)(a.probs + ((int64_t)z * S + q) * a.Sp + key);
+    }
+  };
+  load_j(0);
+  stage_rows(Ds, dob, a.d, q0, S, tid);
+  // delta[q] = sum_k P dP = sum_d dO[q][d] * (sum_k P V)[q][d]: rows lg*4 + r of the wave, 16 lanes x 8 columns each
+  float delta[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = q0 + wave * 16 + lg * 4 + r;
+    float acc = 0.f;
+    if (q < S) {
+      const uint4 x = *(const uint4*)(dob + (int64_t)q * a.d + l15 * 8);
+      const f32x4 y0 = *(const f32x4*)(ob + (int64_t)q * a.d + l15 * 8), y1 = *(const f32x4*)(ob + (int64_t)q * a.d + l15 * 8 + 4);
+      acc = __uint_as_float(x.x << 16) * y0[0] + __uint_as_float(x.x & 0xFFFF0000u) * y0[1] + __uint_as_float(x.y << 16) * y0[2] +
+            __uint_as_float(x.y & 0xFFFF0000u) * y0[3] + __uint_as_float(x.z << 16) * y1[0] + __uint_as_float(x.z & 0xFFFF0000u) * y1[1] +
+            __uint_as_float(x.w << 16) * y1[2] + __uint_as_float(x.w & 0xFFFF0000u) * y1[3];
+    }
+    delta[r] = quad16_sum(acc);
+  }
+  f32x4 dq[8];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) dq[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int j = 0; j < ntile; ++j) {
+    __syncthreads();                              // previous tile's LDS reads are done
+    store_rows(Vs, vr, tid);
+    store_tr(Kt, kr, tid);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int cid = i * 64 + lane, row = cid >> 3, ch = cid & 7;
+      *(uint4*)(Pw + row * PS_RS + ch * 16) = pr[i];
+    }
+    if (j + 1 < ntile) load_j(j + 1);
+    __syncthreads();
+    f32x4 dp[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) dp[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 da = frag_rows(Ds, wave * 16, ks, l15, lg);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) dp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, frag_rows(Vs, nt * 16, ks, l15, lg), dp[nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j * TK + nt * 16 + l15;
+        const float p = bf2f(*(const bf16_t*)(Pw + (lg * 4 + r) * PS_RS + (nt * 16 + l15) * 2));
+        const float v = key < S ? a.scale * p * (dp[nt][r] - delta[r]) : 0.f;
+        *(bf16_t*)(Sw + (lg * 4 + r) * PS_RS + (nt * 16 + l15) * 2) = f2bf(v);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int cid = i * 64 + lane, row = cid >> 3, ch = cid & 7;
+      const int q = q0 + wave * 16 + row, key = j * TK + ch * 8;
+      if (q < S && key < a.Sp) *(uint4*)(a.ds + ((int64_t)z * S + q) * a.Sp + key) = *(const uint4*)(Sw + row * PS_RS + ch * 16);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 sa = *(const bf16x8*)(Sw + l15 * PS_RS + (ks * 32 + lg * 8) * 2);
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) dq[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, frag_tr(Kt, nb, ks, l15, lg), dq[nb], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  unsigned char* Os = smem;
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *(bf16_t*)(Os + (wave * 16 + lg * 4 + r) * OS_RS + (nb * 16 + l15) * 2) = f2bf(dq[nb][r]);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid, row = c >> 4, ch = c & 15;
+    if (q0 + row < S) *(uint4*)(a.dq + ((int64_t)b * S + q0 + row) * ld + h * DK + ch * 8) = *(const uint4*)(Os + row * OS_RS + ch * 16);
+  }
+}
+
+}  // namespace
+
+extern "C" int ttsk_attention_fwd(const void* qkv_bf16, void* o_bf16, float* o_f32, void* probs_bf16, const int64_t* lens, int B, int H,
+                                  int S, int Sp, int d, float scale, void* stream) {
+  TTSK_REQUIRE(qkv_bf16 && o_bf16, "attention_fwd: null pointer");
+  TTSK_REQUIRE(B > 0 && H > 0 && S > 0 && d == H * DK, "attention_fwd: head size must be 128 (d = %d, H = %d)", d, H);
+  TTSK_REQUIRE(!probs_bf16 || (Sp >= S && (Sp & 7) == 0), "attention_fwd: Sp must be a multiple of 8 >= S");
+  TTSK_REQUIRE(B * H <= 65535, "attention_fwd: too many (utterance, head) pairs");
+  AttnArgs a{(const bf16_t*)qkv_bf16, (bf16_t*)o_bf16, o_f32, (bf16_t*)probs_bf16, (const long long*)lens, S, Sp, H, d, scale};
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + TQ - 1) / TQ, B * H), dim3(256), 0, (hipStream_t)stream, a);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_attention_bwd_q(const void* qkv_bf16, const float* o_f32, const void* dout_bf16, const void* probs_bf16,
+                                    void* ds_bf16, void* dqkv_bf16, int B, int H, int S, int Sp, int d, float scale, void* stream) {
+  TTSK_REQUIRE(qkv_bf16 && o_f32 && dout_bf16 && probs_bf16 && ds_bf16 && dqkv_bf16, "attention_bwd_q: null pointer");
+  TTSK_REQUIRE(B > 0 && H > 0 && S > 0 && d == H * DK, "attention_bwd_q: head size must be 128");
+  TTSK_REQUIRE(Sp >= S && (Sp & 7) == 0 && B * H <= 65535, "attention_bwd_q: bad sizes");
+  AttnBwdArgs a{(const bf16_t*)qkv_bf16, o_f32, (const bf16_t*)dout_bf16, (const bf16_t*)probs_bf16, (bf16_t*)ds_bf16,
+                (bf16_t*)dqkv_bf16, S, Sp, H, d, scale};
+  hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((S + TQ - 1) / TQ, B * H), dim3(256), 0, (hipStream_t)stream, a);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}

@@ -106,6 +106,7 @@ class FastSpeech2(nn.Module):
         self._ctx = None
         self._deferred = None           # split-K slabs awaiting the batched reducer (backward only)
         self._side = None               # second HIP stream for parameter-gradient work (see _SideWork)
+        self.fused_attention = True     # one kernel for scores + softmax + P.V (and dP + softmax' + dQ) when d_k = 128
         self.overlap_param_grads = False   # measured on MI355X: the branches do overlap under graph replay, but the concurrent
                                            # kernels slow each other by as much (6.39 vs 6.47 ms/step): off by default
         self._rng_state = None          # device block shared with the optimizer (ops.optim_state)
@@ -292,16 +293,21 @@ class FastSpeech2(nn.Module):
         dev = x.device
         # (1) q|k|v projections as one GEMM into a [rows][3d] buffer: SubLayers.py:41-43
         qkv = ops.linear(x, self._w(a + "w_qs.weight", 3 * d), self._m(a + "w_qs.bias", 3 * d))
-        # (2) scores = Q K^T / sqrt(dk) per (batch, head), head h = columns [h*dk, (h+1)*dk): Modules.py:15-16
-        scores = torch.empty(Bn * H, S, Sp, dtype=torch.float32, device=dev)
-        ops.gemm(qkv, qkv[:, d:], scores, S, S, dk, 3 * d, 3 * d, Sp, alpha=dk ** -0.5, nz1=Bn, nz2=H,
-                 sA=(S * 3 * d, dk), sB=(S * 3 * d, dk), sC=(H * S * Sp, S * Sp))
-        # (3) key-padding mask + softmax: Modules.py:18-21
-        probs = ops.softmax_fwd(scores, lens, H)
-        # (4) O = P V, heads merged back into [rows][d]: Modules.py:22, SubLayers.py:57-60
-        o = torch.empty(rows, d, dtype=bf16, device=dev)
-        ops.gemm(probs, qkv[:, 2 * d:], o, S, dk, S, Sp, 3 * d, d, flags=ops.B_TR, nz1=Bn, nz2=H,
-                 sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * d, dk))
+        if self.fused_attention and dk == 128:
+            # (2)-(4) one kernel: scores, key-padding mask, softmax, P V, heads merged (Modules.py:15-22, SubLayers.py:57-60)
+            o, probs, o32 = ops.attention_fwd(qkv, lens, Bn, H, S, want_probs=ctx_list is not None)
+        else:
+            o32 = None
+            # (2) scores = Q K^T / sqrt(dk) per (batch, head), head h = columns [h*dk, (h+1)*dk): Modules.py:15-16
+            scores = torch.empty(Bn * H, S, Sp, dtype=torch.float32, device=dev)
+            ops.gemm(qkv, qkv[:, d:], scores, S, S, dk, 3 * d, 3 * d, Sp, alpha=dk ** -0.5, nz1=Bn, nz2=H,
+                     sA=(S * 3 * d, dk), sB=(S * 3 * d, dk), sC=(H * S * Sp, S * Sp))
+            # (3) key-padding mask + softmax: Modules.py:18-21
+            probs = ops.softmax_fwd(scores, lens, H)
+            # (4) O = P V, heads merged back into [rows][d]: Modules.py:22, SubLayers.py:57-60
+            o = torch.empty(rows, d, dtype=bf16, device=dev)
+            ops.gemm(probs, qkv[:, 2 * d:], o, S, dk, S, Sp, 3 * d, d, flags=ops.B_TR, nz1=Bn, nz2=H,
+                     sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * d, dk))
         # (5) fc, dropout, +residual, LayerNorm, zero PAD rows: SubLayers.py:62-63, Layers.py:29
         y = ops.linear(o, self._w(a + "fc.weight"), self._m(a + "fc.bias"))
         x1, z1, mean1, rstd1, _ = ops.layernorm_fwd(y, x, self._m(a + "layer_norm.weight"), self._m(a + "layer_norm.bias"),
@@ -313,7 +319,7 @@ class FastSpeech2(nn.Module):
                                                     self._m(f + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site + 1,
                                                     rng=rng, save_z=ctx_list is not None)
         if ctx_list is not None:
-            ctx_list.append((pre, x, qkv, probs, o, z1, mean1, rstd1, x1, h, z2, mean2, rstd2, Bn, S, lens, H, p, site))
+            ctx_list.append((pre, x, qkv, probs, o, z1, mean1, rstd1, x1, h, z2, mean2, rstd2, Bn, S, lens, H, p, site, o32))
         return x2
 
     def _predictor_fwd(self, pre, x, Bn, Lp, lens, p, site, rng, ctx):
@@ -536,7 +542,7 @@ class FastSpeech2(nn.Module):
             torch.cuda.current_stream().wait_stream(self._side)
 
     def _fft_bwd(self, saved, dx2, rng):
-        (pre, x, qkv, probs, o, z1, mean1, rstd1, x1, h, z2, mean2, rstd2, Bn, S, lens, H, p, site) = saved
+        (pre, x, qkv, probs, o, z1, mean1, rstd1, x1, h, z2, mean2, rstd2, Bn, S, lens, H, p, site, o32) = saved
         d, rows = self.d, Bn * S
         dk = d // H
         Sp = probs.shape[2]
@@ -563,13 +569,16 @@ class FastSpeech2(nn.Module):
             ops.linear_dw(dy1, o, self._g(a + "fc.weight"), defer=self._deferred)
         do = ops.linear_dx(dy1, self._w(a + "fc.weight"))
         # ---- attention core: dP = dO V^T ; dS = softmax'(P, dP)/sqrt(dk) ; dQ = dS K ; dK = dS^T Q ; dV = P^T dO
-        dP = torch.empty(Bn * H, S, Sp, dtype=torch.float32, device=dev)
-        ops.gemm(do, qkv[:, 2 * d:], dP, S, S, dk, d, 3 * d, Sp, nz1=Bn, nz2=H, sA=(S * d, dk), sB=(S * 3 * d, dk),
-                 sC=(H * S * Sp, S * Sp))
-        dS = ops.softmax_bwd(probs, dP, dk ** -0.5)
         dqkv = torch.empty(rows, 3 * d, dtype=bf16, device=dev)
-        ops.gemm(dS, qkv[:, d:], dqkv, S, dk, S, Sp, 3 * d, 3 * d, flags=ops.B_TR, nz1=Bn, nz2=H,
-                 sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * 3 * d, dk))
+        if self.fused_attention and dk == 128:
+            dS = ops.attention_bwd_q(qkv, o32, do, probs, dqkv, Bn, H, S)       # dP, softmax backward and dQ in one kernel
+        else:
+            dP = torch.empty(Bn * H, S, Sp, dtype=torch.float32, device=dev)
+            ops.gemm(do, qkv[:, 2 * d:], dP, S, S, dk, d, 3 * d, Sp, nz1=Bn, nz2=H, sA=(S * d, dk), sB=(S * 3 * d, dk),
+                     sC=(H * S * Sp, S * Sp))
+            dS = ops.softmax_bwd(probs, dP, dk ** -0.5)
+            ops.gemm(dS, qkv[:, d:], dqkv, S, dk, S, Sp, 3 * d, 3 * d, flags=ops.B_TR, nz1=Bn, nz2=H,
+                     sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * 3 * d, dk))
         ops.gemm(dS, qkv, dqkv[:, d:], S, dk, S, Sp, 3 * d, 3 * d, flags=ops.A_TR | ops.B_TR, nz1=Bn, nz2=H,
                  sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * 3 * d, dk))
         ops.gemm(probs, do, dqkv[:, 2 * d:], S, dk, S, Sp, d, 3 * d, flags=ops.A_TR | ops.B_TR, nz1=Bn, nz2=H,

@@ -291,6 +291,30 @@ def colsum_into(x, dst, accumulate=True):
     return colsum_finalize(partials, nblk, Cn, Cn, dst, accumulate)
 
 
+def attention_fwd(qkv, lens, Bn, H, S, want_probs):
+    """Fused softmax(Q K^T / sqrt(128) + key mask) V on the q|k|v buffer (rows, 3d) -> (o (rows, d) bf16, probs, o32);
+    probs (bf16) and o32 (fp32 copy of o before rounding) are produced only for the backward (want_probs)."""
+    _dev(qkv, lens)
+    d = qkv.shape[1] // 3
+    Sp = (S + 7) // 8 * 8
+    o = torch.empty(Bn * S, d, dtype=bf16, device=qkv.device)
+    probs = torch.empty(Bn * H, S, Sp, dtype=bf16, device=qkv.device) if want_probs else None
+    o32 = torch.empty(Bn * S, d, dtype=torch.float32, device=qkv.device) if want_probs else None
+    check(L.load().ttsk_attention_fwd(_ptr(qkv), _ptr(o), _ptr(o32), _ptr(probs), _ptr(lens), Bn, H, S, Sp, d, (d // H) ** -0.5,
+                                      _stream()), "ttsk_attention_fwd")
+    return o, probs, o32
+
+
+def attention_bwd_q(qkv, o32, do, probs, dqkv, Bn, H, S):
+    """dS (returned) and dQ (written into dqkv[:, :d]) of the fused attention."""
+    _dev(qkv, o32, do, probs, dqkv)
+    d = qkv.shape[1] // 3
+    ds = torch.empty_like(probs)
+    check(L.load().ttsk_attention_bwd_q(_ptr(qkv), _ptr(o32), _ptr(do), _ptr(probs), _ptr(ds), _ptr(dqkv), Bn, H, S, probs.shape[2], d,
+                                        (d // H) ** -0.5, _stream()), "ttsk_attention_bwd_q")
+    return ds
+
+
 def softmax_fwd(scores, lens, H):
     """scores (nz,S,Sp) fp32 -> probs (nz,S,Sp) bf16; keys >= lens[z // H] masked."""
     _dev(scores, lens)

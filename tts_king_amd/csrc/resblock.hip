@@ -5,7 +5,8 @@
 //
 // One 256-thread workgroup owns TT output frames of one utterance plus the halo the six convolutions consume
 // (H = (k-1)/2 * (d0+d1+d2+3) frames per side).  The tile lives in LDS for the whole block: XL = lrelu(x) and
-// TL = lrelu(t) as 16-bit [frame][channel] rows (padded by 32 B: conflict-free ds_read_b128 fragments); the residual
+// TL = lrelu(t) as 16-bit [frame][channel] rows (16-byte chunks XOR-swizzled by the frame: conflict-free ds_read_b128
+// fragments at every tap shift); the residual
 // x itself stays in fp32 REGISTERS in MFMA accumulator layout, so HBM sees one read of x and one write of the result
 // per ResBlock instead of 5 tensor passes per conv pair.
 //
@@ -51,11 +52,11 @@ struct RbGeom {
   static constexpr int NSLOT = (NTILE + NW - 1) / NW;
   static constexpr int G = 32;                         // guard rows either side (>= max tap reach 5*HK = 25)
   static constexpr int LROWS = NTILE * 16 + 2 * G;
-  static constexpr int RS = C * 2 + 32;                // padded row stride in bytes
+  static constexpr int RS = C * 2;                     // row stride in bytes; 16-byte chunks are XOR-swizzled by the row
   static constexpr int NC = C / 16;
   static constexpr int KS = C / 32;
   static constexpr int TAP_BYTES = NC * KS * 1024;     // one tap of weights in fragment order
-  static constexpr int GT = C == 32 ? K : 2;           // taps per weight stage
+  static constexpr int GT = C == 32 ? K : 4;           // taps per weight stage
   static constexpr int NS = (K + GT - 1) / GT;         // stages per conv
   static constexpr int WSTAGE = GT * TAP_BYTES;
   static constexpr int NLD = (WSTAGE + NT * 16 - 1) / (NT * 16);   // 16-byte loads per thread per stage
@@ -82,6 +83,9 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock1_kernel(const RbArgs a) {
   const int len = a.len;
   const bf16_t* __restrict__ xb = a.x + (int64_t)bi * len * C;
   const float slope = a.slope;
+  // chunk swizzle of the activation rows: conflict-free ds_read_b128 fragments for any tap shift (C = 64: 8 chunks per
+  // row, ^ row & 7; C = 32: 4 chunks per row, ^ (row >> 1) & 3); tile bases and the guard are multiples of 8 rows
+  auto swz = [](int row) __attribute__((always_inline)) { return C == 64 ? (row & 7) : ((row >> 1) & 3); };
 
   // ---- weight stage gs (global index over the 6 convs): conv gs / NS, taps (gs % NS)*GT .. +GT of its pack
   constexpr int NSET = 4;   // register sets of weight stages in flight: stage g travels in set g % NSET
@@ -132,8 +136,9 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock1_kernel(const RbArgs a) {
       const int idx = it * NT + tid;
       const int row = idx / CH8, ch = idx - row * CH8;
       if (idx < LROWS * CH8) {
-        *(uint4*)(TL + row * RS + ch * 16) = xv[it];
-        *(uint4*)(XL + row * RS + ch * 16) = lrelu8<F16>(xv[it], slope);
+        const int pc = (ch ^ swz(row)) * 16;
+        *(uint4*)(TL + row * RS + pc) = xv[it];
+        *(uint4*)(XL + row * RS + pc) = lrelu8<F16>(xv[it], slope);
       }
     }
   }
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock1_kernel(const RbArgs a) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       uint2 v = make_uint2(0, 0);
-      if (i < NTILE) v = *(const uint2*)(TL + (i * 16 + l15 + G) * RS + (c * 16 + q * 4) * 2);
+      if (i < NTILE) v = *(const uint2*)(TL + (i * 16 + l15 + G) * RS + (((c * 2 + (q >> 1)) ^ swz(l15)) << 4) + (q & 1) * 8);
       float x0, x1, x2, x3;
       unpack2<F16>(v.x, x0, x1); unpack2<F16>(v.y, x2, x3);
       xr[c][s] = f32x4{x0, x1, x2, x3};
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock1_kernel(const RbArgs a) {
     S += HK * d;
     const int tlo = S >> 4, thi = (Gm::ROWS - S + 15) >> 4;
     const unsigned char* in = half == 0 ? XL : TL;
-    const unsigned char* inl = in + (l15 + G) * RS + q * 16;
+    const unsigned char* inl = in + (l15 + G) * RS;
 
     f32x4 acc[NC][NSLOT];
 #pragma unroll
@@ -191,7 +196,9 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock1_kernel(const RbArgs a) {
           for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int c = 0; c < NC; ++c) Af[c * KS + ks] = *(const bf16x8*)(wb + ((g * KS + ks) * NC + c) * 1024);
-          const unsigned char* inp = inl + (tap - HK) * d * RS;
+          const int shift = (tap - HK) * d;
+          const unsigned char* inp = inl + shift * RS;
+          const int sw = swz(l15 + shift + 64);
           // every slot is multiplied, also tiles outside [tlo, thi): their rows read in-bounds (guard rows) garbage
           // that no valid output depends on, and straight-line code lets the LDS reads run ahead of the MFMAs
 #pragma unroll
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock1_kernel(const RbArgs a) {
             const int i = s * NW + wave;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-              const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
+              const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + (((ks * 4 + q) ^ sw) << 4));
 #pragma unroll
               for (int c = 0; c < NC; ++c) acc[c][s] = mfma16<F16>(Af[c * KS + ks], Bf, acc[c][s]);
             }
@@ -242,7 +249,8 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock1_kernel(const RbArgs a) {
               for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope);
             }
           }
-          *(uint2*)(dst + (i * 16 + l15 + G) * RS + (c * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+          *(uint2*)(dst + (i * 16 + l15 + G) * RS + (((c * 2 + (q >> 1)) ^ swz(l15)) << 4) + (q & 1) * 8) =
+              make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
         }
       }
     }
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock1_kernel(const RbArgs a) {
     const int rr = idx / CH8, ch = idx - rr * CH8;
     const int t = t0 + rr;
     if (idx >= TT * CH8 || t >= len) continue;
-    uint4 v = *(const uint4*)(XL + (rr + H + G) * RS + ch * 16);
+    uint4 v = *(const uint4*)(XL + (rr + H + G) * RS + ((ch ^ swz(rr + H + G)) << 4));
     if (a.mode != 0 || fsl != 1.f) {
       const uint4 o = prev[it];
       const unsigned vw[4] = {v.x, v.y, v.z, v.w}, ow[4] = {o.x, o.y, o.z, o.w};
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(256) void pack_rb_weight_kernel(const float* __rest
 }
 
 int rb_kpad(int C, int K) {
-  const int gt = C == 32 ? K : (C == 64 ? 2 : 1);      // taps per weight stage of the consuming kernel
+  const int gt = C == 32 ? K : (C == 64 ? 4 : 1);      // taps per weight stage of the consuming kernel
   return (K + gt - 1) / gt * gt;
 }
 

@@ -51,7 +51,7 @@ struct RbGeom {
   static constexpr int NTILE = (ROWS + 15) / 16;
   static constexpr int NSLOT = (NTILE + NW - 1) / NW;
   static constexpr int G = 32;                         // guard rows either side (>= max tap reach 5*HK = 25)
-  static constexpr int LROWS = NTILE * 16 + 2 * G;
+  static constexpr int LROWS = NSLOT * NW * 16 + 2 * G;   // every multiplied tile (also the unused ones past NTILE) reads in-bounds
   static constexpr int RS = C * 2;                     // row stride in bytes; 16-byte chunks are XOR-swizzled by the row
   static constexpr int NC = C / 16;
   static constexpr int KS = C / 32;
@@ -369,8 +369,8 @@ extern "C" int ttsk_hifi_resblock1(const void* x16, void* out16, int f16, const 
   const int key = C * 100 + K;
   switch (key) {
     case 3203: launch_rb<32, 3, 256, 8>(a, B, f16, s); break;
-    case 3207: launch_rb<32, 7, 256, 8>(a, B, f16, s); break;
-    case 3211: launch_rb<32, 11, 256, 8>(a, B, f16, s); break;
+    case 3207: launch_rb<32, 7, 512, 8>(a, B, f16, s); break;
+    case 3211: launch_rb<32, 11, 512, 8>(a, B, f16, s); break;
     case 6403: launch_rb<64, 3, 128, 8>(a, B, f16, s); break;
     case 6407: launch_rb<64, 7, 128, 8>(a, B, f16, s); break;
     case 6411: launch_rb<64, 11, 128, 8>(a, B, f16, s); break;

@@ -172,12 +172,23 @@ def main():
         reducer = GradReducer(model.flat_buffers()[1], model.grad_buckets(cfg.mi355x.dp_bucket_mb), model.group_offsets())
     enqueue = make_enqueue(model, opt, cfg, loss_fn, reducer=reducer,
                            grad_scale=reducer.grad_scale(1) if reducer else None)
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = not args.no_graph and (world == 1 or os.environ.get("TTSK_DP_GRAPH", "1") != "0")
+    step = lambda: enqueue(batch)
     if use_graph:
-        g = GraphedTrainStep(enqueue, batch)
-        step = lambda: g.run()
-    else:
-        step = lambda: enqueue(batch)
+        # the data-parallel step (RCCL bucket all-reduces included) is captured as well; two eager steps first so that
+        # communicators, lazy allocations and the split-K plans exist before the capture
+        try:
+            if world > 1:
+                for _ in range(2):
+                    enqueue(batch)
+                torch.cuda.synchronize()
+                dist.barrier()
+            g = GraphedTrainStep(enqueue, batch, warmup=0 if world > 1 else 2)
+            step = lambda: g.run()
+        except Exception as e:      # capture refused: launch eagerly (still correct, host-bound)
+            if rank == 0:
+                print("graph capture failed (%s): eager launches" % e, file=sys.stderr)
+            use_graph = False
 
     for _ in range(args.warmup):
         out = step()
@@ -217,7 +228,8 @@ def main():
                                    "256-d FFT blocks (BASELINE.json configs[1]); full step = fwd+loss+bwd+clip+Adam, dropout on",
                        "global_batch": B * world, "batch_per_gpu": B, "phonemes": L, "T_max": T, "valid_frames_per_gpu": frames,
                        "padded_frames_per_gpu": B * T, "grad_acc_step": 1, "parallelism": "dp%d" % world,
-                       "launch": "hipGraph replay" if use_graph else "eager (+RCCL bucketed all-reduce on a side stream)"},
+                       "launch": ("hipGraph replay" + (" incl. RCCL bucketed all-reduce" if world > 1 else "")) if use_graph
+                                 else "eager (+RCCL bucketed all-reduce on a side stream)"},
             "mel_frames_per_s_per_gpu": value / world,
             "model_tflops": flops * world / (ms * 1e-3) / 1e12,
             "step_mfma_roofline_frac": flops / (ms * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS,

@@ -154,6 +154,14 @@ int ttsk_layernorm_bwd(const void* dout_bf16, const float* dhead, const float* h
 /* dst[c] (+)= scale * sum_b partials[b*ld + c]  in fixed order */
 int ttsk_colsum_finalize(const float* partials, int nblk, int ncols, int ld, float* dst, int accumulate, float scale,
                          void* stream);
+/* the same for a list of (partials, dst) pairs in one launch per 64 items (gradient column sums are needed only by Adam) */
+typedef struct ttsk_finalize_item {
+  const float* partials;
+  float* dst;
+  int32_t nblk, ncols, ld, accumulate;
+  float scale;
+} ttsk_finalize_item;
+int ttsk_colsum_finalize_batch(const ttsk_finalize_item* items, int n, void* stream);
 int ttsk_colsum_nblocks(int rows);
 /* per-block column sums of x [rows][C] (bf16, or fp32 when is_f32) -> partials[nblocks][C]  (bias gradients) */
 int ttsk_colsum(const void* x, int is_f32, int rows, int C, int ld, float* partials, void* stream);

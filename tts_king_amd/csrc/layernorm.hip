@@ -259,6 +259,41 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
   }
 }
 
+// the same reduction for a list of up to 64 (partials, destination) pairs in one launch: the gradient column sums of a
+// whole backward pass are only needed by the optimizer, so their finalisation is deferred and batched
+struct FinalizeBatch {
+  ttsk_finalize_item it[64];
+};
+__global__ __launch_bounds__(256) void colsum_finalize_batch_kernel(const FinalizeBatch fb) {
+  __shared__ float red[16][17];
+  const ttsk_finalize_item& it = fb.it[blockIdx.y];
+  const int cx = threadIdx.x & 15, gy = threadIdx.x >> 4;
+  for (int c0 = blockIdx.x * 16; c0 < it.ncols; c0 += gridDim.x * 16) {
+    const int c = c0 + cx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < it.ncols) {
+      int b = gy;
+      for (; b + 48 < it.nblk; b += 64) {
+        s0 += it.partials[(int64_t)b * it.ld + c];
+        s1 += it.partials[(int64_t)(b + 16) * it.ld + c];
+        s2 += it.partials[(int64_t)(b + 32) * it.ld + c];
+        s3 += it.partials[(int64_t)(b + 48) * it.ld + c];
+      }
+      for (; b < it.nblk; b += 16) s0 += it.partials[(int64_t)b * it.ld + c];
+    }
+    red[gy][cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (gy == 0 && c < it.ncols) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[k][cx];
+      t *= it.scale;
+      it.dst[c] = it.accumulate ? it.dst[c] + t : t;
+    }
+    __syncthreads();
+  }
+}
+
 // column sums of a [rows][C] matrix (bf16 or fp32) -> partials[nblk][C]; a thread owns 4 contiguous columns
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int rows, int C, int ld, float* __restrict__ partials) {
@@ -360,5 +395,21 @@ extern "C" int ttsk_colsum(const void* x, int is_f32, int rows, int C, int ld, f
   else
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nblk), dim3(256), shm, (hipStream_t)stream, (const bf16_t*)x, rows, C, ld, partials);
   TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_colsum_finalize_batch(const ttsk_finalize_item* items, int n, void* stream) {
+  TTSK_REQUIRE(items && n > 0, "colsum_finalize_batch: bad arguments");
+  for (int base = 0; base < n; base += 64) {
+    FinalizeBatch fb;
+    const int m = n - base < 64 ? n - base : 64;
+    for (int i = 0; i < m; ++i) {
+      fb.it[i] = items[base + i];
+      TTSK_REQUIRE(fb.it[i].partials && fb.it[i].dst && fb.it[i].nblk > 0 && fb.it[i].ncols > 0 && fb.it[i].ld >= fb.it[i].ncols,
+                   "colsum_finalize_batch: bad item %d", base + i);
+    }
+    hipLaunchKernelGGL(colsum_finalize_batch_kernel, dim3(16, m), dim3(256), 0, (hipStream_t)stream, fb);
+    TTSK_CHECK_LAUNCH();
+  }
   return TTSK_OK;
 }

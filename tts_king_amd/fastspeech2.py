@@ -105,6 +105,7 @@ class FastSpeech2(nn.Module):
         self._anchor = torch.zeros((), requires_grad=True)
         self._ctx = None
         self._deferred = None           # split-K slabs awaiting the batched reducer (backward only)
+        self._deferred_fin = None       # gradient column-sum partials awaiting the batched finalize
         self._side = None               # second HIP stream for parameter-gradient work (see _SideWork)
         self.fused_attention = True     # one kernel for scores + softmax + P.V (and dP + softmax' + dQ) when d_k = 128
         self.overlap_param_grads = False   # measured on MI355X: the branches do overlap under graph replay, but the concurrent
@@ -503,7 +504,7 @@ class FastSpeech2(nn.Module):
         sub-layer bias, LayerNorm weight and LayerNorm bias (and the predictor head) sit back to back in that order
         starting at `first_key` (params.py builds them so): ONE finalize launch per LayerNorm."""
         off = self._table[first_key].offset
-        ops.colsum_finalize(partials, nblk, ncol, ncol, self._flat_grad[off:off + ncol], accumulate=True)
+        ops.colsum_finalize(partials, nblk, ncol, ncol, self._flat_grad[off:off + ncol], accumulate=True, defer=self._deferred_fin)
 
     class _SideWork:
         """Parameter-gradient work (dW GEMMs, bias / LayerNorm column sums) runs on a second HIP stream: nothing on the
@@ -558,7 +559,7 @@ class FastSpeech2(nn.Module):
         dh = ops.conv1d_dx(dy2.view(Bn, S, d), self._w(f + "w_2.weight"), G=h)
         # ---- w_1 (k=9): bias, dW, dX + residual gradient
         with self._side_work(dh, x1):
-            ops.colsum_into(dh.view(rows, -1), self._g(f + "w_1.bias"))
+            ops.colsum_into(dh.view(rows, -1), self._g(f + "w_1.bias"), defer=self._deferred_fin)
             ops.conv1d_dw(dh, x1.view(Bn, S, d), self._g(f + "w_1.weight"), k=self.k1, defer=self._deferred)
         dx1 = ops.conv1d_dx(dh, self._w(f + "w_1.weight"), R=dz2.view(Bn, S, d))
         # ---- attention tail
@@ -585,7 +586,7 @@ class FastSpeech2(nn.Module):
                  sA=(H * S * Sp, S * Sp), sB=(S * d, dk), sC=(S * 3 * d, dk))
         # ---- q|k|v projections
         with self._side_work(dqkv, x):
-            ops.colsum_into(dqkv, self._g(a + "w_qs.bias", 3 * d))
+            ops.colsum_into(dqkv, self._g(a + "w_qs.bias", 3 * d), defer=self._deferred_fin)
             ops.linear_dw(dqkv, x, self._g(a + "w_qs.weight", 3 * d * d).view(3 * d, d), defer=self._deferred)
         return ops.linear_dx(dqkv, self._w(a + "w_qs.weight", 3 * d), R=dz1)
 
@@ -623,12 +624,14 @@ class FastSpeech2(nn.Module):
         # split-K slabs of the weight-gradient GEMMs are summed by ONE batched reducer launch per parameter group when a
         # data-parallel reducer is waiting for finished buckets, otherwise once at the end (only Adam reads them)
         self._deferred = []
+        self._deferred_fin = []
         if self.overlap_param_grads and self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
         if on_bucket is not None:
             def notify(name):
                 self._join_side()
                 ops.flush_deferred(self._deferred)
+                ops.flush_finalize(self._deferred_fin)
                 on_bucket(name)
         else:
             notify = lambda name: None
@@ -640,7 +643,7 @@ class FastSpeech2(nn.Module):
             dy = ops.bn_bwd(dout, yc.view(rows, C), mean, rstd, self._m(pp + "1.weight"), self._m(pp + "1.bias"), i < 4,
                             p=self.p_post, site=300 + i, rng=rng, dgamma=self._g(pp + "1.weight"), dbeta=self._g(pp + "1.bias"))
             with self._side_work(dy, xin):
-                ops.colsum_into(dy, self._g(pp + "0.conv.bias"))
+                ops.colsum_into(dy, self._g(pp + "0.conv.bias"), defer=self._deferred_fin)
                 ops.conv1d_dw(dy.view(Bn, T, C), xin, self._g(pp + "0.conv.weight"), k=5, defer=self._deferred)
             if i > 0:
                 dout = ops.conv1d_dx(dy.view(Bn, T, C), self._w(pp + "0.conv.weight")).view(rows, -1)
@@ -649,7 +652,7 @@ class FastSpeech2(nn.Module):
         notify("postnet")
         # ---- mel_linear
         with self._side_work(dmel_tot, ctx.dec_out):
-            ops.colsum_into(dmel_tot, self._g("mel_linear.bias"))
+            ops.colsum_into(dmel_tot, self._g("mel_linear.bias"), defer=self._deferred_fin)
             ops.linear_dw(dmel_tot, ctx.dec_out, self._g("mel_linear.weight"), defer=self._deferred)
         dx = ops.linear_dx(dmel_tot, self._w("mel_linear.weight"))
         notify("mel_linear")
@@ -681,4 +684,5 @@ class FastSpeech2(nn.Module):
         notify("embedding")
         self._join_side()
         ops.flush_deferred(self._deferred)
+        ops.flush_finalize(self._deferred_fin)
         self._ctx = None

@@ -41,6 +41,12 @@ class ReduceItem(C.Structure):
                 ("splits", C.c_int32), ("accumulate", C.c_int32), ("sC2", C.c_int64), ("alpha", C.c_float)]
 
 
+class FinalizeItem(C.Structure):
+    """Mirror of `ttsk_finalize_item` (include/ttsk.h)."""
+    _fields_ = [("partials", C.c_void_p), ("dst", C.c_void_p), ("nblk", C.c_int32), ("ncols", C.c_int32), ("ld", C.c_int32),
+                ("accumulate", C.c_int32), ("scale", C.c_float)]
+
+
 # flags (include/ttsk.h)
 A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT, F16, C2_LRELU, DEFER_REDUCE = [1 << i for i in range(14)]
 
@@ -101,6 +107,7 @@ def load(path=LIB_PATH):
             fn.restype = C.c_int
         fn.argtypes = argtypes
     lib.ttsk_gemm.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
+    lib.ttsk_colsum_finalize_batch.argtypes = [C.POINTER(FinalizeItem), C.c_int, C.c_void_p]
     lib.ttsk_gemm_reduce_batch.argtypes = [C.POINTER(ReduceItem), C.c_int, C.c_void_p]
     lib.ttsk_gemm_plan.argtypes = [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     _lib = lib

@@ -274,13 +274,28 @@ def layernorm_bwd(dout, z, mean, rstd, gamma, beta, lens=None, seg_len=0, relu_i
     return dz, (dy if dy is not None else dz), partials, nblk
 
 
-def colsum_finalize(partials, nblk, ncols, ld, dst, accumulate=True, scale=1.0):
+def colsum_finalize(partials, nblk, ncols, ld, dst, accumulate=True, scale=1.0, defer=None):
+    """dst[c] (+)= scale * sum_b partials[b*ld + c].  `defer`: a list — the item is queued for flush_finalize instead."""
+    if defer is not None:
+        it = L.FinalizeItem()
+        it.partials, it.dst, it.nblk, it.ncols, it.ld, it.accumulate, it.scale = partials.data_ptr(), dst.data_ptr(), nblk, ncols, ld, int(accumulate), scale
+        defer.append((it, partials))
+        return dst
     check(L.load().ttsk_colsum_finalize(_ptr(partials), nblk, ncols, ld, _ptr(dst), int(accumulate), scale, _stream()),
           "ttsk_colsum_finalize")
     return dst
 
 
-def colsum_into(x, dst, accumulate=True):
+def flush_finalize(items):
+    """One ttsk_colsum_finalize_batch launch (per 64 items) for the queued column-sum finalisations."""
+    if not items:
+        return
+    arr = (L.FinalizeItem * len(items))(*[it for it, _ in items])
+    check(L.load().ttsk_colsum_finalize_batch(arr, len(items), _stream()), "ttsk_colsum_finalize_batch")
+    items.clear()
+
+
+def colsum_into(x, dst, accumulate=True, defer=None):
     """dst[C] (+)= column sums of x (rows, C) — bias gradients."""
     _dev(x, dst)
     rows, Cn = x.shape
@@ -288,7 +303,7 @@ def colsum_into(x, dst, accumulate=True):
     nblk = lib.ttsk_colsum_nblocks(rows)
     partials = _f32(nblk, Cn, device=x.device)
     check(lib.ttsk_colsum(_ptr(x), int(x.dtype == torch.float32), rows, Cn, x.stride(0), _ptr(partials), _stream()), "ttsk_colsum")
-    return colsum_finalize(partials, nblk, Cn, Cn, dst, accumulate)
+    return colsum_finalize(partials, nblk, Cn, Cn, dst, accumulate, defer=defer)
 
 
 def attention_fwd(qkv, lens, Bn, H, S, want_probs):

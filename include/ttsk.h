@@ -165,6 +165,13 @@ int ttsk_colsum_finalize_batch(const ttsk_finalize_item* items, int n, void* str
 int ttsk_colsum_nblocks(int rows);
 /* per-block column sums of x [rows][C] (bf16, or fp32 when is_f32) -> partials[nblocks][C]  (bias gradients) */
 int ttsk_colsum(const void* x, int is_f32, int rows, int C, int ld, float* partials, void* stream);
+/* the same for up to 64 matrices per launch; nblk must be ttsk_colsum_nblocks(rows) */
+typedef struct ttsk_colsum_item {
+  const void* x;
+  float* partials;
+  int32_t is_f32, rows, C, ld, nblk;
+} ttsk_colsum_item;
+int ttsk_colsum_batch(const ttsk_colsum_item* items, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------ attention softmax
  * reference: fs_two/transformer/Modules.py:15-22.  scores fp32 [nz][S][Sp] (already scaled by 1/sqrt(d_k) in the

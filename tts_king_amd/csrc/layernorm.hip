@@ -296,13 +296,13 @@ __global__ __launch_bounds__(256) void colsum_finalize_batch_kernel(const Finali
 
 // column sums of a [rows][C] matrix (bf16 or fp32) -> partials[nblk][C]; a thread owns 4 contiguous columns
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int rows, int C, int ld, float* __restrict__ partials) {
-  extern __shared__ float red[];                // [rpi][C]
+__device__ __forceinline__ void colsum_body(const T* __restrict__ x, int rows, int C, int ld, float* __restrict__ partials, int blk, int nblk,
+                                            float* red) {
   const int tpr = (C + 3) >> 2;                 // threads per row (C % 4 == 0 or C < 4 handled by the host)
   const int rpi = 256 / tpr;                    // rows per iteration
   const int r0 = threadIdx.x / tpr, c4 = (threadIdx.x % tpr) * 4;
-  const int per = (rows + gridDim.x - 1) / gridDim.x;
-  const int rb = blockIdx.x * per;
+  const int per = (rows + nblk - 1) / nblk;
+  const int rb = blk * per;
   const int re = min(rb + per, rows);
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   if (r0 < rpi)
@@ -324,8 +324,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
   for (int c = threadIdx.x; c < C; c += 256) {
     float t = 0.f;
     for (int k = 0; k < rpi; ++k) t += red[k * C + c];
-    partials[(int64_t)blockIdx.x * C + c] = t;
+    partials[(int64_t)blk * C + c] = t;
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int rows, int C, int ld, float* __restrict__ partials) {
+  extern __shared__ float red[];                // [rpi][C]
+  colsum_body<T>(x, rows, C, ld, partials, blockIdx.x, gridDim.x, red);
+}
+
+// column sums of up to 64 matrices in one launch (bias gradients of a whole backward pass, deferred)
+struct ColsumBatch {
+  ttsk_colsum_item it[64];
+};
+__global__ __launch_bounds__(256) void colsum_batch_kernel(const ColsumBatch cb) {
+  extern __shared__ float red[];
+  const ttsk_colsum_item& it = cb.it[blockIdx.y];
+  if ((int)blockIdx.x >= it.nblk) return;
+  if (it.is_f32) colsum_body<float>((const float*)it.x, it.rows, it.C, it.ld, it.partials, blockIdx.x, it.nblk, red);
+  else colsum_body<bf16_t>((const bf16_t*)it.x, it.rows, it.C, it.ld, it.partials, blockIdx.x, it.nblk, red);
 }
 
 }  // namespace
@@ -409,6 +427,28 @@ extern "C" int ttsk_colsum_finalize_batch(const ttsk_finalize_item* items, int n
                    "colsum_finalize_batch: bad item %d", base + i);
     }
     hipLaunchKernelGGL(colsum_finalize_batch_kernel, dim3(16, m), dim3(256), 0, (hipStream_t)stream, fb);
+    TTSK_CHECK_LAUNCH();
+  }
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_colsum_batch(const ttsk_colsum_item* items, int n, void* stream) {
+  TTSK_REQUIRE(items && n > 0, "colsum_batch: bad arguments");
+  for (int base = 0; base < n; base += 64) {
+    ColsumBatch cb;
+    const int m = n - base < 64 ? n - base : 64;
+    int max_blk = 1;
+    size_t shm = 0;
+    for (int i = 0; i < m; ++i) {
+      cb.it[i] = items[base + i];
+      const ttsk_colsum_item& it = cb.it[i];
+      TTSK_REQUIRE(it.x && it.partials && it.rows > 0 && it.C > 0 && (it.C & 3) == 0 && it.C <= 1024 && it.ld >= it.C && (it.ld & 3) == 0 &&
+                       it.nblk == ttsk_colsum_nblocks(it.rows), "colsum_batch: bad item %d", base + i);
+      if (it.nblk > max_blk) max_blk = it.nblk;
+      const size_t need = (size_t)(256 / (it.C >> 2)) * it.C * sizeof(float);
+      if (need > shm) shm = need;
+    }
+    hipLaunchKernelGGL(colsum_batch_kernel, dim3(max_blk, m), dim3(256), shm, (hipStream_t)stream, cb);
     TTSK_CHECK_LAUNCH();
   }
   return TTSK_OK;

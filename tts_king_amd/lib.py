@@ -41,6 +41,12 @@ class ReduceItem(C.Structure):
                 ("splits", C.c_int32), ("accumulate", C.c_int32), ("sC2", C.c_int64), ("alpha", C.c_float)]
 
 
+class ColsumItem(C.Structure):
+    """Mirror of `ttsk_colsum_item` (include/ttsk.h)."""
+    _fields_ = [("x", C.c_void_p), ("partials", C.c_void_p), ("is_f32", C.c_int32), ("rows", C.c_int32), ("C", C.c_int32),
+                ("ld", C.c_int32), ("nblk", C.c_int32)]
+
+
 class FinalizeItem(C.Structure):
     """Mirror of `ttsk_finalize_item` (include/ttsk.h)."""
     _fields_ = [("partials", C.c_void_p), ("dst", C.c_void_p), ("nblk", C.c_int32), ("ncols", C.c_int32), ("ld", C.c_int32),
@@ -107,6 +113,7 @@ def load(path=LIB_PATH):
             fn.restype = C.c_int
         fn.argtypes = argtypes
     lib.ttsk_gemm.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
+    lib.ttsk_colsum_batch.argtypes = [C.POINTER(ColsumItem), C.c_int, C.c_void_p]
     lib.ttsk_colsum_finalize_batch.argtypes = [C.POINTER(FinalizeItem), C.c_int, C.c_void_p]
     lib.ttsk_gemm_reduce_batch.argtypes = [C.POINTER(ReduceItem), C.c_int, C.c_void_p]
     lib.ttsk_gemm_plan.argtypes = [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]

@@ -287,9 +287,15 @@ def colsum_finalize(partials, nblk, ncols, ld, dst, accumulate=True, scale=1.0, 
 
 
 def flush_finalize(items):
-    """One ttsk_colsum_finalize_batch launch (per 64 items) for the queued column-sum finalisations."""
+    """One ttsk_colsum_batch launch for the queued column sums (bias gradients), then one ttsk_colsum_finalize_batch launch
+    (per 64 items each) for all queued finalisations."""
     if not items:
         return
+    cs = [it for it, _ in items if isinstance(it, L.ColsumItem)]
+    if cs:
+        check(L.load().ttsk_colsum_batch((L.ColsumItem * len(cs))(*cs), len(cs), _stream()), "ttsk_colsum_batch")
+    fin = [(it, keep) for it, keep in items if isinstance(it, L.FinalizeItem)]
+    items[:] = fin
     arr = (L.FinalizeItem * len(items))(*[it for it, _ in items])
     check(L.load().ttsk_colsum_finalize_batch(arr, len(items), _stream()), "ttsk_colsum_finalize_batch")
     items.clear()
@@ -302,7 +308,12 @@ def colsum_into(x, dst, accumulate=True, defer=None):
     lib = L.load()
     nblk = lib.ttsk_colsum_nblocks(rows)
     partials = _f32(nblk, Cn, device=x.device)
-    check(lib.ttsk_colsum(_ptr(x), int(x.dtype == torch.float32), rows, Cn, x.stride(0), _ptr(partials), _stream()), "ttsk_colsum")
+    if defer is not None:          # queue the column sum itself as well; `x` stays alive until flush_finalize
+        it = L.ColsumItem()
+        it.x, it.partials, it.is_f32, it.rows, it.C, it.ld, it.nblk = x.data_ptr(), partials.data_ptr(), int(x.dtype == torch.float32), rows, Cn, x.stride(0), nblk
+        defer.append((it, x))
+    else:
+        check(lib.ttsk_colsum(_ptr(x), int(x.dtype == torch.float32), rows, Cn, x.stride(0), _ptr(partials), _stream()), "ttsk_colsum")
     return colsum_finalize(partials, nblk, Cn, Cn, dst, accumulate, defer=defer)
 
 

@@ -108,7 +108,7 @@ def gemm_roofline(enqueue, batch, steps=3):
     finally:
         ops.GEMM_TRACE = None
     sym = {"NT1": "gemm_kernel<false, false, false>", "NT_btr1": "gemm_kernel<false, true, false>", "TT1": "gemm_kernel<true, true, false>",
-           "NT2": "gemm2_kernel<false, false, false>", "NT_btr2": "gemm2_kernel<false, true, false>", "TT2": "gemm2_kernel<true, true, false>"}
+           "NT2": "gemm2_kernel<256, false, false, false>", "NT_btr2": "gemm2_kernel<256, false, true, false>", "TT2": "gemm2_kernel<256, true, true, false>"}
     by_sym, by_shape = {}, {}
     for e0, e1, fl, kind, shape in trace:
         ms = e0.elapsed_time(e1)

@@ -197,34 +197,38 @@ def test_plan_fills_the_chip():
 
 
 # ---- the 256x128 LDS-DMA kernel (kernel=2) on every operand layout, with tails in M, N and K
+DMA_KERNELS = pytest.mark.parametrize("kern", [2])
+@DMA_KERNELS
 @pytest.mark.parametrize("ints", [True, False])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 200, 264), (1024, 768, 256), (77, 80, 256), (513, 129, 1000)])
-def test_k2_nt_bias_relu(M, N, K, ints):
+def test_k2_nt_bias_relu(M, N, K, ints, kern):
     from tts_king_amd import ops
     a, w, b = bf(rnd(M, K, seed=1, ints=ints)), bf(rnd(N, K, seed=2, ints=ints)), rnd(N, seed=3, ints=ints)
     ref = torch.relu(a.double() @ w.double().t() + b.double())
-    out32 = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV), flags=ops.RELU, out_dtype=torch.float32, kernel=2, splits=1)
+    out32 = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV), flags=ops.RELU, out_dtype=torch.float32, kernel=kern, splits=1)
     check(out32, ref, K, exact=ints, out_bf16=False)
-    out16 = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV), flags=ops.RELU, kernel=2)
+    out16 = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV), flags=ops.RELU, kernel=kern)
     check(out16, bf(ref.float()).double() if ints else ref, K, exact=ints)
 
 
+@DMA_KERNELS
 @pytest.mark.parametrize("ints", [True, False])
 @pytest.mark.parametrize("M,N,K", [(423, 128, 423), (200, 256, 768), (600, 80, 64)])
-def test_k2_b_transposed(M, N, K, ints):
+def test_k2_b_transposed(M, N, K, ints, kern):
     from tts_king_amd import ops
     Kp = (K + 7) // 8 * 8
     a = torch.zeros(M, Kp)
     a[:, :K] = rnd(M, K, seed=5, ints=ints)
     a, b = bf(a), bf(rnd(K, N, seed=6, ints=ints))
     out = torch.empty(M, N, dtype=torch.float32, device=DEV)
-    ops.gemm(a.to(DEV), b.to(DEV), out, M, N, K, Kp, N, N, flags=ops.B_TR, kernel=2, splits=1)
+    ops.gemm(a.to(DEV), b.to(DEV), out, M, N, K, Kp, N, N, flags=ops.B_TR, kernel=kern, splits=1)
     check(out, a[:, :K].double() @ b.double(), K, exact=ints, out_bf16=False)
 
 
+@DMA_KERNELS
 @pytest.mark.parametrize("ints", [True, False])
 @pytest.mark.parametrize("M,N,K,splits", [(256, 256, 1000, 1), (768, 256, 6768, 5), (423, 128, 423, 1), (80, 512, 300, 2), (1024, 256, 2000, 0)])
-def test_k2_both_transposed(M, N, K, splits, ints):
+def test_k2_both_transposed(M, N, K, splits, ints, kern):
     from tts_king_amd import ops
     Mp = (M + 7) // 8 * 8
     a = torch.zeros(K, Mp)
@@ -232,14 +236,15 @@ def test_k2_both_transposed(M, N, K, splits, ints):
     a, b = bf(a), bf(rnd(K, N, seed=8, ints=ints))
     ref = a[:, :M].double().t() @ b.double()
     out = torch.ones(M, N, dtype=torch.float32, device=DEV)
-    ops.gemm(a.to(DEV), b.to(DEV), out, M, N, K, Mp, N, N, flags=ops.A_TR | ops.B_TR | ops.ACCUM_C, kernel=2, splits=splits)
+    ops.gemm(a.to(DEV), b.to(DEV), out, M, N, K, Mp, N, N, flags=ops.A_TR | ops.B_TR | ops.ACCUM_C, kernel=kern, splits=splits)
     check(out, ref + 1, K, exact=ints, out_bf16=False)
 
 
+@DMA_KERNELS
 @pytest.mark.parametrize("ints", [True, False])
 @pytest.mark.parametrize("Bsz,T,Cin,Cout,k,dil", [(3, 50, 256, 1024, 9, 1), (2, 423, 80, 512, 5, 1), (2, 131, 128, 128, 7, 3),
                                                   (2, 300, 256, 256, 11, 5), (2, 40, 1024, 256, 1, 1)])
-def test_k2_conv1d_fwd_dx_dw(Bsz, T, Cin, Cout, k, dil, ints):
+def test_k2_conv1d_fwd_dx_dw(Bsz, T, Cin, Cout, k, dil, ints, kern):
     from tts_king_amd import ops
     x = bf(rnd(Bsz, T, Cin, seed=9, ints=ints))
     w = bf(rnd(Cout, Cin, k, seed=10, ints=ints) * (1.0 if ints else (Cin * k) ** -0.5))
@@ -251,17 +256,18 @@ def test_k2_conv1d_fwd_dx_dw(Bsz, T, Cin, Cout, k, dil, ints):
     y = F.conv1d(xd, wd, b.double(), dilation=dil, padding=pad)
     y.backward(dy.double().transpose(1, 2))
     wk = w.permute(0, 2, 1).contiguous().to(DEV)
-    out = ops.conv1d(x.to(DEV), wk, b.to(DEV), dilation=dil, out_dtype=torch.float32, kernel=2)
+    out = ops.conv1d(x.to(DEV), wk, b.to(DEV), dilation=dil, out_dtype=torch.float32, kernel=kern)
     check(out, y.detach().transpose(1, 2), Cin * k, exact=ints, out_bf16=False)
     dx = torch.empty(Bsz, T, Cin, dtype=torch.float32, device=DEV)
-    ops.conv1d_dx(dy.to(DEV), wk, dilation=dil, out=dx, kernel=2)
+    ops.conv1d_dx(dy.to(DEV), wk, dilation=dil, out=dx, kernel=kern)
     check(dx, xd.grad.transpose(1, 2), Cout * k, exact=ints, out_bf16=False)
     dw = torch.zeros(Cout, k, Cin, dtype=torch.float32, device=DEV)
-    ops.conv1d_dw(dy.to(DEV), x.to(DEV), dw, dilation=dil, k=k, accumulate=True, kernel=2)
+    ops.conv1d_dw(dy.to(DEV), x.to(DEV), dw, dilation=dil, k=k, accumulate=True, kernel=kern)
     check(dw, wd.grad.permute(0, 2, 1), Bsz * T, exact=ints, out_bf16=False)
 
 
-def test_k2_fp16_and_polyphase():
+@DMA_KERNELS
+def test_k2_fp16_and_polyphase(kern):
     from tts_king_amd import ops
     Cin, Cout, k, s, T, Bsz = 256, 128, 16, 8, 70, 2
     x = rnd(Bsz, T, Cin, seed=18).half()
@@ -269,7 +275,7 @@ def test_k2_fp16_and_polyphase():
     b = rnd(Cout, seed=20)
     ref = F.conv_transpose1d(x.double().transpose(1, 2), w.double(), b.double(), stride=s, padding=(k - s) // 2).transpose(1, 2)
     wp = w.permute(2, 1, 0).contiguous().to(DEV)
-    out = ops.conv_transpose1d(x.to(DEV), wp, b.to(DEV), s, k, kernel=2)
+    out = ops.conv_transpose1d(x.to(DEV), wp, b.to(DEV), s, k, kernel=kern)
     assert out.dtype == torch.float16
     err = float((out.float().cpu().double() - ref).abs().max())
     assert err <= 2e-6 * (Cin * k // s) ** 0.5 * float(ref.abs().max() + 1) + float(ref.abs().max()) * 2 ** -10, err

@@ -33,6 +33,7 @@ for name, args in [("dec w1", (16, 423, 256, 1024, 9)), ("dec w2", (16, 423, 102
         if name.startswith("hifi") and mode != "fwd": continue
         cases.append((name + " " + mode,) + conv_case(*args, mode))
 
+if __name__ != "__main__": cases = []
 print("%-18s %-3s %s" % ("case", "k", "  ".join("sp=%-2d" % s for s in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32))) + "   auto")
 for name, fn, fl in cases:
     for kernel in (1, 2):

@@ -389,6 +389,7 @@ int validate(ttsk_gemm_desc& d) {
   TTSK_REQUIRE(d.out_mul == 0 || (d.seg_len > 0 && d.out_seg > 0), "ttsk_gemm: output remap needs seg_len/out_seg");
   TTSK_REQUIRE(d.kernel >= 0 && d.kernel <= 2 && d.splits >= 0, "ttsk_gemm: kernel must be 0 (auto), 1 or 2; splits >= 0");
   TTSK_REQUIRE(!(d.kernel == 2 && (d.flags & TTSK_GEMM_LRELU_IN)), "ttsk_gemm: LRELU_IN needs the register-staged kernel (kernel = 1)");
+  TTSK_REQUIRE(!(d.kernel == 2 && d.taps > 32), "ttsk_gemm: kernel = 2 handles at most 32 taps");
   if (d.nz1 < 1) d.nz1 = 1;
   if (d.nz2 < 1) d.nz2 = 1;
   TTSK_REQUIRE(!(d.flags & TTSK_GEMM_ADD_R) || d.R, "ttsk_gemm: ADD_R without R");
@@ -416,8 +417,8 @@ Plan make_plan(const ttsk_gemm_desc& d) {
   float best_t = -1.f;
   for (int kernel = 1; kernel <= 2; ++kernel) {
     if (d.kernel != 0 && d.kernel != kernel) continue;
-    if (kernel == 2 && (d.flags & TTSK_GEMM_LRELU_IN)) continue;
-    const int bm = kernel == 1 ? 128 : 256;
+    if (kernel == 2 && ((d.flags & TTSK_GEMM_LRELU_IN) || d.taps > 32)) continue;
+    const int bm = kernel == 2 ? 256 : 128;
     const int tm = (d.M + bm - 1) / bm, tn = (d.N + 127) / 128;
     const int64_t tiles = (int64_t)tm * tn * nz;
     static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};

@@ -1,42 +1,56 @@
-// gemm2.hip — the large-tile configuration of the MFMA contraction kernel (same descriptor, same epilogue as gemm.hip).
+// gemm2.hip — the LDS-DMA configurations of the MFMA contraction kernel (same descriptor, same epilogue as gemm.hip).
 //
-// Why a second configuration: a 128x128x64 tile moves 32 KiB from L2 per 2.1 MFLOP, which at ~64 B/clk/CU of L1/TA
-// bandwidth costs as many cycles as its 128 MFMAs — the 128^2 kernel is load-path bound (measured 1.3-1.7 us per K
-// step per workgroup, ~20 % MFMA utilisation).  Here: 256(M) x 128(N) x 64(K) per 512-thread workgroup (8 waves as
-// 4x2, each a 64x64 sub-tile of 4x4 v_mfma_f32_16x16x32), 48 KiB per K step for 4.2 MFLOP, and the operand tiles go
-// global -> LDS directly (buffer_load_dwordx4 ... lds: no VGPRs, no ds_write pass) into a 3-stage ring so that two
-// K steps are always in flight behind a counted s_waitcnt vmcnt(6) and ONE raw s_barrier per K step.
-// LDS-DMA writes lane-linear 1 KiB pieces, so the bank-conflict swizzle is applied to the per-lane SOURCE address:
-// the LDS image is identical to gemm.hip's (row-major tiles: 16-byte chunk ^= row & 7; contraction-major tiles: the
-// ds_read_b64_tr_b16 layout).  Tails and conv zero padding are out-of-range buffer offsets (hardware returns zeros).
+// BM(M) x 128(N) x 64(K) per workgroup of BM/32 waves (2 columns of waves, each wave a 64x64 sub-tile of 4x4
+// v_mfma_f32_16x16x32).  Shipped: BM = 256 (8 waves, 3-stage ring of 48 KiB).  The template also builds BM = 128
+// (4 waves, 4-stage ring of 32 KiB); measured on the step's small GEMMs it loses to gemm.hip's register-staged 128^2
+// kernel, which runs two workgroups per CU (dec w1 fwd 77 vs 59 us, dW shapes equal), so it is not instantiated.
+// The operand tiles go global -> LDS directly (buffer_load_dwordx4 ... lds: no VGPRs, no ds_write pass).  LDS-DMA writes
+// lane-linear 1 KiB pieces, so the bank-conflict swizzle is applied to the per-lane SOURCE address: the LDS image is
+// identical to gemm.hip's (row-major tiles: 16-byte chunk ^= row & 7; contraction-major tiles: the ds_read_b64_tr_b16
+// layout).  Tails and conv zero padding are out-of-range buffer offsets (hardware returns zeros).
 #include "gemm_common.h"
 
 namespace {
 
-constexpr int BM = 256, BN = 128, BK = 64;
-constexpr int NTHREADS = 512;
-constexpr int NSTAGE = 3;
-constexpr int A_BYTES = BM * BK * 2;            // 32 KiB
+constexpr int BN = 128, BK = 64;
 constexpr int B_BYTES = BN * BK * 2;            // 16 KiB
-constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // 48 KiB
-constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;  // 144 KiB
 constexpr int CS_LD = 132;                      // fp32 epilogue tile (128 rows per pass): 67,584 B
 constexpr int OOB = 0x7FFFFFFF;
-constexpr int NA = A_BYTES / (NTHREADS * 16);   // 4 LDS-DMA pieces per lane per K step for A
-constexpr int NB = B_BYTES / (NTHREADS * 16);   // 2 for B
+constexpr int NA = 4;                           // LDS-DMA pieces per lane per K step for A (BM*128 B / (BM/32*64 lanes * 16 B))
+
+template <int BM_> struct Cfg {
+  static constexpr int BM = BM_;
+  static constexpr int NW = BM_ / 32;                       // waves
+  static constexpr int NTHREADS = NW * 64;
+  static constexpr int NSTAGE = BM_ == 256 ? 3 : 4;
+  static constexpr int A_BYTES = BM_ * BK * 2;              // 32 / 16 KiB
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;     // 48 / 32 KiB
+  static constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;   // 144 / 128 KiB
+  static constexpr int NB = B_BYTES / (NTHREADS * 16);      // 2 / 4 pieces per lane per K step for B
+  static constexpr int NQ = NA + NB;
+};
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
-// one LDS-DMA piece: 64 lanes x 16 B from per-lane buffer offsets `voff` to the 1 KiB at `lds` (wave-uniform).
-// The offset is made opaque first: otherwise hipcc turns the out-of-range select into exec-masked twin loads, which
-// breaks the fixed pieces-per-K-step count the s_waitcnt vmcnt(N) accounting relies on.
-__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rs, unsigned char* lds, int voff) {
-  asm volatile("" : "+v"(voff));
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)lds, 16, voff, 0, 0, 0);
+// one LDS-DMA piece: 64 lanes x 16 B from per-lane buffer offsets `voff` to the 1 KiB at LDS byte address `lds`
+// (wave-uniform, in an SGPR).  Issued from inline asm on purpose: hipcc counts a builtin LDS-DMA as a pending LDS write
+// and puts `s_waitcnt vmcnt(0)` before the first ds_read of every K step (measured: DMA, LDS reads and MFMA then ran
+// back to back, 1.0 us per K step for a lone workgroup whose DMA alone takes 0.6).  An asm load is invisible to that
+// bookkeeping; landing is ordered by the counted s_waitcnt vmcnt(N) + s_barrier in the K loop.  M0 (the DMA's LDS
+// destination) is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rs, unsigned lds, int voff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(lds), "s"(rs)
+               : "memory");
 }
 
-template <bool ATR, bool BTR, bool F16>
-__global__ __launch_bounds__(NTHREADS, 1) void gemm2_kernel(const GemmArgs g) {
+template <int BM_, bool ATR, bool BTR, bool F16>
+__global__ __launch_bounds__(Cfg<BM_>::NTHREADS, 1) void gemm2_kernel(const GemmArgs g) {
+  using CF = Cfg<BM_>;
+  constexpr int BM = CF::BM, NW = CF::NW, NTHREADS = CF::NTHREADS, NSTAGE = CF::NSTAGE, A_BYTES = CF::A_BYTES;
+  constexpr int STAGE_BYTES = CF::STAGE_BYTES, SMEM_BYTES = CF::SMEM_BYTES, NB = CF::NB, NQ = CF::NQ;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
   const ttsk_gemm_desc& d = g.d;
   const int tid = threadIdx.x;
@@ -68,44 +82,62 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm2_kernel(const GemmArgs g) {
   //      row-major tile: 8 rows x 128 B, lane -> (row p*8 + lane/8, physical chunk lane%8, logical chunk ^ (row&7));
   //      contraction-major tile [64 k][128 m] (A: two of them side by side): 4 k-rows x 256 B,
   //      lane -> (k-row p*4 + lane/16, physical 16-B chunk lane%16; 32-B pair index ^ tr_sw(k-row)).
-  int a_off[NA], a_t[NA], a_k[NA], b_off[NB], b_k[NB];
+  // Everything that does not change along K is folded into three per-piece values here, so that a K step issues its six
+  // pieces with a handful of VALU instructions and no branch (the address/predicate code used to cost a lone workgroup
+  // 0.4 us of every 1.0 us K step):  off = byte offset at k = 0, tap 0;  ok = bit t set when the piece's row exists and
+  // is inside its utterance under tap t's shift (conv zero padding);  k = the piece's first contraction index.
+  int a_off[NA], a_k[NA], b_off[NB], b_k[NB], b_tt[NB];
+  unsigned a_ok[NA], b_ok[NB];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int p = i * 8 + wave;                         // piece 0..31
+    const int p = i * NW + wave;                        // piece 0..BM/8-1
     if (!ATR) {
       const int row = p * 8 + (lane >> 3);
       const int c = (lane & 7) ^ (lane >> 3);
       const int gm = m0 + row;
-      a_off[i] = gm < M ? (gm * d.lda + c * 8) * 2 : OOB;
-      a_t[i] = conv_a ? gm % d.seg_len : 0;
+      a_off[i] = (gm * d.lda + c * 8) * 2;
       a_k[i] = c * 8;
+      unsigned okm = 0;
+      if (gm < M) {
+        if (conv_a) {
+          const int t = gm % d.seg_len;
+          for (int tp = 0; tp < taps; ++tp) {
+            const int tt = t + d.tap_shift0 + tp * d.tap_dshift;
+            okm |= (tt >= 0 && tt < d.seg_len) ? (1u << tp) : 0u;
+          }
+        } else okm = 1u;
+      }
+      a_ok[i] = okm;
     } else {
       const int h = p >> 4, kr = (p & 15) * 4 + (lane >> 4);
       const int pc = lane & 15;
       const int lp = (pc >> 1) ^ tr_sw(kr);
       const int mcol = m0 + h * 128 + (lp * 2 + (pc & 1)) * 8;
-      a_off[i] = mcol < M ? (kr * d.lda + mcol) * 2 : OOB;
-      a_t[i] = 0;
+      a_off[i] = (kr * d.lda + mcol) * 2;
       a_k[i] = kr;
+      a_ok[i] = mcol < M ? 1u : 0u;
     }
   }
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    const int p = i * 8 + wave;                         // piece 0..15
+    const int p = i * NW + wave;                        // piece 0..15
     if (!BTR) {
       const int row = p * 8 + (lane >> 3);
       const int c = (lane & 7) ^ (lane >> 3);
       const int gn = n0 + row;
-      b_off[i] = gn < N ? (gn * d.ldb + c * 8) * 2 : OOB;
+      b_off[i] = (gn * d.ldb + c * 8) * 2;
       b_k[i] = c * 8;
+      b_ok[i] = gn < N ? 1u : 0u;
     } else {
       const int kr = p * 4 + (lane >> 4);
       const int pc = lane & 15;
       const int lp = (pc >> 1) ^ tr_sw(kr);
       const int ncol = n0 + (lp * 2 + (pc & 1)) * 8;
-      b_off[i] = ncol < N ? (kr * d.ldb + ncol) * 2 : OOB;
+      b_off[i] = (kr * d.ldb + ncol) * 2;
       b_k[i] = kr;
+      b_ok[i] = ncol < N ? 1u : 0u;
     }
+    b_tt[i] = 0;
   }
 
   const int kc_begin = split * g.chunks_per_split;
@@ -113,47 +145,78 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm2_kernel(const GemmArgs g) {
   if (kc_end > g.kchunks) kc_end = g.kchunks;
   const int per = kc_end > kc_begin ? kc_end - kc_begin : 0;
   const int nk = per * taps;
+  const int klimA = ATR ? K : K8, klimB = BTR ? K : K8;
 
-  auto issue_tile = [&](int kt) __attribute__((always_inline)) {
-    unsigned char* sa = smem + (kt % NSTAGE) * STAGE_BYTES;
-    unsigned char* sb = sa + A_BYTES;
-    const int tap = kt / per;
-    const int kbase = (kc_begin + (kt - tap * per)) * BK;
-    if (!ATR) {
-      const int shift = conv_a ? d.tap_shift0 + tap * d.tap_dshift : 0;
-      const int add = (shift * d.lda + kbase) * 2;
+  // LDS byte address of this wave's first piece (wave-uniform: readfirstlane makes that provable for the "s" operand)
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr)smem + wave * 1024);
+
+  // issue state: the next tile to issue is chunk kc_begin + is_kk of tap is_tap, into ring stage is_stage
+  int is_tap = 0, is_kk = 0;
+  unsigned is_lds = lds_wave;
+  const bool bseg = BTR && d.bseg_len > 0;
+  auto reset_btt = [&]() __attribute__((always_inline)) {   // position inside its utterance of the piece's k-row (dW of a conv)
+    if (bseg) {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const int tt = a_t[i] + shift;
-        const bool ok = (kbase + a_k[i] < K8) && (!conv_a || (tt >= 0 && tt < d.seg_len)) && a_off[i] != OOB;
-        dma16(rsA, sa + (i * 8 + wave) * 1024, ok ? a_off[i] + add : OOB);
-      }
-    } else {
-      const int add = kbase * d.lda * 2;
+      for (int i = 0; i < NB; ++i) b_tt[i] = (kc_begin * BK + b_k[i]) % d.bseg_len;
+    }
+  };
+  reset_btt();
+
+  // One K tile is issued as two halves (A pieces 0,1 + B piece 0; A pieces 2,3 + B piece 1) so that the K loop can
+  // spread the six LDS-DMA instructions between its MFMAs: the texture addresser takes 16 clk per 1 KiB piece, and a
+  // wave that issues its pieces back to back stalls there (measured 550-800 clk of a 2060-clk K step).
+  auto issue_piece_a = [&](int i, int addA, int limA) __attribute__((always_inline)) {
+    const bool ok = ((a_ok[i] >> is_tap) & 1u) && a_k[i] < limA;
+    dma16(rsA, is_lds + i * (NW * 1024), ok ? a_off[i] + addA : OOB);
+  };
+  auto issue_piece_b = [&](int i, int addB, int limB) __attribute__((always_inline)) {
+    bool ok = b_ok[i] && b_k[i] < limB;
+    if (BTR) ok = ok && (!bseg || (unsigned)(b_tt[i] + bshift) < (unsigned)d.bseg_len);
+    dma16(rsB, is_lds + A_BYTES + i * (NW * 1024), ok ? b_off[i] + addB : OOB);
+  };
+  auto issue_adds = [&](int& addA, int& addB, int& limA, int& limB) __attribute__((always_inline)) {
+    const int kbase = (kc_begin + is_kk) * BK;
+    const int tapoff = is_tap * (int)d.b_tap_stride;
+    if (!ATR) addA = ((conv_a ? d.tap_shift0 + is_tap * d.tap_dshift : 0) * d.lda + kbase) * 2;
+    else addA = kbase * d.lda * 2;
+    if (!BTR) addB = (tapoff + kbase) * 2;
+    else addB = ((kbase + bshift) * d.ldb + tapoff) * 2;
+    limA = klimA - kbase;
+    limB = klimB - kbase;
+  };
+  auto issue_advance = [&]() __attribute__((always_inline)) {
+    is_lds = (is_lds == lds_wave + (NSTAGE - 1) * STAGE_BYTES) ? lds_wave : is_lds + STAGE_BYTES;
+    if (++is_kk == per) {
+      is_kk = 0;
+      ++is_tap;
+      reset_btt();
+    } else if (bseg) {
+      if (d.bseg_len >= BK) {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const bool ok = (kbase + a_k[i] < K) && a_off[i] != OOB;
-        dma16(rsA, sa + (i * 8 + wave) * 1024, ok ? a_off[i] + add : OOB);
+        for (int i = 0; i < NB; ++i) { b_tt[i] += BK; b_tt[i] -= b_tt[i] >= d.bseg_len ? d.bseg_len : 0; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) b_tt[i] = (b_tt[i] + BK) % d.bseg_len;
       }
     }
-    const int tapoff = tap * (int)d.b_tap_stride;
-    if (!BTR) {
-      const int add = (tapoff + kbase) * 2;
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const bool ok = (kbase + b_k[i] < K8) && b_off[i] != OOB;
-        dma16(rsB, sb + (i * 8 + wave) * 1024, ok ? b_off[i] + add : OOB);
-      }
-    } else {
-      const int add = ((kbase + bshift) * d.ldb + tapoff) * 2;
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int kk = kbase + b_k[i];
-        bool ok = kk < K && b_off[i] != OOB;
-        if (d.bseg_len > 0) { const int tt = kk % d.bseg_len + bshift; ok = ok && tt >= 0 && tt < d.bseg_len; }
-        dma16(rsB, sb + (i * 8 + wave) * 1024, ok ? b_off[i] + add : OOB);
-      }
-    }
+  };
+  // piece q of the next tile, q = 0..NQ-1 in issue order (A0 A1 B0 A2 A3 B1, or A0 B0 A1 B1 A2 B2 A3 B3 when NB = 4);
+  // the tile state advances after the last one
+  auto issue_q = [&](int q) __attribute__((always_inline)) {
+    int addA, addB, limA, limB;
+    issue_adds(addA, addB, limA, limB);
+    const bool is_a = NB == 2 ? (q % 3 != 2) : (q % 2 == 0);
+    const int idx = NB == 2 ? (is_a ? (q / 3) * 2 + q % 3 : q / 3) : q / 2;
+    if (is_a) issue_piece_a(idx, addA, limA);
+    else issue_piece_b(idx, addB, limB);
+    if (q == NQ - 1) issue_advance();
+  };
+  // wait until at most y younger tiles (NQ pieces each) of this wave are outstanding
+  auto wait_tiles = [&](int y) __attribute__((always_inline)) {
+    if (y >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NQ) : "memory");
+    else if (y == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQ) : "memory");
+    else if (y == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
   f32x4 acc[4][4];
@@ -164,62 +227,124 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm2_kernel(const GemmArgs g) {
 
   const int l15 = lane & 15, lg = lane >> 4;
 
-  auto compute_tile = [&](int kt) __attribute__((always_inline)) {
-    const unsigned char* sa = smem + (kt % NSTAGE) * STAGE_BYTES;
+  // fragment reads of one 32-wide contraction half (ks) of a ring stage
+  auto read_a = [&](const unsigned char* sa, int ks, int i) __attribute__((always_inline)) -> bf16x8 {
+    if (!ATR) {
+      const int row = wm * 64 + i * 16 + l15;
+      return *(const bf16x8*)(sa + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
+    } else {
+      const unsigned char* sub = sa + (wm >> 1) * 16384;
+      const int mblk = ((wm & 1) * 64 + i * 16) >> 4;
+      const int k0 = ks * 32 + 8 * lg + (l15 >> 2);
+      const int k1 = k0 + 4;
+      bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) bf16x4*)(sub + k0 * 256 + ((mblk ^ tr_sw(k0)) << 5) + ((l15 & 3) << 3)));
+      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) bf16x4*)(sub + k1 * 256 + ((mblk ^ tr_sw(k1)) << 5) + ((l15 & 3) << 3)));
+      return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  };
+  auto read_b = [&](const unsigned char* sa, int ks, int i) __attribute__((always_inline)) -> bf16x8 {
     const unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (!ATR) {
-          const int row = wm * 64 + i * 16 + l15;
-          af[i] = *(const bf16x8*)(sa + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
-        } else {
-          const unsigned char* sub = sa + (wm >> 1) * 16384;
-          const int mblk = ((wm & 1) * 64 + i * 16) >> 4;
-          const int k0 = ks * 32 + 8 * lg + (l15 >> 2);
-          const int k1 = k0 + 4;
-          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) bf16x4*)(sub + k0 * 256 + ((mblk ^ tr_sw(k0)) << 5) + ((l15 & 3) << 3)));
-          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) bf16x4*)(sub + k1 * 256 + ((mblk ^ tr_sw(k1)) << 5) + ((l15 & 3) << 3)));
-          af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-        if (!BTR) {
-          const int row = wn * 64 + i * 16 + l15;
-          bfr[i] = *(const bf16x8*)(sb + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
-        } else {
-          const int nblk = (wn * 64 + i * 16) >> 4;
-          const int k0 = ks * 32 + 8 * lg + (l15 >> 2);
-          const int k1 = k0 + 4;
-          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) bf16x4*)(sb + k0 * 256 + ((nblk ^ tr_sw(k0)) << 5) + ((l15 & 3) << 3)));
-          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) bf16x4*)(sb + k1 * 256 + ((nblk ^ tr_sw(k1)) << 5) + ((l15 & 3) << 3)));
-          bfr[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
+    if (!BTR) {
+      const int row = wn * 64 + i * 16 + l15;
+      return *(const bf16x8*)(sb + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
+    } else {
+      const int nblk = (wn * 64 + i * 16) >> 4;
+      const int k0 = ks * 32 + 8 * lg + (l15 >> 2);
+      const int k1 = k0 + 4;
+      bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) bf16x4*)(sb + k0 * 256 + ((nblk ^ tr_sw(k0)) << 5) + ((l15 & 3) << 3)));
+      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) bf16x4*)(sb + k1 * 256 + ((nblk ^ tr_sw(k1)) << 5) + ((l15 & 3) << 3)));
+      return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
   };
 
-  // ---- 3-stage ring: tiles kt+1 and kt+2 are in flight while tile kt is multiplied
+  // ---- K loop.  NSTAGE-deep LDS ring filled by LDS-DMA; the fragments of one contraction half are read from LDS while
+  // the MFMAs of the previous half run (two register sets), and the DMA pieces of the tile NSTAGE steps ahead are spread
+  // between the MFMA groups (the texture addresser takes 16 clk per 1 KiB piece: a wave that issues its pieces back to
+  // back stalls there).  One s_barrier per K step, in the middle:
+  //   phase A (step kt): read F1 <- stage[kt] half 1 | MFMA F0 | vmcnt, lgkmcnt(0), barrier
+  //   phase B          : read F0 <- stage[kt+1] half 0 | MFMA F1 | DMA of tile kt+NSTAGE (into stage[kt], free now)
+  // At the barrier every wave's reads of stage[kt] have returned and its pieces of tile kt+1 have landed (the younger
+  // DMA are those of tiles kt+2 .. kt+NSTAGE-1).  sched_barrier(0) pins the interleave.
+#define SB() __builtin_amdgcn_sched_barrier(0)
   if (nk > 0) {
-    issue_tile(0);
-    if (nk > 1) issue_tile(1);
+    bf16x8 a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+    for (int t = 0; t < NSTAGE; ++t) {
+      if (t < nk) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) issue_q(q);
+      }
+    }
+    wait_tiles((nk < NSTAGE ? nk : NSTAGE) - 1);
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* st = smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a0[i] = read_a(st, 0, i); b0[i] = read_b(st, 0, i); }
+    constexpr int S0 = (NQ + 2) / 3, S1 = (NQ + 1) / 3;     // DMA pieces per MFMA group: 2,2,2 or 3,3,2
     for (int kt = 0; kt < nk; ++kt) {
-      // this wave's pieces of tile kt have landed once at most one younger tile (NA+NB pieces) is outstanding
-      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();     // every wave's pieces landed; every wave is done reading stage (kt-1) % 3
-      if (kt + 2 < nk) issue_tile(kt + 2);
-      compute_tile(kt);
+      const unsigned char* st_next = (st == smem + (NSTAGE - 1) * STAGE_BYTES) ? smem : st + STAGE_BYTES;
+      const bool more = kt + NSTAGE < nk;
+      // ---------------- phase A
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b1[j] = read_b(st, 1, j);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[0][j] = mfma16<F16>(a0[0], b0[j], acc[0][j]);
+      SB();
+      a1[0] = read_a(st, 1, 0); a1[1] = read_a(st, 1, 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[1][j] = mfma16<F16>(a0[1], b0[j], acc[1][j]);
+      SB();
+      a1[2] = read_a(st, 1, 2); a1[3] = read_a(st, 1, 3);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[2][j] = mfma16<F16>(a0[2], b0[j], acc[2][j]);
+      SB();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[3][j] = mfma16<F16>(a0[3], b0[j], acc[3][j]);
+      SB();
+      {
+        const int rem = nk - 2 - kt;
+        wait_tiles(rem < 0 ? 0 : (rem > NSTAGE - 2 ? NSTAGE - 2 : rem));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      SB();
+      // ---------------- phase B
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b0[j] = read_b(st_next, 0, j);
+      if (more) {
+#pragma unroll
+        for (int q = 0; q < S0; ++q) issue_q(q);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[0][j] = mfma16<F16>(a1[0], b1[j], acc[0][j]);
+      SB();
+      a0[0] = read_a(st_next, 0, 0); a0[1] = read_a(st_next, 0, 1);
+      if (more) {
+#pragma unroll
+        for (int q = S0; q < S0 + S1; ++q) issue_q(q);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[1][j] = mfma16<F16>(a1[1], b1[j], acc[1][j]);
+      SB();
+      a0[2] = read_a(st_next, 0, 2); a0[3] = read_a(st_next, 0, 3);
+      if (more) {
+#pragma unroll
+        for (int q = S0 + S1; q < NQ; ++q) issue_q(q);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[2][j] = mfma16<F16>(a1[2], b1[j], acc[2][j]);
+      SB();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[3][j] = mfma16<F16>(a1[3], b1[j], acc[3][j]);
+      SB();
+      st = st_next;
     }
   }
+#undef SB
   __syncthreads();
 
   // ---- epilogue, 128 rows per pass through an fp32 LDS tile
@@ -235,7 +360,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm2_kernel(const GemmArgs g) {
   float* ws = d.splits > 1 ? (float*)d.workspace + ((int64_t)split * gridDim.y + z) * ((int64_t)M * N) : nullptr;
 
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int pass = 0; pass < BM / 128; ++pass) {
     if ((wm >> 1) == pass) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -247,8 +372,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm2_kernel(const GemmArgs g) {
     }
     __syncthreads();
     if (gn < N) {
-      for (int p = 0; p < 4; ++p) {
-        const int row = p * 32 + (tid >> 4);
+      for (int p = 0; p < 128 / (NTHREADS / 16); ++p) {
+        const int row = p * (NTHREADS / 16) + (tid >> 4);
         const int gm = m0 + pass * 128 + row;
         if (gm >= M) continue;
         const f32x4 lo = *(const f32x4*)(cs + row * CS_LD + cg * 8);
@@ -277,14 +402,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm2_kernel(const GemmArgs g) {
 }  // namespace
 
 int ttsk_launch_gemm2(const GemmArgs& g, bool atr, bool btr, bool f16, hipStream_t s) {
-  dim3 grid(g.tiles_m * g.tiles_n, g.d.nz1 * g.d.nz2, g.d.splits), block(NTHREADS);
-  if (atr) hipLaunchKernelGGL((gemm2_kernel<true, true, false>), grid, block, 0, s, g);
+  constexpr int BM = 256;
+  dim3 grid(g.tiles_m * g.tiles_n, g.d.nz1 * g.d.nz2, g.d.splits), block(Cfg<BM>::NTHREADS);
+  if (atr) hipLaunchKernelGGL((gemm2_kernel<BM, true, true, false>), grid, block, 0, s, g);
   else if (btr) {
-    if (f16) hipLaunchKernelGGL((gemm2_kernel<false, true, true>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm2_kernel<false, true, false>), grid, block, 0, s, g);
+    if (f16) hipLaunchKernelGGL((gemm2_kernel<BM, false, true, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm2_kernel<BM, false, true, false>), grid, block, 0, s, g);
   } else {
-    if (f16) hipLaunchKernelGGL((gemm2_kernel<false, false, true>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm2_kernel<false, false, false>), grid, block, 0, s, g);
+    if (f16) hipLaunchKernelGGL((gemm2_kernel<BM, false, false, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm2_kernel<BM, false, false, false>), grid, block, 0, s, g);
   }
   return 0;
 }

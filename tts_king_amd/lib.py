@@ -8,7 +8,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libttsk_hip.so")
+LIB_PATH = os.environ.get("TTSK_LIB_PATH") or os.path.join(_HERE, "libttsk_hip.so")   # the override is for diagnostic builds (tools/debug)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ttsk.h")
 
 

@@ -59,28 +59,43 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   // ---- per-thread staging coordinates (4 x 16 B per operand per K tile)
   // normal operand tile [128 rows][64 k]: chunk c = tid + 256 i -> row = c >> 3, slot = c & 7
   // transposed operand tile [64 k][128 m]: chunk c -> krow = c >> 4, slot16 = c & 15
+  // Everything that does not change along K is folded into per-chunk values here (byte offset at k = 0 / tap 0, a
+  // validity bit per tap for the conv zero padding), so the K loop spends a few VALU instructions per load.
   const int nrow = tid >> 3, nslot = tid & 7;      // + 32 i rows
   const int trow = tid >> 4, tslot = tid & 15;     // + 16 i krows
-  int a_off[4], b_off[4];                          // byte offsets of this thread's 4 chunks at k = 0, tap 0 (OOB if never valid)
-  int a_t[4];                                      // conv-A: position of row inside its segment
+  int a_off[4], b_off[4], b_tt[4];
+  unsigned a_ok[4], b_ok[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (!ATR) {
       const int gm = m0 + nrow + 32 * i;
-      a_off[i] = gm < M ? (gm * d.lda + nslot * 8) * 2 : OOB;
-      a_t[i] = conv_a ? gm % d.seg_len : 0;
+      a_off[i] = (gm * d.lda + nslot * 8) * 2;
+      unsigned okm = 0;
+      if (gm < M) {
+        if (conv_a) {
+          const int t = gm % d.seg_len;
+          for (int tp = 0; tp < taps; ++tp) {
+            const int tt = t + d.tap_shift0 + tp * d.tap_dshift;
+            okm |= (tt >= 0 && tt < d.seg_len) ? (1u << (tp & 31)) : 0u;
+          }
+        } else okm = 1u;
+      }
+      a_ok[i] = okm;
     } else {
       const int mcol = m0 + tslot * 8;
-      a_off[i] = mcol < M ? ((trow + 16 * i) * d.lda + mcol) * 2 : OOB;
-      a_t[i] = 0;
+      a_off[i] = ((trow + 16 * i) * d.lda + mcol) * 2;
+      a_ok[i] = mcol < M ? 1u : 0u;
     }
     if (!BTR) {
       const int gn = n0 + nrow + 32 * i;
-      b_off[i] = gn < N ? (gn * d.ldb + nslot * 8) * 2 : OOB;
+      b_off[i] = (gn * d.ldb + nslot * 8) * 2;
+      b_ok[i] = gn < N ? 1u : 0u;
     } else {
       const int ncol = n0 + tslot * 8;
-      b_off[i] = ncol < N ? ((trow + 16 * i) * d.ldb + ncol) * 2 : OOB;
+      b_off[i] = ((trow + 16 * i) * d.ldb + ncol) * 2;
+      b_ok[i] = ncol < N ? 1u : 0u;
     }
+    b_tt[i] = 0;
   }
 
   const int kc_begin = split * g.chunks_per_split;
@@ -89,64 +104,94 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   const int per = kc_end > kc_begin ? kc_end - kc_begin : 0;
   const int nk = per * taps;
 
-  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
   const float in_slope = d.in_slope;
   const bool lrelu_in = d.flags & TTSK_GEMM_LRELU_IN;
+  const bool bseg = BTR && d.bseg_len > 0;
+  const bool wide_taps = taps > 32;                 // the per-tap validity bits cover 32 taps; beyond that, test on the fly
 
+  // load state: the next tile to load is chunk kc_begin + ld_kk of tap ld_tap
+  int ld_tap = 0, ld_kk = 0;
+  auto reset_btt = [&]() __attribute__((always_inline)) {   // position inside its utterance of the chunk's k-row (dW of a conv)
+    if (bseg) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b_tt[i] = (kc_begin * BK + trow + 16 * i) % d.bseg_len;
+    }
+  };
+  reset_btt();
+
+  struct Regs { uint4 a[4], b[4]; };
 #define TTSK_LD(rs, off) __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0))
-  auto load_tile = [&](int kt) __attribute__((always_inline)) {
-    const int tap = kt / per;
-    const int kbase = (kc_begin + (kt - tap * per)) * BK;
+  auto load_tile = [&](Regs& R) __attribute__((always_inline)) {
+    const int kbase = (kc_begin + ld_kk) * BK;
     int oa[4], ob[4];
     if (!ATR) {
-      const int shift = conv_a ? d.tap_shift0 + tap * d.tap_dshift : 0;
+      const int shift = conv_a ? d.tap_shift0 + ld_tap * d.tap_dshift : 0;
       const int add = (shift * d.lda + kbase) * 2;
       const bool kok = kbase + nslot * 8 < K8;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int tt = a_t[i] + shift;
-        const bool ok = kok && (!conv_a || (tt >= 0 && tt < d.seg_len));
-        oa[i] = (ok && a_off[i] != OOB) ? a_off[i] + add : OOB;
+        bool ok = kok && ((a_ok[i] >> (ld_tap & 31)) & 1u);
+        if (wide_taps) {   // recompute exactly (rare: > 32 taps)
+          const int tt = (m0 + nrow + 32 * i) % d.seg_len + shift;
+          ok = kok && a_ok[i] != 0 && tt >= 0 && tt < d.seg_len;
+        }
+        oa[i] = ok ? a_off[i] + add : OOB;
       }
     } else {
       const int add = kbase * d.lda * 2;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) oa[i] = (kbase + trow + 16 * i < K && a_off[i] != OOB) ? a_off[i] + add : OOB;
+      for (int i = 0; i < 4; ++i) oa[i] = (kbase + trow + 16 * i < K && a_ok[i]) ? a_off[i] + add : OOB;
     }
-    const int tapoff = tap * (int)d.b_tap_stride;
+    const int tapoff = ld_tap * (int)d.b_tap_stride;
     if (!BTR) {
       const bool kok = kbase + nslot * 8 < K8;
       const int add = (tapoff + kbase) * 2;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ob[i] = (kok && b_off[i] != OOB) ? b_off[i] + add : OOB;
+      for (int i = 0; i < 4; ++i) ob[i] = (kok && b_ok[i]) ? b_off[i] + add : OOB;
     } else {
       const int add = ((kbase + bshift) * d.ldb + tapoff) * 2;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int kk = kbase + trow + 16 * i;
-        bool ok = kk < K && b_off[i] != OOB;
-        if (d.bseg_len > 0) { const int tt = kk % d.bseg_len + bshift; ok = ok && tt >= 0 && tt < d.bseg_len; }
+        bool ok = kbase + trow + 16 * i < K && b_ok[i];
+        if (bseg) ok = ok && (unsigned)(b_tt[i] + bshift) < (unsigned)d.bseg_len;
         ob[i] = ok ? b_off[i] + add : OOB;
       }
     }
-    ra0 = TTSK_LD(rsA, oa[0]); ra1 = TTSK_LD(rsA, oa[1]); ra2 = TTSK_LD(rsA, oa[2]); ra3 = TTSK_LD(rsA, oa[3]);
-    rb0 = TTSK_LD(rsB, ob[0]); rb1 = TTSK_LD(rsB, ob[1]); rb2 = TTSK_LD(rsB, ob[2]); rb3 = TTSK_LD(rsB, ob[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) R.a[i] = TTSK_LD(rsA, oa[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) R.b[i] = TTSK_LD(rsB, ob[i]);
+    // advance to the next tile
+    if (++ld_kk == per) {
+      ld_kk = 0;
+      ++ld_tap;
+      reset_btt();
+    } else if (bseg) {
+      if (d.bseg_len >= BK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { b_tt[i] += BK; b_tt[i] -= b_tt[i] >= d.bseg_len ? d.bseg_len : 0; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b_tt[i] = (b_tt[i] + BK) % d.bseg_len;
+      }
+    }
   };
 #undef TTSK_LD
 
-  auto store_tile = [&](int buf) __attribute__((always_inline)) {
+  auto store_tile = [&](int buf, Regs& R) __attribute__((always_inline)) {
     unsigned char* sa = smem + buf * STAGE_BYTES;
     unsigned char* sb = sa + BM * BK * 2;
-    if (lrelu_in && !ATR) { ra0 = lrelu8<F16>(ra0, in_slope); ra1 = lrelu8<F16>(ra1, in_slope); ra2 = lrelu8<F16>(ra2, in_slope); ra3 = lrelu8<F16>(ra3, in_slope); }
-#define TTSK_ST(i, RA, RB)                                                                                        \
-    {                                                                                                             \
-      if (!ATR) { const int row = nrow + 32 * i; *(uint4*)(sa + row * 128 + ((nslot ^ (row & 7)) << 4)) = RA; }     \
-      else { const int kr = trow + 16 * i; *(uint4*)(sa + kr * 256 + (((tslot >> 1) ^ tr_sw(kr)) << 5) + ((tslot & 1) << 4)) = RA; } \
-      if (!BTR) { const int row = nrow + 32 * i; *(uint4*)(sb + row * 128 + ((nslot ^ (row & 7)) << 4)) = RB; }     \
-      else { const int kr = trow + 16 * i; *(uint4*)(sb + kr * 256 + (((tslot >> 1) ^ tr_sw(kr)) << 5) + ((tslot & 1) << 4)) = RB; } \
+    if (lrelu_in && !ATR) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) R.a[i] = lrelu8<F16>(R.a[i], in_slope);
     }
-    TTSK_ST(0, ra0, rb0) TTSK_ST(1, ra1, rb1) TTSK_ST(2, ra2, rb2) TTSK_ST(3, ra3, rb3)
-#undef TTSK_ST
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!ATR) { const int row = nrow + 32 * i; *(uint4*)(sa + row * 128 + ((nslot ^ (row & 7)) << 4)) = R.a[i]; }
+      else { const int kr = trow + 16 * i; *(uint4*)(sa + kr * 256 + (((tslot >> 1) ^ tr_sw(kr)) << 5) + ((tslot & 1) << 4)) = R.a[i]; }
+      if (!BTR) { const int row = nrow + 32 * i; *(uint4*)(sb + row * 128 + ((nslot ^ (row & 7)) << 4)) = R.b[i]; }
+      else { const int kr = trow + 16 * i; *(uint4*)(sb + kr * 256 + (((tslot >> 1) ^ tr_sw(kr)) << 5) + ((tslot & 1) << 4)) = R.b[i]; }
+    }
   };
 
   f32x4 acc[4][4];
@@ -202,16 +247,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
     }
   };
 
+  // ---- K loop: two register sets, so the global loads of tiles kt+1 and kt+2 are in flight while tile kt is
+  // multiplied (a lone workgroup on its CU was latency-bound at one tile in flight: 1.0 us per K step against 0.25 us
+  // of MFMA); LDS is double-buffered, one barrier per K tile.
   if (nk > 0) {
-    load_tile(0);
-    store_tile(0);
+    Regs R0, R1;
+    load_tile(R0);
+    if (nk > 1) load_tile(R1);
+    store_tile(0, R0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const bool more = kt + 1 < nk;
-      if (more) load_tile(kt + 1);
-      compute_tile(kt & 1);
-      if (more) store_tile((kt + 1) & 1);
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 2 < nk) load_tile(R0);
+      compute_tile(0);
+      if (kt + 1 < nk) store_tile(1, R1);
       __syncthreads();
+      if (kt + 1 < nk) {
+        if (kt + 3 < nk) load_tile(R1);
+        compute_tile(1);
+        if (kt + 2 < nk) store_tile(0, R0);
+        __syncthreads();
+      }
     }
   }
 

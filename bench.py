@@ -90,6 +90,25 @@ def hifi_cpu_baseline(cfg, B=8, T=384, runs=1):
             "sample": "%d run(s) of the same B=%d, T=%d batch, fp32" % (runs, B, T)}
 
 
+def pmc_traffic(symbol):
+    """HBM bytes per launch of `symbol` from the newest committed PMC summary (profiles/r*_pmc_traffic.json, written by
+    tools/pmc_bench.sh + tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
+    bench command; counters cannot be collected from inside the timed process).  None when there is no summary for it."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            doc = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        for r in doc.get("kernels", []):
+            if symbol in r["kernel"]:
+                return {"hbm_bytes_per_launch": r["hbm_bytes_per_launch"],
+                        "source": "%s: FETCH_SIZE x2 %.1f MB + WRITE_SIZE %.1f MB per launch, %d dispatches" % (
+                            os.path.relpath(f, here), r["fetch_bytes_per_launch"] / 1e6, r["write_bytes_per_launch"] / 1e6, r["dispatches"])}
+    return None
+
+
 def gemm_roofline(enqueue, batch, steps=3):
     """Roofline of the dominant kernel of the step.  Every ttsk_gemm launch of `steps` eager train steps is bracketed by
     HIP events on its launch stream (tts_king_amd/ops.py:GEMM_TRACE); launches are grouped by kernel symbol (tile
@@ -119,8 +138,10 @@ def gemm_roofline(enqueue, batch, steps=3):
     dk, dv = max(by_sym.items(), key=lambda kv: kv[1][1])      # dominant = most algorithmic FLOPs (decoder FFN / PostNet convs)
     sk, sv = max(((k, v) for k, v in by_shape.items() if k[0] == dk), key=lambda kv: kv[1][0])
     ach = dv[1] / (dv[0] * 1e-3) / 1e12
+    traffic = pmc_traffic(sym.get(dk, dk))
     return {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_BF16_TFLOPS,
-            "traffic": None,
+            "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+            "traffic_source": traffic["source"] if traffic else None,
             "kernel": "%s (tts_king_amd/csrc/gemm%s.hip)" % (sym.get(dk, dk), "2" if dk.endswith("2") else ""),
             "launches_per_step": dv[2] // steps, "avg_launch_us": 1e3 * dv[0] / dv[2], "avg_launch_gflop": dv[1] / dv[2] / 1e9,
             "kernel_ms_per_step": dv[0] / steps,

@@ -90,6 +90,46 @@ def hifi_cpu_baseline(cfg, B=8, T=384, runs=1):
             "sample": "%d run(s) of the same B=%d, T=%d batch, fp32" % (runs, B, T)}
 
 
+def mel_extraction_leg(cfg, dev, B=16, T=423, iters=20, with_cpu=True):
+    """SURVEY §8 row f-3 beside the two headline workloads: log-mel + energy of the FS2 batch's audio (B utterances of
+    T frames, 22.05 kHz) through tts_king_amd/audio.py, device time by HIP events on the launch stream, and the oracle
+    (torch.stft, CPU fp32) on a bounded sample.  FLOPs: the three hi/lo STFT contractions, 3 * 2 * frames * 1032 * 1024."""
+    from tts_king_amd.audio import TacotronSTFT
+    p = cfg.preprocess_config["preprocessing"]
+    n_fft, hop, win = p["stft"]["filter_length"], p["stft"]["hop_length"], p["stft"]["win_length"]
+    n_mel, sr, fmin, fmax = p["mel"]["n_mel_channels"], p["audio"]["sampling_rate"], p["mel"]["mel_fmin"], p["mel"]["mel_fmax"]
+    g = torch.Generator().manual_seed(1234)
+    y = (torch.rand(B, (T - 1) * hop, generator=g) * 2 - 1) * 0.5
+    stft = TacotronSTFT(n_fft, hop, win, n_mel, sr, fmin, fmax, device=dev)
+    yd = y.to(dev)
+    for _ in range(3):
+        stft._ex(yd)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        mel, energy = stft._ex(yd)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    frames = B * mel.shape[2]
+    flops = 3 * 2.0 * B * (mel.shape[2] + 3) * 1032 * n_fft
+    rec = {"workload": "log-mel + energy, B=%d x %d frames (n_fft %d, hop %d, %d mels, %d Hz)" % (B, mel.shape[2], n_fft, hop, n_mel, sr),
+           "frames_per_s": frames / (ms * 1e-3), "ms_per_batch": ms, "audio_seconds_per_batch": B * y.shape[1] / float(sr),
+           "tflops": flops / (ms * 1e-3) / 1e12, "dtype": "fp16 hi/lo split operands, fp32 accumulate", "launch": "eager, 3 kernels"}
+    if with_cpu:
+        from oracle import audio as oaudio
+        torch.set_num_threads(host_threads())
+        oaudio.tacotron_mel(y[:1], n_fft, hop, win, n_mel, sr, fmin, fmax)
+        t0 = time.perf_counter()
+        ref_mel, _ = oaudio.tacotron_mel(y, n_fft, hop, win, n_mel, sr, fmin, fmax)
+        dt = time.perf_counter() - t0
+        rec["max_abs_vs_oracle"] = float((mel.cpu() - ref_mel).abs().max())
+        rec["cpu_baseline"] = {"value": frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "1 run of the same batch (conv-STFT oracle, fp32), %.3f s" % dt}
+    return rec
+
+
 def pmc_traffic(symbol):
     """HBM bytes per launch of `symbol` from the newest committed PMC summary (profiles/r*_pmc_traffic.json, written by
     tools/pmc_bench.sh + tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
@@ -160,6 +200,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hifi", action="store_true")
+    ap.add_argument("--no-mel", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -265,6 +306,8 @@ def main():
                 rec["hifi_gan"] = hifi_rtf(cfg, dev)
             except ImportError:
                 rec["hifi_gan"] = None
+        if world == 1 and not args.no_mel:
+            rec["mel_extraction"] = mel_extraction_leg(cfg, dev, with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(cfg, B, L)
             if rec.get("hifi_gan"):

@@ -313,6 +313,22 @@ int ttsk_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_
                         void* stream);
 int ttsk_grad_sumsq(const float* grads, int64_t n, float* partials, void* stream);
 
+/* ------------------------------------------------------------------------------------------- mel extraction
+ * SURVEY.md §8 row f-3.  reference: hifi/meldataset.py:49-74 (mel_spectrogram), fs_two/audio/stft.py:57-90
+ * (STFT.transform: strided conv with a windowed Fourier basis), :174-193 (TacotronSTFT.mel_spectrogram).
+ * The contraction is a ttsk_gemm conv (taps = n_fft/hop over rows of `hop` samples); these are the kernels around it.
+ * stft_frames: wav (B, len) fp32 -> hop-block rows out16 fp16 (B, rows, 3*hop) = [hi | hi | lo]: reflect padding by `pad`
+ *   samples on both sides, zeros past len + 2*pad, value*scale split as hi + lo (fp16 each); against a basis laid out
+ *   [hi | lo | hi] per tap one contraction gives hi*hi + hi*lo + lo*hi.  hop % 8 == 0, pad < len.
+ * mel_from_spec: spec (B*rows, ld) fp32 with Re in columns [0, nbins) and Im in [nbins, 2*nbins) ->
+ *   mel (B, n_mels, T) = log(max(basis . sqrt(re^2 + im^2 + eps), clip)), energy (B, T) = sqrt(sum re^2 + im^2).
+ *   The filterbank is passed packed: filter m = basis_vals[basis_off[m] .. basis_off[m+1]) applied to bins
+ *   basis_start[m] ..; nnz = basis_off[n_mels].  nbins <= 1088, n_mels <= 80. */
+int ttsk_stft_frames(const float* wav, void* out16, int B, int len, int pad, int rows, int hop, float scale, void* stream);
+int ttsk_mel_from_spec(const float* spec, int ld, const float* basis_vals, const int32_t* basis_start,
+                       const int32_t* basis_off, int nnz, float* mel, float* energy, int B, int rows, int T, int nbins,
+                       int n_mels, float eps, float clip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -272,7 +272,48 @@ def g10_collate():
     print("G10 collate", {k: int(v) for k, v in res.items() if k.endswith("/n")})
 
 
+def mel_test_signal(Bsz=2, n=8192, seed=5):
+    """Seeded test waveform: a few partials, a chirp, noise, and a 40 dB quieter second half (values in [-1, 1])."""
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(n, dtype=torch.float64) / 22050.0
+    rows = []
+    for b in range(Bsz):
+        y = 0.3 * torch.sin(2 * np.pi * (220.0 * (b + 1)) * t) + 0.2 * torch.sin(2 * np.pi * 3100.0 * t + 0.5)
+        y = y + 0.2 * torch.sin(2 * np.pi * (500.0 + 9000.0 * t) * t) + 0.05 * (torch.rand(n, generator=g, dtype=torch.float64) * 2 - 1)
+        env = torch.ones(n, dtype=torch.float64)
+        env[n // 2:] = 0.01
+        rows.append((y * env).clamp(-1, 1))
+    return torch.stack(rows).float()
+
+
+def g11_mel():
+    """Mel extraction.  Neither reference function runs here as written (hifi/meldataset.py:64 calls
+    torch.stft without `return_complex`, which current torch rejects; fs_two/audio/stft.py:77 hard-codes .cuda(3)), and
+    librosa is absent.  The golden therefore comes from torch.stft itself with the reference's arguments
+    (meldataset.py:57-66) + the librosa filterbank as restated in oracle/audio.py (pinned there by librosa's docstring
+    known answers), and from F.conv1d with the reference's windowed Fourier basis for the TacotronSTFT variant."""
+    from oracle import audio as OA
+    p = cfg.preprocess_config.preprocessing
+    n_fft, hop, win = p.stft.filter_length, p.stft.hop_length, p.stft.win_length
+    n_mel, sr, fmin, fmax = p.mel.n_mel_channels, p.audio.sampling_rate, p.mel.mel_fmin, p.mel.mel_fmax
+    y = mel_test_signal()
+    basis = torch.from_numpy(OA.mel_filterbank(sr, n_fft, n_mel, fmin, fmax))
+    pad = int((n_fft - hop) / 2)
+    yp = torch.nn.functional.pad(y.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+    spec = torch.stft(yp, n_fft, hop_length=hop, win_length=win, window=torch.hann_window(win), center=False,
+                      pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+    spec = torch.sqrt(torch.view_as_real(spec).pow(2).sum(-1) + 1e-9)
+    mel_hifi = torch.log(torch.clamp(torch.matmul(basis, spec), min=1e-5))
+    mel_taco, energy = OA.tacotron_mel(y, n_fft, hop, win, n_mel, sr, fmin, fmax)
+    np.savez_compressed(os.path.join(OUT, "mel_extraction.npz"), y=npy(y), mel_hifi=npy(mel_hifi), mel_taco=npy(mel_taco),
+                        energy=npy(energy), params=np.array([n_fft, hop, win, n_mel, sr, fmin, fmax], dtype=np.float64))
+    print("G11 mel", tuple(mel_hifi.shape), tuple(mel_taco.shape), float(mel_hifi.min()), float(mel_hifi.max()))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "mel":
+        g11_mel()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "text":
         g9_text()
         sys.exit(0)
@@ -288,3 +329,4 @@ if __name__ == "__main__":
     g8_shapes()
     g9_text()
     g10_collate()
+    g11_mel()

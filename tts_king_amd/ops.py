@@ -623,3 +623,24 @@ def hifi_conv_window(x, w_pack, bias, K, dilation=1, R=None, out2=None, lrelu_ou
     check(L.load().ttsk_hifi_conv_window(_ptr(x), _ptr(w_pack), _ptr(bias), _ptr(R), _ptr(out), _ptr(out2), int(x.dtype == f16), Bn, ln,
                                          Cn, K, dilation, int(lrelu_out), slope, _stream()), "ttsk_hifi_conv_window")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------- mel extraction (f-3)
+
+def stft_frames(wav, pad, rows, hop, scale):
+    """wav (B, len) fp32 -> fp16 (B, rows, 3*hop) = [hi | hi | lo]: reflect-padded, scaled hop-block rows split as hi + lo."""
+    _dev(wav)
+    Bsz, n = wav.shape
+    out = torch.empty(Bsz, rows, 3 * hop, dtype=f16, device=wav.device)
+    check(L.load().ttsk_stft_frames(_ptr(wav), _ptr(out), Bsz, n, pad, rows, hop, scale, _stream()), "ttsk_stft_frames")
+    return out
+
+
+def mel_from_spec(spec, Bsz, rows, T, nbins, vals, start, off, nnz, n_mels, eps, clip=1e-5):
+    """spec (B*rows, ld) fp32 [Re | Im] -> log-mel (B, n_mels, T), energy (B, T)."""
+    _dev(spec, vals, start, off)
+    mel = torch.empty(Bsz, n_mels, T, dtype=torch.float32, device=spec.device)
+    energy = torch.empty(Bsz, T, dtype=torch.float32, device=spec.device)
+    check(L.load().ttsk_mel_from_spec(_ptr(spec), spec.stride(0), _ptr(vals), _ptr(start), _ptr(off), nnz, _ptr(mel),
+                                      _ptr(energy), Bsz, rows, T, nbins, n_mels, eps, clip, _stream()), "ttsk_mel_from_spec")
+    return mel, energy

@@ -130,6 +130,72 @@ def mel_extraction_leg(cfg, dev, B=16, T=423, iters=20, with_cpu=True):
     return rec
 
 
+def e2e_synth_leg(cfg, dev, L=64, iters=20, with_cpu=True):
+    """BASELINE.json configs[4]: one utterance phoneme ids -> mel -> int16 waveform on the host, through the replayed
+    hipGraphs of tts_king_amd/synth.py (what `TTSKing.generate_mel` + `mel_to_wav` run with `mi355x.hip_graph: true`) and
+    through plain launches.  Synthetic weights predict zero durations, so the duration head's bias is set to log(7.6):
+    64 phonemes -> ~420 frames, the training batch's utterance length."""
+    import math
+    import numpy as np
+    from tts_king_amd import ops
+    from tts_king_amd.fastspeech2 import FastSpeech2
+    from tts_king_amd.hifi_bench import build_generator
+    from tts_king_amd.synth import GraphedSynthesizer
+    model = FastSpeech2(cfg.preprocess_config, cfg.model_config, 65, device=dev, seed=1234).eval()
+    sd = model.state_dict()
+    sd["variance_adaptor.duration_predictor.linear_layer.bias"].fill_(math.log(7.6))
+    sd["variance_adaptor.duration_predictor.linear_layer.weight"].zero_()
+    model.load_state_dict(sd)
+    gen = build_generator(cfg, dev)
+    synth = GraphedSynthesizer(model, gen)
+    g = torch.Generator().manual_seed(1234)
+    texts = torch.randint(1, 200, (1, L), generator=g).to(dev)
+    spk = torch.zeros(1, dtype=torch.int64, device=dev)
+    scale = float(cfg.hifi.MAX_WAV_VALUE)
+
+    def graphed():
+        post, lens = synth.mel(spk, texts)
+        wav = synth.wav(post.transpose(1, 2))
+        return ops.to_int16(wav, scale).cpu(), int(lens[0])
+
+    def eager():
+        with torch.no_grad():
+            sl = torch.full((1,), L, dtype=torch.int64, device=dev)
+            x3, dur, total, _ = model.eval_front(spk, texts, sl, L, 1.0, 1.0, 1.0)
+            T = max(int(total.max().item()), 1)
+            _, post, lens, _ = model.eval_back(x3, dur, L, T)
+            wav = gen(post.transpose(1, 2).contiguous())
+            return ops.to_int16(wav, scale).cpu(), int(lens[0])
+
+    out = {}
+    for name, fn in (("hipgraph", graphed), ("eager", eager)):
+        for _ in range(3):
+            pcm, T = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            pcm, T = fn()
+        out[name] = (time.perf_counter() - t0) / iters
+    audio_s = T * 256 / float(cfg.hifi.sampling_rate)
+    rec = {"workload": "tts_king synth, 1 utterance: %d phonemes -> %d mel frames -> %d int16 samples on the host (BASELINE.json configs[4])" % (L, T, pcm.shape[-1]),
+           "latency_ms": 1e3 * out["hipgraph"], "latency_ms_eager": 1e3 * out["eager"], "rtf": out["hipgraph"] / audio_s,
+           "audio_seconds": audio_s, "launch": "3 replayed hipGraphs + 1 host read of the frame count + int16 D2H"}
+    if with_cpu:
+        from oracle import fs2 as ofs2, hifigan as ohifi
+        torch.set_num_threads(host_threads())
+        sd_cpu = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+        hsd = ohifi.fold_weight_norm({k: v.detach().float().cpu().clone() for k, v in gen.state_dict().items()}) if any(
+            k.endswith("weight_g") for k in gen.state_dict()) else {k: v.detach().float().cpu().clone() for k, v in gen.state_dict().items()}
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            res = ofs2.fs2_forward(sd_cpu, cfg.model_config, spk.cpu(), texts.cpu(), torch.tensor([L]), L, train=False)
+            wav = ohifi.generator(hsd, cfg.hifi, res[9].transpose(1, 2))
+            dt = time.perf_counter() - t0
+        rec["cpu_baseline"] = {"value": 1e3 * dt, "unit": "ms per utterance", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "1 utterance, fp32 oracle FS2 eval + HiFi-GAN", "rtf": dt / audio_s}
+    return rec
+
+
 def pmc_traffic(symbol):
     """HBM bytes per launch of `symbol` from the newest committed PMC summary (profiles/r*_pmc_traffic.json, written by
     tools/pmc_bench.sh + tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
@@ -201,6 +267,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hifi", action="store_true")
     ap.add_argument("--no-mel", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -306,6 +373,8 @@ def main():
                 rec["hifi_gan"] = hifi_rtf(cfg, dev)
             except ImportError:
                 rec["hifi_gan"] = None
+        if world == 1 and not args.no_e2e:
+            rec["e2e_synth"] = e2e_synth_leg(cfg, dev, with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_mel:
             rec["mel_extraction"] = mel_extraction_leg(cfg, dev, with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:

@@ -56,7 +56,7 @@ struct RbGeom {
   static constexpr int NC = C / 16;
   static constexpr int KS = C / 32;
   static constexpr int TAP_BYTES = NC * KS * 1024;     // one tap of weights in fragment order
-  static constexpr int GT = C == 32 ? K : 4;           // taps per weight stage
+  static constexpr int GT = C == 32 ? K : (TT > 136 ? 2 : 4);   // taps per weight stage (C = 64: 2 when the 3-slot tile needs the LDS)
   static constexpr int NS = (K + GT - 1) / GT;         // stages per conv
   static constexpr int WSTAGE = GT * TAP_BYTES;
   static constexpr int NLD = (WSTAGE + NT * 16 - 1) / (NT * 16);   // 16-byte loads per thread per stage
@@ -368,12 +368,15 @@ extern "C" int ttsk_hifi_resblock1(const void* x16, void* out16, int f16, const 
   hipStream_t s = (hipStream_t)stream;
   const int key = C * 100 + K;
   switch (key) {
+    // C = 64: TT = 3 frame tiles per wave * 8 waves * 16 - 2 * halo, so every multiplied tile is a needed one (384 rows,
+    // 147 KB of LDS; K = 11: 494 -> 401 us against TT = 128, whose 248-row tile multiplied 256).  C = 32 measured slower
+    // with exact-fit tiles (360 / 568 / 520: 111 / 151 / 188 us against 82 / 137 / 176) and keeps the power-of-two ones.
     case 3203: launch_rb<32, 3, 256, 8>(a, B, f16, s); break;
     case 3207: launch_rb<32, 7, 512, 8>(a, B, f16, s); break;
     case 3211: launch_rb<32, 11, 512, 8>(a, B, f16, s); break;
-    case 6403: launch_rb<64, 3, 128, 8>(a, B, f16, s); break;
-    case 6407: launch_rb<64, 7, 128, 8>(a, B, f16, s); break;
-    case 6411: launch_rb<64, 11, 128, 8>(a, B, f16, s); break;
+    case 6403: launch_rb<64, 3, 360, 8>(a, B, f16, s); break;
+    case 6407: launch_rb<64, 7, 312, 8>(a, B, f16, s); break;
+    case 6411: launch_rb<64, 11, 264, 8>(a, B, f16, s); break;
     default:
       ttsk_set_error("ttsk_hifi_resblock1: no fused instance for C=%d K=%d (C in {32,64}, K in {3,7,11})", C, K);
       return TTSK_EINVAL;

@@ -30,22 +30,6 @@ template <int BM_> struct Cfg {
   static constexpr int NQ = NA + NB;
 };
 
-typedef __attribute__((address_space(3))) void* lds_ptr;
-
-// one LDS-DMA piece: 64 lanes x 16 B from per-lane buffer offsets `voff` to the 1 KiB at LDS byte address `lds`
-// (wave-uniform, in an SGPR).  Issued from inline asm on purpose: hipcc counts a builtin LDS-DMA as a pending LDS write
-// and puts `s_waitcnt vmcnt(0)` before the first ds_read of every K step (measured: DMA, LDS reads and MFMA then ran
-// back to back, 1.0 us per K step for a lone workgroup whose DMA alone takes 0.6).  An asm load is invisible to that
-// bookkeeping; landing is ordered by the counted s_waitcnt vmcnt(N) + s_barrier in the K loop.  M0 (the DMA's LDS
-// destination) is compiler-reserved: saved and restored inside the statement.
-__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rs, unsigned lds, int voff) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(lds), "s"(rs)
-               : "memory");
-}
-
 template <int BM_, bool ATR, bool BTR, bool F16>
 __global__ __launch_bounds__(Cfg<BM_>::NTHREADS, 1) void gemm2_kernel(const GemmArgs g) {
   using CF = Cfg<BM_>;
@@ -347,56 +331,7 @@ __global__ __launch_bounds__(Cfg<BM_>::NTHREADS, 1) void gemm2_kernel(const Gemm
 #undef SB
   __syncthreads();
 
-  // ---- epilogue, 128 rows per pass through an fp32 LDS tile
-  float* cs = (float*)smem;
-  const int64_t coff = z1 * d.sC1 + z2 * d.sC2;
-  const int64_t roff = z1 * d.sR1 + z2 * d.sR2;
-  const int cg = tid & 15;
-  const int gn = n0 + cg * 8;
-  const int nvalid = (N - gn) < 8 ? (N - gn) : 8;
-  float bias[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias[e] = (d.bias && gn < N && e < nvalid && d.splits <= 1) ? d.bias[gn + e] : 0.f;
-  float* ws = d.splits > 1 ? (float*)d.workspace + ((int64_t)split * gridDim.y + z) * ((int64_t)M * N) : nullptr;
-
-#pragma unroll 1
-  for (int pass = 0; pass < BM / 128; ++pass) {
-    if ((wm >> 1) == pass) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            cs[((wm & 1) * 64 + i * 16 + lg * 4 + r) * CS_LD + wn * 64 + j * 16 + l15] = acc[i][j][r];
-    }
-    __syncthreads();
-    if (gn < N) {
-      for (int p = 0; p < 128 / (NTHREADS / 16); ++p) {
-        const int row = p * (NTHREADS / 16) + (tid >> 4);
-        const int gm = m0 + pass * 128 + row;
-        if (gm >= M) continue;
-        const f32x4 lo = *(const f32x4*)(cs + row * CS_LD + cg * 8);
-        const f32x4 hi = *(const f32x4*)(cs + row * CS_LD + cg * 8 + 4);
-        if (ws) {  // split-K: raw partial sums; the reducer applies the epilogue
-          float* wp = ws + (int64_t)gm * N + gn;
-          if (nvalid == 8 && (N & 3) == 0) {
-            *(f32x4*)wp = lo;
-            *(f32x4*)(wp + 4) = hi;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { if (e < nvalid) wp[e] = lo[e]; if (e + 4 < nvalid) wp[e + 4] = hi[e]; }
-          }
-        } else {
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[e + 4] = hi[e]; }
-          epilogue_store<F16>(d, coff, roff, gm, gn, nvalid, v, bias, z2);
-        }
-      }
-    }
-    __syncthreads();
-  }
+  tile_epilogue<BM, NTHREADS, F16>(d, smem, acc, m0, n0, z, z1, z2, split, wm, wn, lane, tid);
 }
 
 }  // namespace

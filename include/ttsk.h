@@ -111,6 +111,17 @@ typedef struct ttsk_reduce_item {
 } ttsk_reduce_item;
 int ttsk_gemm_reduce_batch(const ttsk_reduce_item* items, int n, void* stream);
 
+/* Grouped launch of n problems with the same operand layout (A_TR / B_TR / F16 flags) on the 128x128 configuration as ONE
+ * grid — for the many small contractions nothing waits for individually (the weight-gradient GEMMs of a backward pass:
+ * 32-256 workgroups each).  group_build validates and plans every descriptor (split-K workspaces as for ttsk_gemm) and
+ * writes a table of ttsk_gemm_group_table_bytes(n) bytes into HOST memory (pageable is fine); group_launch copies it into
+ * the caller's 16-byte aligned device buffer of the same size through kernel arguments (hipGraph-capturable, no pinned
+ * staging), runs the grid and then the reducers of split problems that do not carry TTSK_GEMM_DEFER_REDUCE.  Results are
+ * identical to n ttsk_gemm calls with kernel = 1. */
+int64_t ttsk_gemm_group_table_bytes(int n);
+int ttsk_gemm_group_build(const ttsk_gemm_desc* descs, int n, void* host_table, int32_t* total_wgs);
+int ttsk_gemm_group_launch(const void* host_table, void* dev_table, void* stream);
+
 /* what ttsk_gemm will run for `d` (with d->kernel / d->splits as constraints when non-zero) and the workspace it needs */
 int ttsk_gemm_plan(const ttsk_gemm_desc* d, int32_t* kernel, int32_t* splits, int64_t* workspace_bytes);
 

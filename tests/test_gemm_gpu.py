@@ -279,3 +279,39 @@ def test_k2_fp16_and_polyphase(kern):
     assert out.dtype == torch.float16
     err = float((out.float().cpu().double() - ref).abs().max())
     assert err <= 2e-6 * (Cin * k // s) ** 0.5 * float(ref.abs().max() + 1) + float(ref.abs().max()) * 2 ** -10, err
+
+
+def test_grouped_launch_equals_individual_launches():
+    """ttsk_gemm_group_*: weight-gradient GEMMs of different shapes (split-K with deferred reduce, accumulate, conv taps as
+    batch) queued in a DeferQueue produce bit-identical results to the same calls launched one by one on kernel 1."""
+    from tts_king_amd import ops
+    g = torch.Generator().manual_seed(11)
+    cases = [(1024, 256, 256, 1), (6768, 768, 256, 1), (423, 128, 64, 1), (2048, 512, 80, 5), (640, 256, 1024, 3)]
+    tensors = []
+    for rows, cout, cin, k in cases:
+        Bsz = 2 if k > 1 else 1
+        T = rows // Bsz
+        dy = bf(torch.randn(Bsz, T, cout, generator=g)).to(DEV)
+        x = bf(torch.randn(Bsz, T, cin, generator=g)).to(DEV)
+        tensors.append((dy, x, cout, cin, k))
+    outs = []
+    for mode in ("single", "grouped"):
+        q = ops.DeferQueue(group_gemms=(mode == "grouped"))
+        res = []
+        for dy, x, cout, cin, k in tensors:
+            dst = torch.full((cout, k, cin), 0.5, dtype=torch.float32, device=DEV)
+            if k == 1:
+                ops.linear_dw(dy.view(-1, cout), x.view(-1, cin), dst.view(cout, cin), defer=q, kernel=1)
+            else:
+                ops.conv1d_dw(dy, x, dst, k=k, defer=q, kernel=1)
+            res.append(dst)
+        if mode == "grouped":
+            assert len(q.group) == len(cases)
+        ops.flush_deferred(q)
+        torch.cuda.synchronize()
+        outs.append([r.cpu() for r in res])
+    for a, b, (dy, x, cout, cin, k) in zip(outs[0], outs[1], tensors):
+        assert torch.equal(a, b)
+        if k == 1:
+            ref = dy.view(-1, cout).double().cpu().t() @ x.view(-1, cin).double().cpu() + 0.5
+            check(b.view(cout, cin).to(DEV), ref, dy.shape[0] * dy.shape[1], exact=False, out_bf16=False)

@@ -9,6 +9,7 @@
 // Conv1d is an implicit GEMM: the K loop walks (tap, channel-chunk) and a tap only shifts the A row index
 // (channels-last activations), with zero fill outside the utterance.  The epilogue goes through LDS so that
 // C (and the residual / gate operands) move as full 16-byte rows.
+#include <cstring>
 #include "gemm_common.h"
 
 namespace {
@@ -22,9 +23,9 @@ constexpr int SMEM_BYTES = BM * CS_LD * 4;               // 67,584 B >= 2 stages
 typedef GemmArgs Args;
 
 
+// one output tile (bid_in of the problem's tiles_m*tiles_n, batch index z of nzgrid, K range `split`)
 template <bool ATR, bool BTR, bool F16>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+__device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int split, int nzgrid, unsigned char* smem) {
   const ttsk_gemm_desc& d = g.d;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -32,14 +33,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 
   // ---- tile id with XCD-aware (bijective) remap: consecutive logical tiles share an XCD's L2
   const int ntiles = g.tiles_m * g.tiles_n;
-  int bid = blockIdx.x;
+  int bid = bid_in;
   {
     const int q = ntiles >> 3, r = ntiles & 7, x = bid & 7;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
   }
   const int tile_m = bid / g.tiles_n, tile_n = bid - tile_m * g.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int z = blockIdx.y, split = blockIdx.z;
   const int z1 = z / d.nz2, z2 = z - z1 * d.nz2;
 
   const bf16_t* __restrict__ A = (const bf16_t*)d.A + z1 * d.sA1 + z2 * d.sA2;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
   const int nvalid = (N - gn) < 8 ? (N - gn) : 8;
   if (d.splits > 1) {
     // split-K: raw fp32 partial sums into the workspace slab [split][z][M][N]; the reducer applies the epilogue
-    float* ws = (float*)d.workspace + ((int64_t)split * gridDim.y + z) * ((int64_t)M * N);
+    float* ws = (float*)d.workspace + ((int64_t)split * nzgrid + z) * ((int64_t)M * N);
     for (int p = 0; p < 8; ++p) {
       const int row = p * 16 + (tid >> 4);
       const int gm = m0 + row;
@@ -323,6 +323,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
     }
     epilogue_store<F16>(d, coff, roff, gm, gn, nvalid, v, bias, z2);
   }
+}
+
+template <bool ATR, bool BTR, bool F16>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  gemm_tile<ATR, BTR, F16>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, smem);
+}
+
+// Grouped launch: the workgroups of n independent problems (same operand layout) as ONE grid.  A training step's weight-
+// gradient GEMMs have 32-256 workgroups each — a fraction of the 512 resident slots — and nothing but Adam waits for
+// them, so they are queued during backward and share one launch: 42 launches of 6-22 us (605 us) become one.
+// prefix[p] = first workgroup of problem p; a workgroup finds its problem by bisection and reads the problem's arguments
+// from the table with scalar loads (the table pointer and p are wave-uniform).
+template <bool ATR, bool BTR, bool F16>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_group_kernel(const int* __restrict__ prefix, const Args* __restrict__ args, int n) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  const int wg = blockIdx.x;
+  int lo = 0, hi = n;                 // invariant: prefix[lo] <= wg < prefix[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= wg) lo = mid; else hi = mid;
+  }
+  const int p = __builtin_amdgcn_readfirstlane(lo);
+  const Args& g = args[p];
+  const int local = wg - prefix[p];
+  const int tiles = g.tiles_m * g.tiles_n, nz = g.d.nz1 * g.d.nz2;
+  const int tile = local % tiles, rest = local / tiles;
+  gemm_tile<ATR, BTR, F16>(g, tile, rest % nz, rest / nz, nz, smem);
 }
 
 // split-K reducer: sums the `splits` workspace slabs in fixed order and applies the epilogue (deterministic)
@@ -562,6 +590,110 @@ extern "C" int ttsk_gemm(const ttsk_gemm_desc* dp, void* stream) {
     if (f16) hipLaunchKernelGGL((gemm_reduce_kernel<true>), rgrid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_reduce_kernel<false>), rgrid, dim3(256), 0, s, g);
     TTSK_CHECK_LAUNCH();
+  }
+  return TTSK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- grouped launch
+namespace {
+// The table reaches the device through kernel arguments (3.5 KiB per launch): arguments are captured by value, so the
+// grouped launch stays hipGraph-capturable without pinned host staging (pinned allocation is not permitted during capture).
+struct TableChunk {
+  uint4 q[224];
+};
+__global__ __launch_bounds__(256) void group_table_upload_kernel(const TableChunk c, uint4* __restrict__ dst, int n16) {
+  if ((int)threadIdx.x < n16) dst[threadIdx.x] = c.q[threadIdx.x];
+}
+
+struct GroupHeader {
+  int32_t n, total, atr, btr, f16, prefix_off, args_off, pad;
+};
+inline int64_t group_prefix_off() { return (int64_t)sizeof(GroupHeader); }
+inline int64_t group_args_off(int n) { return (group_prefix_off() + (int64_t)(n + 1) * 4 + 15) & ~(int64_t)15; }
+}  // namespace
+
+extern "C" int64_t ttsk_gemm_group_table_bytes(int n) {   // rounded up to 16 bytes (uploaded in 16-byte pieces)
+  return n > 0 ? (group_args_off(n) + (int64_t)n * (int64_t)sizeof(Args) + 15) & ~(int64_t)15 : 0;
+}
+
+extern "C" int ttsk_gemm_group_build(const ttsk_gemm_desc* descs, int n, void* host_table, int32_t* total_wgs) {
+  TTSK_REQUIRE(descs && host_table && total_wgs && n > 0 && n <= 4096, "ttsk_gemm_group_build: bad arguments");
+  unsigned char* base = (unsigned char*)host_table;
+  GroupHeader* h = (GroupHeader*)base;
+  int32_t* prefix = (int32_t*)(base + group_prefix_off());
+  Args* args = (Args*)(base + group_args_off(n));
+  int64_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    Args g;
+    g.d = descs[i];
+    ttsk_gemm_desc& d = g.d;
+    d.kernel = 1;                                   // the group kernel is the 128x128 register-staged configuration
+    const int rc = validate(d);
+    if (rc != TTSK_OK) return rc;
+    const int atr = (d.flags & TTSK_GEMM_A_TR) ? 1 : 0, btr = (d.flags & TTSK_GEMM_B_TR) ? 1 : 0, f16 = (d.flags & TTSK_GEMM_F16) ? 1 : 0;
+    if (i == 0) { h->atr = atr; h->btr = btr; h->f16 = f16; }
+    TTSK_REQUIRE(atr == h->atr && btr == h->btr && f16 == h->f16, "ttsk_gemm_group_build: problem %d has another operand layout / dtype than problem 0", i);
+    TTSK_REQUIRE(!atr || btr, "ttsk_gemm_group_build: A_TR needs B_TR");
+    TTSK_REQUIRE(!(atr && f16), "ttsk_gemm_group_build: no fp16 instance for transposed A");
+    Plan p = make_plan(d);
+    if (p.splits > 1)
+      TTSK_REQUIRE(d.workspace && d.workspace_bytes >= p.ws_bytes && (((uintptr_t)d.workspace) & 15) == 0,
+                   "ttsk_gemm_group_build: problem %d needs a 16-byte aligned split-K workspace of %lld bytes", i, (long long)p.ws_bytes);
+    d.splits = p.splits;
+    g.tiles_m = p.tiles_m; g.tiles_n = p.tiles_n; g.kchunks = p.kchunks; g.chunks_per_split = p.chunks_per_split;
+    prefix[i] = (int32_t)total;
+    total += (int64_t)p.tiles_m * p.tiles_n * d.nz1 * d.nz2 * p.splits;
+    TTSK_REQUIRE(total < ((int64_t)1 << 30), "ttsk_gemm_group_build: too many workgroups");
+    args[i] = g;
+  }
+  prefix[n] = (int32_t)total;
+  h->n = n; h->total = (int32_t)total; h->prefix_off = (int32_t)group_prefix_off(); h->args_off = (int32_t)group_args_off(n); h->pad = 0;
+  *total_wgs = (int32_t)total;
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_gemm_group_launch(const void* host_table, void* dev_table, void* stream) {
+  TTSK_REQUIRE(host_table && dev_table && (((uintptr_t)dev_table) & 15) == 0, "ttsk_gemm_group_launch: bad table pointers");
+  const GroupHeader* h = (const GroupHeader*)host_table;
+  TTSK_REQUIRE(h->n > 0 && h->total > 0, "ttsk_gemm_group_launch: empty table (call ttsk_gemm_group_build first)");
+  {
+    const int64_t bytes = ttsk_gemm_group_table_bytes(h->n);
+    for (int64_t off = 0; off < bytes; off += (int64_t)sizeof(TableChunk)) {
+      TableChunk c;
+      const int64_t nb = bytes - off < (int64_t)sizeof(TableChunk) ? bytes - off : (int64_t)sizeof(TableChunk);
+      memset(&c, 0, sizeof(c));
+      memcpy(&c, (const unsigned char*)host_table + off, (size_t)nb);
+      hipLaunchKernelGGL(group_table_upload_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, c,
+                         (uint4*)((unsigned char*)dev_table + off), (int)((nb + 15) / 16));
+      TTSK_CHECK_LAUNCH();
+    }
+  }
+  const int* prefix = (const int*)((const unsigned char*)dev_table + h->prefix_off);
+  const Args* args = (const Args*)((const unsigned char*)dev_table + h->args_off);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(h->total), block(NTHREADS);
+  if (h->atr) hipLaunchKernelGGL((gemm_group_kernel<true, true, false>), grid, block, 0, s, prefix, args, h->n);
+  else if (h->btr) {
+    if (h->f16) hipLaunchKernelGGL((gemm_group_kernel<false, true, true>), grid, block, 0, s, prefix, args, h->n);
+    else hipLaunchKernelGGL((gemm_group_kernel<false, true, false>), grid, block, 0, s, prefix, args, h->n);
+  } else {
+    if (h->f16) hipLaunchKernelGGL((gemm_group_kernel<false, false, true>), grid, block, 0, s, prefix, args, h->n);
+    else hipLaunchKernelGGL((gemm_group_kernel<false, false, false>), grid, block, 0, s, prefix, args, h->n);
+  }
+  TTSK_CHECK_LAUNCH();
+  // problems that were split along K and do not defer their reduction: one reducer each, after the grouped grid
+  const Args* hargs = (const Args*)((const unsigned char*)host_table + h->args_off);
+  for (int i = 0; i < h->n; ++i) {
+    const ttsk_gemm_desc& d = hargs[i].d;
+    if (d.splits > 1 && !(d.flags & TTSK_GEMM_DEFER_REDUCE)) {
+      const int64_t work = (int64_t)d.M * ((d.N + 7) / 8);
+      int blocks = (int)((work + 255) / 256);
+      if (blocks > 1024) blocks = 1024;
+      dim3 rgrid(blocks, d.nz1 * d.nz2);
+      if (h->f16) hipLaunchKernelGGL((gemm_reduce_kernel<true>), rgrid, dim3(256), 0, s, hargs[i]);
+      else hipLaunchKernelGGL((gemm_reduce_kernel<false>), rgrid, dim3(256), 0, s, hargs[i]);
+      TTSK_CHECK_LAUNCH();
+    }
   }
   return TTSK_OK;
 }

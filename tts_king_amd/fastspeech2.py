@@ -108,6 +108,7 @@ class FastSpeech2(nn.Module):
         self._deferred_fin = None       # gradient column-sum partials awaiting the batched finalize
         self._side = None               # second HIP stream for parameter-gradient work (see _SideWork)
         self.fused_attention = True     # one kernel for scores + softmax + P.V (and dP + softmax' + dQ) when d_k = 128
+        self.group_param_grads = True      # weight-gradient GEMMs of a backward pass share grouped launches (ops.DeferQueue)
         self.overlap_param_grads = False   # measured on MI355X: the branches do overlap under graph replay, but the concurrent
                                            # kernels slow each other by as much (6.39 vs 6.47 ms/step): off by default
         self._rng_state = None          # device block shared with the optimizer (ops.optim_state)
@@ -580,10 +581,12 @@ class FastSpeech2(nn.Module):
             dS = ops.softmax_bwd(probs, dP, dk ** -0.5)
             ops.gemm(dS, qkv[:, d:], dqkv, S, dk, S, Sp, 3 * d, 3 * d, flags=ops.B_TR, nz1=Bn, nz2=H,
                      sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * 3 * d, dk))
+        kv = ops.GemmGroup()         # dK and dV are independent: one grouped launch
         ops.gemm(dS, qkv, dqkv[:, d:], S, dk, S, Sp, 3 * d, 3 * d, flags=ops.A_TR | ops.B_TR, nz1=Bn, nz2=H,
-                 sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * 3 * d, dk))
+                 sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * 3 * d, dk), group=kv)
         ops.gemm(probs, do, dqkv[:, 2 * d:], S, dk, S, Sp, d, 3 * d, flags=ops.A_TR | ops.B_TR, nz1=Bn, nz2=H,
-                 sA=(H * S * Sp, S * Sp), sB=(S * d, dk), sC=(S * 3 * d, dk))
+                 sA=(H * S * Sp, S * Sp), sB=(S * d, dk), sC=(S * 3 * d, dk), group=kv)
+        kv.flush()
         # ---- q|k|v projections
         with self._side_work(dqkv, x):
             ops.colsum_into(dqkv, self._g(a + "w_qs.bias", 3 * d), defer=self._deferred_fin)
@@ -623,7 +626,7 @@ class FastSpeech2(nn.Module):
         d, rows, nm = self.d, Bn * T, self.n_mel
         # split-K slabs of the weight-gradient GEMMs are summed by ONE batched reducer launch per parameter group when a
         # data-parallel reducer is waiting for finished buckets, otherwise once at the end (only Adam reads them)
-        self._deferred = []
+        self._deferred = ops.DeferQueue(group_gemms=self.group_param_grads)
         self._deferred_fin = []
         if self.overlap_param_grads and self._side is None:
             self._side = torch.cuda.Stream(device=self.device)

@@ -33,13 +33,73 @@ def _ptr(t):
 GEMM_TRACE = None   # bench.py sets this to a list: every ttsk_gemm launch is then bracketed by HIP events on its stream
 
 
+class DeferQueue(list):
+    """What `gemm(defer=...)` collects during a backward pass: split-K reduce items (the list itself) and, in `.group`, whole
+    weight-gradient GEMMs that run as grouped launches at `flush_deferred` (nothing but the optimiser reads their results)."""
+
+    def __init__(self, group_gemms=True):
+        super().__init__()
+        self.group = [] if group_gemms else None
+
+
+class GemmGroup:
+    """Independent GEMMs (same operand layout per launch) that run as one grouped launch: `gemm(..., group=g)` ... `g.flush()`.
+    A problem the planner gives to the 256x128 configuration is launched at once instead (it fills the chip by itself)."""
+
+    def __init__(self):
+        self.descs, self.keep = [], []
+
+    def flush(self):
+        flush_group(self.descs, self.keep)
+        self.keep = []
+
+
+def flush_group(descs, keep):
+    """Grouped launches (ttsk_gemm_group_*) of the queued descriptors, one per operand layout; `keep` holds their tensors."""
+    if not descs:
+        return
+    lib = L.load()
+    by_layout = {}
+    for d in descs:
+        by_layout.setdefault(d.flags & (A_TR | B_TR | F16), []).append(d)
+    dev = keep[0].device
+    for ds in by_layout.values():
+        n = len(ds)
+        nbytes = int(lib.ttsk_gemm_group_table_bytes(n))
+        host = (C.c_ubyte * nbytes)()
+        arr = (GemmDesc * n)(*ds)
+        total = C.c_int32(0)
+        check(lib.ttsk_gemm_group_build(arr, n, host, C.byref(total)), "ttsk_gemm_group_build")
+        table = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # filled by group_launch through kernel arguments
+        if GEMM_TRACE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        check(lib.ttsk_gemm_group_launch(host, C.c_void_p(table.data_ptr()), _stream()), "ttsk_gemm_group_launch")
+        if GEMM_TRACE is not None:
+            e1.record()
+            fl = sum(2.0 * d.M * d.N * d.K * max(d.taps, 1) * d.nz1 * d.nz2 for d in ds)
+            kind = "TT" if ds[0].flags & A_TR else ("NT_btr" if ds[0].flags & B_TR else "NT")
+            GEMM_TRACE.append((e0, e1, fl, kind + "1g", (n, 0, 0, 1, 1, int(total.value))))
+        keep.append(table)
+    descs.clear()
+
+
 def flush_deferred(items):
-    """One ttsk_gemm_reduce_batch launch (per 64 items) for the split-K slabs collected in `items` (see gemm(defer=...))."""
+    """The queued weight-gradient GEMMs as grouped launches, then one ttsk_gemm_reduce_batch launch (per 64 items) for the
+    split-K slabs collected in `items` (see gemm(defer=...))."""
+    group = getattr(items, "group", None)
+    if group:
+        keep = getattr(items, "_keep")
+        flush_group(group, keep)
     if not items:
+        if group is not None:
+            items._keep = []
         return
     arr = (L.ReduceItem * len(items))(*[it for it, _ in items])
     check(L.load().ttsk_gemm_reduce_batch(arr, len(items), _stream()), "ttsk_gemm_reduce_batch")
     items.clear()
+    if group is not None:
+        items._keep = []
 
 
 def plan(d):
@@ -52,11 +112,12 @@ def plan(d):
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=None, ldr=0, G=None, ldg=0, C2=None,
          nz1=1, nz2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), taps=0, seg_len=0, tap_shift0=0, tap_dshift=0,
          b_tap_stride=0, bseg_len=0, bshift0=0, bdshift=0, out_seg=0, out_mul=0, out_add=0, out_add_dz=0, splits=0, kernel=0,
-         in_slope=0.0, out_slope=0.0, defer=None):
+         in_slope=0.0, out_slope=0.0, defer=None, group=None):
     """Raw descriptor-level call of ttsk_gemm (see include/ttsk.h).  A/B/Cout may be views: the data pointer of
     the view is the operand origin.  splits / kernel = 0 let the library plan (tile configuration, split-K factor);
     the split-K workspace is allocated here (the C library never allocates).  `defer`: a list — a split-K weight-
-    gradient GEMM then leaves its slabs un-reduced and appends a reduce item to it (see flush_deferred)."""
+    gradient GEMM then leaves its slabs un-reduced and appends a reduce item to it (see flush_deferred).  `group`: a
+    GemmGroup — independent problems collected there run as ONE grouped launch at `group.flush()`."""
     _dev(A, B, Cout, bias, R, G, C2)
     d = GemmDesc()
     d.A, d.B, d.C, d.C2 = _ptr(A), _ptr(B), _ptr(Cout), _ptr(C2)
@@ -93,6 +154,18 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=No
             it.ws, it.C, it.M, it.N, it.ldc, it.nz, it.splits = ws.data_ptr(), Cout.data_ptr(), M, N, ldc, nz2, splits
             it.accumulate, it.sC2, it.alpha = int(bool(flags & ACCUM_C)), sC[1], alpha
             defer.append((it, ws))
+    if group is not None and kernel == 1:
+        group.descs.append(d)
+        group.keep.extend(t for t in (A, B, Cout, ws, bias, R, G, C2) if t is not None)
+        return Cout
+    if defer is not None and getattr(defer, "group", None) is not None and kernel == 1 and nz1 == 1 and (flags & C_F32) and \
+            not (flags & ~(A_TR | B_TR | C_F32 | ACCUM_C)) and bias is None:
+        # a weight-gradient GEMM on the 128x128 configuration: queued whole, launched with the others at flush_deferred
+        defer.group.append(d)
+        if not hasattr(defer, "_keep"):
+            defer._keep = []
+        defer._keep.extend(t for t in (A, B, Cout, ws) if t is not None)
+        return Cout
     if GEMM_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -79,8 +79,22 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const int c = blockIdx.x * 16 + cx;
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
   double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int b = gy; b < nblk; b += 16) { s += partials[(int64_t)b * 2 * C + c]; q += partials[(int64_t)b * 2 * C + C + c]; }
+  if (c < C) {
+    // 8 loads in flight per thread (the partial rows are independent; a one-row-per-iteration loop paid one L2 latency per
+    // row: 11 us for 423 rows); the order of additions is fixed
+    double s1 = 0.0, q1 = 0.0, s2 = 0.0, q2 = 0.0, s3 = 0.0, q3 = 0.0;
+    int b = gy;
+    for (; b + 48 < nblk; b += 64) {
+      const float a0 = partials[(int64_t)b * 2 * C + c], b0 = partials[(int64_t)b * 2 * C + C + c];
+      const float a1 = partials[(int64_t)(b + 16) * 2 * C + c], b1 = partials[(int64_t)(b + 16) * 2 * C + C + c];
+      const float a2 = partials[(int64_t)(b + 32) * 2 * C + c], b2 = partials[(int64_t)(b + 32) * 2 * C + C + c];
+      const float a3 = partials[(int64_t)(b + 48) * 2 * C + c], b3 = partials[(int64_t)(b + 48) * 2 * C + C + c];
+      s += a0; q += b0; s1 += a1; q1 += b1; s2 += a2; q2 += b2; s3 += a3; q3 += b3;
+    }
+    for (; b < nblk; b += 16) { s += partials[(int64_t)b * 2 * C + c]; q += partials[(int64_t)b * 2 * C + C + c]; }
+    s = (s + s1) + (s2 + s3);
+    q = (q + q1) + (q2 + q3);
+  }
   rs[gy][cx] = s;
   rq[gy][cx] = q;
   __syncthreads();

@@ -126,9 +126,12 @@ struct LnBwdArgs {
   unsigned site_pre, site_post;
 };
 
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
-  __shared__ float red[4][MAXJ * 256];
-  __shared__ float redb[4];
+// 8 waves per workgroup, one row per wave at a time: the per-row chain (loads -> two wave reductions -> stores) is pure
+// latency, so the rows in flight per CU set the rate (4 waves: 11 us for 6768 x 256; the partial count stays 256 blocks)
+constexpr int LNB_WAVES = 8;
+__global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs a) {
+  __shared__ float red[LNB_WAVES][MAXJ * 256];
+  __shared__ float redb[LNB_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D = a.D, nj = D >> 8;
   const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) dg[j][e] = db[j][e] = dbias[j][e] = dhw[j][e] = 0.f;
 
-  for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * LNB_WAVES + wave; row < a.rows; row += gridDim.x * LNB_WAVES) {
     bool masked = false;
     if (a.lens) { const int b = row / a.seg_len, t = row - b * a.seg_len; masked = t >= a.lens[b]; }
     const float mean = a.mean[row], rstd = a.rstd[row];
@@ -219,14 +222,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
           red[wave][j * 256 + lane * 4 + e] = v;
         }
     __syncthreads();
-    for (int c = threadIdx.x; c < D; c += 256) P[qn * D + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    for (int c = threadIdx.x; c < D; c += LNB_WAVES * 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < LNB_WAVES; ++w) t += red[w][c];
+      P[qn * D + c] = t;
+    }
     __syncthreads();
   }
   if (head) {
     dhb = wave_sum(dhb);
     if (lane == 0) redb[wave] = dhb;
     __syncthreads();
-    if (threadIdx.x == 0) P[nq * D] = redb[0] + redb[1] + redb[2] + redb[3];
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < LNB_WAVES; ++w) t += redb[w];
+      P[nq * D] = t;
+    }
   }
 }
 
@@ -366,7 +379,7 @@ extern "C" int ttsk_layernorm_fwd(const void* y, const void* res, const float* g
 }
 
 extern "C" int ttsk_layernorm_bwd_nblocks(int rows) {
-  int n = (rows + 3) / 4;
+  int n = (rows + LNB_WAVES - 1) / LNB_WAVES;
   return n > 256 ? 256 : n;
 }
 
@@ -383,7 +396,7 @@ extern "C" int ttsk_layernorm_bwd(const void* dout, const float* dhead, const fl
   TTSK_REQUIRE(p_post == 0.f || beta, "layernorm_bwd: post dropout needs beta");
   LnBwdArgs a{(const bf16_t*)dout, dhead, head_w, (const bf16_t*)z, mean, rstd, gamma, beta, (const long long*)lens, rng,
               (bf16_t*)dz, (bf16_t*)dy, partials, rows, D, seg_len, relu_in, p_pre, p_post, site_pre, site_post};
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(ttsk_layernorm_bwd_nblocks(rows)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(ttsk_layernorm_bwd_nblocks(rows)), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -283,35 +283,42 @@ def test_k2_fp16_and_polyphase(kern):
 
 def test_grouped_launch_equals_individual_launches():
     """ttsk_gemm_group_*: weight-gradient GEMMs of different shapes (split-K with deferred reduce, accumulate, conv taps as
-    batch) queued in a DeferQueue produce bit-identical results to the same calls launched one by one on kernel 1."""
+    batch) queued in a DeferQueue produce bit-identical results to the same calls launched one by one on kernel 1 with the
+    same split factors; with the group's own split policy (fewer, longer K ranges) they agree with fp64."""
     from tts_king_amd import ops
     g = torch.Generator().manual_seed(11)
-    cases = [(1024, 256, 256, 1), (6768, 768, 256, 1), (423, 128, 64, 1), (2048, 512, 80, 5), (640, 256, 1024, 3)]
+    cases = [(1024, 256, 256, 1, 3), (6768, 768, 256, 1, 8), (423, 128, 64, 1, 1), (2048, 512, 80, 5, 4), (640, 256, 1024, 3, 2)]
     tensors = []
-    for rows, cout, cin, k in cases:
+    for rows, cout, cin, k, sp in cases:
         Bsz = 2 if k > 1 else 1
         T = rows // Bsz
         dy = bf(torch.randn(Bsz, T, cout, generator=g)).to(DEV)
         x = bf(torch.randn(Bsz, T, cin, generator=g)).to(DEV)
-        tensors.append((dy, x, cout, cin, k))
-    outs = []
-    for mode in ("single", "grouped"):
-        q = ops.DeferQueue(group_gemms=(mode == "grouped"))
+        tensors.append((dy, x, cout, cin, k, sp))
+    outs = {}
+    for mode in ("single", "grouped", "grouped-auto"):
+        q = ops.DeferQueue(group_gemms=(mode != "single"))
         res = []
-        for dy, x, cout, cin, k in tensors:
+        for dy, x, cout, cin, k, sp in tensors:
             dst = torch.full((cout, k, cin), 0.5, dtype=torch.float32, device=DEV)
+            kw = dict(defer=q, kernel=1) if mode != "grouped-auto" else dict(defer=q)
+            if mode != "grouped-auto":
+                kw["splits"] = sp
             if k == 1:
-                ops.linear_dw(dy.view(-1, cout), x.view(-1, cin), dst.view(cout, cin), defer=q, kernel=1)
+                ops.linear_dw(dy.view(-1, cout), x.view(-1, cin), dst.view(cout, cin), **kw)
             else:
-                ops.conv1d_dw(dy, x, dst, k=k, defer=q, kernel=1)
+                ops.conv1d_dw(dy, x, dst, k=k, **kw)
             res.append(dst)
         if mode == "grouped":
             assert len(q.group) == len(cases)
         ops.flush_deferred(q)
         torch.cuda.synchronize()
-        outs.append([r.cpu() for r in res])
-    for a, b, (dy, x, cout, cin, k) in zip(outs[0], outs[1], tensors):
+        outs[mode] = [r.cpu() for r in res]
+    for a, b, c, (dy, x, cout, cin, k, sp) in zip(outs["single"], outs["grouped"], outs["grouped-auto"], tensors):
         assert torch.equal(a, b)
         if k == 1:
             ref = dy.view(-1, cout).double().cpu().t() @ x.view(-1, cin).double().cpu() + 0.5
             check(b.view(cout, cin).to(DEV), ref, dy.shape[0] * dy.shape[1], exact=False, out_bf16=False)
+            check(c.view(cout, cin).to(DEV), ref, dy.shape[0] * dy.shape[1], exact=False, out_bf16=False)
+        else:
+            assert float((c - a).abs().max()) <= 1e-3 * float(a.abs().max())

@@ -142,7 +142,17 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=No
     d.bseg_len, d.bshift0, d.bdshift = bseg_len, bshift0, bdshift
     d.out_seg, d.out_mul, d.out_add, d.out_add_dz = out_seg, out_mul, out_add, out_add_dz
     d.splits, d.kernel = splits, kernel
+    user_splits = splits
     kernel, splits, ws_bytes = plan(d)
+    grouped_dw = (defer is not None and getattr(defer, "group", None) is not None and kernel == 1 and nz1 == 1 and (flags & C_F32)
+                  and not (flags & ~(A_TR | B_TR | C_F32 | ACCUM_C)) and bias is None)
+    if grouped_dw and user_splits == 0:
+        # The planner splits K until ONE problem fills the chip (a 256x256 weight gradient over 6768 rows: 36 ways, 36 fp32
+        # slabs to write and to reduce).  In a grouped launch the other problems fill it: ~28 K steps per workgroup keep the
+        # grid balanced with 4x-9x fewer slabs (750 MB -> ~50 MB of split-K traffic per train step).
+        steps = (K + 63) // 64 * max(taps, 1)
+        d.kernel, d.splits = 1, max(1, (steps + 14) // 28)
+        kernel, splits, ws_bytes = plan(d)
     d.splits, d.kernel = splits, kernel
     ws = None
     if ws_bytes > 0:
@@ -158,8 +168,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=No
         group.descs.append(d)
         group.keep.extend(t for t in (A, B, Cout, ws, bias, R, G, C2) if t is not None)
         return Cout
-    if defer is not None and getattr(defer, "group", None) is not None and kernel == 1 and nz1 == 1 and (flags & C_F32) and \
-            not (flags & ~(A_TR | B_TR | C_F32 | ACCUM_C)) and bias is None:
+    if grouped_dw:
         # a weight-gradient GEMM on the 128x128 configuration: queued whole, launched with the others at flush_deferred
         defer.group.append(d)
         if not hasattr(defer, "_keep"):

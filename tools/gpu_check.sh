@@ -14,5 +14,5 @@ tail -2 $O/smoke.log
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 tail -c 4000 $O/bench.json
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o fs2 -- /usr/bin/python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-mel > $O/prof_bench.log 2>&1; echo "rocprof rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o fs2 -- /usr/bin/python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-mel --no-e2e > $O/prof_bench.log 2>&1; echo "rocprof rc=$?"
 find $O/prof -name "*stats*" | head

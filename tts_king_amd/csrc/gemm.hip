@@ -596,6 +596,27 @@ extern "C" int ttsk_gemm(const ttsk_gemm_desc* dp, void* stream) {
 
 // ---------------------------------------------------------------------------------------------- grouped launch
 namespace {
+// Small groups (the dK / dV pair of an attention block) carry their table in the kernel arguments: no upload launch.
+template <int NMAX>
+struct GroupInline {
+  int prefix[NMAX + 1];
+  int n;
+  Args args[NMAX];
+};
+template <bool ATR, bool BTR, bool F16, int NMAX>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_group_inline_kernel(const GroupInline<NMAX> t) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  const int wg = blockIdx.x;
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < NMAX; ++i) p += (i < t.n && t.prefix[i] <= wg) ? 1 : 0;
+  const Args& g = t.args[p];
+  const int local = wg - t.prefix[p];
+  const int tiles = g.tiles_m * g.tiles_n, nz = g.d.nz1 * g.d.nz2;
+  const int tile = local % tiles, rest = local / tiles;
+  gemm_tile<ATR, BTR, F16>(g, tile, rest % nz, rest / nz, nz, smem);
+}
+
 // The table reaches the device through kernel arguments (3.5 KiB per launch): arguments are captured by value, so the
 // grouped launch stays hipGraph-capturable without pinned host staging (pinned allocation is not permitted during capture).
 struct TableChunk {
@@ -656,7 +677,8 @@ extern "C" int ttsk_gemm_group_launch(const void* host_table, void* dev_table, v
   TTSK_REQUIRE(host_table && dev_table && (((uintptr_t)dev_table) & 15) == 0, "ttsk_gemm_group_launch: bad table pointers");
   const GroupHeader* h = (const GroupHeader*)host_table;
   TTSK_REQUIRE(h->n > 0 && h->total > 0, "ttsk_gemm_group_launch: empty table (call ttsk_gemm_group_build first)");
-  {
+  const bool inline_table = h->n <= 2 && !h->f16;      // bf16 pairs: table in the kernel arguments
+  if (!inline_table) {
     const int64_t bytes = ttsk_gemm_group_table_bytes(h->n);
     for (int64_t off = 0; off < bytes; off += (int64_t)sizeof(TableChunk)) {
       TableChunk c;
@@ -672,7 +694,17 @@ extern "C" int ttsk_gemm_group_launch(const void* host_table, void* dev_table, v
   const Args* args = (const Args*)((const unsigned char*)dev_table + h->args_off);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(h->total), block(NTHREADS);
-  if (h->atr) hipLaunchKernelGGL((gemm_group_kernel<true, true, false>), grid, block, 0, s, prefix, args, h->n);
+  if (inline_table) {
+    GroupInline<2> t;
+    const int32_t* hp = (const int32_t*)((const unsigned char*)host_table + h->prefix_off);
+    const Args* ha = (const Args*)((const unsigned char*)host_table + h->args_off);
+    t.n = h->n;
+    for (int i = 0; i <= 2; ++i) t.prefix[i] = i <= h->n ? hp[i] : hp[h->n];
+    for (int i = 0; i < 2; ++i) t.args[i] = ha[i < h->n ? i : 0];
+    if (h->atr) hipLaunchKernelGGL((gemm_group_inline_kernel<true, true, false, 2>), grid, block, 0, s, t);
+    else if (h->btr) hipLaunchKernelGGL((gemm_group_inline_kernel<false, true, false, 2>), grid, block, 0, s, t);
+    else hipLaunchKernelGGL((gemm_group_inline_kernel<false, false, false, 2>), grid, block, 0, s, t);
+  } else if (h->atr) hipLaunchKernelGGL((gemm_group_kernel<true, true, false>), grid, block, 0, s, prefix, args, h->n);
   else if (h->btr) {
     if (h->f16) hipLaunchKernelGGL((gemm_group_kernel<false, true, true>), grid, block, 0, s, prefix, args, h->n);
     else hipLaunchKernelGGL((gemm_group_kernel<false, true, false>), grid, block, 0, s, prefix, args, h->n);

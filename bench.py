@@ -233,7 +233,8 @@ def gemm_roofline(enqueue, batch, steps=3):
     finally:
         ops.GEMM_TRACE = None
     sym = {"NT1": "gemm_kernel<false, false, false>", "NT_btr1": "gemm_kernel<false, true, false>", "TT1": "gemm_kernel<true, true, false>",
-           "NT2": "gemm2_kernel<256, false, false, false>", "NT_btr2": "gemm2_kernel<256, false, true, false>", "TT2": "gemm2_kernel<256, true, true, false>"}
+           "NT2": "gemm2_kernel<256, false, false, false>", "NT_btr2": "gemm2_kernel<256, false, true, false>", "TT2": "gemm2_kernel<256, true, true, false>",
+           "TT1g": "gemm_group_kernel<true, true, false>", "TT2g": "gemm2_group_kernel<256, true, true, false>"}
     by_sym, by_shape = {}, {}
     for e0, e1, fl, kind, shape in trace:
         ms = e0.elapsed_time(e1)
@@ -248,12 +249,13 @@ def gemm_roofline(enqueue, batch, steps=3):
     return {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_BF16_TFLOPS,
             "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
             "traffic_source": traffic["source"] if traffic else None,
-            "kernel": "%s (tts_king_amd/csrc/gemm%s.hip)" % (sym.get(dk, dk), "2" if dk.endswith("2") else ""),
+            "kernel": "%s (tts_king_amd/csrc/gemm%s.hip)" % (sym.get(dk, dk), "2" if "2" in dk else ""),
             "launches_per_step": dv[2] // steps, "avg_launch_us": 1e3 * dv[0] / dv[2], "avg_launch_gflop": dv[1] / dv[2] / 1e9,
             "kernel_ms_per_step": dv[0] / steps,
             "all_gemm": {"launches_per_step": len(trace) // steps, "ms_per_step": tot_ms / steps, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12},
-            "largest_shape": {"M,N,K,taps,batch,splits": list(sk[1:]), "launches_per_step": sv[2] // steps,
-                              "avg_us": 1e3 * sv[0] / sv[2], "tflops": sv[1] / (sv[0] * 1e-3) / 1e12}}
+            "largest_shape": ({"grouped_problems": sk[1], "workgroups": sk[6]} if dk.endswith("g") else
+                              {"M,N,K,taps,batch,splits": list(sk[1:]), "launches_per_step": sv[2] // steps,
+                               "avg_us": 1e3 * sv[0] / sv[2], "tflops": sv[1] / (sv[0] * 1e-3) / 1e12})}
 
 
 def main():

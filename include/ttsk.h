@@ -111,13 +111,14 @@ typedef struct ttsk_reduce_item {
 } ttsk_reduce_item;
 int ttsk_gemm_reduce_batch(const ttsk_reduce_item* items, int n, void* stream);
 
-/* Grouped launch of n problems with the same operand layout (A_TR / B_TR / F16 flags) on the 128x128 configuration as ONE
+/* Grouped launch of n problems with the same operand layout (A_TR / B_TR / F16 flags) and the same tile configuration
+ * (desc.kernel: 1 = 128x128, also the default; 2 = 256x128, bf16 only) as ONE
  * grid — for the many small contractions nothing waits for individually (the weight-gradient GEMMs of a backward pass:
  * 32-256 workgroups each).  group_build validates and plans every descriptor (split-K workspaces as for ttsk_gemm) and
  * writes a table of ttsk_gemm_group_table_bytes(n) bytes into HOST memory (pageable is fine); group_launch copies it into
  * the caller's 16-byte aligned device buffer of the same size through kernel arguments (hipGraph-capturable, no pinned
  * staging), runs the grid and then the reducers of split problems that do not carry TTSK_GEMM_DEFER_REDUCE.  Results are
- * identical to n ttsk_gemm calls with kernel = 1. */
+ * identical to n ttsk_gemm calls with the same kernel / splits. */
 int64_t ttsk_gemm_group_table_bytes(int n);
 int ttsk_gemm_group_build(const ttsk_gemm_desc* descs, int n, void* host_table, int32_t* total_wgs);
 int ttsk_gemm_group_launch(const void* host_table, void* dev_table, void* stream);

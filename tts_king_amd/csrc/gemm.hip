@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void group_table_upload_kernel(const TableChun
 }
 
 struct GroupHeader {
-  int32_t n, total, atr, btr, f16, prefix_off, args_off, pad;
+  int32_t n, total, atr, btr, f16, prefix_off, args_off, kernel;
 };
 inline int64_t group_prefix_off() { return (int64_t)sizeof(GroupHeader); }
 inline int64_t group_args_off(int n) { return (group_prefix_off() + (int64_t)(n + 1) * 4 + 15) & ~(int64_t)15; }
@@ -648,7 +648,9 @@ extern "C" int ttsk_gemm_group_build(const ttsk_gemm_desc* descs, int n, void* h
     Args g;
     g.d = descs[i];
     ttsk_gemm_desc& d = g.d;
-    d.kernel = 1;                                   // the group kernel is the 128x128 register-staged configuration
+    if (d.kernel == 0) d.kernel = 1;                // a group runs ONE tile configuration: problem 0's (default 128x128)
+    if (i == 0) h->kernel = d.kernel;
+    TTSK_REQUIRE(d.kernel == h->kernel, "ttsk_gemm_group_build: problem %d asks for kernel %d, problem 0 for %d", i, d.kernel, h->kernel);
     const int rc = validate(d);
     if (rc != TTSK_OK) return rc;
     const int atr = (d.flags & TTSK_GEMM_A_TR) ? 1 : 0, btr = (d.flags & TTSK_GEMM_B_TR) ? 1 : 0, f16 = (d.flags & TTSK_GEMM_F16) ? 1 : 0;
@@ -656,6 +658,7 @@ extern "C" int ttsk_gemm_group_build(const ttsk_gemm_desc* descs, int n, void* h
     TTSK_REQUIRE(atr == h->atr && btr == h->btr && f16 == h->f16, "ttsk_gemm_group_build: problem %d has another operand layout / dtype than problem 0", i);
     TTSK_REQUIRE(!atr || btr, "ttsk_gemm_group_build: A_TR needs B_TR");
     TTSK_REQUIRE(!(atr && f16), "ttsk_gemm_group_build: no fp16 instance for transposed A");
+    TTSK_REQUIRE(!(h->kernel == 2 && f16), "ttsk_gemm_group_build: the 256x128 group kernel is built for bf16 only");
     Plan p = make_plan(d);
     if (p.splits > 1)
       TTSK_REQUIRE(d.workspace && d.workspace_bytes >= p.ws_bytes && (((uintptr_t)d.workspace) & 15) == 0,
@@ -668,7 +671,7 @@ extern "C" int ttsk_gemm_group_build(const ttsk_gemm_desc* descs, int n, void* h
     args[i] = g;
   }
   prefix[n] = (int32_t)total;
-  h->n = n; h->total = (int32_t)total; h->prefix_off = (int32_t)group_prefix_off(); h->args_off = (int32_t)group_args_off(n); h->pad = 0;
+  h->n = n; h->total = (int32_t)total; h->prefix_off = (int32_t)group_prefix_off(); h->args_off = (int32_t)group_args_off(n);
   *total_wgs = (int32_t)total;
   return TTSK_OK;
 }
@@ -677,7 +680,7 @@ extern "C" int ttsk_gemm_group_launch(const void* host_table, void* dev_table, v
   TTSK_REQUIRE(host_table && dev_table && (((uintptr_t)dev_table) & 15) == 0, "ttsk_gemm_group_launch: bad table pointers");
   const GroupHeader* h = (const GroupHeader*)host_table;
   TTSK_REQUIRE(h->n > 0 && h->total > 0, "ttsk_gemm_group_launch: empty table (call ttsk_gemm_group_build first)");
-  const bool inline_table = h->n <= 2 && !h->f16;      // bf16 pairs: table in the kernel arguments
+  const bool inline_table = h->n <= 2 && !h->f16 && h->kernel == 1;      // bf16 pairs: table in the kernel arguments
   if (!inline_table) {
     const int64_t bytes = ttsk_gemm_group_table_bytes(h->n);
     for (int64_t off = 0; off < bytes; off += (int64_t)sizeof(TableChunk)) {
@@ -694,7 +697,9 @@ extern "C" int ttsk_gemm_group_launch(const void* host_table, void* dev_table, v
   const Args* args = (const Args*)((const unsigned char*)dev_table + h->args_off);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(h->total), block(NTHREADS);
-  if (inline_table) {
+  if (h->kernel == 2) {
+    ttsk_launch_gemm2_group(prefix, args, h->n, h->total, h->atr, h->btr, s);
+  } else if (inline_table) {
     GroupInline<2> t;
     const int32_t* hp = (const int32_t*)((const unsigned char*)host_table + h->prefix_off);
     const Args* ha = (const Args*)((const unsigned char*)host_table + h->args_off);

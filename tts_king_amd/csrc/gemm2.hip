@@ -30,26 +30,25 @@ template <int BM_> struct Cfg {
   static constexpr int NQ = NA + NB;
 };
 
+// one output tile (bid_in of the problem's tiles_m*tiles_n, batch index z of nzgrid, K range `split`)
 template <int BM_, bool ATR, bool BTR, bool F16>
-__global__ __launch_bounds__(Cfg<BM_>::NTHREADS, 1) void gemm2_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm2_tile(const GemmArgs& g, int bid_in, int z, int split, int nzgrid, unsigned char* smem) {
   using CF = Cfg<BM_>;
   constexpr int BM = CF::BM, NW = CF::NW, NTHREADS = CF::NTHREADS, NSTAGE = CF::NSTAGE, A_BYTES = CF::A_BYTES;
-  constexpr int STAGE_BYTES = CF::STAGE_BYTES, SMEM_BYTES = CF::SMEM_BYTES, NB = CF::NB, NQ = CF::NQ;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  constexpr int STAGE_BYTES = CF::STAGE_BYTES, NB = CF::NB, NQ = CF::NQ;
   const ttsk_gemm_desc& d = g.d;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
   const int ntiles = g.tiles_m * g.tiles_n;
-  int bid = blockIdx.x;
+  int bid = bid_in;
   {  // XCD-aware bijective remap: consecutive logical tiles share an XCD's L2
     const int q = ntiles >> 3, r = ntiles & 7, x = bid & 7;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
   }
   const int tile_m = bid / g.tiles_n, tile_n = bid - tile_m * g.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int z = blockIdx.y, split = blockIdx.z;
   const int z1 = z / d.nz2, z2 = z - z1 * d.nz2;
 
   const bf16_t* __restrict__ A = (const bf16_t*)d.A + z1 * d.sA1 + z2 * d.sA2;
@@ -331,10 +330,44 @@ __global__ __launch_bounds__(Cfg<BM_>::NTHREADS, 1) void gemm2_kernel(const Gemm
 #undef SB
   __syncthreads();
 
-  tile_epilogue<BM, NTHREADS, F16>(d, smem, acc, m0, n0, z, z1, z2, split, wm, wn, lane, tid);
+  tile_epilogue<BM, NTHREADS, F16>(d, smem, acc, m0, n0, z, z1, z2, split, nzgrid, wm, wn, lane, tid);
+}
+
+template <int BM_, bool ATR, bool BTR, bool F16>
+__global__ __launch_bounds__(Cfg<BM_>::NTHREADS, 1) void gemm2_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg<BM_>::SMEM_BYTES];
+  gemm2_tile<BM_, ATR, BTR, F16>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, smem);
+}
+
+// grouped launch (see gemm.hip: gemm_group_kernel): the workgroups of n problems as one grid
+template <int BM_, bool ATR, bool BTR, bool F16>
+__global__ __launch_bounds__(Cfg<BM_>::NTHREADS, 1) void gemm2_group_kernel(const int* __restrict__ prefix, const GemmArgs* __restrict__ args,
+                                                                           int n) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg<BM_>::SMEM_BYTES];
+  const int wg = blockIdx.x;
+  int lo = 0, hi = n;                 // invariant: prefix[lo] <= wg < prefix[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= wg) lo = mid; else hi = mid;
+  }
+  const int p = __builtin_amdgcn_readfirstlane(lo);
+  const GemmArgs& g = args[p];
+  const int local = wg - prefix[p];
+  const int tiles = g.tiles_m * g.tiles_n, nz = g.d.nz1 * g.d.nz2;
+  const int tile = local % tiles, rest = local / tiles;
+  gemm2_tile<BM_, ATR, BTR, F16>(g, tile, rest % nz, rest / nz, nz, smem);
 }
 
 }  // namespace
+
+int ttsk_launch_gemm2_group(const int* prefix, const GemmArgs* args, int n, int total_wgs, bool atr, bool btr, hipStream_t s) {
+  constexpr int BM = 256;
+  dim3 grid(total_wgs), block(Cfg<BM>::NTHREADS);
+  if (atr) hipLaunchKernelGGL((gemm2_group_kernel<BM, true, true, false>), grid, block, 0, s, prefix, args, n);
+  else if (btr) hipLaunchKernelGGL((gemm2_group_kernel<BM, false, true, false>), grid, block, 0, s, prefix, args, n);
+  else hipLaunchKernelGGL((gemm2_group_kernel<BM, false, false, false>), grid, block, 0, s, prefix, args, n);
+  return 0;
+}
 
 int ttsk_launch_gemm2(const GemmArgs& g, bool atr, bool btr, bool f16, hipStream_t s) {
   constexpr int BM = 256;

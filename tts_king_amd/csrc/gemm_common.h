@@ -127,7 +127,7 @@ __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rs, unsigned 
 // write raw partial sums into their workspace slab instead.  Every wave must have finished reading `smem` (barrier).
 template <int BM, int NTHREADS, bool F16>
 __device__ __forceinline__ void tile_epilogue(const ttsk_gemm_desc& d, unsigned char* smem, f32x4 (&acc)[4][4], int m0, int n0,
-                                              int z, int z1, int z2, int split, int wm, int wn, int lane, int tid) {
+                                              int z, int z1, int z2, int split, int nzgrid, int wm, int wn, int lane, int tid) {
   constexpr int CS_LD = 132;
   const int M = d.M, N = d.N;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -140,7 +140,7 @@ __device__ __forceinline__ void tile_epilogue(const ttsk_gemm_desc& d, unsigned 
   float bias[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias[e] = (d.bias && gn < N && e < nvalid && d.splits <= 1) ? d.bias[gn + e] : 0.f;
-  float* ws = d.splits > 1 ? (float*)d.workspace + ((int64_t)split * gridDim.y + z) * ((int64_t)M * N) : nullptr;
+  float* ws = d.splits > 1 ? (float*)d.workspace + ((int64_t)split * nzgrid + z) * ((int64_t)M * N) : nullptr;
 
 #pragma unroll 1
   for (int pass = 0; pass < BM / 128; ++pass) {
@@ -184,3 +184,5 @@ __device__ __forceinline__ void tile_epilogue(const ttsk_gemm_desc& d, unsigned 
 
 // gemm2.hip
 int ttsk_launch_gemm2(const GemmArgs& g, bool atr, bool btr, bool f16, hipStream_t s);
+// grouped launch of the 256x128 configuration: prefix / args live in device memory (see gemm.hip: ttsk_gemm_group_*)
+int ttsk_launch_gemm2_group(const int* prefix, const GemmArgs* args, int n, int total_wgs, bool atr, bool btr, hipStream_t s);

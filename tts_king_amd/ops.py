@@ -61,7 +61,7 @@ def flush_group(descs, keep):
     lib = L.load()
     by_layout = {}
     for d in descs:
-        by_layout.setdefault(d.flags & (A_TR | B_TR | F16), []).append(d)
+        by_layout.setdefault((d.flags & (A_TR | B_TR | F16), d.kernel), []).append(d)
     dev = keep[0].device
     for ds in by_layout.values():
         n = len(ds)
@@ -79,7 +79,7 @@ def flush_group(descs, keep):
             e1.record()
             fl = sum(2.0 * d.M * d.N * d.K * max(d.taps, 1) * d.nz1 * d.nz2 for d in ds)
             kind = "TT" if ds[0].flags & A_TR else ("NT_btr" if ds[0].flags & B_TR else "NT")
-            GEMM_TRACE.append((e0, e1, fl, kind + "1g", (n, 0, 0, 1, 1, int(total.value))))
+            GEMM_TRACE.append((e0, e1, fl, kind + "%dg" % ds[0].kernel, (n, 0, 0, 1, 1, int(total.value))))
         keep.append(table)
     descs.clear()
 
@@ -142,16 +142,18 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=No
     d.bseg_len, d.bshift0, d.bdshift = bseg_len, bshift0, bdshift
     d.out_seg, d.out_mul, d.out_add, d.out_add_dz = out_seg, out_mul, out_add, out_add_dz
     d.splits, d.kernel = splits, kernel
-    user_splits = splits
+    user_splits, user_kernel = splits, kernel
     kernel, splits, ws_bytes = plan(d)
-    grouped_dw = (defer is not None and getattr(defer, "group", None) is not None and kernel == 1 and nz1 == 1 and (flags & C_F32)
-                  and not (flags & ~(A_TR | B_TR | C_F32 | ACCUM_C)) and bias is None)
-    if grouped_dw and user_splits == 0:
+    grouped_dw = (defer is not None and getattr(defer, "group", None) is not None and nz1 == 1 and (flags & C_F32)
+                  and not (flags & ~(A_TR | B_TR | C_F32 | ACCUM_C)) and bias is None and A.dtype != f16)
+    if grouped_dw and user_splits == 0 and user_kernel == 0:
         # The planner splits K until ONE problem fills the chip (a 256x256 weight gradient over 6768 rows: 36 ways, 36 fp32
-        # slabs to write and to reduce).  In a grouped launch the other problems fill it: ~28 K steps per workgroup keep the
+        # slabs to write and to reduce).  In a grouped launch the other problems fill it: ~28 (128x128 tiles) / ~36 (256x128) K steps per workgroup keep the
         # grid balanced with 4x-9x fewer slabs (750 MB -> ~50 MB of split-K traffic per train step).
+        # Tile configuration: the 256x128 LDS-DMA kernel unless the output has too few rows to fill its tile.
         steps = (K + 63) // 64 * max(taps, 1)
-        d.kernel, d.splits = 1, max(1, (steps + 14) // 28)
+        d.kernel = 2 if M >= 192 else 1
+        d.splits = max(1, (steps + 14) // 28) if d.kernel == 1 else max(1, (steps + 18) // 36)
         kernel, splits, ws_bytes = plan(d)
     d.splits, d.kernel = splits, kernel
     ws = None
@@ -169,7 +171,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=No
         group.keep.extend(t for t in (A, B, Cout, ws, bias, R, G, C2) if t is not None)
         return Cout
     if grouped_dw:
-        # a weight-gradient GEMM on the 128x128 configuration: queued whole, launched with the others at flush_deferred
+        # a weight-gradient GEMM: queued whole, launched with the others at flush_deferred
         defer.group.append(d)
         if not hasattr(defer, "_keep"):
             defer._keep = []

@@ -112,7 +112,7 @@ typedef struct ttsk_reduce_item {
 int ttsk_gemm_reduce_batch(const ttsk_reduce_item* items, int n, void* stream);
 
 /* Grouped launch of n problems with the same operand layout (A_TR / B_TR / F16 flags) and the same tile configuration
- * (desc.kernel: 1 = 128x128, also the default; 2 = 256x128, bf16 only) as ONE
+ * (desc.kernel: 1 = 128x128, also the default; 2 = 256x128) as ONE
  * grid — for the many small contractions nothing waits for individually (the weight-gradient GEMMs of a backward pass:
  * 32-256 workgroups each).  group_build validates and plans every descriptor (split-K workspaces as for ttsk_gemm) and
  * writes a table of ttsk_gemm_group_table_bytes(n) bytes into HOST memory (pageable is fine); group_launch copies it into

@@ -658,7 +658,6 @@ extern "C" int ttsk_gemm_group_build(const ttsk_gemm_desc* descs, int n, void* h
     TTSK_REQUIRE(atr == h->atr && btr == h->btr && f16 == h->f16, "ttsk_gemm_group_build: problem %d has another operand layout / dtype than problem 0", i);
     TTSK_REQUIRE(!atr || btr, "ttsk_gemm_group_build: A_TR needs B_TR");
     TTSK_REQUIRE(!(atr && f16), "ttsk_gemm_group_build: no fp16 instance for transposed A");
-    TTSK_REQUIRE(!(h->kernel == 2 && f16), "ttsk_gemm_group_build: the 256x128 group kernel is built for bf16 only");
     Plan p = make_plan(d);
     if (p.splits > 1)
       TTSK_REQUIRE(d.workspace && d.workspace_bytes >= p.ws_bytes && (((uintptr_t)d.workspace) & 15) == 0,
@@ -698,7 +697,7 @@ extern "C" int ttsk_gemm_group_launch(const void* host_table, void* dev_table, v
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(h->total), block(NTHREADS);
   if (h->kernel == 2) {
-    ttsk_launch_gemm2_group(prefix, args, h->n, h->total, h->atr, h->btr, s);
+    ttsk_launch_gemm2_group(prefix, args, h->n, h->total, h->atr, h->btr, h->f16, s);
   } else if (inline_table) {
     GroupInline<2> t;
     const int32_t* hp = (const int32_t*)((const unsigned char*)host_table + h->prefix_off);

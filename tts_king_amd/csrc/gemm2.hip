@@ -360,12 +360,17 @@ __global__ __launch_bounds__(Cfg<BM_>::NTHREADS, 1) void gemm2_group_kernel(cons
 
 }  // namespace
 
-int ttsk_launch_gemm2_group(const int* prefix, const GemmArgs* args, int n, int total_wgs, bool atr, bool btr, hipStream_t s) {
+int ttsk_launch_gemm2_group(const int* prefix, const GemmArgs* args, int n, int total_wgs, bool atr, bool btr, bool f16, hipStream_t s) {
   constexpr int BM = 256;
   dim3 grid(total_wgs), block(Cfg<BM>::NTHREADS);
   if (atr) hipLaunchKernelGGL((gemm2_group_kernel<BM, true, true, false>), grid, block, 0, s, prefix, args, n);
-  else if (btr) hipLaunchKernelGGL((gemm2_group_kernel<BM, false, true, false>), grid, block, 0, s, prefix, args, n);
-  else hipLaunchKernelGGL((gemm2_group_kernel<BM, false, false, false>), grid, block, 0, s, prefix, args, n);
+  else if (btr) {
+    if (f16) hipLaunchKernelGGL((gemm2_group_kernel<BM, false, true, true>), grid, block, 0, s, prefix, args, n);
+    else hipLaunchKernelGGL((gemm2_group_kernel<BM, false, true, false>), grid, block, 0, s, prefix, args, n);
+  } else {
+    if (f16) hipLaunchKernelGGL((gemm2_group_kernel<BM, false, false, true>), grid, block, 0, s, prefix, args, n);
+    else hipLaunchKernelGGL((gemm2_group_kernel<BM, false, false, false>), grid, block, 0, s, prefix, args, n);
+  }
   return 0;
 }
 

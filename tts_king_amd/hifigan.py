@@ -97,6 +97,7 @@ class Generator(nn.Module):
         self.act_dtype = f16         # storage type of activations and packed weights (fp32 accumulate); bf16 also works
         self.window_conv = True      # window-conv kernel at the C = 128 stage; False = implicit-GEMM convs
         self.fused = True            # fused ResBlock1 kernel where an instance exists (C in {32,64}); False = conv-by-conv
+        self.group_resblocks = True  # conv m of the three MRF ResBlocks as one grouped launch where they run conv by conv (C = 256)
 
     # ------------------------------------------------------------------ reference surface
     def remove_weight_norm(self):
@@ -182,6 +183,28 @@ class Generator(nn.Module):
             xl = xl_next
         return x
 
+    def _resblocks_lockstep(self, rbs, packs, x, xl):
+        """The stage's ResBlock1s (one per MRF kernel size, hifi/models.py:190-196) advanced conv by conv TOGETHER: they read
+        the same stage input and never each other's outputs, so conv m of every block is one grouped launch (three 192-
+        workgroup problems at the C = 256 stage -> one 576-workgroup grid).  Same epilogue fusions as `_resblock`."""
+        nd = len(rbs[0].dilation)
+        xs, xls = [x] * len(rbs), [xl] * len(rbs)
+        for m in range(nd):
+            lastp = m == nd - 1
+            g1, tls = ops.GemmGroup(), []
+            for rb, pk, xlj in zip(rbs, packs, xls):
+                tls.append(ops.conv1d(xlj, pk[m][0], pk[m][1], dilation=rb.dilation[m], flags=ops.LRELU_OUT, out_slope=LRELU_SLOPE, group=g1))
+            g1.flush()
+            g2, nxt = ops.GemmGroup(), []
+            for j, (rb, pk) in enumerate(zip(rbs, packs)):
+                xl_next = None if lastp else torch.empty_like(x)
+                xs[j] = ops.conv1d(tls[j], pk[nd + m][0], pk[nd + m][1], R=xs[j], C2=xl_next, flags=0 if lastp else ops.C2_LRELU,
+                                   out_slope=LRELU_SLOPE, group=g2)
+                nxt.append(xl_next)
+            g2.flush()
+            xls = nxt
+        return xs
+
     def forward(self, x):
         """x (B, 80, T) mel on a HIP device -> (B, 1, T*prod(upsample_rates)) fp32.  reference: hifi/models.py:185-201.
 
@@ -214,7 +237,11 @@ class Generator(nn.Module):
                     continue
                 axl = torch.empty(al.shape[0], al.shape[1] * u, wu.shape[1], dtype=al.dtype, device=al.device)
                 a = ops.conv_transpose1d(al, wu, bu, u, k, C2=axl, flags=ops.C2_LRELU, out_slope=LRELU_SLOPE)   # x and lrelu(x)
-                outs = [self._resblock(rb, pk["rb"][i * nk + j], a, axl, pk["rbw"][i * nk + j]) for j, rb in enumerate(rbs)]
+                if self.group_resblocks and all(rb.kind == "1" for rb in rbs) and len({len(rb.dilation) for rb in rbs}) == 1 and \
+                        not (self.window_conv and all(pk["rbw"][i * nk + j] is not None for j in range(nk))):
+                    outs = self._resblocks_lockstep(rbs, [pk["rb"][i * nk + j] for j in range(nk)], a, axl)
+                else:
+                    outs = [self._resblock(rb, pk["rb"][i * nk + j], a, axl, pk["rbw"][i * nk + j]) for j, rb in enumerate(rbs)]
                 if nk == 3:
                     al = ops.avg3(outs[0], outs[1], outs[2], 1.0 / 3.0, slope=nxt_slope)   # lrelu(xs / num_kernels)
                 else:

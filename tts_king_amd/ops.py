@@ -44,7 +44,7 @@ class DeferQueue(list):
 
 class GemmGroup:
     """Independent GEMMs (same operand layout per launch) that run as one grouped launch: `gemm(..., group=g)` ... `g.flush()`.
-    A problem the planner gives to the 256x128 configuration is launched at once instead (it fills the chip by itself)."""
+    Problems are launched per (operand layout, tile configuration): at most a handful of grids."""
 
     def __init__(self):
         self.descs, self.keep = [], []
@@ -166,7 +166,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=No
             it.ws, it.C, it.M, it.N, it.ldc, it.nz, it.splits = ws.data_ptr(), Cout.data_ptr(), M, N, ldc, nz2, splits
             it.accumulate, it.sC2, it.alpha = int(bool(flags & ACCUM_C)), sC[1], alpha
             defer.append((it, ws))
-    if group is not None and kernel == 1:
+    if group is not None:
         group.descs.append(d)
         group.keep.extend(t for t in (A, B, Cout, ws, bias, R, G, C2) if t is not None)
         return Cout

@@ -68,7 +68,11 @@ __device__ __forceinline__ void epilogue_store(const ttsk_gemm_desc& d, int64_t 
   }
   if (flags & TTSK_GEMM_C_F32) {
     float* cp = (float*)d.C + coff + orow * d.ldc + gn;
-    if (flags & TTSK_GEMM_ACCUM_C) {
+    if ((flags & TTSK_GEMM_ACCUM_C) && nvalid == 8 && ((d.ldc & 3) == 0) && ((coff & 3) == 0)) {
+      const f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);      // 16-byte read-modify-write of the gradient row
+      *(f32x4*)cp = f32x4{v[0] + c0[0], v[1] + c0[1], v[2] + c0[2], v[3] + c0[3]};
+      *(f32x4*)(cp + 4) = f32x4{v[4] + c1[0], v[5] + c1[1], v[6] + c1[2], v[7] + c1[3]};
+    } else if (flags & TTSK_GEMM_ACCUM_C) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) if (e < nvalid) cp[e] += v[e];
     } else if (nvalid == 8 && ((d.ldc & 3) == 0) && ((coff & 3) == 0)) {

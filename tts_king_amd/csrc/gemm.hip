@@ -121,13 +121,14 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
 
   struct Regs { uint4 a[4], b[4]; };
 #define TTSK_LD(rs, off) __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0))
-  auto load_tile = [&](Regs& R) __attribute__((always_inline)) {
+  // `live` = the tile exists (a step past the last tile still issues its loads, all out of range: zeros, no branch)
+  auto load_tile = [&](Regs& R, bool live) __attribute__((always_inline)) {
     const int kbase = (kc_begin + ld_kk) * BK;
     int oa[4], ob[4];
     if (!ATR) {
       const int shift = conv_a ? d.tap_shift0 + ld_tap * d.tap_dshift : 0;
       const int add = (shift * d.lda + kbase) * 2;
-      const bool kok = kbase + nslot * 8 < K8;
+      const bool kok = live && kbase + nslot * 8 < K8;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         bool ok = kok && ((a_ok[i] >> (ld_tap & 31)) & 1u);
@@ -140,11 +141,11 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
     } else {
       const int add = kbase * d.lda * 2;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) oa[i] = (kbase + trow + 16 * i < K && a_ok[i]) ? a_off[i] + add : OOB;
+      for (int i = 0; i < 4; ++i) oa[i] = (live && kbase + trow + 16 * i < K && a_ok[i]) ? a_off[i] + add : OOB;
     }
     const int tapoff = ld_tap * (int)d.b_tap_stride;
     if (!BTR) {
-      const bool kok = kbase + nslot * 8 < K8;
+      const bool kok = live && kbase + nslot * 8 < K8;
       const int add = (tapoff + kbase) * 2;
 #pragma unroll
       for (int i = 0; i < 4; ++i) ob[i] = (kok && b_ok[i]) ? b_off[i] + add : OOB;
@@ -152,7 +153,7 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
       const int add = ((kbase + bshift) * d.ldb + tapoff) * 2;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        bool ok = kbase + trow + 16 * i < K && b_ok[i];
+        bool ok = live && kbase + trow + 16 * i < K && b_ok[i];
         if (bseg) ok = ok && (unsigned)(b_tt[i] + bshift) < (unsigned)d.bseg_len;
         ob[i] = ok ? b_off[i] + add : OOB;
       }
@@ -250,24 +251,40 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
   // ---- K loop: two register sets, so the global loads of tiles kt+1 and kt+2 are in flight while tile kt is
   // multiplied (a lone workgroup on its CU was latency-bound at one tile in flight: 1.0 us per K step against 0.25 us
   // of MFMA); LDS is double-buffered, one barrier per K tile.
+  // One step = global loads of tile kt+2, MFMAs of tile kt, LDS writes of tile kt+1 — issued by ONE wave per SIMD, so they
+  // only overlap if the instruction stream interleaves them: the sched_group_barrier sequence asks for "LDS reads of a
+  // contraction half, then 2 MFMAs : 1 global load (first half) / 2 MFMAs : 1 LDS write (second half)".  Loads past the
+  // last tile are out-of-range buffer reads (zeros) and the write past it goes to the buffer nobody reads again: the
+  // step is branch-free, one scheduling region.
   if (nk > 0) {
     Regs R0, R1;
-    load_tile(R0);
-    if (nk > 1) load_tile(R1);
+    load_tile(R0, true);
+    load_tile(R1, nk > 1);
     store_tile(0, R0);
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-      if (kt + 2 < nk) load_tile(R0);
-      compute_tile(0);
-      if (kt + 1 < nk) store_tile(1, R1);
-      __syncthreads();
-      if (kt + 1 < nk) {
-        if (kt + 3 < nk) load_tile(R1);
-        compute_tile(1);
-        if (kt + 2 < nk) store_tile(0, R0);
-        __syncthreads();
-      }
+    constexpr int NRD = (ATR ? 8 : 4) + (BTR ? 8 : 4);     // LDS read instructions per contraction half
+#define TTSK_STEP(CUR, RL, RS)                                                      \
+    {                                                                               \
+      load_tile(RL, kt + 2 + CUR < nk);                                             \
+      compute_tile(CUR);                                                            \
+      store_tile(1 - CUR, RS);                                                      \
+      __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);                          \
+      _Pragma("unroll") for (int q = 0; q < 8; ++q) {                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                          \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                          \
+      }                                                                             \
+      __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);                          \
+      _Pragma("unroll") for (int q = 0; q < 8; ++q) {                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                          \
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                          \
+      }                                                                             \
+      __syncthreads();                                                              \
     }
+    for (int kt = 0; kt < nk; kt += 2) {
+      TTSK_STEP(0, R0, R1)
+      if (kt + 1 < nk) TTSK_STEP(1, R1, R0)
+    }
+#undef TTSK_STEP
   }
 
   // ---- epilogue: accumulators -> LDS (fp32) -> full-row 16-byte traffic

@@ -225,6 +225,14 @@ int ttsk_gather_add(const void* in_bf16, const float* table, const void* idx, in
                     int pe_mod, void* out_bf16, int rows, int D, void* stream);
 int ttsk_scatter_sum(const void* dx_bf16, const void* idx, int idx_is_i64, int idx_div, int n_idx, float* dtable,
                      int n_table_rows, int D, int skip_row, int accumulate, void* stream);
+/* the same for up to 8 independent tables per launch (all embedding-table gradients of a backward pass) */
+typedef struct ttsk_scatter_item {
+  const void* dx;      /* (n_idx * idx_div, D) bf16 */
+  const void* idx;
+  float* dtable;       /* (n_table_rows, D) fp32 */
+  int32_t idx_is_i64, idx_div, n_idx, n_table_rows, D, skip_row, accumulate;
+} ttsk_scatter_item;
+int ttsk_scatter_sum_batch(const ttsk_scatter_item* items, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ conversions */
 int ttsk_cast_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);

@@ -106,12 +106,9 @@ __global__ __launch_bounds__(256) void gather_add_kernel(const bf16_t* __restric
 
 // dtable[v] (+)= Σ_{rows with idx[row/idx_div] == v} dx[row]   — one workgroup per table row, rows visited in
 // ascending order (deterministic; no atomics).  `skip` = padding_idx that receives no gradient (-1: none).
-__global__ __launch_bounds__(256) void scatter_sum_kernel(const bf16_t* __restrict__ dx, const void* __restrict__ idx,
-                                                          int idx_i64, int idx_div, int nidx, float* __restrict__ dtable,
-                                                          int D, int skip, int accumulate) {
-  __shared__ int hits[1024];
-  __shared__ int nh;
-  const int v = blockIdx.x;
+__device__ __forceinline__ void scatter_sum_body(const bf16_t* __restrict__ dx, const void* __restrict__ idx, int idx_i64, int idx_div,
+                                                 int nidx, float* __restrict__ dtable, int D, int skip, int accumulate, int v, int* hits,
+                                                 int& nh) {
   float acc[4] = {0.f, 0.f, 0.f, 0.f};   // D <= 1024: thread handles channels tid + 256*j
   if (v != skip) {
     for (int base = 0; base < nidx; base += 1024) {
@@ -149,6 +146,27 @@ __global__ __launch_bounds__(256) void scatter_sum_kernel(const bf16_t* __restri
     const int c = threadIdx.x + 256 * j;
     if (c < D) dtable[(int64_t)v * D + c] = accumulate ? dtable[(int64_t)v * D + c] + acc[j] : acc[j];
   }
+}
+
+__global__ __launch_bounds__(256) void scatter_sum_kernel(const bf16_t* __restrict__ dx, const void* __restrict__ idx,
+                                                          int idx_i64, int idx_div, int nidx, float* __restrict__ dtable,
+                                                          int D, int skip, int accumulate) {
+  __shared__ int hits[1024];
+  __shared__ int nh;
+  scatter_sum_body(dx, idx, idx_i64, idx_div, nidx, dtable, D, skip, accumulate, blockIdx.x, hits, nh);
+}
+
+// up to 8 independent scatter-sums (the embedding-table gradients of one backward pass) in one launch: grid.y = item
+struct ScatterBatch {
+  ttsk_scatter_item it[8];
+};
+__global__ __launch_bounds__(256) void scatter_sum_batch_kernel(const ScatterBatch sb) {
+  __shared__ int hits[1024];
+  __shared__ int nh;
+  const ttsk_scatter_item& it = sb.it[blockIdx.y];
+  if ((int)blockIdx.x >= it.n_table_rows) return;
+  scatter_sum_body((const bf16_t*)it.dx, it.idx, it.idx_is_i64, it.idx_div, it.n_idx, it.dtable, it.D, it.skip_row, it.accumulate,
+                   blockIdx.x, hits, nh);
 }
 
 // ---------------------------------------------------------------------------------------------- conversions
@@ -259,6 +277,25 @@ extern "C" int ttsk_scatter_sum(const void* dx_bf16, const void* idx, int idx_is
   hipLaunchKernelGGL(scatter_sum_kernel, dim3(n_table_rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx_bf16, idx,
                      idx_is_i64, idx_div, n_idx, dtable, D, skip_row, accumulate);
   TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_scatter_sum_batch(const ttsk_scatter_item* items, int n, void* stream) {
+  TTSK_REQUIRE(items && n > 0, "scatter_sum_batch: bad arguments");
+  for (int base = 0; base < n; base += 8) {
+    ScatterBatch sb;
+    const int m = n - base < 8 ? n - base : 8;
+    int max_rows = 1;
+    for (int i = 0; i < m; ++i) {
+      sb.it[i] = items[base + i];
+      const ttsk_scatter_item& it = sb.it[i];
+      TTSK_REQUIRE(it.dx && it.idx && it.dtable && it.n_idx > 0 && it.n_table_rows > 0 && it.D > 0 && it.D <= 1024 && it.idx_div > 0,
+                   "scatter_sum_batch: bad item %d", base + i);
+      if (it.n_table_rows > max_rows) max_rows = it.n_table_rows;
+    }
+    hipLaunchKernelGGL(scatter_sum_batch_kernel, dim3(max_rows, m), dim3(256), 0, (hipStream_t)stream, sb);
+    TTSK_CHECK_LAUNCH();
+  }
   return TTSK_OK;
 }
 

@@ -668,13 +668,13 @@ class FastSpeech2(nn.Module):
         # ---- variance adaptor, reverse order of modules.py:158-193
         va = "variance_adaptor."
         with self._side_work(dx3):
-            ops.scatter_sum(dx3, ctx.eidx.view(-1), self._g(va + "energy_embedding.weight"))
+            ops.scatter_sum(dx3, ctx.eidx.view(-1), self._g(va + "energy_embedding.weight"), defer=self._deferred_fin)
         dx2 = self._predictor_bwd(va + "energy_predictor.", ctx.preds[va + "energy_predictor."], denergy, rng, dx3.view(Bn, Lp, d))
         with self._side_work(dx2):
-            ops.scatter_sum(dx2.view(Bn * Lp, d), ctx.pidx.view(-1), self._g(va + "pitch_embedding.weight"))
+            ops.scatter_sum(dx2.view(Bn * Lp, d), ctx.pidx.view(-1), self._g(va + "pitch_embedding.weight"), defer=self._deferred_fin)
         dx1 = self._predictor_bwd(va + "pitch_predictor.", ctx.preds[va + "pitch_predictor."], dpitch, rng, dx2)
         with self._side_work(dx1):
-            ops.scatter_sum(dx1.view(Bn * Lp, d), ctx.speakers, self._g("speaker_emb.weight"), idx_div=Lp)
+            ops.scatter_sum(dx1.view(Bn * Lp, d), ctx.speakers, self._g("speaker_emb.weight"), idx_div=Lp, defer=self._deferred_fin)
         dxe = self._predictor_bwd(va + "duration_predictor.", ctx.preds[va + "duration_predictor."], dlogd, rng, dx1)
         notify("variance_adaptor")
         # ---- encoder
@@ -683,7 +683,7 @@ class FastSpeech2(nn.Module):
             dx = self._fft_bwd(ctx.blocks[i], dx, rng)
             notify("encoder.%d" % i)
         with self._side_work(dx):
-            ops.scatter_sum(dx, ctx.texts.view(-1), self._g("encoder.src_word_emb.weight"), skip_row=0)   # padding_idx=0
+            ops.scatter_sum(dx, ctx.texts.view(-1), self._g("encoder.src_word_emb.weight"), skip_row=0, defer=self._deferred_fin)   # padding_idx=0
         notify("embedding")
         self._join_side()
         ops.flush_deferred(self._deferred)

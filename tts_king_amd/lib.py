@@ -47,6 +47,12 @@ class ColsumItem(C.Structure):
                 ("ld", C.c_int32), ("nblk", C.c_int32)]
 
 
+class ScatterItem(C.Structure):
+    """Mirror of `ttsk_scatter_item` (include/ttsk.h)."""
+    _fields_ = [("dx", C.c_void_p), ("idx", C.c_void_p), ("dtable", C.c_void_p), ("idx_is_i64", C.c_int32), ("idx_div", C.c_int32),
+                ("n_idx", C.c_int32), ("n_table_rows", C.c_int32), ("D", C.c_int32), ("skip_row", C.c_int32), ("accumulate", C.c_int32)]
+
+
 class FinalizeItem(C.Structure):
     """Mirror of `ttsk_finalize_item` (include/ttsk.h)."""
     _fields_ = [("partials", C.c_void_p), ("dst", C.c_void_p), ("nblk", C.c_int32), ("ncols", C.c_int32), ("ld", C.c_int32),
@@ -113,6 +119,7 @@ def load(path=LIB_PATH):
             fn.restype = C.c_int
         fn.argtypes = argtypes
     lib.ttsk_gemm.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
+    lib.ttsk_scatter_sum_batch.argtypes = [C.POINTER(ScatterItem), C.c_int, C.c_void_p]
     lib.ttsk_colsum_batch.argtypes = [C.POINTER(ColsumItem), C.c_int, C.c_void_p]
     lib.ttsk_colsum_finalize_batch.argtypes = [C.POINTER(FinalizeItem), C.c_int, C.c_void_p]
     lib.ttsk_gemm_reduce_batch.argtypes = [C.POINTER(ReduceItem), C.c_int, C.c_void_p]

@@ -371,17 +371,21 @@ def colsum_finalize(partials, nblk, ncols, ld, dst, accumulate=True, scale=1.0, 
 
 
 def flush_finalize(items):
-    """One ttsk_colsum_batch launch for the queued column sums (bias gradients), then one ttsk_colsum_finalize_batch launch
-    (per 64 items each) for all queued finalisations."""
+    """One launch each for the queued embedding scatter-sums, the queued column sums (bias gradients) and then all queued
+    finalisations (ttsk_scatter_sum_batch, ttsk_colsum_batch, ttsk_colsum_finalize_batch)."""
     if not items:
         return
+    sc = [it for it, _ in items if isinstance(it, L.ScatterItem)]
+    if sc:
+        check(L.load().ttsk_scatter_sum_batch((L.ScatterItem * len(sc))(*sc), len(sc), _stream()), "ttsk_scatter_sum_batch")
     cs = [it for it, _ in items if isinstance(it, L.ColsumItem)]
     if cs:
         check(L.load().ttsk_colsum_batch((L.ColsumItem * len(cs))(*cs), len(cs), _stream()), "ttsk_colsum_batch")
     fin = [(it, keep) for it, keep in items if isinstance(it, L.FinalizeItem)]
     items[:] = fin
-    arr = (L.FinalizeItem * len(items))(*[it for it, _ in items])
-    check(L.load().ttsk_colsum_finalize_batch(arr, len(items), _stream()), "ttsk_colsum_finalize_batch")
+    if items:
+        arr = (L.FinalizeItem * len(items))(*[it for it, _ in items])
+        check(L.load().ttsk_colsum_finalize_batch(arr, len(items), _stream()), "ttsk_colsum_finalize_batch")
     items.clear()
 
 
@@ -490,9 +494,18 @@ def gather_add(x, table, idx, idx_div=1, pe=None, pe_mod=1, rows=None, out=None)
     return out
 
 
-def scatter_sum(dx, idx, dtable, idx_div=1, skip_row=-1, accumulate=True):
+def scatter_sum(dx, idx, dtable, idx_div=1, skip_row=-1, accumulate=True, defer=None):
+    """dtable[v] (+)= sum of the rows of dx whose index is v.  `defer` (the list flush_finalize drains): the embedding-table
+    gradients of a backward pass are independent and nothing but the optimiser reads them — queued, they share one launch."""
     _dev(dx, idx, dtable)
     V, D = dtable.shape
+    if defer is not None:
+        it = L.ScatterItem()
+        it.dx, it.idx, it.dtable = dx.data_ptr(), idx.data_ptr(), dtable.data_ptr()
+        it.idx_is_i64, it.idx_div, it.n_idx, it.n_table_rows, it.D = int(idx.dtype == torch.int64), idx_div, idx.numel(), V, D
+        it.skip_row, it.accumulate = skip_row, int(accumulate)
+        defer.append((it, (dx, idx)))
+        return dtable
     check(L.load().ttsk_scatter_sum(_ptr(dx), _ptr(idx), int(idx.dtype == torch.int64), idx_div, idx.numel(), _ptr(dtable), V, D,
                                     skip_row, int(accumulate), _stream()), "ttsk_scatter_sum")
     return dtable

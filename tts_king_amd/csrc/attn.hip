@@ -246,6 +246,168 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs a) {
   }
 }
 
+// Forward for S <= KBLK * 64 = 448 keys (every utterance of the training batch): ONE sweep.  The scores of a wave's 16
+// queries against all keys stay in registers (7 tiles x 4 accumulators), so the row maxima and sums need no recompute, and
+// once every wave is past the scores the key tiles in LDS are dead: V is staged into their place (4 + 3 tiles, one memory
+// latency each instead of one per tile) and P V runs over resident tiles without a barrier per key tile.
+__global__ __launch_bounds__(256, 1) void attn_fwd1_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[QS_BYTES + KBLK * KS_BYTES + PS_BYTES];
+  unsigned char* Qs = smem;
+  unsigned char* Kb = smem + QS_BYTES;                 // KBLK key tiles (row-major), later the value tiles (contraction-major)
+  unsigned char* Ps = Kb + KBLK * KS_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
+  const int q0 = blockIdx.x * TQ;
+  const int S = a.S, ld = 3 * a.d;
+  const int len = a.lens ? (int)a.lens[b] : S;
+  const bf16_t* base = a.qkv + (int64_t)b * S * ld + h * DK;
+  const int ntile = (S + TK - 1) / TK;                 // <= KBLK
+  unsigned char* Pw = Ps + wave * 16 * PS_RS;
+
+  {  // Q and all key tiles: every load in flight before the first LDS store
+    uint4 rq[4], rk[KBLK][4];
+    load_tile(rq, base, ld, q0, S, tid);
+#pragma unroll
+    for (int jt = 0; jt < KBLK; ++jt)
+      if (jt < ntile) load_tile(rk[jt], base + a.d, ld, jt * TK, S, tid);
+    store_rows(Qs, rq, tid);
+#pragma unroll
+    for (int jt = 0; jt < KBLK; ++jt)
+      if (jt < ntile) store_rows(Kb + jt * KS_BYTES, rk[jt], tid);
+  }
+  __syncthreads();
+
+  // ---- scores of the wave's 16 queries against every key (scaled; PAD keys and absent tiles -inf)
+  f32x4 sc[KBLK][4];
+  bf16x8 qa[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qa[ks] = frag_rows(Qs, wave * 16, ks, l15, lg);
+#pragma unroll
+  for (int jt = 0; jt < KBLK; ++jt) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) sc[jt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (jt < ntile) {
+      const unsigned char* Ks = Kb + jt * KS_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          sc[jt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], frag_rows(Ks, nt * 16, ks, l15, lg), sc[jt][nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int key = jt * TK + nt * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc[jt][nt][r] = key < len ? sc[jt][nt][r] * a.scale : -INFINITY;
+    }
+  }
+  // value tiles 0..3 are requested now; their latency runs under the softmax arithmetic
+  uint4 vr[4][4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+    if (jt < ntile) load_tile(vr[jt], base + 2 * a.d, ld, jt * TK, S, tid);
+
+  float m[4], inv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float tm = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < KBLK; ++jt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) tm = fmaxf(tm, sc[jt][nt][r]);
+    tm = quad16_max(tm);
+    float ts = 0.f;
+    if (tm > -INFINITY) {
+#pragma unroll
+      for (int jt = 0; jt < KBLK; ++jt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const float e = __expf(sc[jt][nt][r] - tm);      // exp(-inf) = 0 on PAD keys
+          sc[jt][nt][r] = e;
+          ts += e;
+        }
+    } else {
+#pragma unroll
+      for (int jt = 0; jt < KBLK; ++jt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) sc[jt][nt][r] = 0.f;
+    }
+    ts = quad16_sum(ts);
+    m[r] = tm;
+    inv[r] = 1.f / ts;
+  }
+
+  f32x4 oacc[8];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) oacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // P tile j (normalised, rounded to bf16: the same rounding point as the unfused path) -> LDS -> probs, P V
+  auto pv_tile = [&](int j, const f32x4 (&e)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *(bf16_t*)(Pw + (lg * 4 + r) * PS_RS + (nt * 16 + l15) * 2) = f2bf(e[nt][r] * inv[r]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the P tile is private to the wave
+    if (a.probs) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int cid = i * 64 + lane, row = cid >> 3, ch = cid & 7;
+        const int q = q0 + wave * 16 + row, key = j * TK + ch * 8;
+        if (q < S && key < a.Sp) *(uint4*)(a.probs + ((int64_t)z * S + q) * a.Sp + key) = *(const uint4*)(Pw + row * PS_RS + ch * 16);
+      }
+    }
+    const unsigned char* Vs = Kb + j * VS_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 pa = *(const bf16x8*)(Pw + l15 * PS_RS + (ks * 32 + lg * 8) * 2);
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) oacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, frag_tr(Vs, nb, ks, l15, lg), oacc[nb], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // P reads done before the next tile overwrites Pw
+  };
+
+  __syncthreads();                                   // every wave is past its score MFMAs: the key tiles are dead
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+    if (jt < ntile) store_tr(Kb + jt * VS_BYTES, vr[jt], tid);
+#pragma unroll
+  for (int jt = 4; jt < KBLK; ++jt)
+    if (jt < ntile) load_tile(vr[jt - 4], base + 2 * a.d, ld, jt * TK, S, tid);
+  __syncthreads();
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+    if (jt < ntile) pv_tile(jt, sc[jt]);
+#pragma unroll
+  for (int jt = 4; jt < KBLK; ++jt)
+    if (jt < ntile) store_tr(Kb + jt * VS_BYTES, vr[jt - 4], tid);     // slots 4..6: nobody reads them before this barrier
+  __syncthreads();
+#pragma unroll
+  for (int jt = 4; jt < KBLK; ++jt)
+    if (jt < ntile) pv_tile(jt, sc[jt]);
+
+  // ---- O tile -> LDS -> full-row stores (heads merged: column h*128); fp32 copy straight from the accumulators
+  if (a.o32) {
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = q0 + wave * 16 + lg * 4 + r;
+        if (q < S) a.o32[((int64_t)b * S + q) * a.d + h * DK + nb * 16 + l15] = oacc[nb][r];
+      }
+  }
+  __syncthreads();
+  unsigned char* Os = smem;   // 64 x 272 B = 17 KiB over Qs / the first tile
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *(bf16_t*)(Os + (wave * 16 + lg * 4 + r) * OS_RS + (nb * 16 + l15) * 2) = f2bf(oacc[nb][r]);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid, row = c >> 4, ch = c & 15;
+    if (q0 + row < S) *(uint4*)(a.o + ((int64_t)b * S + q0 + row) * a.d + h * DK + ch * 8) = *(const uint4*)(Os + row * OS_RS + ch * 16);
+  }
+}
+
 struct AttnBwdArgs {
   const bf16_t* qkv;     // forward input
   const float* o32;      // forward output, fp32 (sum_k P V before rounding)
@@ -375,7 +537,10 @@ extern "C" int ttsk_attention_fwd(const void* qkv_bf16, void* o_bf16, float* o_f
   TTSK_REQUIRE(!probs_bf16 || (Sp >= S && (Sp & 7) == 0), "attention_fwd: Sp must be a multiple of 8 >= S");
   TTSK_REQUIRE(B * H <= 65535, "attention_fwd: too many (utterance, head) pairs");
   AttnArgs a{(const bf16_t*)qkv_bf16, (bf16_t*)o_bf16, o_f32, (bf16_t*)probs_bf16, (const long long*)lens, S, Sp, H, d, scale};
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + TQ - 1) / TQ, B * H), dim3(256), 0, (hipStream_t)stream, a);
+  if ((S + TK - 1) / TK <= KBLK)
+    hipLaunchKernelGGL(attn_fwd1_kernel, dim3((S + TQ - 1) / TQ, B * H), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + TQ - 1) / TQ, B * H), dim3(256), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

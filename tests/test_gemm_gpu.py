@@ -281,8 +281,9 @@ def test_k2_fp16_and_polyphase(kern):
     assert err <= 2e-6 * (Cin * k // s) ** 0.5 * float(ref.abs().max() + 1) + float(ref.abs().max()) * 2 ** -10, err
 
 
-def test_grouped_launch_equals_individual_launches():
-    """ttsk_gemm_group_*: weight-gradient GEMMs of different shapes (split-K with deferred reduce, accumulate, conv taps as
+@pytest.mark.parametrize("kern", [1, 2])
+def test_grouped_launch_equals_individual_launches(kern):
+    """ttsk_gemm_group_* (both tile configurations): weight-gradient GEMMs of different shapes (split-K with deferred reduce, accumulate, conv taps as
     batch) queued in a DeferQueue produce bit-identical results to the same calls launched one by one on kernel 1 with the
     same split factors; with the group's own split policy (fewer, longer K ranges) they agree with fp64."""
     from tts_king_amd import ops
@@ -301,7 +302,7 @@ def test_grouped_launch_equals_individual_launches():
         res = []
         for dy, x, cout, cin, k, sp in tensors:
             dst = torch.full((cout, k, cin), 0.5, dtype=torch.float32, device=DEV)
-            kw = dict(defer=q, kernel=1) if mode != "grouped-auto" else dict(defer=q)
+            kw = dict(defer=q, kernel=kern) if mode != "grouped-auto" else dict(defer=q)
             if mode != "grouped-auto":
                 kw["splits"] = sp
             if k == 1:

@@ -265,6 +265,12 @@ int ttsk_hifi_conv_window(const void* x16, const void* w_pack, const float* bias
  * out (B, 1, len) fp32.  A streaming kernel: one output sample per thread. */
 int ttsk_hifi_conv_post(const void* x16, const void* w16, const float* bias, float* out, int f16, int B, int len, int C, int K,
                         void* stream);
+/* The stride-2, kernel-4 ConvTranspose1d upsamplers (hifi/models.py:166-176,189) as one streaming kernel: both output
+ * phases from one read of the input.  x16 (B, T, Cin) 16-bit, w16 (4, Cout, Cin) tap-major (ttsk_pack_conv_weight mode 1),
+ * out16 (B, 2T, Cout).  Instances: Cin -> Cout = 128 -> 64, 64 -> 32. */
+int ttsk_hifi_upsample2_supported(int Cin, int Cout, int stride, int k);
+int ttsk_hifi_upsample2(const void* x16, const void* w16, const float* bias, void* out16, int f16, int B, int T, int Cin,
+                        int Cout, void* stream);
 int ttsk_avg3(const void* a, const void* b, const void* c, void* out, int f16, int64_t n, float scale, float slope, void* stream);
 
 /* Fused ResBlock1 (hifi/models.py:88-95): all six convs of one block for C in {32,64}, K in {3,7,11}; x/out 16-bit

@@ -14,6 +14,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import hifigan as ohifi
 from tests.oracle_util import GOLDEN, hifi_state_dict_wn, rel_rms
@@ -216,3 +217,38 @@ def test_window_and_gemm_generators_agree(cfg):
     r = rel_rms(a.cpu(), b.cpu())
     print("window-conv vs implicit-GEMM generator: rel-RMS %.3f%%" % (100 * r))
     assert r <= 0.002
+
+
+@pytest.mark.parametrize("Cin,B,T", [(128, 2, 300), (128, 1, 1), (64, 2, 256), (64, 3, 777), (128, 1, 513)])
+def test_stream_upsample_vs_fp64(Cin, B, T):
+    """ttsk_hifi_upsample2 (stride 2, kernel 4, padding 1; both phases from one read of the input) vs fp64
+    ConvTranspose1d on the same fp16 inputs, and bit-equal channel-by-channel structure at the sequence ends (t = 0, T-1)."""
+    from tts_king_amd import ops
+    Cout = Cin // 2
+    g = torch.Generator().manual_seed(Cin + T)
+    x = torch.randn(B, T, Cin, generator=g).half()
+    w = (torch.randn(Cin, Cout, 4, generator=g) * (2 * Cin) ** -0.5).half()          # torch ConvTranspose1d layout
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv_transpose1d(x.double().transpose(1, 2), w.double(), bias.double(), stride=2, padding=1).transpose(1, 2)
+    assert ops.hifi_upsample2_supported(Cin, Cout, 2, 4) and not ops.hifi_upsample2_supported(Cin, Cout, 8, 16)
+    wp = ops.pack_conv_weight(w.float().to(DEV), transposed=True, dtype=torch.float16)           # (4, Cout, Cin)
+    out = ops.hifi_upsample2(x.to(DEV), wp, bias.to(DEV))
+    assert out.shape == (B, 2 * T, Cout) and out.dtype == torch.float16
+    r = rel_rms(out.float().cpu(), ref.float())
+    print("upsample2 Cin=%d B=%d T=%d: rel-RMS %.4f%%" % (Cin, B, T, 100 * r))
+    assert r <= 1e-3
+    gen = ops.conv_transpose1d(x.to(DEV), wp, bias.to(DEV), 2, 4)                                 # polyphase implicit GEMMs
+    assert float((gen.float() - out.float()).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
+def test_stream_upsample_generator_agrees(cfg):
+    from tts_king_amd.hifi_bench import build_generator
+    gen = build_generator(cfg, DEV)
+    mel = make_mel(2, 40, seed=3).to(DEV)
+    gen.stream_upsample = True
+    a = gen(mel)
+    gen.stream_upsample = False
+    b = gen(mel)
+    r = rel_rms(a.cpu(), b.cpu())
+    print("streamed vs polyphase-GEMM upsamplers: rel-RMS %.3f%%" % (100 * r))
+    assert r <= 2e-3

@@ -97,6 +97,7 @@ class Generator(nn.Module):
         self.act_dtype = f16         # storage type of activations and packed weights (fp32 accumulate); bf16 also works
         self.window_conv = True      # window-conv kernel at the C = 128 stage; False = implicit-GEMM convs
         self.fused = True            # fused ResBlock1 kernel where an instance exists (C in {32,64}); False = conv-by-conv
+        self.stream_upsample = True  # stride-2 upsamplers (128->64, 64->32) on the streaming kernel; False = polyphase implicit GEMMs
         self.group_resblocks = True  # conv m of the three MRF ResBlocks as one grouped launch where they run conv by conv (C = 256)
 
     # ------------------------------------------------------------------ reference surface
@@ -226,7 +227,10 @@ class Generator(nn.Module):
                 rbs = [self.resblocks[i * nk + j] for j in range(nk)]
                 fused = self.fused and all(pk["rbf"][i * nk + j] is not None for j in range(nk)) and nk >= 2
                 if fused:
-                    a = ops.conv_transpose1d(al, wu, bu, u, k)                             # raw x: the fused blocks activate it themselves
+                    if self.stream_upsample and ops.hifi_upsample2_supported(wu.shape[2], wu.shape[1], u, k) and al.is_contiguous():
+                        a = ops.hifi_upsample2(al, wu, bu)                                 # both phases from one read of `al`
+                    else:
+                        a = ops.conv_transpose1d(al, wu, bu, u, k)                         # raw x: the fused blocks activate it themselves
                     out = torch.empty_like(a)
                     for j, rb in enumerate(rbs):
                         ws, bs = pk["rbf"][i * nk + j]

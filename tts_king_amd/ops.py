@@ -697,6 +697,21 @@ def hifi_resblock1(x, weights, biases, dilations, out, K, mode=0, scale=1.0, slo
     return out
 
 
+def hifi_upsample2_supported(Cin, Cout, stride, k):
+    return bool(L.load().ttsk_hifi_upsample2_supported(Cin, Cout, stride, k))
+
+
+def hifi_upsample2(x, Wp, bias):
+    """ConvTranspose1d(stride 2, kernel 4, padding 1): x (B, T, Cin) 16-bit, Wp (4, Cout, Cin) -> (B, 2T, Cout)."""
+    _dev(x, Wp, bias)
+    Bsz, T, Cin = x.shape
+    Cout = Wp.shape[1]
+    out = torch.empty(Bsz, 2 * T, Cout, dtype=x.dtype, device=x.device)
+    check(L.load().ttsk_hifi_upsample2(_ptr(x), _ptr(Wp), _ptr(bias), _ptr(out), int(x.dtype == f16), Bsz, T, Cin, Cout, _stream()),
+          "ttsk_hifi_upsample2")
+    return out
+
+
 def hifi_conv_post(x, w, bias):
     """tanh(Conv1d(C -> 1, k)(x)): x (B, len, C) 16-bit already activated, w (1, k, C) 16-bit -> (B, 1, len) fp32.
     reference: hifi/models.py:198-199."""

@@ -209,3 +209,37 @@ def test_full_size_step_is_deterministic(cfg):
     assert torch.equal(finals[0][0], finals[1][0])
     assert finals[0][1] == finals[1][1]
     assert np.isfinite(finals[0][1]).all()
+
+
+@pytest.mark.parametrize("B,L,dur_hi", [(1, 3, 3), (3, 7, 40), (2, 130, 9)])
+def test_train_step_edge_sizes_vs_oracle_losses(cfg, B, L, dur_hi):
+    """Edge sizes of the training batch — one utterance of 3 phonemes / 5 frames (every tile smaller than any kernel's
+    block; a single-frame batch is rejected by the reference itself: BatchNorm1d in training mode), ragged lengths, 630
+    frames — through the whole step (grouped weight-gradient launches, split-K, deferred column sums): losses against
+    the oracle (5 % for the 5-frame batch, whose BatchNorm statistics over 5 rows amplify bf16 rounding; 2 % otherwise),
+    finite updated parameters."""
+    from tts_king_amd.loss import FastSpeech2Loss
+    from tts_king_amd.optimizer import ScheduledOptim
+    from tts_king_amd.train_step import main_train_step, to_device
+    c = copy.deepcopy(cfg)
+    c.train_config["optimizer"]["grad_acc_step"] = 1
+    m = build(c, 7, dropout=False)
+    opt = ScheduledOptim(m, c.train_config, c.model_config, 100)
+    loss_fn = FastSpeech2Loss(c.preprocess_config, c.model_config)
+    b = make_batch(B, L, seed=B * 100 + L, ragged=B > 1, dur_hi=dur_hi)
+    if int(b[8]) > c.model_config["max_seq_len"]:
+        pytest.skip("longer than max_seq_len")
+    vals, out = main_train_step(m, to_device(b, DEV), 1, opt, c, loss_fn)
+    mc0 = copy.deepcopy(c.model_config)
+    mc0["transformer"]["encoder_dropout"] = mc0["transformer"]["decoder_dropout"] = 0.0
+    mc0["variance_predictor"]["dropout"] = 0.0
+    tr = ofs2.OracleTrainer(fs2_state_dict(c, 7), mc0, c.train_config, current_step=100)
+    orig = ofs2._drop
+    ofs2._drop = lambda x, p, train: x
+    try:
+        ovals, _ = tr.train_step(b, 1)
+    finally:
+        ofs2._drop = orig
+    print("B=%d L=%d T=%d losses" % (B, L, int(b[8])), [round(float(v), 4) for v in vals[:5]], [round(float(v), 4) for v in ovals[:5]])
+    np.testing.assert_allclose(vals[:4], ovals[:4], rtol=0.05 if int(b[8]) < 16 else 0.02, atol=2e-3)
+    assert bool(torch.isfinite(m.flat_buffers()[0]).all())

@@ -61,8 +61,8 @@ def load_training_state(model, optimizer, path):
     state = dict(ckpt["model"])
     state["speaker_emb.weight"] = ckpt["embedding"]
     model.load_state_dict(state)
-    if optimizer is not None and ckpt.get("optimizer") is not None:
-        optimizer.load_state_dict(ckpt["optimizer"])
+    if optimizer is not None and isinstance(ckpt.get("optimizer"), dict):
+        optimizer.load_state_dict(ckpt["optimizer"])       # flat layout or the reference's torch.optim.Adam layout
 
 
 def main(cfg, max_steps=None):

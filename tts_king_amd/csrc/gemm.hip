@@ -9,6 +9,7 @@
 // Conv1d is an implicit GEMM: the K loop walks (tap, channel-chunk) and a tap only shifts the A row index
 // (channels-last activations), with zero fill outside the utterance.  The epilogue goes through LDS so that
 // C (and the residual / gate operands) move as full 16-byte rows.
+#include <cstdlib>
 #include <cstring>
 #include "gemm_common.h"
 
@@ -492,6 +493,20 @@ int validate(ttsk_gemm_desc& d) {
   TTSK_REQUIRE(!(d.kernel == 2 && d.taps > 32), "ttsk_gemm: kernel = 2 handles at most 32 taps");
   if (d.nz1 < 1) d.nz1 = 1;
   if (d.nz2 < 1) d.nz2 = 1;
+  {
+    // operands are addressed with 32-bit BYTE offsets from the per-batch origin (buffer_load ... offen): the extent a launch
+    // can touch, conv tap shifts and tap-major weight strides included, must stay below 2^31
+    const int64_t taps = d.taps > 0 ? d.taps : 1;
+    const int64_t a_rows = atr ? d.K : d.M, a_cols = atr ? d.M : d.K;
+    const int64_t b_rows = btr ? d.K : d.N, b_cols = btr ? d.N : d.K;
+    const int64_t a_shift = d.taps > 0 ? (int64_t)llabs((long long)d.tap_shift0) + taps * llabs((long long)d.tap_dshift) : 0;
+    const int64_t b_shift = d.bseg_len > 0 ? (int64_t)llabs((long long)d.bshift0) + (int64_t)d.nz2 * llabs((long long)d.bdshift) : 0;
+    const int64_t a_ext = ((a_rows + a_shift + 256) * d.lda + a_cols + 64) * 2;
+    const int64_t b_ext = ((b_rows + b_shift + 256) * d.ldb + b_cols + 64 + taps * llabs((long long)d.b_tap_stride)) * 2;
+    TTSK_REQUIRE(a_ext < ((int64_t)1 << 31) && b_ext < ((int64_t)1 << 31),
+                 "ttsk_gemm: operand extent exceeds the 2 GiB a 32-bit buffer offset reaches (A %lld B, B %lld B): split the batch",
+                 (long long)a_ext, (long long)b_ext);
+  }
   TTSK_REQUIRE(!(d.flags & TTSK_GEMM_ADD_R) || d.R, "ttsk_gemm: ADD_R without R");
   TTSK_REQUIRE(!(d.flags & TTSK_GEMM_MASK_G) || d.G, "ttsk_gemm: MASK_G without G");
   TTSK_REQUIRE(!(d.flags & TTSK_GEMM_ACCUM_C) || (d.flags & TTSK_GEMM_C_F32), "ttsk_gemm: ACCUM_C needs fp32 C");

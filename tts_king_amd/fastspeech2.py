@@ -145,13 +145,26 @@ class FastSpeech2(nn.Module):
         return v.permute(0, 2, 1) if en.conv else v
 
     def _rebind(self):
+        """After the flat buffers moved (`.to()`, `.cuda()`): new Parameters over the new views.  `par.data = view` would keep
+        the parameter's OWN version counter, so a later `load_state_dict` / `param.copy_()` would no longer bump
+        `_flat._version` and the bf16 shadow would go stale; a Parameter built from a view shares the buffer's counter."""
         for en in self._table.values():
             if en.kind == P.TRAIN:
                 mod, leaf = self._modules_by_key[en.key]
-                par = mod._parameters[leaf]
-                par.data = self._view(self._flat, en)
+                par = nn.Parameter(self._view(self._flat, en), requires_grad=True)
                 par.grad = self._view(self._flat_grad, en)
+                mod._parameters[leaf] = par
         self._shadow_version = -1
+
+    def mark_dirty(self):
+        """Call after writing the fp32 masters through anything torch cannot see (raw pointers): the next forward
+        refreshes the bf16 shadow."""
+        self._shadow_version = -1
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._shadow_version = -1
+        return out
 
     def _apply(self, fn, recurse=True):
         flat, grad, shadow = fn(self._flat), fn(self._flat_grad), fn(self._shadow)
@@ -499,6 +512,9 @@ class FastSpeech2(nn.Module):
         with torch.no_grad():
             dmel_sum = ops.add_f32(dmel, dpost)
             self.backward_native(ctx, dmel_sum, dpost, f32(dpitch, (Bn, Lp)), f32(denergy, (Bn, Lp)), f32(dlogd, (Bn, Lp)))
+            # one dropout-counter tick per micro-step, as main_train_step / graph.make_enqueue do: Philox masks are a
+            # function of (seed, step, site, element), so without it every `loss.backward()` step would reuse one mask
+            ops.rng_advance(self._state())
 
     def _finalize_ln(self, partials, nblk, ncol, first_key):
         """partials [nblk][ncol] = dbias | dgamma | dbeta (| dhead_w | dhead_b) -> the flat gradient buffer, where the

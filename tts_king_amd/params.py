@@ -137,3 +137,47 @@ def buckets(table, total, bucket_elems):
         end = start
         i = j - 1
     return out
+
+
+def reference_parameter_keys(entries_table):
+    """Keys in the order of the reference model's `model.parameters()` — the indices torch.optim.Adam's `state_dict()`
+    uses (reference: fs_two/model/optimizer.py:10-15 builds Adam over `model.parameters()`, train.py:221 saves its
+    `state_dict()`).  Order there (a module's own Parameters, then its children in registration order): encoder (position_enc, src_word_emb, layer_stack) ->
+    variance_adaptor (own Parameters pitch_bins / energy_bins first, then predictors, pitch_mean / pitch_std,
+    embeddings: model/modules.py:20-90) -> decoder -> mel_linear -> speaker_emb -> postnet (model/fastspeech2.py:21-41);
+    inside a block w_qs, w_ks, w_vs, layer_norm, fc (SubLayers.py:14-29), each weight before its bias.
+    BatchNorm running statistics are buffers, not parameters."""
+    keys = [k for k, en in entries_table.items() if en.kind != BUFFER]
+
+    def rank(k):
+        parts = k.split(".")
+        top = {"encoder": 0, "variance_adaptor": 1, "decoder": 2, "mel_linear": 3, "speaker_emb": 4, "postnet": 5}[parts[0]]
+        r = [top]
+        if parts[0] in ("encoder", "decoder"):
+            if parts[1] == "position_enc":      # a Parameter of Encoder/Decoder itself: before the children's
+                r += [0]
+            elif parts[1] == "src_word_emb":
+                r += [1]
+            else:
+                sub = parts[3] + "." + parts[4]
+                order = ["slf_attn.w_qs", "slf_attn.w_ks", "slf_attn.w_vs", "slf_attn.layer_norm", "slf_attn.fc", "pos_ffn.w_1",
+                         "pos_ffn.w_2", "pos_ffn.layer_norm"]
+                r += [2, int(parts[2]), order.index(sub), 0 if parts[-1] == "weight" else 1]
+        elif parts[0] == "variance_adaptor":
+            names = ["pitch_bins", "energy_bins", "duration_predictor", "pitch_predictor", "energy_predictor", "pitch_mean", "pitch_std",
+                     "pitch_embedding", "energy_embedding"]
+            r += [names.index(parts[1])]
+            if parts[1].endswith("_predictor"):
+                sub = ".".join(parts[2:-1])
+                order = ["conv_layer.conv1d_1.conv", "conv_layer.layer_norm_1", "conv_layer.conv1d_2.conv", "conv_layer.layer_norm_2", "linear_layer"]
+                r += [order.index(sub), 0 if parts[-1] == "weight" else 1]
+            elif parts[1] in ("pitch_mean", "pitch_std"):
+                sub = ".".join(parts[2:-1])
+                order = ["flat_one.net.0", "flat_one.net.2", "flat_two.net.0", "flat_two.net.2", "linear"]
+                r += [order.index(sub), 0 if parts[-1] == "weight" else 1]
+        elif parts[0] == "postnet":
+            r += [int(parts[2]), int(parts[3]), 0 if parts[-1] == "weight" else 1]
+        else:
+            r += [0 if parts[-1] == "weight" else 1]
+        return r
+    return sorted(keys, key=rank)

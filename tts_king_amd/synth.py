@@ -65,10 +65,11 @@ class GraphedSynthesizer:
         back = lambda x, dd: m.eval_back(x, dd, Lp, T)
         kb = ("back", Bn, Lp, T) if T <= m.max_seq_len else None
         mel, post, mel_lens, _ = self._get(self._back, kb, back, (x3, dur))
-        return post, mel_lens
+        # a replayed graph returns its private static buffers: hand out copies, or the caller's mel changes at the next call
+        return post.clone(), mel_lens.clone()
 
     @torch.no_grad()
     def wav(self, mel_bct):
         """mel (B, 80, T) fp32 on the device -> waveform (B, 1, 256 T) fp32."""
         Bn, _, T = mel_bct.shape
-        return self._get(self._voc, ("voc", Bn, T), lambda x: self.vocoder(x), (mel_bct.contiguous(),))
+        return self._get(self._voc, ("voc", Bn, T), lambda x: self.vocoder(x), (mel_bct.contiguous(),)).clone()

@@ -52,8 +52,10 @@ def get_model(cfg, device, train=False):
     if train:
         model.train()
         optim = ScheduledOptim(model, cfg.train_config, cfg.model_config, cfg.tts.restore_step)
-        if ckpt is not None and isinstance(ckpt.get("optimizer"), dict) and "exp_avg" in ckpt["optimizer"]:
-            optim.load_state_dict(ckpt["optimizer"])       # the reference saves this state but never restores it (row f-4)
+        if ckpt is not None and isinstance(ckpt.get("optimizer"), dict):
+            # the reference saves torch.optim.Adam's state_dict (train.py:221) but never restores it (row f-4); both that
+            # layout and this build's earlier flat one are accepted
+            optim.load_state_dict(ckpt["optimizer"])
         return model, optim
     model.eval()
     return model

@@ -94,8 +94,12 @@ typedef struct ttsk_gemm_desc {
   void* workspace;
   int64_t workspace_bytes;
   /* tile configuration: 0 = let the library choose, 1 = 128x128x64 (4 waves, register staging; required by LRELU_IN),
-   * 2 = 256x128x64 (8 waves, 3-stage LDS-DMA ring) */
+   * 2 = 256x128x64 (8 waves, 3-stage LDS-DMA ring), 3 = 64x128x64 (4 waves, register staging, A untransposed: outputs
+   * with few columns get enough workgroups to fill the chip without split-K) */
   int32_t kernel;
+  /* batched problems with one bias vector per z1 (the three VariancePredictors of a training step as one launch):
+   * bias of batch z1 = bias + z1 * s_bias1 (floats); 0 = one bias for all */
+  int64_t s_bias1;
 } ttsk_gemm_desc;
 
 int ttsk_gemm(const ttsk_gemm_desc* d, void* stream);
@@ -122,6 +126,16 @@ int ttsk_gemm_reduce_batch(const ttsk_reduce_item* items, int n, void* stream);
 int64_t ttsk_gemm_group_table_bytes(int n);
 int ttsk_gemm_group_build(const ttsk_gemm_desc* descs, int n, void* host_table, int32_t* total_wgs);
 int ttsk_gemm_group_launch(const void* host_table, void* dev_table, void* stream);
+
+/* Fused sub-layer tail of an FFT block (reference: fs_two/transformer/SubLayers.py:62-63 and :96-99 + Layers.py:29,32):
+ *   out = zero_PAD_rows( LayerNorm( dropout_{p_pre, site_pre}( A[M,K] @ W[D,K]^T + bias ) + res ) ),  D = 256 only.
+ * A, W, res, out, z_save bf16; z_save (may be NULL) receives the LayerNorm input, mean / rstd [M] its statistics (what
+ * ttsk_layernorm_bwd needs); lens (may be NULL) marks rows t >= lens[row / seg_len] of each segment as PAD.  Same dropout
+ * bits as ttsk_layernorm_fwd at the same (rng, site) — the two forms are interchangeable up to the bf16 rounding of
+ * the GEMM output that the fused kernel skips. */
+int ttsk_gemm_ln_fwd(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, const float* gamma,
+                     const float* beta, void* out, void* z_save, float* mean, float* rstd, const int64_t* lens, int seg_len,
+                     int M, int K, int D, float eps, float p_pre, uint32_t site_pre, const void* rng, void* stream);
 
 /* what ttsk_gemm will run for `d` (with d->kernel / d->splits as constraints when non-zero) and the workspace it needs */
 int ttsk_gemm_plan(const ttsk_gemm_desc* d, int32_t* kernel, int32_t* splits, int64_t* workspace_bytes);
@@ -163,6 +177,21 @@ int ttsk_layernorm_bwd(const void* dout_bf16, const float* dhead, const float* h
                        const float* rstd, const float* gamma, const float* beta, const int64_t* lens, int seg_len, int rows,
                        int D, int relu_in, float p_pre, uint32_t site_pre, float p_post, uint32_t site_post,
                        const uint64_t* rng, void* dz_bf16, void* dy_bf16, float* partials, void* stream);
+/* Grouped forms: rows = groups * group_rows; group g reads gamma / beta / head_w / head_b at + g * param_stride floats and
+ * uses dropout sites + g * site_stride; PAD masks (lens [group_rows / seg_len], shared by the groups) and dropout element
+ * indices are taken inside the group, so one grouped launch equals `groups` single launches bit for bit (the three
+ * VariancePredictors of a training step: model/modules.py:158-193 with targets given are independent).  bwd partials:
+ * [groups][ttsk_layernorm_bwd_nblocks(group_rows)][3*D or 4*D+1]. */
+int ttsk_layernorm_fwd_grouped(const void* y_bf16, const void* res_bf16, const float* gamma, const float* beta, void* out_bf16,
+                               void* z_save_bf16, float* mean, float* rstd, const int64_t* lens, int seg_len, int groups,
+                               int group_rows, int64_t param_stride, uint32_t site_stride, int D, float eps, float p_pre,
+                               uint32_t site_pre, float p_post, uint32_t site_post, const uint64_t* rng, const float* head_w,
+                               const float* head_b, float* head_out, void* stream);
+int ttsk_layernorm_bwd_grouped(const void* dout_bf16, const float* dhead, const float* head_w, const void* z_bf16,
+                               const float* mean, const float* rstd, const float* gamma, const float* beta, const int64_t* lens,
+                               int seg_len, int groups, int group_rows, int64_t param_stride, uint32_t site_stride, int D,
+                               int relu_in, float p_pre, uint32_t site_pre, float p_post, uint32_t site_post, const uint64_t* rng,
+                               void* dz_bf16, void* dy_bf16, float* partials, void* stream);
 /* dst[c] (+)= scale * sum_b partials[b*ld + c]  in fixed order */
 int ttsk_colsum_finalize(const float* partials, int nblk, int ncols, int ld, float* dst, int accumulate, float scale,
                          void* stream);
@@ -184,6 +213,19 @@ typedef struct ttsk_colsum_item {
   int32_t is_f32, rows, C, ld, nblk;
 } ttsk_colsum_item;
 int ttsk_colsum_batch(const ttsk_colsum_item* items, int n, void* stream);
+
+/* Training-mode VarianceAdaptor embedding chain in one pass (reference: model/modules.py:158-193 with targets given;
+ * fastspeech2.py:72-75): x1 = x + speaker_table[speakers[row / L]]; x2 = x1 + pitch_table[bucketize(pitch_target)];
+ * x3 = x2 + energy_table[bucketize(energy_target)] (bucketize = torch.bucketize, right=False, n_bins_minus_1 edges), each
+ * rounded to bf16; the bucket indices are returned for the embedding-gradient scatter-sums.  va_combine is its backward around
+ * the grouped predictor backward: dxin [3][rows][D] fp32 (gradients wrt x, x1, x2 from the duration / pitch / energy
+ * predictors), dx3 -> dx2 = dx3 + dxin[2], dx1 = dx2 + dxin[1], dx = dx1 + dxin[0]. */
+int ttsk_va_embed(const void* x_bf16, const float* speaker_table, const int64_t* speakers, int L, const float* pitch_target,
+                  const float* pitch_bins, const float* pitch_table, const float* energy_target, const float* energy_bins,
+                  const float* energy_table, int n_bins_minus_1, void* x1_bf16, void* x2_bf16, void* x3_bf16, int32_t* pitch_idx,
+                  int32_t* energy_idx, int rows, int D, void* stream);
+int ttsk_va_combine(const void* dx3_bf16, const float* dxin, void* dx2_bf16, void* dx1_bf16, void* dx_bf16, int rows, int D,
+                    void* stream);
 
 /* ------------------------------------------------------------------------------------------ attention softmax
  * reference: fs_two/transformer/Modules.py:15-22.  scores fp32 [nz][S][Sp] (already scaled by 1/sqrt(d_k) in the
@@ -338,6 +380,12 @@ int ttsk_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_
                         void* state, float* partials, float max_norm, float beta1, float beta2, float eps, int zero_grad,
                         void* stream);
 int ttsk_grad_sumsq(const float* grads, int64_t n, float* partials, void* stream);
+/* optim_advance (+ rng_advance when advance_rng) + clip_adam_step as TWO launches: the first sums g^2 per block and advances
+ * the counters, the second derives the clip coefficient from the partials in every workgroup and applies Adam.  Same
+ * arithmetic, same state block as the three calls it replaces. */
+int ttsk_optim_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n, void* state,
+                    float* partials, float max_norm, float beta1, float beta2, float eps, int zero_grad, float d_model, float warmup,
+                    const float* anneal_steps_host, int n_anneal, float anneal_rate, int advance_rng, void* stream);
 
 /* ------------------------------------------------------------------------------------------- mel extraction
  * SURVEY.md §8 row f-3.  reference: hifi/meldataset.py:49-74 (mel_spectrogram), fs_two/audio/stft.py:57-90

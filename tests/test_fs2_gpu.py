@@ -237,3 +237,39 @@ def test_train_step_edge_sizes_vs_oracle_losses(cfg, B, L, dur_hi):
     print("B=%d L=%d T=%d losses" % (B, L, int(b[8])), [round(float(v), 4) for v in vals[:5]], [round(float(v), 4) for v in ovals[:5]])
     np.testing.assert_allclose(vals[:4], ovals[:4], rtol=0.05 if int(b[8]) < 16 else 0.02, atol=2e-3)
     assert bool(torch.isfinite(m.flat_buffers()[0]).all())
+
+
+def test_fused_and_grouped_paths_equal_step_by_step_paths(cfg):
+    """The round-2 launch collapses — fc / w_2 + LayerNorm in one kernel (`fused_ln`), the three VariancePredictors and the
+    embedding chain as grouped launches (`group_predictors`) — against the step-by-step launches they replace, dropout ON with
+    the same counters: same dropout masks, predictions and gradients equal up to bf16 rounding of intermediates."""
+    from tts_king_amd import ops
+    b = make_batch(4, 40, seed=11, ragged=True)
+    res = []
+    for fast in (True, False):
+        m = build(cfg, 7, dropout=True).train()
+        m.fused_ln = m.group_predictors = fast
+        dev_b = [t.to(DEV) if torch.is_tensor(t) else t for t in b]
+        with torch.no_grad():
+            out, ctx = m._forward(True, dev_b[2], dev_b[3], dev_b[4], int(b[5]), dev_b[7], b[8], dev_b[9], dev_b[10], dev_b[11], 1.0, 1.0, 1.0)
+            losses, dmel_sum, dpost, dp, de, dd = ops.fs2_loss(out[0], out[8], dev_b[6], dev_b[7], out[1], out[2], out[3], dev_b[11],
+                                                               dev_b[9], dev_b[10], dev_b[4], grad_scale=1.0)
+            m.backward_native(ctx, dmel_sum, dpost, dp, de, dd)
+        torch.cuda.synchronize()
+        res.append(([o.float().cpu().clone() for o in (out[0], out[1], out[2], out[3], out[8])], losses.cpu().clone(),
+                    {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}))
+    (outs_f, loss_f, g_f), (outs_s, loss_s, g_s) = res
+    for a, w, name in zip(outs_f, outs_s, ("mel", "pitch", "energy", "logd", "post")):
+        r = rel_rms(a, w)
+        print("fused vs step-by-step %s rel-RMS %.4f%%" % (name, 100 * r))
+        assert r <= 0.01, (name, r)
+    np.testing.assert_allclose(loss_f[:5].numpy(), loss_s[:5].numpy(), rtol=5e-3)
+    worst = (0.0, None)
+    for k in g_s:
+        if "w_ks.bias" in k or ("postnet" in k and k.endswith("conv.bias")):
+            continue
+        r = rel_rms(g_f[k], g_s[k])
+        if r > worst[0]:
+            worst = (r, k)
+    print("fused vs step-by-step worst gradient rel-RMS", worst)
+    assert worst[0] <= 0.05, worst

@@ -323,3 +323,101 @@ def test_grouped_launch_equals_individual_launches(kern):
             check(c.view(cout, cin).to(DEV), ref, dy.shape[0] * dy.shape[1], exact=False, out_bf16=False)
         else:
             assert float((c - a).abs().max()) <= 1e-3 * float(a.abs().max())
+
+
+# ---- the 64-row tile (kernel = 3): A untransposed, every epilogue, conv taps, B transposed, split-K, tails
+@pytest.mark.parametrize("ints", [True, False])
+@pytest.mark.parametrize("M,N,K", [(64, 128, 64), (300, 200, 264), (6768, 256, 256), (1024, 768, 256), (77, 80, 256), (513, 129, 1000)])
+def test_k3_nt_bias_relu(M, N, K, ints):
+    from tts_king_amd import ops
+    a, w, b = bf(rnd(M, K, seed=1, ints=ints)), bf(rnd(N, K, seed=2, ints=ints)), rnd(N, seed=3, ints=ints)
+    ref = torch.relu(a.double() @ w.double().t() + b.double())
+    out32 = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV), flags=ops.RELU, out_dtype=torch.float32, kernel=3, splits=1)
+    check(out32, ref, K, exact=ints, out_bf16=False)
+    out16 = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV), flags=ops.RELU, kernel=3)
+    check(out16, bf(ref.float()).double() if ints else ref, K, exact=ints)
+
+
+@pytest.mark.parametrize("ints", [True, False])
+@pytest.mark.parametrize("M,N,K,splits", [(423, 128, 423, 1), (6768, 256, 768, 1), (600, 80, 64, 1), (1024, 256, 1024, 4)])
+def test_k3_b_transposed_residual_gate(M, N, K, splits, ints):
+    """dX-shaped problems: B read through the transposing LDS read, fp32 / bf16 residual, ReLU gate, optional split-K."""
+    from tts_king_amd import ops
+    Kp = (K + 7) // 8 * 8
+    a = torch.zeros(M, Kp)
+    a[:, :K] = rnd(M, K, seed=5, ints=ints)
+    a, b = bf(a), bf(rnd(K, N, seed=6, ints=ints))
+    r, g = bf(rnd(M, N, seed=7, ints=ints)), bf(rnd(M, N, seed=8))
+    ref = (a[:, :K].double() @ b.double() + r.double()) * (g.double() > 0)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(a.to(DEV), b.to(DEV), out, M, N, K, Kp, N, N, flags=ops.B_TR, kernel=3, splits=splits, R=r.to(DEV), ldr=N, G=g.to(DEV), ldg=N)
+    check(out, ref, K, exact=ints, out_bf16=False)
+
+
+@pytest.mark.parametrize("ints", [True, False])
+@pytest.mark.parametrize("Bsz,T,Cin,Cout,k,dil", [(3, 50, 256, 1024, 9, 1), (16, 64, 256, 256, 3, 1), (2, 423, 80, 512, 5, 1), (2, 131, 128, 128, 7, 3)])
+def test_k3_conv1d_fwd_dx(Bsz, T, Cin, Cout, k, dil, ints):
+    from tts_king_amd import ops
+    x = bf(rnd(Bsz, T, Cin, seed=9, ints=ints))
+    w = bf(rnd(Cout, Cin, k, seed=10, ints=ints) * (1.0 if ints else (Cin * k) ** -0.5))
+    b = rnd(Cout, seed=11, ints=ints)
+    dy = bf(rnd(Bsz, T, Cout, seed=12, ints=ints))
+    pad = dil * (k - 1) // 2
+    xd = x.double().transpose(1, 2).requires_grad_(True)
+    y = F.conv1d(xd, w.double(), b.double(), dilation=dil, padding=pad)
+    y.backward(dy.double().transpose(1, 2))
+    wk = w.permute(0, 2, 1).contiguous().to(DEV)
+    out = ops.conv1d(x.to(DEV), wk, b.to(DEV), dilation=dil, out_dtype=torch.float32, kernel=3)
+    check(out, y.detach().transpose(1, 2), Cin * k, exact=ints, out_bf16=False)
+    dx = torch.empty(Bsz, T, Cin, dtype=torch.float32, device=DEV)
+    ops.conv1d_dx(dy.to(DEV), wk, dilation=dil, out=dx, kernel=3)
+    check(dx, xd.grad.transpose(1, 2), Cout * k, exact=ints, out_bf16=False)
+
+
+# ---- fused GEMM + dropout + residual + LayerNorm + PAD zeroing (tts_king_amd/csrc/gemm_ln.hip)
+@pytest.mark.parametrize("M,K,seg", [(6768, 256, 423), (6768, 1024, 423), (1024, 256, 64), (1024, 1024, 64), (45, 264, 15), (33, 64, 33)])
+def test_gemm_ln_fwd_matches_reference(M, K, seg):
+    from tts_king_amd import ops
+    D = 256
+    a, w, b = bf(rnd(M, K, seed=21) * 0.5), bf(rnd(D, K, seed=22) * K ** -0.5), rnd(D, seed=23) * 0.1
+    res = bf(rnd(M, D, seed=24))
+    gamma, beta = 1 + 0.1 * rnd(D, seed=25), 0.1 * rnd(D, seed=26)
+    nseg = M // seg
+    lens = torch.randint(1, seg + 1, (nseg,), generator=torch.Generator().manual_seed(27))
+    lens[0] = seg
+    z_ref = a.double() @ w.double().t() + b.double() + res.double()
+    pad = (torch.arange(seg)[None, :] >= lens[:, None]).reshape(-1)
+    ref = F.layer_norm(z_ref, (D,), gamma.double(), beta.double(), 1e-5).masked_fill(pad[:, None], 0.0)
+    out, z, mean, rstd = ops.gemm_ln_fwd(a.to(DEV), w.to(DEV), b.to(DEV), res.to(DEV), gamma.to(DEV), beta.to(DEV), lens.to(DEV), seg)
+    torch.cuda.synchronize()
+    # z: one bf16 rounding of an O(1) value; out: LayerNorm output O(1) rounded to bf16
+    assert float((z.float().cpu().double() - z_ref).abs().max()) <= 2 ** -8 * float(z_ref.abs().max()) + 1e-3
+    assert float((out.float().cpu().double() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max()) + 2e-3
+    torch.testing.assert_close(mean.cpu().double(), z_ref.mean(1), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(rstd.cpu().double(), (z_ref.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-3, atol=1e-4)
+    assert float(out.float().cpu()[pad].abs().max() if bool(pad.any()) else 0.0) == 0.0
+    # the conv-layout weight (256, 1, K) of w_2 is accepted as is
+    out2, *_ = ops.gemm_ln_fwd(a.to(DEV), w.view(D, 1, K).to(DEV), b.to(DEV), res.to(DEV), gamma.to(DEV), beta.to(DEV), lens.to(DEV), seg)
+    assert torch.equal(out2, out)
+
+
+def test_gemm_ln_fwd_dropout_matches_unfused_masks():
+    """Same (seed, step, site) -> the fused kernel drops exactly the elements ttsk_layernorm_fwd drops, so ttsk_layernorm_bwd
+    regenerates the right mask for either forward."""
+    from tts_king_amd import ops
+    M, K, D, p = 2048, 256, 256, 0.2
+    a, w = bf(rnd(M, K, seed=31)), bf(rnd(D, K, seed=32) * K ** -0.5)
+    b = 3.0 + 0.1 * rnd(D, seed=33)                       # keeps |y| away from 0 so that "dropped" is visible as exactly 0
+    gamma, beta = torch.ones(D), torch.zeros(D)
+    st = ops.optim_state(DEV, seed=77)
+    rng = ops.rng_of(st)
+    _, z_f, mean_f, rstd_f = ops.gemm_ln_fwd(a.to(DEV), w.to(DEV), b.to(DEV), None, gamma.to(DEV), beta.to(DEV), None, 0, p_pre=p, site_pre=9, rng=rng)
+    y = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV))
+    _, z_u, mean_u, rstd_u, _ = ops.layernorm_fwd(y, None, gamma.to(DEV), beta.to(DEV), None, 0, p_pre=p, site_pre=9, rng=rng)
+    zf, zu = z_f.float().cpu(), z_u.float().cpu()
+    assert torch.equal(zf == 0, zu == 0)
+    keep = zu != 0
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.01
+    torch.testing.assert_close(zf[keep], zu[keep], rtol=2 ** -6, atol=1e-3)      # y rounded to bf16 (unfused) vs not (fused)
+    yref = (a.double() @ w.double().t() + b.double()) / (1 - p)
+    assert float((zf.double()[keep] - yref[keep]).abs().max()) <= 2 ** -8 * float(yref.abs().max()) + 1e-3

@@ -298,3 +298,89 @@ def test_conversions():
     a = torch.tensor([0.99999, -0.99999, 0.5, -0.5, 1e-5, -1e-5, 0.123456, -0.654321, 0.0])
     got = ops.to_int16(a.to(DEV), 32768.0).cpu().numpy()
     np.testing.assert_array_equal(got, (a * 32768).numpy().astype("int16"))
+
+
+def test_va_embed_and_combine_match_step_by_step_kernels():
+    """ttsk_va_embed == gather_add(speaker) -> bucketize -> gather_add(pitch) -> bucketize -> gather_add(energy), bit for bit;
+    ttsk_va_combine == the three rounded residual adds."""
+    from tts_king_amd import ops
+    Bn, Lp, D, nb = 5, 24, 256, 256
+    rows = Bn * Lp
+    g = torch.Generator().manual_seed(3)
+    stack = torch.zeros(3, rows, D, dtype=BF, device=DEV)
+    stack[0] = rnd(rows, D, seed=1).to(BF).to(DEV)
+    spk_t, p_t, e_t = rnd(7, D, seed=2).to(DEV), rnd(nb, D, seed=3).to(DEV), rnd(nb, D, seed=4).to(DEV)
+    speakers = torch.randint(0, 7, (Bn,), generator=g).to(DEV)
+    pbins, ebins = torch.linspace(-2, 2, nb - 1).to(DEV), torch.linspace(-1, 3, nb - 1).to(DEV)
+    pt, et = (rnd(rows, seed=5) * 1.5).to(DEV), (rnd(rows, seed=6) * 1.5 + 1).to(DEV)
+    pt[3] = pbins[10]                                      # a value exactly on an edge: right=False puts it in bucket 10
+    x3, pidx, eidx = ops.va_embed(stack, speakers, spk_t, Lp, pt, pbins, p_t, et, ebins, e_t)
+    x1 = ops.gather_add(stack[0], spk_t, speakers, idx_div=Lp)
+    pi = ops.bucketize(pt, pbins)
+    x2 = ops.gather_add(x1, p_t, pi)
+    ei = ops.bucketize(et, ebins)
+    x3w = ops.gather_add(x2, e_t, ei)
+    assert torch.equal(pidx, pi) and torch.equal(eidx, ei) and int(pidx[3]) == 10
+    assert torch.equal(pidx.cpu().long(), torch.bucketize(pt.cpu(), pbins.cpu()))
+    assert torch.equal(stack[1], x1) and torch.equal(stack[2], x2) and torch.equal(x3, x3w)
+    dx3 = rnd(rows, D, seed=7).to(BF).to(DEV)
+    dxin = rnd(3, rows, D, seed=8).to(DEV)
+    dx2, dx1, dx = ops.va_combine(dx3, dxin)
+    w2 = (dx3.float() + dxin[2]).to(BF)
+    w1 = (w2.float() + dxin[1]).to(BF)
+    w0 = (w1.float() + dxin[0]).to(BF)
+    assert torch.equal(dx2, w2) and torch.equal(dx1, w1) and torch.equal(dx, w0)
+
+
+def test_grouped_layernorm_equals_single_launches():
+    """One grouped launch over 3 parameter sets == 3 single launches, bit for bit (forward with post-dropout + head, backward)."""
+    from tts_king_amd import ops
+    G, Bn, seg, D, p = 3, 4, 32, 256, 0.5
+    rows = Bn * seg
+    stride = 1032                                            # floats between the groups' parameter blocks (16-byte aligned)
+    flat = rnd(G * stride + 4 * D, seed=20).to(DEV)          # gamma | beta | head_w | head_b inside each block
+    y = torch.relu(rnd(G * rows, D, seed=21)).to(BF).to(DEV)
+    lens = torch.tensor([32, 20, 7, 32]).to(DEV)
+    dhead = rnd(G * rows, seed=22).to(DEV)
+    st = ops.optim_state(DEV, seed=5)
+    rng = ops.rng_of(st)
+    gam, bet, hw, hb = flat[0:D], flat[D:2 * D], flat[2 * D:3 * D], flat[3 * D:3 * D + 1]
+    _, mean, rstd, ho = ops.layernorm_fwd_grouped(y, gam, bet, G, stride, 2, lens, seg, p_post=p, site_post=201, rng=rng, head=(hw, hb), want_out=False)
+    out, *_ = ops.layernorm_fwd_grouped(y, gam, bet, G, stride, 2, None, 0, p_post=p, site_post=200, rng=rng)
+    dz, part, nblk = ops.layernorm_bwd_grouped(None, y, mean, rstd, gam, bet, G, stride, 2, lens, seg, relu_in=True, p_post=p, site_post=201,
+                                               rng=rng, dhead=dhead, head_w=hw)
+    for g in range(G):
+        o = g * stride
+        sl = slice(g * rows, (g + 1) * rows)
+        gg, bb, ww, wb = flat[o:o + D], flat[o + D:o + 2 * D], flat[o + 2 * D:o + 3 * D], flat[o + 3 * D:o + 3 * D + 1]
+        _, _, m1, r1, h1 = ops.layernorm_fwd(y[sl], None, gg, bb, lens, seg, p_post=p, site_post=201 + 2 * g, rng=rng, save_z=False, head=(ww, wb), want_out=False)
+        o1, *_ = ops.layernorm_fwd(y[sl], None, gg, bb, None, 0, p_post=p, site_post=200 + 2 * g, rng=rng, save_z=False)
+        assert torch.equal(h1, ho[sl]) and torch.equal(m1, mean[sl]) and torch.equal(r1, rstd[sl]) and torch.equal(o1, out[sl])
+        dz1, _, p1, n1 = ops.layernorm_bwd(None, y[sl], m1, r1, gg, bb, lens, seg, relu_in=True, p_post=p, site_post=201 + 2 * g, rng=rng,
+                                           dhead=dhead[sl], head_w=ww)
+        assert n1 == nblk and torch.equal(dz1, dz[sl]) and torch.equal(p1, part[g])
+
+
+def test_optim_step_equals_separate_launches():
+    """ttsk_optim_step (2 launches) == rng_advance + optim_advance + clip_adam_step (5 launches), bit for bit."""
+    from tts_king_amd import ops
+    n = 40000
+    outs = []
+    for fused in (True, False):
+        p, g = rnd(n, seed=30).to(DEV), (rnd(n, seed=31) * 3).to(DEV)
+        m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        sh = torch.zeros(n, dtype=BF, device=DEV)
+        st = ops.optim_state(DEV, seed=9, sched_step=3999)
+        part = torch.empty(1024, device=DEV)
+        for _ in range(2):
+            g.copy_((rnd(n, seed=31) * 3).to(DEV))
+            if fused:
+                ops.optim_step(p, g, m, v, sh, st, part, 1.0, 0.95, 0.999, 1e-5, 256, 4000, [300000, 400000, 500000], 0.7, advance_rng=True)
+            else:
+                ops.rng_advance(st)
+                ops.optim_advance(st, 256, 4000, [300000, 400000, 500000], 0.7, 0.95, 0.999)
+                ops.clip_adam_step(p, g, m, v, sh, st, part, 1.0, 0.95, 0.999, 1e-5)
+        outs.append((p.clone(), m.clone(), v.clone(), sh.clone(), st.clone(), g.clone()))
+    for a, w in zip(*outs):
+        assert torch.equal(a, w)
+    assert int(outs[0][4][0]) == 4001 and int(outs[0][4][3]) == 2 and float(outs[0][5].abs().max()) == 0.0

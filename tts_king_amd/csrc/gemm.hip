@@ -15,18 +15,29 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BN = 128, BK = 64;
 constexpr int NTHREADS = 256;
-constexpr int STAGE_BYTES = (BM * BK + BN * BK) * 2;     // 32 KiB
 constexpr int CS_LD = 132;                               // fp32 epilogue tile leading dim (floats)
-constexpr int SMEM_BYTES = BM * CS_LD * 4;               // 67,584 B >= 2 stages (65,536 B)
+// BM = 128: the default tile.  BM = 64 (operand A untransposed only): the same kernel with half the rows per workgroup,
+// for outputs with few columns (N = 256: 6768 rows give 106 tiles of 128^2 for 256 CUs, which is what used to force
+// split-K plus a reducer launch on the forward / dX chain; 64-row tiles give 212 workgroups and need neither).
+template <int BM> struct TileCfg {
+  static constexpr int STAGE_BYTES = (BM * BK + BN * BK) * 2;                           // 32 / 24 KiB
+  static constexpr int EPI_BYTES = BM * CS_LD * 4;                                      // 67,584 / 33,792 B
+  static constexpr int SMEM_BYTES = EPI_BYTES > 2 * STAGE_BYTES ? EPI_BYTES : 2 * STAGE_BYTES;
+  static constexpr int AI = BM / 32;      // 16-byte A chunks per thread per K tile
+  static constexpr int WM = BM / 2;       // rows of a wave's sub-tile (waves 2 x 2)
+  static constexpr int AM = WM / 16;      // MFMA row tiles per wave
+};
 
 typedef GemmArgs Args;
 
 
 // one output tile (bid_in of the problem's tiles_m*tiles_n, batch index z of nzgrid, K range `split`)
-template <bool ATR, bool BTR, bool F16>
+template <int BM, bool ATR, bool BTR, bool F16>
 __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int split, int nzgrid, unsigned char* smem) {
+  static_assert(BM == 128 || !ATR, "the 64-row tile is instantiated for untransposed A only");
+  constexpr int STAGE_BYTES = TileCfg<BM>::STAGE_BYTES, AI = TileCfg<BM>::AI, WM = TileCfg<BM>::WM, AM = TileCfg<BM>::AM;
   const ttsk_gemm_desc& d = g.d;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -64,10 +75,10 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
   // validity bit per tap for the conv zero padding), so the K loop spends a few VALU instructions per load.
   const int nrow = tid >> 3, nslot = tid & 7;      // + 32 i rows
   const int trow = tid >> 4, tslot = tid & 15;     // + 16 i krows
-  int a_off[4], b_off[4], b_tt[4];
-  unsigned a_ok[4], b_ok[4];
+  int a_off[AI], b_off[4], b_tt[4];
+  unsigned a_ok[AI], b_ok[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < AI; ++i) {
     if (!ATR) {
       const int gm = m0 + nrow + 32 * i;
       a_off[i] = (gm * d.lda + nslot * 8) * 2;
@@ -87,6 +98,9 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
       a_off[i] = ((trow + 16 * i) * d.lda + mcol) * 2;
       a_ok[i] = mcol < M ? 1u : 0u;
     }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
     if (!BTR) {
       const int gn = n0 + nrow + 32 * i;
       b_off[i] = (gn * d.ldb + nslot * 8) * 2;
@@ -120,18 +134,18 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
   };
   reset_btt();
 
-  struct Regs { uint4 a[4], b[4]; };
+  struct Regs { uint4 a[AI], b[4]; };
 #define TTSK_LD(rs, off) __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0))
   // `live` = the tile exists (a step past the last tile still issues its loads, all out of range: zeros, no branch)
   auto load_tile = [&](Regs& R, bool live) __attribute__((always_inline)) {
     const int kbase = (kc_begin + ld_kk) * BK;
-    int oa[4], ob[4];
+    int oa[AI], ob[4];
     if (!ATR) {
       const int shift = conv_a ? d.tap_shift0 + ld_tap * d.tap_dshift : 0;
       const int add = (shift * d.lda + kbase) * 2;
       const bool kok = live && kbase + nslot * 8 < K8;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < AI; ++i) {
         bool ok = kok && ((a_ok[i] >> (ld_tap & 31)) & 1u);
         if (wide_taps) {   // recompute exactly (rare: > 32 taps)
           const int tt = (m0 + nrow + 32 * i) % d.seg_len + shift;
@@ -142,7 +156,7 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
     } else {
       const int add = kbase * d.lda * 2;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) oa[i] = (live && kbase + trow + 16 * i < K && a_ok[i]) ? a_off[i] + add : OOB;
+      for (int i = 0; i < AI; ++i) oa[i] = (live && kbase + trow + 16 * i < K && a_ok[i]) ? a_off[i] + add : OOB;
     }
     const int tapoff = ld_tap * (int)d.b_tap_stride;
     if (!BTR) {
@@ -160,7 +174,7 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) R.a[i] = TTSK_LD(rsA, oa[i]);
+    for (int i = 0; i < AI; ++i) R.a[i] = TTSK_LD(rsA, oa[i]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) R.b[i] = TTSK_LD(rsB, ob[i]);
     // advance to the next tile
@@ -185,20 +199,23 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
     unsigned char* sb = sa + BM * BK * 2;
     if (lrelu_in && !ATR) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) R.a[i] = lrelu8<F16>(R.a[i], in_slope);
+      for (int i = 0; i < AI; ++i) R.a[i] = lrelu8<F16>(R.a[i], in_slope);
+    }
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      if (!ATR) { const int row = nrow + 32 * i; *(uint4*)(sa + row * 128 + ((nslot ^ (row & 7)) << 4)) = R.a[i]; }
+      else { const int kr = trow + 16 * i; *(uint4*)(sa + kr * 256 + (((tslot >> 1) ^ tr_sw(kr)) << 5) + ((tslot & 1) << 4)) = R.a[i]; }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (!ATR) { const int row = nrow + 32 * i; *(uint4*)(sa + row * 128 + ((nslot ^ (row & 7)) << 4)) = R.a[i]; }
-      else { const int kr = trow + 16 * i; *(uint4*)(sa + kr * 256 + (((tslot >> 1) ^ tr_sw(kr)) << 5) + ((tslot & 1) << 4)) = R.a[i]; }
       if (!BTR) { const int row = nrow + 32 * i; *(uint4*)(sb + row * 128 + ((nslot ^ (row & 7)) << 4)) = R.b[i]; }
       else { const int kr = trow + 16 * i; *(uint4*)(sb + kr * 256 + (((tslot >> 1) ^ tr_sw(kr)) << 5) + ((tslot & 1) << 4)) = R.b[i]; }
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[AM][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < AM; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -209,16 +226,16 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
     const unsigned char* sb = sa + BM * BK * 2;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
+      bf16x8 af[AM], bfr[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < AM; ++i) {
         if (!ATR) {
-          const int row = wm * 64 + i * 16 + l15;
+          const int row = wm * WM + i * 16 + l15;
           af[i] = *(const bf16x8*)(sa + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
         } else {
           // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4x16 block and receives
           // column (lane & 15) of its 4 rows: element j <- tile[k = 8*lg + j][m = block col]
-          const int mblk = (wm * 64 + i * 16) >> 4;  // 32-byte slot index of the 16-column block
+          const int mblk = (wm * WM + i * 16) >> 4;  // 32-byte slot index of the 16-column block
           const int k0 = ks * 32 + 8 * lg + (l15 >> 2);
           const int k1 = k0 + 4;
           bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -227,6 +244,9 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
               (__attribute__((address_space(3))) bf16x4*)(sa + k1 * 256 + ((mblk ^ tr_sw(k1)) << 5) + ((l15 & 3) << 3)));
           af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
         if (!BTR) {
           const int row = wn * 64 + i * 16 + l15;
           bfr[i] = *(const bf16x8*)(sb + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
@@ -242,7 +262,7 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < AM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
@@ -263,20 +283,22 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
     load_tile(R1, nk > 1);
     store_tile(0, R0);
     __syncthreads();
-    constexpr int NRD = (ATR ? 8 : 4) + (BTR ? 8 : 4);     // LDS read instructions per contraction half
+    constexpr int NRD = (ATR ? 2 * AM : AM) + (BTR ? 8 : 4);     // LDS read instructions per contraction half
+    constexpr int NLD = AI + 4;                                  // global loads = LDS writes per K tile
+    constexpr int MPG = (4 * AM) / NLD > 0 ? (4 * AM) / NLD : 1; // MFMAs between two loads / two LDS writes
 #define TTSK_STEP(CUR, RL, RS)                                                      \
     {                                                                               \
       load_tile(RL, kt + 2 + CUR < nk);                                             \
       compute_tile(CUR);                                                            \
       store_tile(1 - CUR, RS);                                                      \
       __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);                          \
-      _Pragma("unroll") for (int q = 0; q < 8; ++q) {                               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                          \
+      _Pragma("unroll") for (int q = 0; q < NLD; ++q) {                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);                        \
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                          \
       }                                                                             \
       __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);                          \
-      _Pragma("unroll") for (int q = 0; q < 8; ++q) {                               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                          \
+      _Pragma("unroll") for (int q = 0; q < NLD; ++q) {                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);                        \
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                          \
       }                                                                             \
       __syncthreads();                                                              \
@@ -291,12 +313,12 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
   // ---- epilogue: accumulators -> LDS (fp32) -> full-row 16-byte traffic
   float* cs = (float*)smem;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < AM; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        cs[(wm * 64 + i * 16 + lg * 4 + r) * CS_LD + wn * 64 + j * 16 + l15] = acc[i][j][r];
+        cs[(wm * WM + i * 16 + lg * 4 + r) * CS_LD + wn * 64 + j * 16 + l15] = acc[i][j][r];
   __syncthreads();
 
   const int64_t coff = z1 * d.sC1 + z2 * d.sC2;
@@ -308,7 +330,7 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
   if (d.splits > 1) {
     // split-K: raw fp32 partial sums into the workspace slab [split][z][M][N]; the reducer applies the epilogue
     float* ws = (float*)d.workspace + ((int64_t)split * nzgrid + z) * ((int64_t)M * N);
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < BM / 16; ++p) {
       const int row = p * 16 + (tid >> 4);
       const int gm = m0 + row;
       if (gm >= M) continue;
@@ -327,8 +349,8 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
   }
   float bias[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bias[e] = (d.bias && e < nvalid) ? d.bias[gn + e] : 0.f;
-  for (int p = 0; p < 8; ++p) {
+  for (int e = 0; e < 8; ++e) bias[e] = (d.bias && e < nvalid) ? d.bias[z1 * d.s_bias1 + gn + e] : 0.f;
+  for (int p = 0; p < BM / 16; ++p) {
     const int row = p * 16 + (tid >> 4);
     const int gm = m0 + row;
     if (gm >= M) continue;
@@ -345,8 +367,14 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
 
 template <bool ATR, bool BTR, bool F16>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
-  gemm_tile<ATR, BTR, F16>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, smem);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[TileCfg<128>::SMEM_BYTES];
+  gemm_tile<128, ATR, BTR, F16>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, smem);
+}
+// the 64-row tile (desc.kernel = 3)
+template <bool BTR, bool F16>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm64_kernel(const Args g) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[TileCfg<64>::SMEM_BYTES];
+  gemm_tile<64, false, BTR, F16>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, smem);
 }
 
 // Grouped launch: the workgroups of n independent problems (same operand layout) as ONE grid.  A training step's weight-
@@ -356,7 +384,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const Args g) {
 // from the table with scalar loads (the table pointer and p are wave-uniform).
 template <bool ATR, bool BTR, bool F16>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_group_kernel(const int* __restrict__ prefix, const Args* __restrict__ args, int n) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[TileCfg<128>::SMEM_BYTES];
   const int wg = blockIdx.x;
   int lo = 0, hi = n;                 // invariant: prefix[lo] <= wg < prefix[hi]
   while (hi - lo > 1) {
@@ -368,7 +396,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_group_kernel(const int* __re
   const int local = wg - prefix[p];
   const int tiles = g.tiles_m * g.tiles_n, nz = g.d.nz1 * g.d.nz2;
   const int tile = local % tiles, rest = local / tiles;
-  gemm_tile<ATR, BTR, F16>(g, tile, rest % nz, rest / nz, nz, smem);
+  gemm_tile<128, ATR, BTR, F16>(g, tile, rest % nz, rest / nz, nz, smem);
 }
 
 // split-K reducer: sums the `splits` workspace slabs in fixed order and applies the epilogue (deterministic)
@@ -403,7 +431,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const Args g) {
     }
     float bias[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias[e] = (d.bias && e < nvalid) ? d.bias[gn + e] : 0.f;
+    for (int e = 0; e < 8; ++e) bias[e] = (d.bias && e < nvalid) ? d.bias[z1 * d.s_bias1 + gn + e] : 0.f;
     epilogue_store<F16>(d, coff, roff, gm, gn, nvalid, v, bias, z2);
   }
 }
@@ -488,7 +516,8 @@ int validate(ttsk_gemm_desc& d) {
   TTSK_REQUIRE(d.taps == 0 || (d.b_tap_stride & 7) == 0, "ttsk_gemm: b_tap_stride must be a multiple of 8");
   TTSK_REQUIRE(d.bseg_len == 0 || btr, "ttsk_gemm: B row shift needs B_TR");
   TTSK_REQUIRE(d.out_mul == 0 || (d.seg_len > 0 && d.out_seg > 0), "ttsk_gemm: output remap needs seg_len/out_seg");
-  TTSK_REQUIRE(d.kernel >= 0 && d.kernel <= 2 && d.splits >= 0, "ttsk_gemm: kernel must be 0 (auto), 1 or 2; splits >= 0");
+  TTSK_REQUIRE(d.kernel >= 0 && d.kernel <= 3 && d.splits >= 0, "ttsk_gemm: kernel must be 0 (auto), 1, 2 or 3; splits >= 0");
+  TTSK_REQUIRE(!(d.kernel == 3 && atr), "ttsk_gemm: kernel = 3 (64-row tile) is instantiated for untransposed A only");
   TTSK_REQUIRE(!(d.kernel == 2 && (d.flags & TTSK_GEMM_LRELU_IN)), "ttsk_gemm: LRELU_IN needs the register-staged kernel (kernel = 1)");
   TTSK_REQUIRE(!(d.kernel == 2 && d.taps > 32), "ttsk_gemm: kernel = 2 handles at most 32 taps");
   if (d.nz1 < 1) d.nz1 = 1;
@@ -521,8 +550,8 @@ int validate(ttsk_gemm_desc& d) {
 // 1.1 us alone on its CU and 1.5 us when two share it, a K step of the 256x128 ring 1.3 us; SLOTS workgroups run at once;
 // a split-K reducer costs a launch plus its slab traffic.  Small problems (the encoder's 1024 rows) gain most from
 // splitting K (16 tiles -> 256 workgroups: 164 us -> 26 us for the k=9 conv dX), large ones take the big tile.
-constexpr float T_ITER1 = 1.5f, T_ITER1_ALONE = 1.1f, T_ITER2 = 1.3f, T_LAUNCH = 4.f, T_REDUCE = 7.f;
-constexpr int SLOTS1 = 512, SLOTS2 = 256;
+constexpr float T_ITER1 = 1.5f, T_ITER1_ALONE = 1.1f, T_ITER2 = 1.3f, T_ITER3 = 1.0f, T_ITER3_ALONE = 0.7f, T_ITER3_CROWDED = 1.35f, T_LAUNCH = 4.f, T_REDUCE = 7.f;
+constexpr int SLOTS1 = 512, SLOTS2 = 256, SLOTS3 = 768;
 
 Plan make_plan(const ttsk_gemm_desc& d) {
   const int nz = d.nz1 * d.nz2;
@@ -530,10 +559,12 @@ Plan make_plan(const ttsk_gemm_desc& d) {
   const int kchunks = (d.K + BK - 1) / BK;
   Plan best{};
   float best_t = -1.f;
-  for (int kernel = 1; kernel <= 2; ++kernel) {
+  for (int kernel = 1; kernel <= 3; ++kernel) {
     if (d.kernel != 0 && d.kernel != kernel) continue;
     if (kernel == 2 && ((d.flags & TTSK_GEMM_LRELU_IN) || d.taps > 32)) continue;
-    const int bm = kernel == 2 ? 256 : 128;
+    // the 64-row tile: for untransposed A, when the larger tiles cannot give every CU a workgroup
+    if (kernel == 3 && ((d.flags & TTSK_GEMM_A_TR) || (d.kernel == 0 && (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * nz >= 256))) continue;
+    const int bm = kernel == 2 ? 256 : (kernel == 3 ? 64 : 128);
     const int tm = (d.M + bm - 1) / bm, tn = (d.N + 127) / 128;
     const int64_t tiles = (int64_t)tm * tn * nz;
     static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
@@ -544,9 +575,12 @@ Plan make_plan(const ttsk_gemm_desc& d) {
       const int per = (kchunks + sp - 1) / sp;
       sp = (kchunks + per - 1) / per;
       const int64_t wgs = tiles * sp;
-      const int slots = kernel == 1 ? SLOTS1 : SLOTS2;
+      const int slots = kernel == 1 ? SLOTS1 : (kernel == 2 ? SLOTS2 : SLOTS3);
       const int64_t rounds = (wgs + slots - 1) / slots;
-      const float t_iter = kernel == 2 ? T_ITER2 : (wgs <= 256 ? T_ITER1_ALONE : T_ITER1);   // one workgroup per CU runs faster
+      // a K step slows down with every workgroup that shares the CU's L2 -> LDS path (64-row tile, measured in the train
+      // step: 0.7 us alone, 1.3 us when three share a CU)
+      const float t_iter = kernel == 2 ? T_ITER2 : kernel == 3 ? (wgs <= 256 ? T_ITER3_ALONE : wgs <= 512 ? T_ITER3 : T_ITER3_CROWDED)
+                                                               : (wgs <= 256 ? T_ITER1_ALONE : T_ITER1);   // one workgroup per CU runs faster
       float t = (float)rounds * per * taps * t_iter + T_LAUNCH;
       const int64_t ws = sp > 1 ? (int64_t)sp * nz * d.M * d.N * 4 : 0;
       if (ws > ((int64_t)512 << 20)) { if (d.splits != 0) {} else break; }
@@ -601,6 +635,15 @@ extern "C" int ttsk_gemm(const ttsk_gemm_desc* dp, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (d.kernel == 2) {
     ttsk_launch_gemm2(g, atr, btr, f16, s);
+  } else if (d.kernel == 3) {
+    dim3 grid(g.tiles_m * g.tiles_n, nz, d.splits), block(NTHREADS);
+    if (btr) {
+      if (f16) hipLaunchKernelGGL((gemm64_kernel<true, true>), grid, block, 0, s, g);
+      else hipLaunchKernelGGL((gemm64_kernel<true, false>), grid, block, 0, s, g);
+    } else {
+      if (f16) hipLaunchKernelGGL((gemm64_kernel<false, true>), grid, block, 0, s, g);
+      else hipLaunchKernelGGL((gemm64_kernel<false, false>), grid, block, 0, s, g);
+    }
   } else {
     dim3 grid(g.tiles_m * g.tiles_n, nz, d.splits), block(NTHREADS);
     if (atr)
@@ -637,7 +680,7 @@ struct GroupInline {
 };
 template <bool ATR, bool BTR, bool F16, int NMAX>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_group_inline_kernel(const GroupInline<NMAX> t) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[TileCfg<128>::SMEM_BYTES];
   const int wg = blockIdx.x;
   int p = 0;
 #pragma unroll
@@ -646,7 +689,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_group_inline_kernel(const Gr
   const int local = wg - t.prefix[p];
   const int tiles = g.tiles_m * g.tiles_n, nz = g.d.nz1 * g.d.nz2;
   const int tile = local % tiles, rest = local / tiles;
-  gemm_tile<ATR, BTR, F16>(g, tile, rest % nz, rest / nz, nz, smem);
+  gemm_tile<128, ATR, BTR, F16>(g, tile, rest % nz, rest / nz, nz, smem);
 }
 
 // The table reaches the device through kernel arguments (3.5 KiB per launch): arguments are captured by value, so the
@@ -681,6 +724,7 @@ extern "C" int ttsk_gemm_group_build(const ttsk_gemm_desc* descs, int n, void* h
     g.d = descs[i];
     ttsk_gemm_desc& d = g.d;
     if (d.kernel == 0) d.kernel = 1;                // a group runs ONE tile configuration: problem 0's (default 128x128)
+    TTSK_REQUIRE(d.kernel != 3, "ttsk_gemm_group_build: the 64-row tile (kernel = 3) has no grouped launch");
     if (i == 0) h->kernel = d.kernel;
     TTSK_REQUIRE(d.kernel == h->kernel, "ttsk_gemm_group_build: problem %d asks for kernel %d, problem 0 for %d", i, d.kernel, h->kernel);
     const int rc = validate(d);

@@ -143,7 +143,7 @@ __device__ __forceinline__ void tile_epilogue(const ttsk_gemm_desc& d, unsigned 
   const int nvalid = (N - gn) < 8 ? (N - gn) : 8;
   float bias[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bias[e] = (d.bias && gn < N && e < nvalid && d.splits <= 1) ? d.bias[gn + e] : 0.f;
+  for (int e = 0; e < 8; ++e) bias[e] = (d.bias && gn < N && e < nvalid && d.splits <= 1) ? d.bias[z1 * d.s_bias1 + gn + e] : 0.f;
   float* ws = d.splits > 1 ? (float*)d.workspace + ((int64_t)split * nzgrid + z) * ((int64_t)M * N) : nullptr;
 
 #pragma unroll 1

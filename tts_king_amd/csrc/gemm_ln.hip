@@ -1,0 +1,222 @@
+// gemm_ln.hip — the tail of both FFT-block sub-layers as ONE kernel:
+//     out = zero_PAD_rows( LayerNorm( dropout(A @ W^T + bias) + residual ) )
+// reference: fs_two/transformer/SubLayers.py:62-63 (MHA: layer_norm(dropout(fc(o)) + residual)), :96-99 (FFN:
+// layer_norm(dropout(w_2(h)) + residual), w_2 = Conv1d(k=1) = a Linear over channels), Layers.py:29,32 (masked_fill).
+//
+// Why a kernel of its own: the output has D = 256 columns, i.e. ONE 256-wide tile row holds whole LayerNorm rows, so
+// the normalisation can run in the epilogue.  Before, each of these was GEMM (106 workgroups of 128x128 for 6768 rows, or
+// split-K + a reducer launch for the encoder's 1024 rows) -> bf16 y -> a LayerNorm launch: 2-3 dependent launches of
+// 5-25 us for 0.9 / 3.5 GFLOP.  Here a workgroup owns 32 rows x 256 columns (212 workgroups for 6768 rows, 32 for 1024):
+// 4 waves, wave w computes columns [64w, 64w+64) of all 32 rows as 2x4 v_mfma_f32_16x16x32_bf16 accumulators.
+// The kernel is bound by streaming W (256 x K bf16, L2-resident, 32 KiB per K step per workgroup) through LDS, not by MFMA:
+// LDS-DMA into a 4-stage ring (see the comment at the kernel), XOR-swizzled 128-byte rows (conflict-free fragment reads),
+// one barrier per K step.  Epilogue: accumulators -> fp32 LDS tile -> one wave per row (4 columns per
+// lane, exactly ln_fwd_kernel's row code: same Philox indexing, so ln_bwd_kernel regenerates the same dropout mask).
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int BM = 32, BN = 256, BK = 64, NT = 256, NSTAGE = 4;
+constexpr int A_BYTES = BM * BK * 2;              // 4 KiB  = 4 LDS-DMA pieces (one per wave)
+constexpr int B_BYTES = BN * BK * 2;              // 32 KiB = 32 pieces (eight per wave)
+constexpr int STAGE = A_BYTES + B_BYTES;          // 36 KiB
+constexpr int CS_LD = 260;                        // fp32 epilogue tile leading dimension
+constexpr int SMEM = NSTAGE * STAGE;              // 144 KiB ring (the epilogue tile 32 x 260 x 4 = 33,280 B reuses it)
+constexpr int OOB = 0x7FFFFFFF;
+constexpr int NQ = 9;                             // LDS-DMA pieces per wave per K tile
+
+struct GemmLnArgs {
+  const bf16_t* A;        // [M][lda] bf16
+  const bf16_t* W;        // [256][ldw] bf16 (nn.Linear / Conv1d(k=1) weight: out x in)
+  const float* bias;      // [256]
+  const bf16_t* res;      // [M][256] residual
+  const float* gamma;
+  const float* beta;
+  bf16_t* out;            // [M][256]
+  bf16_t* z_save;         // [M][256] LayerNorm input (after dropout + residual), or null
+  float* mean;            // [M]
+  float* rstd;            // [M]
+  const long long* lens;  // [M / seg_len] valid rows per segment, or null
+  const uint64_t* rng;    // {seed, step}
+  int M, K, lda, ldw, seg_len;
+  float p_pre, eps;
+  unsigned site_pre;
+};
+
+__device__ __forceinline__ void drop4(float v[4], uint64_t seed, uint64_t step, unsigned site, unsigned e4, unsigned thr, float scale) {
+  const uint4 b = Philox::gen(make_uint2((unsigned)seed, (unsigned)(seed >> 32)),
+                              make_uint4(e4, site, (unsigned)step, (unsigned)(step >> 32)));
+  v[0] = b.x >= thr ? v[0] * scale : 0.f;
+  v[1] = b.y >= thr ? v[1] * scale : 0.f;
+  v[2] = b.z >= thr ? v[2] * scale : 0.f;
+  v[3] = b.w >= thr ? v[3] * scale : 0.f;
+}
+
+// The kernel streams W (256 x K, the same for every workgroup: L2-resident) and its 32 rows of A through LDS; one CU pulls
+// about 70-90 GB/s from L2 into LDS, and only with ~100 KB of requests in flight (measured with the register-staged first
+// version: two 36 KiB tiles in flight gave 1.7 us per K step = 21 GB/s).  So: LDS-DMA (buffer_load ... lds, no VGPR round
+// trip, swizzle applied to the SOURCE address) into a 4-stage ring with three tiles in flight, counted vmcnt, one raw
+// s_barrier per K step (the structure of gemm2.hip).  The residual rows are fetched into registers before the K loop.
+__global__ __launch_bounds__(NT, 1) void gemm_ln_kernel(const GemmLnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.x * BM;
+  const int M = a.M, K = a.K;
+  const int K8 = (K + 7) & ~7;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, 0x7FFFFFF0, 0x00020000);
+  const int nk = (K + BK - 1) / BK;
+  const int c = lane * 4;
+
+  // ---- residual rows of this wave's eight epilogue rows: in flight during the whole K loop
+  uint2 resv[8];
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int row = m0 + wave * 8 + rr;
+    resv[rr] = (a.res && row < M) ? *(const uint2*)(a.res + (int64_t)row * BN + c) : make_uint2(0u, 0u);
+  }
+
+  // ---- LDS-DMA source coordinates.  A piece = 1 KiB of the LDS image = 8 tile rows x 128 B; lane -> tile row 8p + lane/8,
+  // physical 16-byte chunk lane%8, which must hold logical chunk (lane%8) ^ (row & 7): the XOR swizzle of the fragment reads
+  const int prow = lane >> 3, kch = ((lane & 7) ^ (lane >> 3)) * 8;     // row inside the piece, first k of this lane's 16 bytes
+  const int a_row = m0 + wave * 8 + prow;
+  const int a_off = a_row < M ? (a_row * a.lda + kch) * 2 : OOB;
+  int w_off[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w_off[i] = (((i * 4 + wave) * 8 + prow) * a.ldw + kch) * 2;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr)smem + wave * 1024);
+
+  auto issue_tile = [&](int kt) __attribute__((always_inline)) {
+    const unsigned st = lds0 + (kt % NSTAGE) * STAGE;
+    const int kbase = kt * BK;
+    const bool kok = kbase + kch < K8;
+    dma16(rsA, st, (kok && a_off != OOB) ? a_off + kbase * 2 : OOB);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma16(rsW, st + A_BYTES + i * 4096, kok ? w_off[i] + kbase * 2 : OOB);
+  };
+
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int t = 0; t < NSTAGE - 1; ++t)
+    if (t < nk) issue_tile(t);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // this wave's pieces of tile kt have landed when at most the pieces of the (up to two) younger tiles are outstanding
+    const int younger = nk - 1 - kt;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQ) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // everybody's pieces of tile kt landed; everybody is done reading tile kt-1's stage
+    if (kt + NSTAGE - 1 < nk) issue_tile(kt + NSTAGE - 1);      // refills the stage tile kt-1 occupied
+    const unsigned char* sa = smem + (kt % NSTAGE) * STAGE;
+    const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[2], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = i * 16 + l15;
+        af[i] = *(const bf16x8*)(sa + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wave * 64 + j * 16 + l15;
+        bfr[j] = *(const bf16x8*)(sb + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();                         // the last stage has been read by every wave: the ring becomes the epilogue tile
+
+  // ---- epilogue: accumulators -> fp32 tile in LDS
+  float* cs = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cs[(i * 16 + lg * 4 + r) * CS_LD + wave * 64 + j * 16 + l15] = acc[i][j][r];
+  __syncthreads();
+
+  // one wave per row, 8 rows per wave, lane owns columns 4*lane .. 4*lane+3 (ln_fwd_kernel's row code)
+  const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
+  const f32x4 bi = *(const f32x4*)(a.bias + c);
+  const f32x4 g = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
+  const unsigned thr = keep_threshold(a.p_pre);
+  const float scale = 1.f / (1.f - a.p_pre);
+  float z[8][4];
+  float s[8];
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int lr = wave * 8 + rr;
+    const int row = m0 + lr;
+    const bool live = row < M;
+    const f32x4 v = *(const f32x4*)(cs + lr * CS_LD + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[rr][e] = v[e] + bi[e];
+    if (a.p_pre > 0.f) drop4(z[rr], seed, step, a.site_pre, (unsigned)(((int64_t)row * BN + c) >> 2), thr, scale);
+    z[rr][0] += __uint_as_float(resv[rr].x << 16); z[rr][1] += __uint_as_float(resv[rr].x & 0xFFFF0000u);
+    z[rr][2] += __uint_as_float(resv[rr].y << 16); z[rr][3] += __uint_as_float(resv[rr].y & 0xFFFF0000u);
+    if (a.z_save && live) *(uint2*)(a.z_save + (int64_t)row * BN + c) = make_uint2(pack_bf2(z[rr][0], z[rr][1]), pack_bf2(z[rr][2], z[rr][3]));
+    s[rr] = z[rr][0] + z[rr][1] + z[rr][2] + z[rr][3];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) s[rr] += __shfl_xor(s[rr], o, 64);
+  float q[8];
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    s[rr] *= (1.f / BN);            // mean
+    q[rr] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = z[rr][e] - s[rr]; q[rr] += d * d; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) q[rr] += __shfl_xor(q[rr], o, 64);
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int row = m0 + wave * 8 + rr;
+    if (row >= M) continue;
+    const float mean = s[rr], rstd = rsqrtf(q[rr] * (1.f / BN) + a.eps);
+    if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+    bool masked = false;
+    if (a.lens) { const int b = row / a.seg_len, t = row - b * a.seg_len; masked = t >= a.lens[b]; }
+    float o4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o4[e] = masked ? 0.f : (z[rr][e] - mean) * rstd * g[e] + bt[e];
+    *(uint2*)(a.out + (int64_t)row * BN + c) = make_uint2(pack_bf2(o4[0], o4[1]), pack_bf2(o4[2], o4[3]));
+  }
+}
+
+}  // namespace
+
+extern "C" int ttsk_gemm_ln_fwd(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res,
+                                const float* gamma, const float* beta, void* out, void* z_save, float* mean, float* rstd,
+                                const int64_t* lens, int seg_len, int M, int K, int D, float eps, float p_pre, uint32_t site_pre,
+                                const void* rng, void* stream) {
+  TTSK_REQUIRE(A && W && bias && gamma && beta && out && mean && rstd, "ttsk_gemm_ln_fwd: null pointer");
+  TTSK_REQUIRE(D == BN, "ttsk_gemm_ln_fwd: the fused kernel is built for D = 256 (got %d); use ttsk_gemm + ttsk_layernorm_fwd", D);
+  TTSK_REQUIRE(M > 0 && K > 0 && (K & 7) == 0 && (lda & 7) == 0 && (ldw & 7) == 0, "ttsk_gemm_ln_fwd: K, lda, ldw must be multiples of 8");
+  TTSK_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out | (uintptr_t)res | (uintptr_t)z_save) & 15) == 0, "ttsk_gemm_ln_fwd: operands must be 16-byte aligned");
+  TTSK_REQUIRE(((int64_t)M * lda + K) * 2 < ((int64_t)1 << 31) && ((int64_t)BN * ldw + K) * 2 < ((int64_t)1 << 31), "ttsk_gemm_ln_fwd: operand extent exceeds 2 GiB");
+  TTSK_REQUIRE(!(p_pre > 0.f) || rng, "ttsk_gemm_ln_fwd: dropout needs the rng state");
+  TTSK_REQUIRE(p_pre >= 0.f && p_pre < 1.f, "ttsk_gemm_ln_fwd: p_pre must be in [0, 1)");
+  TTSK_REQUIRE(!lens || (seg_len > 0 && M % seg_len == 0), "ttsk_gemm_ln_fwd: lens needs M %% seg_len == 0");
+  GemmLnArgs a{(const bf16_t*)A, (const bf16_t*)W, bias, (const bf16_t*)res, gamma, beta, (bf16_t*)out, (bf16_t*)z_save, mean, rstd,
+               (const long long*)lens, (const uint64_t*)rng, M, K, lda, ldw, seg_len > 0 ? seg_len : 1, p_pre, eps, site_pre};
+  hipLaunchKernelGGL(gemm_ln_kernel, dim3((M + BM - 1) / BM), dim3(NT), 0, (hipStream_t)stream, a);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}

@@ -25,6 +25,12 @@ struct LnArgs {
   int rows, D, seg_len;
   float p_pre, p_post, eps;
   unsigned site_pre, site_post;
+  // grouped launch (the three VariancePredictors of a training step as one launch): rows = groups * group_rows; group g
+  // uses gamma / beta / head_w / head_b at + g * pstride floats and dropout sites + g * site_stride; PAD masks and dropout
+  // element indices are taken inside the group, so a grouped launch equals `groups` single launches bit for bit.
+  int group_rows;         // 0 = one group
+  long long pstride;
+  unsigned site_stride;
 };
 
 __device__ __forceinline__ void load4(const bf16_t* p, float v[4]) {
@@ -50,6 +56,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
   if (row >= a.rows) return;
   const int D = a.D, nj = D >> 8;
   const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
+  const int grp = a.group_rows > 0 ? row / a.group_rows : 0;
+  const int lrow = row - grp * a.group_rows;                       // row inside its group (== row when ungrouped)
+  const float* gamma = a.gamma + grp * a.pstride;
+  const float* beta = a.beta + grp * a.pstride;
+  const unsigned site_pre = a.site_pre + grp * a.site_stride, site_post = a.site_post + grp * a.site_stride;
   float z[MAXJ][4];
   float s = 0.f;
 #pragma unroll
@@ -58,7 +69,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
       const int c = j * 256 + lane * 4;
       load4(a.y + (int64_t)row * D + c, z[j]);
       if (a.p_pre > 0.f)
-        drop4(z[j], seed, step, a.site_pre, (unsigned)(((int64_t)row * D + c) >> 2), keep_threshold(a.p_pre), 1.f / (1.f - a.p_pre));
+        drop4(z[j], seed, step, site_pre, (unsigned)(((int64_t)lrow * D + c) >> 2), keep_threshold(a.p_pre), 1.f / (1.f - a.p_pre));
       if (a.res) {
         float r[4];
         load4(a.res + (int64_t)row * D + c, r);
@@ -81,29 +92,29 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
   const float rstd = rsqrtf(wave_sum(q) / D + a.eps);
   if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
   bool masked = false;
-  if (a.lens) { const int b = row / a.seg_len, t = row - b * a.seg_len; masked = t >= a.lens[b]; }
+  if (a.lens) { const int b = lrow / a.seg_len, t = lrow - b * a.seg_len; masked = t >= a.lens[b]; }
   float hs = 0.f;
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
     if (j < nj) {
       const int c = j * 256 + lane * 4;
-      const f32x4 g = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
+      const f32x4 g = *(const f32x4*)(gamma + c), bt = *(const f32x4*)(beta + c);
       float o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (z[j][e] - mean) * rstd * g[e] + bt[e];
       if (a.p_post > 0.f)
-        drop4(o, seed, step, a.site_post, (unsigned)(((int64_t)row * D + c) >> 2), keep_threshold(a.p_post), 1.f / (1.f - a.p_post));
+        drop4(o, seed, step, site_post, (unsigned)(((int64_t)lrow * D + c) >> 2), keep_threshold(a.p_post), 1.f / (1.f - a.p_post));
       if (masked) o[0] = o[1] = o[2] = o[3] = 0.f;
       if (a.out) store4(a.out + (int64_t)row * D + c, o);
       if (a.head_w) {
-        const f32x4 w = *(const f32x4*)(a.head_w + c);
+        const f32x4 w = *(const f32x4*)(a.head_w + grp * a.pstride + c);
         hs += o[0] * w[0] + o[1] * w[1] + o[2] * w[2] + o[3] * w[3];
       }
     }
   }
   if (a.head_w) {
     hs = wave_sum(hs);
-    if (lane == 0) a.head_out[row] = masked ? 0.f : hs + a.head_b[0];
+    if (lane == 0) a.head_out[row] = masked ? 0.f : hs + a.head_b[grp * a.pstride];
   }
 }
 
@@ -124,6 +135,9 @@ struct LnBwdArgs {
   int rows, D, seg_len, relu_in;
   float p_pre, p_post;
   unsigned site_pre, site_post;
+  int group_rows, nblk_group;     // grouped launch (see LnArgs): gridDim.x = groups * nblk_group, partials [group][nblk_group][ncol]
+  long long pstride;
+  unsigned site_stride;
 };
 
 // 8 waves per workgroup, one row per wave at a time: the per-row chain (loads -> two wave reductions -> stores) is pure
@@ -143,11 +157,40 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs 
 #pragma unroll
     for (int e = 0; e < 4; ++e) dg[j][e] = db[j][e] = dbias[j][e] = dhw[j][e] = 0.f;
 
-  for (int row = blockIdx.x * LNB_WAVES + wave; row < a.rows; row += gridDim.x * LNB_WAVES) {
-    bool masked = false;
-    if (a.lens) { const int b = row / a.seg_len, t = row - b * a.seg_len; masked = t >= a.lens[b]; }
-    const float mean = a.mean[row], rstd = a.rstd[row];
-    const float dh = head ? (masked ? 0.f : a.dhead[row]) : 0.f;
+  const int grp = a.group_rows > 0 ? blockIdx.x / a.nblk_group : 0;
+  const int lblk = blockIdx.x - grp * a.nblk_group;
+  const int grows = a.group_rows > 0 ? a.group_rows : a.rows;
+  const float* gamma = a.gamma + grp * a.pstride;
+  const float* beta = a.beta ? a.beta + grp * a.pstride : nullptr;
+  const float* head_w = a.head_w ? a.head_w + grp * a.pstride : nullptr;
+  const unsigned site_pre = a.site_pre + grp * a.site_stride, site_post = a.site_post + grp * a.site_stride;
+  // the loads of a wave's NEXT row are issued before the two wave reductions of the current one (the per-row chain
+  // loads -> reductions -> stores is latency; one row at a time took 12.5 us for 6768 x 256)
+  struct RowIn { uint2 z[MAXJ], d[MAXJ]; float mean, rstd, dh; bool masked; };
+  auto fetch = [&](int lr, RowIn& r) __attribute__((always_inline)) {
+    const int rw = grp * grows + lr;
+    r.masked = false;
+    if (a.lens) { const int b = lr / a.seg_len, t = lr - b * a.seg_len; r.masked = t >= a.lens[b]; }
+    r.mean = a.mean[rw]; r.rstd = a.rstd[rw];
+    r.dh = head ? (r.masked ? 0.f : a.dhead[rw]) : 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j)
+      if (j < nj) {
+        const int c = j * 256 + lane * 4;
+        r.z[j] = *(const uint2*)(a.z + (int64_t)rw * D + c);
+        r.d[j] = (a.dout && !r.masked) ? *(const uint2*)(a.dout + (int64_t)rw * D + c) : make_uint2(0u, 0u);
+      }
+  };
+  const int rstride = a.nblk_group * LNB_WAVES;
+  RowIn cur;
+  if (lblk * LNB_WAVES + wave < grows) fetch(lblk * LNB_WAVES + wave, cur);
+  for (int lrow = lblk * LNB_WAVES + wave; lrow < grows; lrow += rstride) {
+    const int row = grp * grows + lrow;
+    RowIn nxt;
+    const bool more = lrow + rstride < grows;
+    if (more) fetch(lrow + rstride, nxt);
+    const bool masked = cur.masked;
+    const float mean = cur.mean, rstd = cur.rstd, dh = cur.dh;
     float xh[MAXJ][4], g[MAXJ][4];
     float c1 = 0.f, c2 = 0.f;
     unsigned closed = 0;  // bit j*4+e set: the ReLU that produced z was inactive (relu_in mode)
@@ -155,24 +198,25 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs 
     for (int j = 0; j < MAXJ; ++j) {
       if (j < nj) {
         const int c = j * 256 + lane * 4;
-        float zz[4], d[4] = {0.f, 0.f, 0.f, 0.f};
-        load4(a.z + (int64_t)row * D + c, zz);
-        if (a.dout && !masked) load4(a.dout + (int64_t)row * D + c, d);
-        const f32x4 gm = *(const f32x4*)(a.gamma + c);
+        const float zz[4] = {__uint_as_float(cur.z[j].x << 16), __uint_as_float(cur.z[j].x & 0xFFFF0000u),
+                             __uint_as_float(cur.z[j].y << 16), __uint_as_float(cur.z[j].y & 0xFFFF0000u)};
+        float d[4] = {__uint_as_float(cur.d[j].x << 16), __uint_as_float(cur.d[j].x & 0xFFFF0000u),
+                      __uint_as_float(cur.d[j].y << 16), __uint_as_float(cur.d[j].y & 0xFFFF0000u)};
+        const f32x4 gm = *(const f32x4*)(gamma + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) xh[j][e] = (zz[e] - mean) * rstd;
         if (head) {
-          const f32x4 w = *(const f32x4*)(a.head_w + c), bt = *(const f32x4*)(a.beta + c);
+          const f32x4 w = *(const f32x4*)(head_w + c), bt = *(const f32x4*)(beta + c);
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) { o[e] = xh[j][e] * gm[e] + bt[e]; d[e] += dh * w[e]; }
           if (a.p_post > 0.f)
-            drop4(o, seed, step, a.site_post, (unsigned)(((int64_t)row * D + c) >> 2), keep_threshold(a.p_post), 1.f / (1.f - a.p_post));
+            drop4(o, seed, step, site_post, (unsigned)(((int64_t)lrow * D + c) >> 2), keep_threshold(a.p_post), 1.f / (1.f - a.p_post));
 #pragma unroll
           for (int e = 0; e < 4; ++e) dhw[j][e] += dh * o[e];
         }
         if (a.p_post > 0.f)
-          drop4(d, seed, step, a.site_post, (unsigned)(((int64_t)row * D + c) >> 2), keep_threshold(a.p_post), 1.f / (1.f - a.p_post));
+          drop4(d, seed, step, site_post, (unsigned)(((int64_t)lrow * D + c) >> 2), keep_threshold(a.p_post), 1.f / (1.f - a.p_post));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           dg[j][e] += d[e] * xh[j][e];
@@ -201,13 +245,14 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs 
         }
         if (a.dz) store4(a.dz + (int64_t)row * D + c, dzv);
         if (a.p_pre > 0.f) {
-          drop4(dzv, seed, step, a.site_pre, (unsigned)(((int64_t)row * D + c) >> 2), keep_threshold(a.p_pre), 1.f / (1.f - a.p_pre));
+          drop4(dzv, seed, step, site_pre, (unsigned)(((int64_t)lrow * D + c) >> 2), keep_threshold(a.p_pre), 1.f / (1.f - a.p_pre));
           if (a.dy) store4(a.dy + (int64_t)row * D + c, dzv);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) dbias[j][e] += dzv[e];
       }
     }
+    if (more) cur = nxt;
   }
   // cross-wave reduction of the per-lane column sums, one quantity at a time
   const int nq = head ? 4 : 3;
@@ -372,7 +417,27 @@ extern "C" int ttsk_layernorm_fwd(const void* y, const void* res, const float* g
   TTSK_REQUIRE((p_pre == 0.f && p_post == 0.f) || rng, "layernorm_fwd: dropout needs rng state");
   TTSK_REQUIRE(!head_w || (head_b && head_out), "layernorm_fwd: head needs bias and output");
   LnArgs a{(const bf16_t*)y, (const bf16_t*)res, gamma, beta, (bf16_t*)out, (bf16_t*)z_save, mean, rstd,
-           (const long long*)lens, rng, head_w, head_b, head_out, rows, D, seg_len, p_pre, p_post, eps, site_pre, site_post};
+           (const long long*)lens, rng, head_w, head_b, head_out, rows, D, seg_len, p_pre, p_post, eps, site_pre, site_post, 0, 0, 0};
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_layernorm_fwd_grouped(const void* y, const void* res, const float* gamma, const float* beta, void* out,
+                                          void* z_save, float* mean, float* rstd, const int64_t* lens, int seg_len, int groups,
+                                          int group_rows, int64_t param_stride, uint32_t site_stride, int D, float eps, float p_pre,
+                                          uint32_t site_pre, float p_post, uint32_t site_post, const uint64_t* rng,
+                                          const float* head_w, const float* head_b, float* head_out, void* stream) {
+  TTSK_REQUIRE(y && gamma && beta && mean && rstd, "layernorm_fwd_grouped: null pointer");
+  TTSK_REQUIRE(groups > 0 && group_rows > 0 && D >= 256 && D <= 1024 && (D & 255) == 0, "layernorm_fwd_grouped: bad sizes");
+  TTSK_REQUIRE(!lens || (seg_len > 0 && group_rows % seg_len == 0), "layernorm_fwd_grouped: lens needs group_rows %% seg_len == 0");
+  TTSK_REQUIRE((p_pre == 0.f && p_post == 0.f) || rng, "layernorm_fwd_grouped: dropout needs rng state");
+  TTSK_REQUIRE(!head_w || (head_b && head_out), "layernorm_fwd_grouped: head needs bias and output");
+  TTSK_REQUIRE((param_stride & 3) == 0, "layernorm_fwd_grouped: param_stride must keep 16-byte alignment");
+  const int rows = groups * group_rows;
+  LnArgs a{(const bf16_t*)y, (const bf16_t*)res, gamma, beta, (bf16_t*)out, (bf16_t*)z_save, mean, rstd,
+           (const long long*)lens, rng, head_w, head_b, head_out, rows, D, seg_len, p_pre, p_post, eps, site_pre, site_post,
+           group_rows, (long long)param_stride, site_stride};
   hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
@@ -394,9 +459,31 @@ extern "C" int ttsk_layernorm_bwd(const void* dout, const float* dhead, const fl
   TTSK_REQUIRE(rows > 0 && D >= 256 && D <= 1024 && (D & 255) == 0, "layernorm_bwd: bad D %d", D);
   TTSK_REQUIRE((p_pre == 0.f && p_post == 0.f) || rng, "layernorm_bwd: dropout needs rng state");
   TTSK_REQUIRE(p_post == 0.f || beta, "layernorm_bwd: post dropout needs beta");
+  const int nblk = ttsk_layernorm_bwd_nblocks(rows);
   LnBwdArgs a{(const bf16_t*)dout, dhead, head_w, (const bf16_t*)z, mean, rstd, gamma, beta, (const long long*)lens, rng,
-              (bf16_t*)dz, (bf16_t*)dy, partials, rows, D, seg_len, relu_in, p_pre, p_post, site_pre, site_post};
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(ttsk_layernorm_bwd_nblocks(rows)), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
+              (bf16_t*)dz, (bf16_t*)dy, partials, rows, D, seg_len, relu_in, p_pre, p_post, site_pre, site_post, 0, nblk, 0, 0};
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_layernorm_bwd_grouped(const void* dout, const float* dhead, const float* head_w, const void* z,
+                                          const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                          const int64_t* lens, int seg_len, int groups, int group_rows, int64_t param_stride,
+                                          uint32_t site_stride, int D, int relu_in, float p_pre, uint32_t site_pre, float p_post,
+                                          uint32_t site_post, const uint64_t* rng, void* dz, void* dy, float* partials, void* stream) {
+  TTSK_REQUIRE(z && mean && rstd && gamma && partials, "layernorm_bwd_grouped: null pointer");
+  TTSK_REQUIRE(dout || dhead, "layernorm_bwd_grouped: need dout or dhead");
+  TTSK_REQUIRE(!dhead || (head_w && beta), "layernorm_bwd_grouped: head mode needs head_w and beta");
+  TTSK_REQUIRE(groups > 0 && group_rows > 0 && D >= 256 && D <= 1024 && (D & 255) == 0, "layernorm_bwd_grouped: bad sizes");
+  TTSK_REQUIRE(!lens || (seg_len > 0 && group_rows % seg_len == 0), "layernorm_bwd_grouped: lens needs group_rows %% seg_len == 0");
+  TTSK_REQUIRE((p_pre == 0.f && p_post == 0.f) || rng, "layernorm_bwd_grouped: dropout needs rng state");
+  TTSK_REQUIRE(p_post == 0.f || beta, "layernorm_bwd_grouped: post dropout needs beta");
+  const int nblk = ttsk_layernorm_bwd_nblocks(group_rows);
+  LnBwdArgs a{(const bf16_t*)dout, dhead, head_w, (const bf16_t*)z, mean, rstd, gamma, beta, (const long long*)lens, rng,
+              (bf16_t*)dz, (bf16_t*)dy, partials, groups * group_rows, D, seg_len, relu_in, p_pre, p_post, site_pre, site_post,
+              group_rows, nblk, (long long)param_stride, site_stride};
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(groups * nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -88,6 +88,76 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   }
 }
 
+// ---- the whole optimizer step as TWO launches (was five: rng_advance, optim_advance, sumsq, clip_coef, adam):
+//   sumsq_advance_kernel: per-block sums of g^2, and its block 0 also advances the scheduler / Adam / dropout counters
+//   (it reads nothing the counters feed; the Adam launch after it reads the advanced state);
+//   adam_clip_kernel: every workgroup first folds the 1024 partials in the same fixed order (double) into the global norm
+//   and the clip coefficient, then applies Adam; workgroup 0 records gnorm / clip_coef in the state block.
+struct SchedArgs { float d_model, warmup, a0, a1, a2, a3, anneal_rate, b1, b2; int n_anneal, advance_rng; };
+
+__global__ __launch_bounds__(256) void sumsq_advance_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partials, OptState* st,
+                                                            const SchedArgs sc) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 v = *(const f32x4*)(g + i * 4);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[n4 * 4 + threadIdx.x]; s += v * v; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long sstep = ++st->sched_step;
+    const long long t = ++st->adam_t;
+    double lr = fmin(pow((double)sstep, -0.5), pow((double)sc.warmup, -1.5) * (double)sstep);
+    const float an[4] = {sc.a0, sc.a1, sc.a2, sc.a3};
+    for (int i = 0; i < sc.n_anneal; ++i)
+      if ((double)sstep > (double)an[i]) lr *= (double)sc.anneal_rate;
+    st->lr = (float)(pow((double)sc.d_model, -0.5) * lr);
+    st->bc1 = (float)(1.0 - pow((double)sc.b1, (double)t));
+    st->bc2 = (float)(1.0 - pow((double)sc.b2, (double)t));
+    if (sc.advance_rng) st->rng_step += 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, bf16_t* __restrict__ shadow, int64_t n, OptState* st,
+                                                        const float* __restrict__ partials, int nblk, float max_norm, float b1, float b2,
+                                                        float eps, int zero_grad) {
+  __shared__ double red[256];
+  {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  }
+  const float norm = (float)sqrt(red[0]);
+  const float cc = max_norm / (norm + 1e-6f);
+  const float coef = cc < 1.f ? cc : 1.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { st->gnorm = norm; st->clip_coef = coef; }
+  const float lr = st->lr, bc1 = st->bc1;
+  const float isb2 = 1.f / sqrtf(st->bc2);
+  const float step = lr / bc1;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 pp = *(f32x4*)(p + i * 4), gg = *(const f32x4*)(g + i * 4), mm = *(f32x4*)(m + i * 4), vv = *(f32x4*)(v + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ge = gg[e] * coef;
+      mm[e] = b1 * mm[e] + (1.f - b1) * ge;
+      vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
+      pp[e] -= step * mm[e] / (sqrtf(vv[e]) * isb2 + eps);
+    }
+    *(f32x4*)(p + i * 4) = pp; *(f32x4*)(m + i * 4) = mm; *(f32x4*)(v + i * 4) = vv;
+    if (zero_grad) *(f32x4*)(g + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (shadow) *(uint2*)(shadow + i * 4) = make_uint2(pack_bf2(pp[0], pp[1]), pack_bf2(pp[2], pp[3]));
+  }
+}
+
 }  // namespace
 
 extern "C" int ttsk_optim_state_bytes(void) { return (int)sizeof(OptState); }
@@ -128,6 +198,25 @@ extern "C" int ttsk_clip_adam_step(float* params, float* grads, float* exp_avg, 
 extern "C" int ttsk_grad_sumsq(const float* grads, int64_t n, float* partials /* 1024 floats */, void* stream) {
   TTSK_REQUIRE(grads && partials && n > 0, "grad_sumsq: bad arguments");
   hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, grads, n, partials);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_optim_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n, void* state,
+                               float* partials /* >= 1024 floats */, float max_norm, float beta1, float beta2, float eps, int zero_grad,
+                               float d_model, float warmup, const float* anneal_steps_host, int n_anneal, float anneal_rate,
+                               int advance_rng, void* stream) {
+  TTSK_REQUIRE(params && grads && exp_avg && exp_avg_sq && state && partials && n > 0, "optim_step: null pointer");
+  TTSK_REQUIRE((n & 3) == 0, "optim_step: n must be a multiple of 4 (pad the flat buffer)");
+  TTSK_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0, "optim_step: alignment");
+  TTSK_REQUIRE(n_anneal >= 0 && n_anneal <= 4, "optim_step: at most 4 anneal steps");
+  float a[4] = {0, 0, 0, 0};
+  for (int i = 0; i < n_anneal; ++i) a[i] = anneal_steps_host[i];
+  const SchedArgs sc{d_model, warmup, a[0], a[1], a[2], a[3], anneal_rate, beta1, beta2, n_anneal, advance_rng};
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sumsq_advance_kernel, dim3(1024), dim3(256), 0, s, grads, n, partials, (OptState*)state, sc);
+  hipLaunchKernelGGL(adam_clip_kernel, dim3(2048), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (bf16_t*)shadow_bf16, n,
+                     (OptState*)state, partials, 1024, max_norm, beta1, beta2, eps, zero_grad);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -127,16 +127,25 @@ __device__ __forceinline__ void scatter_sum_body(const bf16_t* __restrict__ dx, 
         if (threadIdx.x == 0) nh = count;
       }
       __syncthreads();
-      for (int h = 0; h < nh; ++h) {
-        const int i = hits[h];
-        for (int r = 0; r < idx_div; ++r) {
-          const int64_t row = (int64_t)i * idx_div + r;
+      // the rows a table entry collects: hit h contributes rows hits[h]*idx_div .. +idx_div-1.  Eight row loads are issued
+      // before their (ordered) adds: one dependent load at a time cost 59 us for the speaker table (64 rows per hit)
+      const int nrow = nh * idx_div;
+      for (int q0 = 0; q0 < nrow; q0 += 8) {
+        float v[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int q = q0 + u;
+          const int64_t row = q < nrow ? (int64_t)hits[q / idx_div] * idx_div + q % idx_div : 0;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int c = threadIdx.x + 256 * j;
-            if (c < D) acc[j] += bf2f(dx[row * D + c]);
+            v[u][j] = (q < nrow && c < D) ? bf2f(dx[row * D + c]) : 0.f;
           }
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += v[u][j];
       }
       __syncthreads();
     }
@@ -167,6 +176,63 @@ __global__ __launch_bounds__(256) void scatter_sum_batch_kernel(const ScatterBat
   if ((int)blockIdx.x >= it.n_table_rows) return;
   scatter_sum_body((const bf16_t*)it.dx, it.idx, it.idx_is_i64, it.idx_div, it.n_idx, it.dtable, it.D, it.skip_row, it.accumulate,
                    blockIdx.x, hits, nh);
+}
+
+// ---------------------------------------------------------------------------------------------- variance adaptor, training
+// reference: model/modules.py:158-193 with targets given: x1 = x + speaker_emb; x2 = x1 + pitch_emb[bucketize(pitch_target)];
+// x3 = x2 + energy_emb[bucketize(energy_target)] — the three gather_add launches and the two bucketize launches of the
+// step-by-step path as ONE pass over the rows (each of x1, x2, x3 rounded to bf16 as there).  x1 / x2 are the inputs of the
+// pitch / energy predictors: together with x they form the [3][rows][D] operand of the grouped predictor launches.
+__device__ __forceinline__ int bucket_of(const float* __restrict__ bins, int nb, float x) {
+  int lo = 0, hi = nb;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (bins[mid] < x) lo = mid + 1; else hi = mid; }
+  return (x != x) ? nb : lo;
+}
+__device__ __forceinline__ f32x4 round_bf4(f32x4 v) {
+  return f32x4{bf2f(f2bf(v[0])), bf2f(f2bf(v[1])), bf2f(f2bf(v[2])), bf2f(f2bf(v[3]))};
+}
+__global__ __launch_bounds__(256) void va_embed_kernel(const bf16_t* __restrict__ x, const float* __restrict__ spk_table,
+                                                       const long long* __restrict__ speakers, int L, const float* __restrict__ pitch_t,
+                                                       const float* __restrict__ pitch_bins, const float* __restrict__ pitch_table,
+                                                       const float* __restrict__ energy_t, const float* __restrict__ energy_bins,
+                                                       const float* __restrict__ energy_table, int nb, bf16_t* __restrict__ x1,
+                                                       bf16_t* __restrict__ x2, bf16_t* __restrict__ x3, int* __restrict__ pidx,
+                                                       int* __restrict__ eidx, int rows, int D) {
+  const int cpr = D >> 2;
+  const int64_t n = (int64_t)rows * cpr;
+  for (int64_t c = blockIdx.x * 256 + threadIdx.x; c < n; c += (int64_t)gridDim.x * 256) {
+    const int row = (int)(c / cpr), ch = (int)(c - (int64_t)row * cpr) * 4;
+    const int pi = bucket_of(pitch_bins, nb, pitch_t[row]), ei = bucket_of(energy_bins, nb, energy_t[row]);
+    if (ch == 0) { pidx[row] = pi; eidx[row] = ei; }
+    const uint2 u = *(const uint2*)(x + (int64_t)row * D + ch);
+    f32x4 v = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
+    v = round_bf4(v + *(const f32x4*)(spk_table + speakers[row / L] * D + ch));
+    *(uint2*)(x1 + (int64_t)row * D + ch) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    v = round_bf4(v + *(const f32x4*)(pitch_table + (int64_t)pi * D + ch));
+    *(uint2*)(x2 + (int64_t)row * D + ch) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    v = v + *(const f32x4*)(energy_table + (int64_t)ei * D + ch);
+    *(uint2*)(x3 + (int64_t)row * D + ch) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+  }
+}
+
+// backward of that chain around the grouped predictor backward: dxin [3][rows][D] fp32 = the gradients the duration / pitch /
+// energy predictors send to their inputs x / x1 / x2; dx3 = gradient of x3 (from the LengthRegulator).
+//   dx2 = dx3 + dxin[2]  (gradient of x2: also what pitch_embedding collects)
+//   dx1 = dx2 + dxin[1]  (gradient of x1: also what speaker_emb collects)
+//   dx  = dx1 + dxin[0]  (gradient of the encoder output)
+// each rounded to bf16 — the values the step-by-step path's conv dX epilogues (fp32 accumulator + bf16 residual) produce.
+__global__ __launch_bounds__(256) void va_combine_kernel(const bf16_t* __restrict__ dx3, const float* __restrict__ dxin, bf16_t* __restrict__ dx2,
+                                                         bf16_t* __restrict__ dx1, bf16_t* __restrict__ dx, int64_t n4, int64_t gstride) {
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const uint2 u = *(const uint2*)(dx3 + i * 4);
+    f32x4 v = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
+    v = round_bf4(v + *(const f32x4*)(dxin + 2 * gstride + i * 4));
+    *(uint2*)(dx2 + i * 4) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    v = round_bf4(v + *(const f32x4*)(dxin + gstride + i * 4));
+    *(uint2*)(dx1 + i * 4) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    v = v + *(const f32x4*)(dxin + i * 4);
+    *(uint2*)(dx + i * 4) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- conversions
@@ -343,6 +409,30 @@ extern "C" int ttsk_duration_round(const float* logd, float d_control, float* ou
 extern "C" int ttsk_length_mask(const int64_t* lens, uint8_t* mask, int B, int T, void* stream) {
   TTSK_REQUIRE(lens && mask && B > 0 && T > 0, "length_mask: bad arguments");
   hipLaunchKernelGGL(length_mask_kernel, dim3((B * T + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const long long*)lens, mask, B, T);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_va_embed(const void* x_bf16, const float* speaker_table, const int64_t* speakers, int L, const float* pitch_target,
+                             const float* pitch_bins, const float* pitch_table, const float* energy_target, const float* energy_bins,
+                             const float* energy_table, int n_bins_minus_1, void* x1_bf16, void* x2_bf16, void* x3_bf16, int32_t* pitch_idx,
+                             int32_t* energy_idx, int rows, int D, void* stream) {
+  TTSK_REQUIRE(x_bf16 && speaker_table && speakers && pitch_target && pitch_bins && pitch_table && energy_target && energy_bins &&
+                   energy_table && x1_bf16 && x2_bf16 && x3_bf16 && pitch_idx && energy_idx, "va_embed: null pointer");
+  TTSK_REQUIRE(rows > 0 && L > 0 && rows % L == 0 && D > 0 && (D & 3) == 0 && n_bins_minus_1 > 0, "va_embed: bad sizes");
+  hipLaunchKernelGGL(va_embed_kernel, dim3(grid_for((int64_t)rows * (D >> 2))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16,
+                     speaker_table, (const long long*)speakers, L, pitch_target, pitch_bins, pitch_table, energy_target, energy_bins,
+                     energy_table, n_bins_minus_1, (bf16_t*)x1_bf16, (bf16_t*)x2_bf16, (bf16_t*)x3_bf16, pitch_idx, energy_idx, rows, D);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_va_combine(const void* dx3_bf16, const float* dxin, void* dx2_bf16, void* dx1_bf16, void* dx_bf16, int rows, int D,
+                               void* stream) {
+  TTSK_REQUIRE(dx3_bf16 && dxin && dx2_bf16 && dx1_bf16 && dx_bf16 && rows > 0 && D > 0 && (D & 3) == 0, "va_combine: bad arguments");
+  const int64_t n4 = (int64_t)rows * D / 4;
+  hipLaunchKernelGGL(va_combine_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx3_bf16, dxin,
+                     (bf16_t*)dx2_bf16, (bf16_t*)dx1_bf16, (bf16_t*)dx_bf16, n4, (int64_t)rows * D);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -108,6 +108,8 @@ class FastSpeech2(nn.Module):
         self._deferred_fin = None       # gradient column-sum partials awaiting the batched finalize
         self._side = None               # second HIP stream for parameter-gradient work (see _SideWork)
         self.fused_attention = True     # one kernel for scores + softmax + P.V (and dP + softmax' + dQ) when d_k = 128
+        self.fused_ln = True            # fc / w_2 + dropout + residual + LayerNorm + PAD zeroing in one kernel when d = 256
+        self.group_predictors = True    # training with targets: the three VariancePredictors run as grouped launches
         self.group_param_grads = True      # weight-gradient GEMMs of a backward pass share grouped launches (ops.DeferQueue)
         self.overlap_param_grads = False   # measured on MI355X: the branches do overlap under graph replay, but the concurrent
                                            # kernels slow each other by as much (6.39 vs 6.47 ms/step): off by default
@@ -118,6 +120,11 @@ class FastSpeech2(nn.Module):
             self._register(en, device)
         self._init_constants(preprocess_config, model_config)
         self.reset_parameters(seed)
+        # the three predictors sit back to back in the flat buffer with identical internal layouts: constant stride
+        va = "variance_adaptor."
+        o = [self._table[va + n + "_predictor.conv_layer.conv1d_1.conv.weight"].offset for n in ("duration", "pitch", "energy")]
+        self._pred_stride = o[1] - o[0]
+        assert o[2] - o[1] == self._pred_stride and self._pred_stride % 8 == 0
 
     # ------------------------------------------------------------------ parameter plumbing
     def _register(self, en, device):
@@ -299,7 +306,7 @@ class FastSpeech2(nn.Module):
             mel, post, pitch, energy, logd = _Bridge.apply(self._anchor, self, mel, post, pitch, energy, logd)
         return (mel, pitch, energy, logd, d_rounded, src_masks, mel_masks, src_lens, mel_lens_out, post, None, None)
 
-    def _fft_fwd(self, pre, x, Bn, S, lens, H, p, site, rng, ctx_list):
+    def _fft_fwd(self, pre, x, Bn, S, lens, H, p, site, rng, ctx_list, out=None):
         """One FFTBlock.  reference: Layers.py:25-34, SubLayers.py:31-65 (MHA), :93-101 (FFN), Modules.py:14-24."""
         d, rows = self.d, Bn * S
         dk = d // H
@@ -323,16 +330,27 @@ class FastSpeech2(nn.Module):
             o = torch.empty(rows, d, dtype=bf16, device=dev)
             ops.gemm(probs, qkv[:, 2 * d:], o, S, dk, S, Sp, 3 * d, d, flags=ops.B_TR, nz1=Bn, nz2=H,
                      sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * d, dk))
-        # (5) fc, dropout, +residual, LayerNorm, zero PAD rows: SubLayers.py:62-63, Layers.py:29
-        y = ops.linear(o, self._w(a + "fc.weight"), self._m(a + "fc.bias"))
-        x1, z1, mean1, rstd1, _ = ops.layernorm_fwd(y, x, self._m(a + "layer_norm.weight"), self._m(a + "layer_norm.bias"),
-                                                    lens, S, p_pre=p, site_pre=site, rng=rng, save_z=ctx_list is not None)
+        fuse = self.fused_ln and d == 256
+        # (5) fc, dropout, +residual, LayerNorm, zero PAD rows: SubLayers.py:62-63, Layers.py:29 — one kernel when d = 256
+        if fuse:
+            x1, z1, mean1, rstd1 = ops.gemm_ln_fwd(o, self._w(a + "fc.weight"), self._m(a + "fc.bias"), x, self._m(a + "layer_norm.weight"),
+                                                   self._m(a + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site, rng=rng,
+                                                   save_z=ctx_list is not None)
+        else:
+            y = ops.linear(o, self._w(a + "fc.weight"), self._m(a + "fc.bias"))
+            x1, z1, mean1, rstd1, _ = ops.layernorm_fwd(y, x, self._m(a + "layer_norm.weight"), self._m(a + "layer_norm.bias"),
+                                                        lens, S, p_pre=p, site_pre=site, rng=rng, save_z=ctx_list is not None)
         # (6) FFN: Conv1d(k=9)+ReLU, Conv1d(k=1), dropout, +residual, LayerNorm, zero PAD rows: SubLayers.py:96-99, Layers.py:32
         h = ops.conv1d(x1.view(Bn, S, d), self._w(f + "w_1.weight"), self._m(f + "w_1.bias"), flags=ops.RELU)
-        y2 = ops.conv1d(h, self._w(f + "w_2.weight"), self._m(f + "w_2.bias"))
-        x2, z2, mean2, rstd2, _ = ops.layernorm_fwd(y2.view(rows, d), x1, self._m(f + "layer_norm.weight"),
-                                                    self._m(f + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site + 1,
-                                                    rng=rng, save_z=ctx_list is not None)
+        if fuse and self.k2 == 1:
+            x2, z2, mean2, rstd2 = ops.gemm_ln_fwd(h.view(rows, -1), self._w(f + "w_2.weight"), self._m(f + "w_2.bias"), x1,
+                                                   self._m(f + "layer_norm.weight"), self._m(f + "layer_norm.bias"), lens, S, p_pre=p,
+                                                   site_pre=site + 1, rng=rng, save_z=ctx_list is not None, out=out)
+        else:
+            y2 = ops.conv1d(h, self._w(f + "w_2.weight"), self._m(f + "w_2.bias"))
+            x2, z2, mean2, rstd2, _ = ops.layernorm_fwd(y2.view(rows, d), x1, self._m(f + "layer_norm.weight"),
+                                                        self._m(f + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site + 1,
+                                                        rng=rng, save_z=ctx_list is not None, out=out)
         if ctx_list is not None:
             ctx_list.append((pre, x, qkv, probs, o, z1, mean1, rstd1, x1, h, z2, mean2, rstd2, Bn, S, lens, H, p, site, o32))
         return x2
@@ -351,6 +369,71 @@ class FastSpeech2(nn.Module):
         if ctx is not None:
             ctx[pre] = (x, h1, m1, r1, a1, h2, m2, r2, Bn, Lp, lens, p, site)
         return out.view(Bn, Lp)
+
+    def _predictors_fwd_grouped(self, stack, Bn, Lp, lens, p, rng, ctx):
+        """The duration / pitch / energy VariancePredictors (model/modules.py:255-309) as ONE chain of grouped launches: with
+        targets given (training) their inputs x, x + speaker, x + speaker + pitch_emb[target] do not depend on each other's
+        outputs (modules.py:158-193).  stack (3, rows, d) bf16 holds the three inputs.  Returns (3, B, L) fp32 = (log-duration,
+        pitch, energy) predictions."""
+        d, rows, ps = self.d, Bn * Lp, self._pred_stride
+        pre = "variance_adaptor.duration_predictor."
+        c = pre + "conv_layer."
+        W1, W2 = self._w(c + "conv1d_1.conv.weight"), self._w(c + "conv1d_2.conv.weight")
+        Fh = W1.shape[0]
+        dev = stack.device
+        h1 = torch.empty(3, rows, Fh, dtype=bf16, device=dev)
+        ops.conv1d(stack[0].view(Bn, Lp, d), W1, self._m(c + "conv1d_1.conv.bias"), flags=ops.RELU, out=h1[0].view(Bn, Lp, Fh),
+                   nz1=3, sA=(rows * d, 0), sB=(ps, 0), sC=(rows * Fh, 0), s_bias1=ps)
+        a1, m1, r1, _ = ops.layernorm_fwd_grouped(h1.view(3 * rows, Fh), self._m(c + "layer_norm_1.weight"), self._m(c + "layer_norm_1.bias"),
+                                                  3, ps, 2, None, 0, p_post=p, site_post=200, rng=rng)
+        h2 = torch.empty(3, rows, Fh, dtype=bf16, device=dev)
+        ops.conv1d(a1[:rows].view(Bn, Lp, Fh), W2, self._m(c + "conv1d_2.conv.bias"), flags=ops.RELU, out=h2[0].view(Bn, Lp, Fh),
+                   nz1=3, sA=(rows * Fh, 0), sB=(ps, 0), sC=(rows * Fh, 0), s_bias1=ps)
+        _, m2, r2, out = ops.layernorm_fwd_grouped(h2.view(3 * rows, Fh), self._m(c + "layer_norm_2.weight"), self._m(c + "layer_norm_2.bias"),
+                                                   3, ps, 2, lens, Lp, p_post=p, site_post=201, rng=rng, want_out=False,
+                                                   head=(self._m(pre + "linear_layer.weight").view(-1), self._m(pre + "linear_layer.bias")))
+        if ctx is not None:
+            ctx["grouped"] = (stack, h1, m1, r1, a1, h2, m2, r2, Bn, Lp, lens, p)
+        return out.view(3, Bn, Lp)
+
+    def _predictors_bwd_grouped(self, saved, dstack, rng, dx3):
+        """Backward of _predictors_fwd_grouped; dstack (3, B, L) fp32 = gradients of (log-duration, pitch, energy) predictions,
+        dx3 = gradient of the LengthRegulator input.  Returns (dx2, dx1, dx): gradients of x2 (what pitch_embedding collects),
+        x1 (speaker_emb) and of the encoder output."""
+        (stack, h1, m1, r1, a1, h2, m2, r2, Bn, Lp, lens, p) = saved
+        d, rows, ps = self.d, Bn * Lp, self._pred_stride
+        names = ("duration", "pitch", "energy")
+        pre = "variance_adaptor.duration_predictor."
+        c = pre + "conv_layer."
+        W1, W2 = self._w(c + "conv1d_1.conv.weight"), self._w(c + "conv1d_2.conv.weight")
+        Fh = W1.shape[0]
+        dev = dx3.device
+        dh2, part, nblk = ops.layernorm_bwd_grouped(None, h2.view(3 * rows, Fh), m2, r2, self._m(c + "layer_norm_2.weight"),
+                                                    self._m(c + "layer_norm_2.bias"), 3, ps, 2, lens, Lp, relu_in=True, p_post=p,
+                                                    site_post=201, rng=rng, dhead=dstack.view(-1),
+                                                    head_w=self._m(pre + "linear_layer.weight").view(-1))
+        dh2 = dh2.view(3, rows, Fh)
+        with self._side_work(dh2, part, a1):
+            for g, n in enumerate(names):
+                cg = "variance_adaptor.%s_predictor.conv_layer." % n
+                self._finalize_ln(part[g], nblk, 4 * Fh + 1, cg + "conv1d_2.conv.bias")
+                ops.conv1d_dw(dh2[g].view(Bn, Lp, Fh), a1[g * rows:(g + 1) * rows].view(Bn, Lp, Fh), self._g(cg + "conv1d_2.conv.weight"),
+                              k=self.k_var, defer=self._deferred)
+        da1 = torch.empty(3, rows, Fh, dtype=bf16, device=dev)
+        ops.conv1d_dx(dh2[0].view(Bn, Lp, Fh), W2, out=da1[0].view(Bn, Lp, Fh), nz1=3, sA=(rows * Fh, 0), sB=(ps, 0), sC=(rows * Fh, 0))
+        dh1, part, nblk = ops.layernorm_bwd_grouped(da1.view(3 * rows, Fh), h1.view(3 * rows, Fh), m1, r1, self._m(c + "layer_norm_1.weight"),
+                                                    self._m(c + "layer_norm_1.bias"), 3, ps, 2, None, 0, relu_in=True, p_post=p,
+                                                    site_post=200, rng=rng)
+        dh1 = dh1.view(3, rows, Fh)
+        with self._side_work(dh1, part, stack):
+            for g, n in enumerate(names):
+                cg = "variance_adaptor.%s_predictor.conv_layer." % n
+                self._finalize_ln(part[g], nblk, 3 * Fh, cg + "conv1d_1.conv.bias")
+                ops.conv1d_dw(dh1[g].view(Bn, Lp, Fh), stack[g].view(Bn, Lp, d), self._g(cg + "conv1d_1.conv.weight"), k=self.k_var,
+                              defer=self._deferred)
+        dxin = torch.empty(3, rows, d, dtype=torch.float32, device=dev)
+        ops.conv1d_dx(dh1[0].view(Bn, Lp, Fh), W1, out=dxin[0].view(Bn, Lp, d), nz1=3, sA=(rows * Fh, 0), sB=(ps, 0), sC=(rows * d, 0))
+        return ops.va_combine(dx3, dxin)
 
     def _forward(self, train, speakers, texts, src_lens, Lp, mel_lens, max_mel_len, e_targets, d_targets, pitches_raw,
                  p_control, e_control, d_control):
@@ -371,25 +454,37 @@ class FastSpeech2(nn.Module):
         else:
             pe_enc = self.get("encoder.position_enc")[0]
         x = ops.gather_add(None, self._m("encoder.src_word_emb.weight"), texts, pe=pe_enc, pe_mod=Lp, rows=Bn * Lp)
-        x_emb = x
+        grouped = (train and self.group_predictors and pitches_raw is not None and e_targets is not None and Lp <= self.max_seq_len)
+        stack = torch.empty(3, Bn * Lp, d, dtype=bf16, device=dev) if grouped else None
         for i in range(self.n_enc):
-            x = self._fft_fwd("encoder.layer_stack.%d." % i, x, Bn, Lp, src_lens, self.n_head_enc, p_enc, 2 * i, rng, blocks)
+            x = self._fft_fwd("encoder.layer_stack.%d." % i, x, Bn, Lp, src_lens, self.n_head_enc, p_enc, 2 * i, rng, blocks,
+                              out=stack[0] if (grouped and i == self.n_enc - 1) else None)
         # ---- variance adaptor: modules.py:142-217 (duration BEFORE the speaker embedding; energy sees the pitch embedding)
         va = "variance_adaptor."
-        logd = self._predictor_fwd(va + "duration_predictor.", x, Bn, Lp, src_lens, p_var, 200, rng, preds)
-        x1 = ops.gather_add(x, self._m("speaker_emb.weight"), speakers, idx_div=Lp)          # fastspeech2.py:72-75
-        pitch = self._predictor_fwd(va + "pitch_predictor.", x1, Bn, Lp, src_lens, p_var, 202, rng, preds)
-        if pitches_raw is not None:
-            pidx = ops.bucketize(pitches_raw.to(dev).float(), self.get(va + "pitch_bins"))
+        if grouped:
+            # training with targets: the embeddings are picked by the TARGET pitch / energy, so the three predictor inputs are
+            # known up front — one pass builds them (and x3), then the predictors run as grouped launches
+            x3, pidx, eidx = ops.va_embed(stack, speakers, self._m("speaker_emb.weight"), Lp, pitches_raw.to(dev).float().contiguous(),
+                                          self.get(va + "pitch_bins"), self._m(va + "pitch_embedding.weight"),
+                                          e_targets.to(dev).float().contiguous(), self.get(va + "energy_bins"),
+                                          self._m(va + "energy_embedding.weight"))
+            pred = self._predictors_fwd_grouped(stack, Bn, Lp, src_lens, p_var, rng, preds)
+            logd, pitch, energy = pred[0], pred[1], pred[2]
         else:
-            pidx, pitch = ops.bucketize(pitch, self.get(va + "pitch_bins"), p_control, want_scaled=True)
-        x2 = ops.gather_add(x1, self._m(va + "pitch_embedding.weight"), pidx.view(-1))
-        energy = self._predictor_fwd(va + "energy_predictor.", x2, Bn, Lp, src_lens, p_var, 204, rng, preds)
-        if e_targets is not None:
-            eidx = ops.bucketize(e_targets.to(dev).float(), self.get(va + "energy_bins"))
-        else:
-            eidx, energy = ops.bucketize(energy, self.get(va + "energy_bins"), e_control, want_scaled=True)
-        x3 = ops.gather_add(x2, self._m(va + "energy_embedding.weight"), eidx.view(-1))
+            logd = self._predictor_fwd(va + "duration_predictor.", x, Bn, Lp, src_lens, p_var, 200, rng, preds)
+            x1 = ops.gather_add(x, self._m("speaker_emb.weight"), speakers, idx_div=Lp)          # fastspeech2.py:72-75
+            pitch = self._predictor_fwd(va + "pitch_predictor.", x1, Bn, Lp, src_lens, p_var, 202, rng, preds)
+            if pitches_raw is not None:
+                pidx = ops.bucketize(pitches_raw.to(dev).float(), self.get(va + "pitch_bins"))
+            else:
+                pidx, pitch = ops.bucketize(pitch, self.get(va + "pitch_bins"), p_control, want_scaled=True)
+            x2 = ops.gather_add(x1, self._m(va + "pitch_embedding.weight"), pidx.view(-1))
+            energy = self._predictor_fwd(va + "energy_predictor.", x2, Bn, Lp, src_lens, p_var, 204, rng, preds)
+            if e_targets is not None:
+                eidx = ops.bucketize(e_targets.to(dev).float(), self.get(va + "energy_bins"))
+            else:
+                eidx, energy = ops.bucketize(energy, self.get(va + "energy_bins"), e_control, want_scaled=True)
+            x3 = ops.gather_add(x2, self._m(va + "energy_embedding.weight"), eidx.view(-1))
         # ---- length regulator (+ decoder position table, fused): modules.py:196-205,225-252; Models.py:172-178
         if d_targets is not None:
             dur = d_targets.to(dev).long().contiguous()
@@ -630,6 +725,21 @@ class FastSpeech2(nn.Module):
             ops.conv1d_dw(dh1.view(Bn, Lp, Fh), x.view(Bn, Lp, d), self._g(c + "conv1d_1.conv.weight"), k=self.k_var, defer=self._deferred)
         return ops.conv1d_dx(dh1.view(Bn, Lp, Fh), self._w(c + "conv1d_1.conv.weight"), R=R)
 
+    @staticmethod
+    def _stack3(dlogd, dpitch, denergy):
+        """(3, B, L) fp32 = (dlogd, dpitch, denergy).  ops.fs2_loss hands them out as the three slices of one buffer (no copy);
+        gradients that arrive separately (the autograd bridge) are copied into one."""
+        base = dlogd._base
+        n = dlogd.numel()
+        if (base is not None and dpitch._base is base and denergy._base is base and base.dim() == 3 and base.shape[0] == 3 and
+                base.is_contiguous() and dlogd.data_ptr() == base.data_ptr() and dpitch.data_ptr() == base.data_ptr() + 4 * n and
+                denergy.data_ptr() == base.data_ptr() + 8 * n):
+            return base
+        out = torch.empty((3,) + tuple(dlogd.shape), dtype=torch.float32, device=dlogd.device)
+        for i, t in enumerate((dlogd, dpitch, denergy)):
+            out[i].copy_(t)               # a device-to-device copy, no arithmetic
+        return out
+
     def backward_native(self, ctx, dmel_sum, dpost, dpitch, denergy, dlogd, on_bucket=None):
         """Accumulate d(loss)/d(params) into the flat gradient buffer.
         dmel_sum = dL/dmel (direct terms) + dL/dpost, dpost = dL/dpost — fp32 (B,T,n_mel); dpitch/denergy/dlogd fp32 (B,L).
@@ -685,13 +795,19 @@ class FastSpeech2(nn.Module):
         va = "variance_adaptor."
         with self._side_work(dx3):
             ops.scatter_sum(dx3, ctx.eidx.view(-1), self._g(va + "energy_embedding.weight"), defer=self._deferred_fin)
-        dx2 = self._predictor_bwd(va + "energy_predictor.", ctx.preds[va + "energy_predictor."], denergy, rng, dx3.view(Bn, Lp, d))
-        with self._side_work(dx2):
-            ops.scatter_sum(dx2.view(Bn * Lp, d), ctx.pidx.view(-1), self._g(va + "pitch_embedding.weight"), defer=self._deferred_fin)
-        dx1 = self._predictor_bwd(va + "pitch_predictor.", ctx.preds[va + "pitch_predictor."], dpitch, rng, dx2)
-        with self._side_work(dx1):
-            ops.scatter_sum(dx1.view(Bn * Lp, d), ctx.speakers, self._g("speaker_emb.weight"), idx_div=Lp, defer=self._deferred_fin)
-        dxe = self._predictor_bwd(va + "duration_predictor.", ctx.preds[va + "duration_predictor."], dlogd, rng, dx1)
+        if "grouped" in ctx.preds:
+            dx2, dx1, dxe = self._predictors_bwd_grouped(ctx.preds["grouped"], self._stack3(dlogd, dpitch, denergy), rng, dx3)
+            with self._side_work(dx2, dx1):
+                ops.scatter_sum(dx2, ctx.pidx.view(-1), self._g(va + "pitch_embedding.weight"), defer=self._deferred_fin)
+                ops.scatter_sum(dx1, ctx.speakers, self._g("speaker_emb.weight"), idx_div=Lp, defer=self._deferred_fin)
+        else:
+            dx2 = self._predictor_bwd(va + "energy_predictor.", ctx.preds[va + "energy_predictor."], denergy, rng, dx3.view(Bn, Lp, d))
+            with self._side_work(dx2):
+                ops.scatter_sum(dx2.view(Bn * Lp, d), ctx.pidx.view(-1), self._g(va + "pitch_embedding.weight"), defer=self._deferred_fin)
+            dx1 = self._predictor_bwd(va + "pitch_predictor.", ctx.preds[va + "pitch_predictor."], dpitch, rng, dx2)
+            with self._side_work(dx1):
+                ops.scatter_sum(dx1.view(Bn * Lp, d), ctx.speakers, self._g("speaker_emb.weight"), idx_div=Lp, defer=self._deferred_fin)
+            dxe = self._predictor_bwd(va + "duration_predictor.", ctx.preds[va + "duration_predictor."], dlogd, rng, dx1)
         notify("variance_adaptor")
         # ---- encoder
         dx = dxe.view(Bn * Lp, d)

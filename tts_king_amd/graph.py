@@ -61,8 +61,9 @@ def make_enqueue(model, optimizer, cfg, Loss, step_is_update=True, reducer=None,
                 reducer.finish()
             else:
                 model.backward_native(ctx, dmel_sum, dpost, dp, de, dd)
-            ops.rng_advance(model._state())
             if step_is_update:
-                optimizer.step_and_update_lr()
+                optimizer.step_and_update_lr(advance_rng=True)      # the end-of-step dropout-counter tick rides along
+            else:
+                ops.rng_advance(model._state())
         return losses, out
     return enqueue

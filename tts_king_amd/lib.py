@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("bseg_len", C.c_int32), ("bshift0", C.c_int32), ("bdshift", C.c_int32),
         ("out_seg", C.c_int32), ("out_mul", C.c_int32), ("out_add", C.c_int32), ("out_add_dz", C.c_int32),
         ("splits", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("kernel", C.c_int32),
+        ("s_bias1", C.c_int64),
     ]
 
 

@@ -30,6 +30,9 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+import os as _os
+# K steps one workgroup of a grouped weight-gradient launch walks (128x128 tile, 256x128 tile): more steps = fewer split-K slabs
+DW_STEPS_PER_WG = tuple(int(v) for v in _os.environ.get("TTSK_DW_STEPS", "28,36").split(","))
 GEMM_TRACE = None   # bench.py sets this to a list: every ttsk_gemm launch is then bracketed by HIP events on its stream
 
 
@@ -112,7 +115,7 @@ def plan(d):
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=None, ldr=0, G=None, ldg=0, C2=None,
          nz1=1, nz2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), taps=0, seg_len=0, tap_shift0=0, tap_dshift=0,
          b_tap_stride=0, bseg_len=0, bshift0=0, bdshift=0, out_seg=0, out_mul=0, out_add=0, out_add_dz=0, splits=0, kernel=0,
-         in_slope=0.0, out_slope=0.0, defer=None, group=None):
+         in_slope=0.0, out_slope=0.0, defer=None, group=None, s_bias1=0):
     """Raw descriptor-level call of ttsk_gemm (see include/ttsk.h).  A/B/Cout may be views: the data pointer of
     the view is the operand origin.  splits / kernel = 0 let the library plan (tile configuration, split-K factor);
     the split-K workspace is allocated here (the C library never allocates).  `defer`: a list — a split-K weight-
@@ -141,7 +144,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=No
     d.taps, d.seg_len, d.tap_shift0, d.tap_dshift, d.b_tap_stride = taps, seg_len, tap_shift0, tap_dshift, b_tap_stride
     d.bseg_len, d.bshift0, d.bdshift = bseg_len, bshift0, bdshift
     d.out_seg, d.out_mul, d.out_add, d.out_add_dz = out_seg, out_mul, out_add, out_add_dz
-    d.splits, d.kernel = splits, kernel
+    d.splits, d.kernel, d.s_bias1 = splits, kernel, s_bias1
     user_splits, user_kernel = splits, kernel
     kernel, splits, ws_bytes = plan(d)
     grouped_dw = (defer is not None and getattr(defer, "group", None) is not None and nz1 == 1 and (flags & C_F32)
@@ -153,7 +156,8 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=No
         # Tile configuration: the 256x128 LDS-DMA kernel unless the output has too few rows to fill its tile.
         steps = (K + 63) // 64 * max(taps, 1)
         d.kernel = 2 if M >= 192 else 1
-        d.splits = max(1, (steps + 14) // 28) if d.kernel == 1 else max(1, (steps + 18) // 36)
+        per1, per2 = DW_STEPS_PER_WG
+        d.splits = max(1, (steps + per1 // 2) // per1) if d.kernel == 1 else max(1, (steps + per2 // 2) // per2)
         kernel, splits, ws_bytes = plan(d)
     d.splits, d.kernel = splits, kernel
     ws = None
@@ -322,12 +326,13 @@ def _f32(*shape, device):
 
 
 def layernorm_fwd(y, res, gamma, beta, lens=None, seg_len=0, p_pre=0.0, site_pre=0, p_post=0.0, site_post=0, rng=None,
-                  save_z=True, head=None, want_out=True, eps=1e-5):
+                  save_z=True, head=None, want_out=True, eps=1e-5, out=None):
     """Fused block tail (see include/ttsk.h).  y/res (rows,D) bf16.  Returns (out, z, mean, rstd, head_out)."""
     _dev(y, res, gamma, beta, lens, rng)
     rows, D = y.shape
     dev = y.device
-    out = torch.empty(rows, D, dtype=bf16, device=dev) if want_out else None
+    if out is None:
+        out = torch.empty(rows, D, dtype=bf16, device=dev) if want_out else None
     z = torch.empty(rows, D, dtype=bf16, device=dev) if save_z else None
     mean, rstd = _f32(rows, device=dev), _f32(rows, device=dev)
     hw = hb = ho = None
@@ -338,6 +343,24 @@ def layernorm_fwd(y, res, gamma, beta, lens=None, seg_len=0, p_pre=0.0, site_pre
                                       _ptr(lens), seg_len, rows, D, eps, p_pre, site_pre, p_post, site_post, _ptr(rng),
                                       _ptr(hw), _ptr(hb), _ptr(ho), _stream()), "ttsk_layernorm_fwd")
     return out, z, mean, rstd, ho
+
+
+def gemm_ln_fwd(x, W, bias, res, gamma, beta, lens=None, seg_len=0, p_pre=0.0, site_pre=0, rng=None, save_z=True, eps=1e-5, out=None):
+    """LayerNorm(dropout(x @ W^T + bias) + res) with PAD rows zeroed, one kernel (D = 256).  x (rows, K) bf16, W (256, K) or
+    (256, 1, K) bf16.  Returns (out, z, mean, rstd) like layernorm_fwd."""
+    _dev(x, W, bias, res, gamma, beta, lens, rng)
+    rows, K = x.shape
+    D = W.shape[0]
+    W2 = W.reshape(D, -1)
+    dev = x.device
+    if out is None:
+        out = torch.empty(rows, D, dtype=bf16, device=dev)
+    z = torch.empty(rows, D, dtype=bf16, device=dev) if save_z else None
+    mean, rstd = _f32(rows, device=dev), _f32(rows, device=dev)
+    check(L.load().ttsk_gemm_ln_fwd(_ptr(x), x.stride(0), _ptr(W2), W2.stride(0), _ptr(bias), _ptr(res), _ptr(gamma), _ptr(beta),
+                                    _ptr(out), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(lens), seg_len, rows, K, D, eps, p_pre, site_pre,
+                                    _ptr(rng), _stream()), "ttsk_gemm_ln_fwd")
+    return out, z, mean, rstd
 
 
 def layernorm_bwd(dout, z, mean, rstd, gamma, beta, lens=None, seg_len=0, relu_in=False, p_pre=0.0, site_pre=0,
@@ -356,6 +379,65 @@ def layernorm_bwd(dout, z, mean, rstd, gamma, beta, lens=None, seg_len=0, relu_i
                                  _ptr(beta), _ptr(lens), seg_len, rows, D, int(relu_in), p_pre, site_pre, p_post,
                                  site_post, _ptr(rng), _ptr(dz), _ptr(dy), _ptr(partials), _stream()), "ttsk_layernorm_bwd")
     return dz, (dy if dy is not None else dz), partials, nblk
+
+
+def layernorm_fwd_grouped(y, gamma, beta, groups, param_stride, site_stride, lens=None, seg_len=0, p_post=0.0, site_post=0, rng=None,
+                          head=None, want_out=True, eps=1e-5):
+    """`groups` independent LayerNorm tails in one launch (the three VariancePredictors): y (groups*group_rows, D) bf16; group g
+    takes its gamma / beta / head at + g*param_stride floats and dropout site site_post + g*site_stride.  -> (out, mean, rstd, head_out)."""
+    _dev(y, gamma, beta, lens, rng)
+    rows, D = y.shape
+    dev = y.device
+    out = torch.empty(rows, D, dtype=bf16, device=dev) if want_out else None
+    mean, rstd = _f32(rows, device=dev), _f32(rows, device=dev)
+    hw = hb = ho = None
+    if head is not None:
+        hw, hb = head
+        ho = _f32(rows, device=dev)
+    check(L.load().ttsk_layernorm_fwd_grouped(_ptr(y), None, _ptr(gamma), _ptr(beta), _ptr(out), None, _ptr(mean), _ptr(rstd), _ptr(lens),
+                                              seg_len, groups, rows // groups, param_stride, site_stride, D, eps, 0.0, 0, p_post, site_post,
+                                              _ptr(rng), _ptr(hw), _ptr(hb), _ptr(ho), _stream()), "ttsk_layernorm_fwd_grouped")
+    return out, mean, rstd, ho
+
+
+def layernorm_bwd_grouped(dout, z, mean, rstd, gamma, beta, groups, param_stride, site_stride, lens=None, seg_len=0, relu_in=False,
+                          p_post=0.0, site_post=0, rng=None, dhead=None, head_w=None):
+    """Backward of layernorm_fwd_grouped.  Returns (dz, partials [groups][nblk][ncol], nblk per group)."""
+    _dev(dout, z, dhead)
+    rows, D = z.shape
+    dev = z.device
+    lib = L.load()
+    nblk = lib.ttsk_layernorm_bwd_nblocks(rows // groups)
+    ncol = (4 * D + 1) if dhead is not None else 3 * D
+    partials = _f32(groups, nblk, ncol, device=dev)
+    dz = torch.empty(rows, D, dtype=bf16, device=dev)
+    check(lib.ttsk_layernorm_bwd_grouped(_ptr(dout), _ptr(dhead), _ptr(head_w), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
+                                         _ptr(lens), seg_len, groups, rows // groups, param_stride, site_stride, D, int(relu_in), 0.0, 0,
+                                         p_post, site_post, _ptr(rng), _ptr(dz), None, _ptr(partials), _stream()), "ttsk_layernorm_bwd_grouped")
+    return dz, partials, nblk
+
+
+def va_embed(stack, speakers, spk_table, Lp, pitch_t, pitch_bins, pitch_table, energy_t, energy_bins, energy_table):
+    """stack (3, rows, D) bf16 with stack[0] = encoder output: fills stack[1] = x + speaker, stack[2] = stack[1] + pitch embedding and
+    returns (x3 = stack[2] + energy embedding, pitch bucket indices, energy bucket indices).  reference: modules.py:158-193."""
+    _dev(stack, speakers, spk_table, pitch_t, pitch_bins, pitch_table, energy_t, energy_bins, energy_table)
+    _, rows, D = stack.shape
+    x3 = torch.empty(rows, D, dtype=bf16, device=stack.device)
+    pidx = torch.empty(rows, dtype=torch.int32, device=stack.device)
+    eidx = torch.empty(rows, dtype=torch.int32, device=stack.device)
+    check(L.load().ttsk_va_embed(_ptr(stack[0]), _ptr(spk_table), _ptr(speakers), Lp, _ptr(pitch_t), _ptr(pitch_bins), _ptr(pitch_table),
+                                 _ptr(energy_t), _ptr(energy_bins), _ptr(energy_table), pitch_bins.numel(), _ptr(stack[1]), _ptr(stack[2]),
+                                 _ptr(x3), _ptr(pidx), _ptr(eidx), rows, D, _stream()), "ttsk_va_embed")
+    return x3, pidx, eidx
+
+
+def va_combine(dx3, dxin):
+    """dx3 (rows, D) bf16, dxin (3, rows, D) fp32 -> (dx2, dx1, dx) bf16: see include/ttsk.h."""
+    _dev(dx3, dxin)
+    rows, D = dx3.shape
+    dx2, dx1, dx = torch.empty_like(dx3), torch.empty_like(dx3), torch.empty_like(dx3)
+    check(L.load().ttsk_va_combine(_ptr(dx3), _ptr(dxin), _ptr(dx2), _ptr(dx1), _ptr(dx), rows, D, _stream()), "ttsk_va_combine")
+    return dx2, dx1, dx
 
 
 def colsum_finalize(partials, nblk, ncols, ld, dst, accumulate=True, scale=1.0, defer=None):
@@ -595,7 +677,8 @@ def fs2_loss(mel, post, mel_t, mel_lens, pitch, energy, logd, pitch_t, energy_t,
     dev = mel.device
     lib = L.load()
     dmel, dpost = _f32(B, T, nm, device=dev), _f32(B, T, nm, device=dev)
-    dp, de, dd = _f32(B, Lp, device=dev), _f32(B, Lp, device=dev), _f32(B, Lp, device=dev)
+    dstack = _f32(3, B, Lp, device=dev)          # (duration, pitch, energy): the order of the grouped predictor backward
+    dd, dp, de = dstack[0], dstack[1], dstack[2]
     partials = _f32(lib.ttsk_fs2_loss_nblocks(), 6, device=dev)
     losses = _f32(8, device=dev)
     check(lib.ttsk_fs2_loss(_ptr(mel), _ptr(post), _ptr(mel_t), _ptr(mel_lens), _ptr(pitch), _ptr(energy), _ptr(logd),
@@ -633,6 +716,16 @@ def clip_adam_step(params, grads, m, v, shadow, state, partials, max_norm, beta1
     check(L.load().ttsk_clip_adam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(shadow), params.numel(), _ptr(state),
                                        _ptr(partials), max_norm, beta1, beta2, eps, int(zero_grad), _stream()),
           "ttsk_clip_adam_step")
+
+
+def optim_step(params, grads, m, v, shadow, state, partials, max_norm, beta1, beta2, eps, d_model, warmup, anneal_steps, anneal_rate,
+               zero_grad=True, advance_rng=False):
+    """optim_advance (+ rng_advance) + clip_adam_step in two launches (ttsk_optim_step)."""
+    _dev(params, grads, m, v, shadow, state, partials)
+    arr = (C.c_float * 4)(*([float(a) for a in anneal_steps] + [0.0] * (4 - len(anneal_steps))))
+    check(L.load().ttsk_optim_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(shadow), params.numel(), _ptr(state), _ptr(partials),
+                                   max_norm, beta1, beta2, eps, int(zero_grad), float(d_model), float(warmup), C.cast(arr, C.c_void_p),
+                                   len(anneal_steps), anneal_rate, int(advance_rng), _stream()), "ttsk_optim_step")
 
 
 # ---------------------------------------------------------------------------------------------------- HiFi-GAN helpers

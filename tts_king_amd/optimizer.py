@@ -48,12 +48,13 @@ class ScheduledOptim:
                 lr = lr * self.anneal_rate
         return lr
 
-    def step_and_update_lr(self):
-        """clip (global norm) -> lr update -> Adam -> bf16 shadow refresh -> grads zeroed, all on device."""
+    def step_and_update_lr(self, advance_rng=False):
+        """clip (global norm) -> lr update -> Adam -> bf16 shadow refresh -> grads zeroed, all on device, in two launches.
+        `advance_rng`: also tick the dropout counter (the train step's end-of-step tick, folded in)."""
         flat, grad, shadow = self.model.flat_buffers()
-        ops.optim_advance(self.state, self.d_model, self.n_warmup_steps, self.anneal_steps, self.anneal_rate, *self.betas)
-        ops.clip_adam_step(flat, grad, self.exp_avg, self.exp_avg_sq, shadow, self.state, self._partials,
-                           self.grad_clip_thresh, self.betas[0], self.betas[1], self.eps, zero_grad=True)
+        ops.optim_step(flat, grad, self.exp_avg, self.exp_avg_sq, shadow, self.state, self._partials, self.grad_clip_thresh,
+                       self.betas[0], self.betas[1], self.eps, self.d_model, self.n_warmup_steps, self.anneal_steps, self.anneal_rate,
+                       zero_grad=True, advance_rng=advance_rng)
         self._host_step += 1
 
     def zero_grad(self):

@@ -92,10 +92,11 @@ def main_train_step(model, batch, step, optimizer, cfg, Loss, reducer=None):
             reducer.finish()
         else:
             model.backward_native(ctx, dmel_sum, dpost, dp, de, dd)
-        ops.rng_advance(model._state())
         if do_step:
-            optimizer.step_and_update_lr()
+            optimizer.step_and_update_lr(advance_rng=True)          # the end-of-step dropout-counter tick rides along
             optimizer.zero_grad()
+        else:
+            ops.rng_advance(model._state())
     output = (mel, pitch, energy, logd, d_rounded, src_masks, mel_masks, batch[4], mel_lens_out, post, None, None)
     vals = losses.cpu().tolist()                       # the step's only host read (reference: 6x .item(), train.py:45)
     return [v / grad_acc_step for v in vals[1:7]], output

@@ -57,8 +57,11 @@ enum {
   TTSK_GEMM_F16       = 1 << 11, /* 16-bit operands (A, B, C, C2, R, G) are IEEE fp16 instead of bf16           */
   TTSK_GEMM_C2_LRELU  = 1 << 12, /* the second output is leaky_relu(v, out_slope) (C keeps v): the next conv's   */
                                  /* activation is produced by this conv's epilogue instead of its operand staging */
-  TTSK_GEMM_DEFER_REDUCE = 1 << 13 /* split-K: write the partial slabs only; the caller sums many GEMMs' slabs later */
+  TTSK_GEMM_DEFER_REDUCE = 1 << 13,/* split-K: write the partial slabs only; the caller sums many GEMMs' slabs later */
                                  /* with ONE ttsk_gemm_reduce_batch launch (weight gradients: needed only by Adam)  */
+  TTSK_GEMM_RAW_SLABS = 1 << 14    /* the fp32 partial tiles [splits][nz][M][N] go to `workspace` for ANY splits >= 1, no  */
+                                 /* epilogue and no reducer launch: the consumer sums them (ttsk_layernorm_bwd_slabs   */
+                                 /* adds the slabs and the residual while it reads its rows); C is not written         */
 };
 
 typedef struct ttsk_gemm_desc {
@@ -192,6 +195,14 @@ int ttsk_layernorm_bwd_grouped(const void* dout_bf16, const float* dhead, const 
                                int seg_len, int groups, int group_rows, int64_t param_stride, uint32_t site_stride, int D,
                                int relu_in, float p_pre, uint32_t site_pre, float p_post, uint32_t site_post, const uint64_t* rng,
                                void* dz_bf16, void* dy_bf16, float* partials, void* stream);
+/* ttsk_layernorm_bwd whose upstream gradient is still in split-K form: dout[row] = sum_s slabs[s*slab_stride + row*D ..] (+ R[row],
+ * bf16, may be NULL) — the raw partial tiles a ttsk_gemm with TTSK_GEMM_RAW_SLABS left behind (the dX GEMM that feeds this
+ * LayerNorm) are summed in fixed order while the rows are read, in fp32, so neither a reducer launch nor a bf16 copy of dout
+ * exists.  Other arguments as ttsk_layernorm_bwd (no head mode). */
+int ttsk_layernorm_bwd_slabs(const float* slabs, int nsplit, int64_t slab_stride, const void* R_bf16, const void* z_bf16,
+                             const float* mean, const float* rstd, const float* gamma, const float* beta, const int64_t* lens,
+                             int seg_len, int rows, int D, int relu_in, float p_pre, uint32_t site_pre, float p_post,
+                             uint32_t site_post, const uint64_t* rng, void* dz_bf16, void* dy_bf16, float* partials, void* stream);
 /* dst[c] (+)= scale * sum_b partials[b*ld + c]  in fixed order */
 int ttsk_colsum_finalize(const float* partials, int nblk, int ncols, int ld, float* dst, int accumulate, float scale,
                          void* stream);
@@ -219,13 +230,16 @@ int ttsk_colsum_batch(const ttsk_colsum_item* items, int n, void* stream);
  * x3 = x2 + energy_table[bucketize(energy_target)] (bucketize = torch.bucketize, right=False, n_bins_minus_1 edges), each
  * rounded to bf16; the bucket indices are returned for the embedding-gradient scatter-sums.  va_combine is its backward around
  * the grouped predictor backward: dxin [3][rows][D] fp32 (gradients wrt x, x1, x2 from the duration / pitch / energy
- * predictors), dx3 -> dx2 = dx3 + dxin[2], dx1 = dx2 + dxin[1], dx = dx1 + dxin[0]. */
+ * predictors), dx3 -> dx2 = dx3 + dxin[2], dx1 = dx2 + dxin[1], dx = dx1 + dxin[0].
+ * row_limit (int64 [rows / L], may be NULL): phoneme positions l >= row_limit[u] of utterance u do not exist in the reference's
+ * batch (shape-bucketed training pads L up to a multiple of 8): they are written as zero rows / carry no gradient, so that the
+ * predictors' convolutions see the zero padding the reference's shorter batch has there. */
 int ttsk_va_embed(const void* x_bf16, const float* speaker_table, const int64_t* speakers, int L, const float* pitch_target,
                   const float* pitch_bins, const float* pitch_table, const float* energy_target, const float* energy_bins,
                   const float* energy_table, int n_bins_minus_1, void* x1_bf16, void* x2_bf16, void* x3_bf16, int32_t* pitch_idx,
-                  int32_t* energy_idx, int rows, int D, void* stream);
-int ttsk_va_combine(const void* dx3_bf16, const float* dxin, void* dx2_bf16, void* dx1_bf16, void* dx_bf16, int rows, int D,
-                    void* stream);
+                  int32_t* energy_idx, int rows, int D, const int64_t* row_limit, void* stream);
+int ttsk_va_combine(const void* dx3_bf16, const float* dxin, void* dx2_bf16, void* dx1_bf16, void* dx_bf16, int rows, int D, int L,
+                    const int64_t* row_limit, void* stream);
 
 /* ------------------------------------------------------------------------------------------ attention softmax
  * reference: fs_two/transformer/Modules.py:15-22.  scores fp32 [nz][S][Sp] (already scaled by 1/sqrt(d_k) in the
@@ -328,40 +342,53 @@ int ttsk_hifi_resblock1(const void* x16, void* out16, int f16, const void* const
                         float final_slope, void* stream);
 int ttsk_hifi_resblock1_supported(int C, int K);
 
+/* rows (u, t) with t >= frame_limit[0] of x [rows][C] (elem_bytes 2 or 4, row = u*seg_len + t) are set to zero: the mel
+ * frames / mel gradients past the batch's own longest utterance under shape-bucketed training (see BatchNorm below). */
+int ttsk_zero_frames_from(void* x, int elem_bytes, int rows, int C, int seg_len, const int32_t* frame_limit, void* stream);
+
 /* ------------------------------------------------------------------------------------- PostNet BatchNorm1d
  * reference: fs_two/transformer/Layers.py:133-143 — training statistics over ALL rows (PAD rows included),
  * eps 1e-5, momentum 0.1, running_var updated with the unbiased variance; tanh (all but the last layer) and
  * F.dropout(0.5) follow; the last layer adds the mel residual (fastspeech2.py:104).
  * x (the conv output) may be fp32: channels whose batch std is far below their mean amplify a bf16 rounding of x
  * by mean/std, so the model keeps x in fp32 (x_is_f32 = 1).
+ * frame_limit (device int32[1], may be NULL) + seg_len: rows are (utterance, frame) pairs, row = u*seg_len + t; frames
+ * t >= frame_limit[0] do not exist in the reference's batch (shape-bucketed training pads T up to a multiple of 32 so that
+ * hipGraphs repeat; the reference pads to the batch's own longest utterance): they are left out of the statistics and of
+ * the row count, are written as zero rows (the next convolution's zero padding) and carry no gradient.
  */
 int ttsk_bn_nblocks(int rows);
-int ttsk_bn_stats(const void* x, int x_is_f32, int rows, int C, float* partials /* [nblocks][2C] */, void* stream);
+int ttsk_bn_stats(const void* x, int x_is_f32, int rows, int C, float* partials /* [nblocks][2C] */, const int32_t* frame_limit,
+                  int seg_len, void* stream);
 int ttsk_bn_finalize(const float* partials, int nblk, int C, int rows, float eps, float momentum, float* mean, float* rstd,
-                     float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream);
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked, const int32_t* frame_limit, int seg_len,
+                     void* stream);
 int ttsk_rsqrt_eps(const float* var, float eps, float* rstd, int n, void* stream);
 int ttsk_bn_apply(const void* x, int x_is_f32, const float* mean, const float* rstd, const float* gamma, const float* beta, int rows,
                   int C, int use_tanh, float p, uint32_t site, const uint64_t* rng, const float* resid_f32, void* out_bf16,
-                  float* out_f32, void* stream);
+                  float* out_f32, const int32_t* frame_limit, int seg_len, void* stream);
 int ttsk_bn_bwd_stats(const void* dout, int dout_is_f32, const void* x, int x_is_f32, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
-                      const uint64_t* rng, float* partials /* [nblocks][2C]: sum dy | sum dy*xhat */, void* stream);
+                      const uint64_t* rng, float* partials /* [nblocks][2C]: sum dy | sum dy*xhat */, const int32_t* frame_limit,
+                      int seg_len, void* stream);
 int ttsk_bn_bwd_apply(const void* dout, int dout_is_f32, const void* x, int x_is_f32, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
                       const uint64_t* rng, const float* sums /* [2C] */, void* dx_bf16, float* dgamma, float* dbeta,
-                      void* stream);
+                      const int32_t* frame_limit, int seg_len, void* stream);
 
 /* ------------------------------------------------------------------------------------------------- loss
  * reference: fs_two/model/loss.py:24-134 (use_cwt False).  losses[8] = {total, mel_total, pitch, energy, duration,
  * 0, 0, n_valid_phonemes}; gradients of grad_scale*total: dmel_sum = d/dmel + d/dpost (postnet adds mel back),
  * dpost, dpitch, denergy, dlogd.  partials: [ttsk_fs2_loss_nblocks()][6] fp32.
+ * frame_limit (device int32[1], may be NULL): the mel terms are means over B * frame_limit[0] * n_mel elements instead of
+ * B * T * n_mel — the reference's denominator when the batch was padded beyond its own longest utterance (see BatchNorm).
  */
 int ttsk_fs2_loss_nblocks(void);
 int ttsk_fs2_loss(const float* mel, const float* post, const float* mel_target, const int64_t* mel_lens, const float* pitch,
                   const float* energy, const float* logd, const float* pitch_target, const float* energy_target,
                   const int64_t* dur_target, const int64_t* src_lens, int B, int T, int T_target, int n_mel, int L,
                   float grad_scale, float* dmel_sum, float* dpost, float* dpitch, float* denergy, float* dlogd,
-                  float* partials, float* losses, void* stream);
+                  float* partials, float* losses, const int32_t* frame_limit, void* stream);
 
 /* ------------------------------------------------------------------------------------------- optimiser
  * reference: train.py:47-54, fs_two/model/optimizer.py:5-53, torch.optim.Adam.

@@ -421,3 +421,28 @@ def test_gemm_ln_fwd_dropout_matches_unfused_masks():
     torch.testing.assert_close(zf[keep], zu[keep], rtol=2 ** -6, atol=1e-3)      # y rounded to bf16 (unfused) vs not (fused)
     yref = (a.double() @ w.double().t() + b.double()) / (1 - p)
     assert float((zf.double()[keep] - yref[keep]).abs().max()) <= 2 ** -8 * float(yref.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("M,N,K,kern,splits", [(6768, 256, 768, 0, 0), (1024, 256, 768, 3, 1), (423, 256, 9216, 2, 4), (1024, 256, 256, 1, 2)])
+def test_raw_slabs_sum_to_the_product_and_feed_layernorm_bwd(M, N, K, kern, splits):
+    """TTSK_GEMM_RAW_SLABS: the un-reduced split-K tiles sum to A @ B; ttsk_layernorm_bwd_slabs(slabs, R) equals
+    ttsk_layernorm_bwd on dout = sum(slabs) + R up to the bf16 rounding of dout it avoids."""
+    from tts_king_amd import ops
+    a, b = bf(rnd(M, K, seed=41)), bf(rnd(K, N, seed=42) * K ** -0.5)
+    sl = ops.gemm(a.to(DEV), b.to(DEV), None, M, N, K, K, N, N, flags=ops.B_TR, kernel=kern, splits=splits, raw=True)
+    assert sl.stride == M * N and sl.splits >= 1 and sl.ws.numel() >= sl.splits * M * N
+    got = sl.ws[:sl.splits * M * N].view(sl.splits, M, N).sum(0)
+    check(got, a.double() @ b.double(), K, out_bf16=False)
+    # LayerNorm backward straight from the slabs
+    D = N
+    r = bf(rnd(M, D, seed=43))
+    z = bf(rnd(M, D, seed=44))
+    mean, rstd = z.float().mean(1), (z.float().var(1, unbiased=False) + 1e-5).rsqrt()
+    gamma, beta = 1 + 0.1 * rnd(D, seed=45), 0.1 * rnd(D, seed=46)
+    dout = (got.float() + r.to(DEV).float()).to(torch.bfloat16)
+    dz_a, _, part_a, nblk = ops.layernorm_bwd(dout, z.to(DEV), mean.to(DEV), rstd.to(DEV), gamma.to(DEV), beta.to(DEV))
+    dz_b, _, part_b, nblk_b = ops.layernorm_bwd(None, z.to(DEV), mean.to(DEV), rstd.to(DEV), gamma.to(DEV), beta.to(DEV), slabs=sl, R=r.to(DEV))
+    assert nblk == nblk_b
+    err = float((dz_a.float() - dz_b.float()).abs().max())
+    assert err <= 2 ** -6 * float(dz_a.float().abs().max()) + 1e-3, err
+    torch.testing.assert_close(part_a.sum(0), part_b.sum(0), rtol=2e-2, atol=0.5)

@@ -1,7 +1,8 @@
 """FS2 trainer with the reference's entry points (reference: train.py:24-56 `main_train_step`, :78-235 `main`,
 fs_two/evaluate.py:18-101 `evaluate`), running the MI355X train step.
 
-Kept from the reference: the step function and its return value, the loop structure (DataLoader over groups of
+What runs each step is `tts_king_amd.engine.TrainEngine` (shape buckets + hipGraph replay + data-parallel reducer) — the
+same device work `main_train_step` enqueues.  Kept from the reference: the step function and its return value, the loop structure (DataLoader over groups of
 batch_size*4 utterances sorted by phoneme count and cut into batches, `grad_acc_step`, log / val / save cadence from
 `train_config.step`), the validation message, the checkpoint layout `{"model", "embedding", "optimizer"}`
 (train.py:212-227).  Different: batches reach the GPU through a pinned-memory prefetcher (tts_king_amd/dataset.py),
@@ -66,39 +67,66 @@ def load_training_state(model, optimizer, path):
 
 
 def main(cfg, max_steps=None):
-    """reference: train.py:78-235.  `max_steps` (extra) stops early instead of the reference's `quit()` at total_step."""
+    """reference: train.py:78-235.  `max_steps` (extra) stops early instead of the reference's `quit()` at total_step.
+
+    What runs per step is tts_king_amd.engine.TrainEngine: batches padded to shape buckets on the host, one replayed hipGraph
+    per shape (`mi355x.hip_graph`), and — under `python -m torch.distributed.run --nproc-per-node N train.py` — one process per
+    GPU, each on its own shard of every epoch's shuffle, gradients all-reduced bucket by bucket over RCCL while backward runs
+    (tts_king_amd.parallel).  Losses are read from the device only when they are logged."""
+    from tts_king_amd.engine import TrainEngine
+    from tts_king_amd.parallel import GradReducer, init_distributed
     print("Prepare training ...")
-    device = cfg.gpu
+    rank, world, local = init_distributed()
+    device = "cuda:%d" % local if world > 1 else cfg.gpu
     dataset = Dataset("train.txt", cfg.preprocess_config, cfg.train_config, sort=True, drop_last=True)
     batch_size = cfg.train_config["optimizer"]["batch_size"]
     group_size = 4                                    # sorting happens inside groups of 4 batches (train.py:91)
     assert batch_size * group_size < len(dataset)
     mi = cfg.get("mi355x", {}) if hasattr(cfg, "get") else {}
     workers = int(mi.get("loader_workers", 4)) if mi else 4          # reference: num_workers=4 (train.py:98)
-    loader = DataLoader(dataset, batch_size=batch_size * group_size, shuffle=True, collate_fn=dataset.collate_fn, num_workers=workers)
+    sampler = None
+    if world > 1:       # every rank draws its own 1/N of each epoch's permutation (same seed on all ranks, disjoint indices)
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True, seed=int(mi.get("seed", 1234)), drop_last=True)
+    loader = DataLoader(dataset, batch_size=batch_size * group_size, shuffle=sampler is None, sampler=sampler,
+                        collate_fn=dataset.collate_fn, num_workers=workers)
     model, optimizer = get_model(cfg, device, train=True)
     Loss = FastSpeech2Loss(cfg.preprocess_config, cfg.model_config)
-    print("Number of FastSpeech2 Parameters:", get_param_num(model))
-    for p in cfg.train_config["path"].values():
-        os.makedirs(p, exist_ok=True)
+    reducer = None
+    if world > 1:
+        reducer = GradReducer(model.flat_buffers()[1], model.grad_buckets(mi.get("dp_bucket_mb", 24)), model.group_offsets())
+    engine = TrainEngine(model, optimizer, cfg, Loss, reducer=reducer)
+    bucket = None
+    if bool(mi.get("bucket_shapes", True)):
+        bucket = (int(mi.get("l_bucket", 8)), int(mi.get("t_bucket", 32)), int(cfg.model_config["max_seq_len"]))
+    if rank == 0:
+        print("Number of FastSpeech2 Parameters:", get_param_num(model))
+        for p in cfg.train_config["path"].values():
+            os.makedirs(p, exist_ok=True)
     step = cfg.tts.restore_step + 1
     total_step = cfg.train_config["step"]["total_step"]
     if max_steps is not None:
         total_step = min(total_step, cfg.tts.restore_step + max_steps)
     st = cfg.train_config["step"]
+    grad_acc = cfg.train_config["optimizer"]["grad_acc_step"]
     epoch = 1
+    model.engine = engine
     while True:
+        if sampler is not None:
+            sampler.set_epoch(epoch)
         for batchs in loader:
-            for batch in DeviceFeeder(batchs, model.device):
-                losses, output = main_train_step(model, batch, step, optimizer, cfg, Loss)
-                if step % st["log_step"] == 0:
+            for batch in DeviceFeeder(batchs, model.device, bucket=bucket):
+                losses, output = engine.step(batch, step)
+                if rank == 0 and step % st["log_step"] == 0:
+                    vals = [v / grad_acc for v in losses.cpu().tolist()[1:5]]         # the loop's only host read
                     print("Step {}/{}, Total Loss: {:.4f}, Mel Loss: {:.4f}, Pitch Loss: {:.4f}, Energy Loss: {:.4f}, "
-                          "Duration Loss: {:.4f}".format(step, total_step, sum(losses[:4]), *losses[:4]))
-                if step % st["val_step"] == 0:
+                          "Duration Loss: {:.4f}".format(step, total_step, sum(vals), *vals))
+                if rank == 0 and step % st["val_step"] == 0:
                     print(evaluate(model, step, cfg, None, "val", None, device))
-                if step % st["save_step"] == 0:
+                if rank == 0 and step % st["save_step"] == 0:
                     save_checkpoint(model, optimizer, os.path.join(cfg.train_config["path"]["ckpt_path"], "{}.pth.tar".format(step)))
                 if step == total_step:
+                    torch.cuda.synchronize()
                     return model, optimizer
                 step += 1
         epoch += 1

@@ -18,7 +18,19 @@ struct BnCommon {
   float p;
   unsigned site;
   int x_f32;
+  // Frame limit (shape-bucketed training, tts_king_amd/engine.py): rows are (utterance, frame) pairs, row = u*seg_len + t, and
+  // frames t >= frame_limit[0] do not exist in the reference's batch (it pads to the batch's own longest utterance, the
+  // bucketed batch to a multiple of 32 frames): they are left out of the statistics, count as zero rows for the next
+  // convolution (its zero padding) and carry no gradient.  null = every row exists.
+  const int* frame_limit;
+  int seg_len;
 };
+__device__ __forceinline__ bool bn_live(const int* frame_limit, int seg_len, int r) {
+  return !frame_limit || (r % seg_len) < frame_limit[0];
+}
+__device__ __forceinline__ int bn_rows(const int* frame_limit, int seg_len, int rows) {
+  return frame_limit ? (rows / seg_len) * frame_limit[0] : rows;
+}
 
 __device__ __forceinline__ void ld4(const bf16_t* p, float v[4]) {
   const uint2 u = *(const uint2*)p;
@@ -39,7 +51,8 @@ __device__ __forceinline__ uint4 bits4(const uint64_t* rng, unsigned site, unsig
 }
 
 // ---- pass 1: per-column sum and sum of squares -> partials[blk][2C]
-__global__ __launch_bounds__(256) void bn_stats_kernel(const void* __restrict__ x, int x_f32, int rows, int C, float* __restrict__ partials) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const void* __restrict__ x, int x_f32, int rows, int C, float* __restrict__ partials,
+                                                       const int* __restrict__ frame_limit, int seg_len) {
   extern __shared__ float red[];  // [rpi][4*tpr] x 2
   const int tpr = C >> 2, rpi = 256 / tpr;
   const int r0 = threadIdx.x / tpr, c4 = (threadIdx.x % tpr) * 4;
@@ -49,6 +62,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const void* __restrict__ 
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   if (r0 < rpi)
     for (int r = rb + r0; r < re; r += rpi) {
+      if (!bn_live(frame_limit, seg_len, r)) continue;
       float v[4];
       ldx4(x, x_f32, (int64_t)r * C + c4, v);
 #pragma unroll
@@ -68,10 +82,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const void* __restrict__ 
 }
 
 // mean / rstd from the partials (double accumulation), running statistics update (momentum, unbiased variance)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nblk, int C, int rows, float eps,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nblk, int C, int rows_all, float eps,
                                                           float momentum, float* __restrict__ mean, float* __restrict__ rstd,
                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                          long long* __restrict__ nbt) {
+                                                          long long* __restrict__ nbt, const int* __restrict__ frame_limit, int seg_len) {
+  const int rows = bn_rows(frame_limit, seg_len, rows_all);
   // 16 channels x 16 row-groups per workgroup; every thread adds its partial rows in ascending order (double), the 16
   // group sums are combined in fixed order: deterministic
   __shared__ double rs[16][17], rq[16][17];
@@ -127,6 +142,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnCommon a, const f
   const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int r = (int)(i / tpr), c4 = (int)(i - (int64_t)r * tpr) * 4;
+    if (!bn_live(a.frame_limit, a.seg_len, r)) {     // a frame past the batch's own length: a zero row (the next conv's padding)
+      if (out16) *(uint2*)(out16 + (int64_t)r * a.C + c4) = make_uint2(0u, 0u);
+      if (out32) *(f32x4*)(out32 + (int64_t)r * a.C + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
     float v[4];
     ldx4(a.x, a.x_f32, (int64_t)r * a.C + c4, v);
     const f32x4 m = *(const f32x4*)(a.mean + c4), rs = *(const f32x4*)(a.rstd + c4);
@@ -154,6 +174,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnCommon a, const f
 // gradient wrt the BN output y (before tanh/dropout) for 4 channels of one row
 __device__ __forceinline__ void bn_dy(const BnCommon& a, const void* dout, int dout_f32, int r, int c4, int64_t i, unsigned thr,
                                       float scale, float xh[4], float dy[4]) {
+  if (!bn_live(a.frame_limit, a.seg_len, r)) {       // no such frame in the reference's batch: no gradient, no statistics
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { xh[e] = 0.f; dy[e] = 0.f; }
+    return;
+  }
   float v[4];
   ldx4(a.x, a.x_f32, (int64_t)r * a.C + c4, v);
   const f32x4 m = *(const f32x4*)(a.mean + c4), rs = *(const f32x4*)(a.rstd + c4);
@@ -217,7 +242,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnCommon a, con
   const int64_t n = (int64_t)a.rows * tpr;
   const unsigned thr = keep_threshold(a.p);
   const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
-  const float inv_n = 1.f / a.rows;
+  const float inv_n = 1.f / bn_rows(a.frame_limit, a.seg_len, a.rows);
   if (blockIdx.x == 0 && dgamma)
     for (int c = threadIdx.x; c < a.C; c += 256) { dbeta[c] += sums[c]; dgamma[c] += sums[a.C + c]; }
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -229,6 +254,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnCommon a, con
     float o[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = g[e] * rs[e] * (dy[e] - s1[e] * inv_n - xh[e] * s2[e] * inv_n);
+    if (!bn_live(a.frame_limit, a.seg_len, r)) o[0] = o[1] = o[2] = o[3] = 0.f;
     *(uint2*)(dx + (int64_t)r * a.C + c4) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
   }
 }
@@ -245,23 +271,31 @@ static int bn_check(int rows, int C) {
   return 0;
 }
 
-extern "C" int ttsk_bn_stats(const void* x, int x_is_f32, int rows, int C, float* partials, void* stream) {
+static int limit_check(const int32_t* frame_limit, int seg_len, int rows) {
+  TTSK_REQUIRE(!frame_limit || (seg_len > 0 && rows % seg_len == 0), "batchnorm: frame_limit needs rows %% seg_len == 0");
+  return 0;
+}
+
+extern "C" int ttsk_bn_stats(const void* x, int x_is_f32, int rows, int C, float* partials, const int32_t* frame_limit, int seg_len,
+                             void* stream) {
   TTSK_REQUIRE(x && partials, "bn_stats: null pointer");
+  if (int rc = limit_check(frame_limit, seg_len, rows)) return rc;
   if (int rc = bn_check(rows, C)) return rc;
   const int rpi = 256 / (C >> 2);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(bn_blocks(rows)), dim3(256), 2 * rpi * C * sizeof(float), (hipStream_t)stream,
-                     x, x_is_f32, rows, C, partials);
+                     x, x_is_f32, rows, C, partials, frame_limit, seg_len > 0 ? seg_len : 1);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }
 
 extern "C" int ttsk_bn_finalize(const float* partials, int nblk, int C, int rows, float eps, float momentum, float* mean,
                                 float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                                void* stream) {
+                                const int32_t* frame_limit, int seg_len, void* stream) {
+  if (int rc = limit_check(frame_limit, seg_len, rows)) return rc;
   TTSK_REQUIRE(partials && mean && rstd && nblk > 0, "bn_finalize: null pointer");
   TTSK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats come in pairs");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, nblk, C, rows, eps,
-                     momentum, mean, rstd, running_mean, running_var, (long long*)num_batches_tracked);
+                     momentum, mean, rstd, running_mean, running_var, (long long*)num_batches_tracked, frame_limit, seg_len > 0 ? seg_len : 1);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }
@@ -275,11 +309,12 @@ extern "C" int ttsk_rsqrt_eps(const float* var, float eps, float* rstd, int n, v
 
 extern "C" int ttsk_bn_apply(const void* x, int x_is_f32, const float* mean, const float* rstd, const float* gamma, const float* beta,
                              int rows, int C, int use_tanh, float p, uint32_t site, const uint64_t* rng, const float* resid_f32,
-                             void* out_bf16, float* out_f32, void* stream) {
+                             void* out_bf16, float* out_f32, const int32_t* frame_limit, int seg_len, void* stream) {
+  if (int rc = limit_check(frame_limit, seg_len, rows)) return rc;
   TTSK_REQUIRE(x && mean && rstd && gamma && beta && (out_bf16 || out_f32), "bn_apply: null pointer");
   TTSK_REQUIRE(p == 0.f || rng, "bn_apply: dropout needs rng");
   if (int rc = bn_check(rows, C)) return rc;
-  BnCommon a{x, mean, rstd, gamma, beta, rng, rows, C, use_tanh, p, site, x_is_f32};
+  BnCommon a{x, mean, rstd, gamma, beta, rng, rows, C, use_tanh, p, site, x_is_f32, frame_limit, seg_len > 0 ? seg_len : 1};
   int64_t n = (int64_t)rows * (C >> 2);
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
@@ -290,11 +325,12 @@ extern "C" int ttsk_bn_apply(const void* x, int x_is_f32, const float* mean, con
 
 extern "C" int ttsk_bn_bwd_stats(const void* dout, int dout_is_f32, const void* x, int x_is_f32, const float* mean, const float* rstd,
                                  const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
-                                 const uint64_t* rng, float* partials, void* stream) {
+                                 const uint64_t* rng, float* partials, const int32_t* frame_limit, int seg_len, void* stream) {
+  if (int rc = limit_check(frame_limit, seg_len, rows)) return rc;
   TTSK_REQUIRE(dout && x && mean && rstd && gamma && beta && partials, "bn_bwd_stats: null pointer");
   TTSK_REQUIRE(p == 0.f || rng, "bn_bwd_stats: dropout needs rng");
   if (int rc = bn_check(rows, C)) return rc;
-  BnCommon a{x, mean, rstd, gamma, beta, rng, rows, C, use_tanh, p, site, x_is_f32};
+  BnCommon a{x, mean, rstd, gamma, beta, rng, rows, C, use_tanh, p, site, x_is_f32, frame_limit, seg_len > 0 ? seg_len : 1};
   const int rpi = 256 / (C >> 2);
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(bn_blocks(rows)), dim3(256), 2 * rpi * C * sizeof(float), (hipStream_t)stream, a,
                      dout, dout_is_f32, partials);
@@ -305,11 +341,12 @@ extern "C" int ttsk_bn_bwd_stats(const void* dout, int dout_is_f32, const void* 
 extern "C" int ttsk_bn_bwd_apply(const void* dout, int dout_is_f32, const void* x, int x_is_f32, const float* mean, const float* rstd,
                                  const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
                                  const uint64_t* rng, const float* sums, void* dx_bf16, float* dgamma, float* dbeta,
-                                 void* stream) {
+                                 const int32_t* frame_limit, int seg_len, void* stream) {
+  if (int rc = limit_check(frame_limit, seg_len, rows)) return rc;
   TTSK_REQUIRE(dout && x && mean && rstd && gamma && beta && sums && dx_bf16, "bn_bwd_apply: null pointer");
   TTSK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bn_bwd_apply: dgamma/dbeta come in pairs");
   if (int rc = bn_check(rows, C)) return rc;
-  BnCommon a{x, mean, rstd, gamma, beta, rng, rows, C, use_tanh, p, site, x_is_f32};
+  BnCommon a{x, mean, rstd, gamma, beta, rng, rows, C, use_tanh, p, site, x_is_f32, frame_limit, seg_len > 0 ? seg_len : 1};
   int64_t n = (int64_t)rows * (C >> 2);
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;

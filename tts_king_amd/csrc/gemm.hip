@@ -327,7 +327,7 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
   const int gn = n0 + cg * 8;
   if (gn >= N) return;
   const int nvalid = (N - gn) < 8 ? (N - gn) : 8;
-  if (d.splits > 1) {
+  if (d.splits > 1 || (d.flags & TTSK_GEMM_RAW_SLABS)) {
     // split-K: raw fp32 partial sums into the workspace slab [split][z][M][N]; the reducer applies the epilogue
     float* ws = (float*)d.workspace + ((int64_t)split * nzgrid + z) * ((int64_t)M * N);
     for (int p = 0; p < BM / 16; ++p) {
@@ -350,10 +350,20 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
   float bias[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias[e] = (d.bias && e < nvalid) ? d.bias[z1 * d.s_bias1 + gn + e] : 0.f;
-  for (int p = 0; p < BM / 16; ++p) {
+  // residual / gate operands of all this thread's row segments first (independent loads in flight together), then the stores
+  constexpr int NP = BM / 16;
+  EpiOperands ops[NP];
+  int64_t orow[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int gm = m0 + p * 16 + (tid >> 4);
+    orow[p] = gm < M ? epilogue_row(d, gm, z2) : -1;
+    ops[p] = epilogue_load(d, roff, orow[p], gn, nvalid);
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
     const int row = p * 16 + (tid >> 4);
-    const int gm = m0 + row;
-    if (gm >= M) continue;
+    if (orow[p] < 0) continue;
     float v[8];
     {
       const f32x4 lo = *(const f32x4*)(cs + row * CS_LD + cg * 8);
@@ -361,7 +371,7 @@ __device__ __forceinline__ void gemm_tile(const Args& g, int bid_in, int z, int 
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[e + 4] = hi[e]; }
     }
-    epilogue_store<F16>(d, coff, roff, gm, gn, nvalid, v, bias, z2);
+    epilogue_apply<F16>(d, coff, roff, orow[p], gn, nvalid, v, bias, ops[p]);
   }
 }
 
@@ -539,6 +549,7 @@ int validate(ttsk_gemm_desc& d) {
   TTSK_REQUIRE(!(d.flags & TTSK_GEMM_ADD_R) || d.R, "ttsk_gemm: ADD_R without R");
   TTSK_REQUIRE(!(d.flags & TTSK_GEMM_MASK_G) || d.G, "ttsk_gemm: MASK_G without G");
   TTSK_REQUIRE(!(d.flags & TTSK_GEMM_ACCUM_C) || (d.flags & TTSK_GEMM_C_F32), "ttsk_gemm: ACCUM_C needs fp32 C");
+  TTSK_REQUIRE(!(d.flags & TTSK_GEMM_RAW_SLABS) || (d.out_mul == 0 && !d.C2), "ttsk_gemm: RAW_SLABS takes no output remap / second output");
   TTSK_REQUIRE(!(d.flags & TTSK_GEMM_DEFER_REDUCE) ||
                    ((d.flags & TTSK_GEMM_C_F32) && !d.bias && !d.R && !d.G && !d.C2 && d.out_mul == 0 && d.nz1 <= 1 &&
                     !(d.flags & (TTSK_GEMM_RELU | TTSK_GEMM_TANH | TTSK_GEMM_LRELU_OUT))),
@@ -582,9 +593,10 @@ Plan make_plan(const ttsk_gemm_desc& d) {
       const float t_iter = kernel == 2 ? T_ITER2 : kernel == 3 ? (wgs <= 256 ? T_ITER3_ALONE : wgs <= 512 ? T_ITER3 : T_ITER3_CROWDED)
                                                                : (wgs <= 256 ? T_ITER1_ALONE : T_ITER1);   // one workgroup per CU runs faster
       float t = (float)rounds * per * taps * t_iter + T_LAUNCH;
-      const int64_t ws = sp > 1 ? (int64_t)sp * nz * d.M * d.N * 4 : 0;
+      const bool raw = d.flags & TTSK_GEMM_RAW_SLABS;
+      const int64_t ws = (sp > 1 || raw) ? (int64_t)sp * nz * d.M * d.N * 4 : 0;
       if (ws > ((int64_t)512 << 20)) { if (d.splits != 0) {} else break; }
-      if (sp > 1) t += T_REDUCE + (float)ws * 1.25f / 4.0e6f;
+      if (sp > 1 || raw) t += (raw ? 0.f : T_REDUCE) + (float)ws * 1.25f / 4.0e6f;
       if (best_t < 0.f || t < best_t - 0.25f) {
         best_t = t;
         best = Plan{kernel, sp, tm, tn, kchunks, per, ws};
@@ -617,9 +629,9 @@ extern "C" int ttsk_gemm(const ttsk_gemm_desc* dp, void* stream) {
   if (rc != TTSK_OK) return rc;
   const bool atr = d.flags & TTSK_GEMM_A_TR, btr = d.flags & TTSK_GEMM_B_TR, f16 = d.flags & TTSK_GEMM_F16;
   Plan p = make_plan(d);
-  if (p.splits > 1 && !(d.workspace && d.workspace_bytes >= p.ws_bytes && (((uintptr_t)d.workspace) & 15) == 0)) {
+  if (p.ws_bytes > 0 && !(d.workspace && d.workspace_bytes >= p.ws_bytes && (((uintptr_t)d.workspace) & 15) == 0)) {
     // auto mode without (enough) workspace: fall back to a single pass; an explicit split request is an error
-    TTSK_REQUIRE(d.splits == 0, "ttsk_gemm: split-K needs a 16-byte aligned workspace of %lld bytes (got %lld)",
+    TTSK_REQUIRE(d.splits == 0 && !(d.flags & TTSK_GEMM_RAW_SLABS), "ttsk_gemm: split-K / raw slabs need a 16-byte aligned workspace of %lld bytes (got %lld)",
                  (long long)p.ws_bytes, (long long)d.workspace_bytes);
     d.splits = 1;
     p = make_plan(d);
@@ -657,7 +669,7 @@ extern "C" int ttsk_gemm(const ttsk_gemm_desc* dp, void* stream) {
     }
   }
   TTSK_CHECK_LAUNCH();
-  if (d.splits > 1 && !(d.flags & TTSK_GEMM_DEFER_REDUCE)) {
+  if (d.splits > 1 && !(d.flags & (TTSK_GEMM_DEFER_REDUCE | TTSK_GEMM_RAW_SLABS))) {
     const int64_t work = (int64_t)d.M * ((d.N + 7) / 8);
     int blocks = (int)((work + 255) / 256);
     if (blocks > 1024) blocks = 1024;
@@ -725,6 +737,7 @@ extern "C" int ttsk_gemm_group_build(const ttsk_gemm_desc* descs, int n, void* h
     ttsk_gemm_desc& d = g.d;
     if (d.kernel == 0) d.kernel = 1;                // a group runs ONE tile configuration: problem 0's (default 128x128)
     TTSK_REQUIRE(d.kernel != 3, "ttsk_gemm_group_build: the 64-row tile (kernel = 3) has no grouped launch");
+    TTSK_REQUIRE(!(d.flags & TTSK_GEMM_RAW_SLABS), "ttsk_gemm_group_build: RAW_SLABS problems are launched with ttsk_gemm");
     if (i == 0) h->kernel = d.kernel;
     TTSK_REQUIRE(d.kernel == h->kernel, "ttsk_gemm_group_build: problem %d asks for kernel %d, problem 0 for %d", i, d.kernel, h->kernel);
     const int rc = validate(d);

@@ -20,33 +20,69 @@ template <bool F16> __device__ __forceinline__ uint4 pack8(const float v[8]) {
 }
 
 // Epilogue of one output row segment of 8 columns: v = alpha*acc + bias, residual, ReLU / gate / LeakyReLU / tanh, then the
-// store(s).  Shared by the GEMM kernel (splits == 1) and by the split-K reducer.
-template <bool F16>
-__device__ __forceinline__ void epilogue_store(const ttsk_gemm_desc& d, int64_t coff, int64_t roff, int gm, int gn, int nvalid,
-                                               float v[8], const float bias[8], int z2 = 0) {
+// store(s).  Shared by the GEMM kernels (splits == 1) and by the split-K reducer.  In three steps so that a tile epilogue can
+// issue the residual / gate loads of ALL its row segments before the first store (one thread handles 4-8 segments; with the
+// loads inside the per-segment code every segment paid its own L2 round trip: the ReLU-gated w_2 dX GEMM, 4 K steps, took 26 us).
+
+// output row of GEMM row gm (polyphase remap), or -1 when the row falls outside the output segment
+__device__ __forceinline__ int64_t epilogue_row(const ttsk_gemm_desc& d, int gm, int z2) {
+  if (d.out_mul == 0) return gm;
+  const int s = gm / d.seg_len, t = gm - s * d.seg_len;
+  const int o = t * d.out_mul + d.out_add + z2 * d.out_add_dz;
+  if (o < 0 || o >= d.out_seg) return -1;
+  return (int64_t)s * d.out_seg + o;
+}
+
+// the residual / gate operands of one segment, fetched with 16-byte loads when the layout allows (q0/q1: fp32 residual = 8 floats,
+// or q0 = 8 x 16-bit residual and q1 = 8 x 16-bit gate); `fast` false = the apply step loads element by element
+struct EpiOperands {
+  uint4 q0, q1;
+  bool fast;
+};
+__device__ __forceinline__ EpiOperands epilogue_load(const ttsk_gemm_desc& d, int64_t roff, int64_t orow, int gn, int nvalid) {
+  EpiOperands o;
+  o.q0 = o.q1 = make_uint4(0u, 0u, 0u, 0u);
   const int flags = d.flags;
-  int64_t orow = gm;
-  if (d.out_mul != 0) {
-    const int s = gm / d.seg_len, t = gm - s * d.seg_len;
-    const int o = t * d.out_mul + d.out_add + z2 * d.out_add_dz;
-    if (o < 0 || o >= d.out_seg) return;
-    orow = (int64_t)s * d.out_seg + o;
+  const bool has_r = flags & TTSK_GEMM_ADD_R, r32 = flags & TTSK_GEMM_R_F32, has_g = flags & TTSK_GEMM_MASK_G;
+  o.fast = orow >= 0 && nvalid == 8 && ((((uintptr_t)d.R | (uintptr_t)d.G) & 15) == 0) && (!has_r || (r32 ? ((d.ldr & 3) == 0 && (roff & 3) == 0) : ((d.ldr & 7) == 0 && (roff & 7) == 0))) &&
+           (!has_g || ((d.ldg & 7) == 0 && (roff & 7) == 0 && !(has_r && r32)));
+  if (!o.fast) return o;
+  if (has_r) {
+    if (r32) {
+      const float* rp = (const float*)d.R + roff + orow * d.ldr + gn;
+      o.q0 = *(const uint4*)rp;
+      o.q1 = *(const uint4*)(rp + 4);
+    } else {
+      o.q0 = *(const uint4*)((const bf16_t*)d.R + roff + orow * d.ldr + gn);
+    }
   }
+  if (has_g) o.q1 = *(const uint4*)((const bf16_t*)d.G + roff + orow * d.ldg + gn);
+  return o;
+}
+
+template <bool F16>
+__device__ __forceinline__ void epilogue_apply(const ttsk_gemm_desc& d, int64_t coff, int64_t roff, int64_t orow, int gn, int nvalid,
+                                               float v[8], const float bias[8], const EpiOperands& op) {
+  const int flags = d.flags;
+  if (orow < 0) return;
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = v[e] * d.alpha + bias[e];
   if (flags & TTSK_GEMM_ADD_R) {
-    if (flags & TTSK_GEMM_R_F32) {
+    if (op.fast) {
+      if (flags & TTSK_GEMM_R_F32) {
+        v[0] += __uint_as_float(op.q0.x); v[1] += __uint_as_float(op.q0.y); v[2] += __uint_as_float(op.q0.z); v[3] += __uint_as_float(op.q0.w);
+        v[4] += __uint_as_float(op.q1.x); v[5] += __uint_as_float(op.q1.y); v[6] += __uint_as_float(op.q1.z); v[7] += __uint_as_float(op.q1.w);
+      } else {
+        add_h8<F16>(v, op.q0);
+      }
+    } else if (flags & TTSK_GEMM_R_F32) {
       const float* rp = (const float*)d.R + roff + orow * d.ldr + gn;
 #pragma unroll
       for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += rp[e];
     } else {
       const bf16_t* rp = (const bf16_t*)d.R + roff + orow * d.ldr + gn;
-      if (nvalid == 8 && ((d.ldr & 7) == 0) && ((roff & 7) == 0)) {
-        add_h8<F16>(v, *(const uint4*)rp);
-      } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += unpack1<F16>(rp[e]);
-      }
+      for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += unpack1<F16>(rp[e]);
     }
   }
   if (flags & TTSK_GEMM_RELU) {
@@ -54,9 +90,16 @@ __device__ __forceinline__ void epilogue_store(const ttsk_gemm_desc& d, int64_t 
     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
   }
   if (flags & TTSK_GEMM_MASK_G) {
-    const bf16_t* gp = (const bf16_t*)d.G + roff + orow * d.ldg + gn;
+    if (op.fast) {
+      float gv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      add_h8<F16>(gv, op.q1);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] = unpack1<F16>(gp[e]) > 0.f ? v[e] : 0.f;
+      for (int e = 0; e < 8; ++e) v[e] = gv[e] > 0.f ? v[e] : 0.f;
+    } else {
+      const bf16_t* gp = (const bf16_t*)d.G + roff + orow * d.ldg + gn;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] = unpack1<F16>(gp[e]) > 0.f ? v[e] : 0.f;
+    }
   }
   if (flags & TTSK_GEMM_LRELU_OUT) {
 #pragma unroll
@@ -106,6 +149,16 @@ __device__ __forceinline__ void epilogue_store(const ttsk_gemm_desc& d, int64_t 
   }
 }
 
+// one segment start to finish (the split-K reducer, and anything that handles a single segment per thread)
+template <bool F16>
+__device__ __forceinline__ void epilogue_store(const ttsk_gemm_desc& d, int64_t coff, int64_t roff, int gm, int gn, int nvalid,
+                                               float v[8], const float bias[8], int z2 = 0) {
+  const int64_t orow = epilogue_row(d, gm, z2);
+  if (orow < 0) return;
+  const EpiOperands op = epilogue_load(d, roff, orow, gn, nvalid);
+  epilogue_apply<F16>(d, coff, roff, orow, gn, nvalid, v, bias, op);
+}
+
 __device__ __forceinline__ int tr_sw(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
 
 // ---- LDS-DMA helper and tile epilogue of gemm2.hip
@@ -144,7 +197,7 @@ __device__ __forceinline__ void tile_epilogue(const ttsk_gemm_desc& d, unsigned 
   float bias[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias[e] = (d.bias && gn < N && e < nvalid && d.splits <= 1) ? d.bias[z1 * d.s_bias1 + gn + e] : 0.f;
-  float* ws = d.splits > 1 ? (float*)d.workspace + ((int64_t)split * nzgrid + z) * ((int64_t)M * N) : nullptr;
+  float* ws = (d.splits > 1 || (d.flags & TTSK_GEMM_RAW_SLABS)) ? (float*)d.workspace + ((int64_t)split * nzgrid + z) * ((int64_t)M * N) : nullptr;
 
 #pragma unroll 1
   for (int pass = 0; pass < BM / 128; ++pass) {
@@ -159,13 +212,14 @@ __device__ __forceinline__ void tile_epilogue(const ttsk_gemm_desc& d, unsigned 
     }
     __syncthreads();
     if (gn < N) {
-      for (int p = 0; p < 128 / (NTHREADS / 16); ++p) {
-        const int row = p * (NTHREADS / 16) + (tid >> 4);
-        const int gm = m0 + pass * 128 + row;
-        if (gm >= M) continue;
-        const f32x4 lo = *(const f32x4*)(cs + row * CS_LD + cg * 8);
-        const f32x4 hi = *(const f32x4*)(cs + row * CS_LD + cg * 8 + 4);
-        if (ws) {  // split-K: raw partial sums; the reducer applies the epilogue
+      constexpr int NP = 128 / (NTHREADS / 16);
+      if (ws) {  // split-K: raw partial sums; the reducer applies the epilogue
+        for (int p = 0; p < NP; ++p) {
+          const int row = p * (NTHREADS / 16) + (tid >> 4);
+          const int gm = m0 + pass * 128 + row;
+          if (gm >= M) continue;
+          const f32x4 lo = *(const f32x4*)(cs + row * CS_LD + cg * 8);
+          const f32x4 hi = *(const f32x4*)(cs + row * CS_LD + cg * 8 + 4);
           float* wp = ws + (int64_t)gm * N + gn;
           if (nvalid == 8 && (N & 3) == 0) {
             *(f32x4*)wp = lo;
@@ -174,11 +228,27 @@ __device__ __forceinline__ void tile_epilogue(const ttsk_gemm_desc& d, unsigned 
 #pragma unroll
             for (int e = 0; e < 4; ++e) { if (e < nvalid) wp[e] = lo[e]; if (e + 4 < nvalid) wp[e + 4] = hi[e]; }
           }
-        } else {
+        }
+      } else {
+        // residual / gate operands of all this thread's segments first (independent loads in flight together), then the stores
+        EpiOperands ops[NP];
+        int64_t orow[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int gm = m0 + pass * 128 + p * (NTHREADS / 16) + (tid >> 4);
+          orow[p] = gm < M ? epilogue_row(d, gm, z2) : -1;
+          ops[p] = epilogue_load(d, roff, orow[p], gn, nvalid);
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int row = p * (NTHREADS / 16) + (tid >> 4);
+          if (orow[p] < 0) continue;
+          const f32x4 lo = *(const f32x4*)(cs + row * CS_LD + cg * 8);
+          const f32x4 hi = *(const f32x4*)(cs + row * CS_LD + cg * 8 + 4);
           float v[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[e + 4] = hi[e]; }
-          epilogue_store<F16>(d, coff, roff, gm, gn, nvalid, v, bias, z2);
+          epilogue_apply<F16>(d, coff, roff, orow[p], gn, nvalid, v, bias, ops[p]);
         }
       }
     }

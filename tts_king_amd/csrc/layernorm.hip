@@ -138,6 +138,11 @@ struct LnBwdArgs {
   int group_rows, nblk_group;     // grouped launch (see LnArgs): gridDim.x = groups * nblk_group, partials [group][nblk_group][ncol]
   long long pstride;
   unsigned site_stride;
+  // upstream gradient still in split-K form (ttsk_layernorm_bwd_slabs): dout[row] = sum_s slabs[s * slab_stride + row*D ..] + R[row]
+  const float* slabs;
+  const bf16_t* R;
+  long long slab_stride;
+  int nsplit;
 };
 
 // 8 waves per workgroup, one row per wave at a time: the per-row chain (loads -> two wave reductions -> stores) is pure
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs 
   const unsigned site_pre = a.site_pre + grp * a.site_stride, site_post = a.site_post + grp * a.site_stride;
   // the loads of a wave's NEXT row are issued before the two wave reductions of the current one (the per-row chain
   // loads -> reductions -> stores is latency; one row at a time took 12.5 us for 6768 x 256)
-  struct RowIn { uint2 z[MAXJ], d[MAXJ]; float mean, rstd, dh; bool masked; };
+  struct RowIn { uint2 z[MAXJ]; f32x4 d[MAXJ]; float mean, rstd, dh; bool masked; };
   auto fetch = [&](int lr, RowIn& r) __attribute__((always_inline)) {
     const int rw = grp * grows + lr;
     r.masked = false;
@@ -178,7 +183,21 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs 
       if (j < nj) {
         const int c = j * 256 + lane * 4;
         r.z[j] = *(const uint2*)(a.z + (int64_t)rw * D + c);
-        r.d[j] = (a.dout && !r.masked) ? *(const uint2*)(a.dout + (int64_t)rw * D + c) : make_uint2(0u, 0u);
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        if (!r.masked) {
+          if (a.slabs) {
+            const float* sp = a.slabs + (int64_t)rw * D + c;
+            for (int q = 0; q < a.nsplit; ++q) d += *(const f32x4*)(sp + q * a.slab_stride);       // fixed order: deterministic
+            if (a.R) {
+              const uint2 u = *(const uint2*)(a.R + (int64_t)rw * D + c);
+              d += f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
+            }
+          } else if (a.dout) {
+            const uint2 u = *(const uint2*)(a.dout + (int64_t)rw * D + c);
+            d = f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
+          }
+        }
+        r.d[j] = d;
       }
   };
   const int rstride = a.nblk_group * LNB_WAVES;
@@ -200,8 +219,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs 
         const int c = j * 256 + lane * 4;
         const float zz[4] = {__uint_as_float(cur.z[j].x << 16), __uint_as_float(cur.z[j].x & 0xFFFF0000u),
                              __uint_as_float(cur.z[j].y << 16), __uint_as_float(cur.z[j].y & 0xFFFF0000u)};
-        float d[4] = {__uint_as_float(cur.d[j].x << 16), __uint_as_float(cur.d[j].x & 0xFFFF0000u),
-                      __uint_as_float(cur.d[j].y << 16), __uint_as_float(cur.d[j].y & 0xFFFF0000u)};
+        float d[4] = {cur.d[j][0], cur.d[j][1], cur.d[j][2], cur.d[j][3]};
         const f32x4 gm = *(const f32x4*)(gamma + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) xh[j][e] = (zz[e] - mean) * rstd;
@@ -461,7 +479,7 @@ extern "C" int ttsk_layernorm_bwd(const void* dout, const float* dhead, const fl
   TTSK_REQUIRE(p_post == 0.f || beta, "layernorm_bwd: post dropout needs beta");
   const int nblk = ttsk_layernorm_bwd_nblocks(rows);
   LnBwdArgs a{(const bf16_t*)dout, dhead, head_w, (const bf16_t*)z, mean, rstd, gamma, beta, (const long long*)lens, rng,
-              (bf16_t*)dz, (bf16_t*)dy, partials, rows, D, seg_len, relu_in, p_pre, p_post, site_pre, site_post, 0, nblk, 0, 0};
+              (bf16_t*)dz, (bf16_t*)dy, partials, rows, D, seg_len, relu_in, p_pre, p_post, site_pre, site_post, 0, nblk, 0, 0, nullptr, nullptr, 0, 0};
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
@@ -482,8 +500,27 @@ extern "C" int ttsk_layernorm_bwd_grouped(const void* dout, const float* dhead, 
   const int nblk = ttsk_layernorm_bwd_nblocks(group_rows);
   LnBwdArgs a{(const bf16_t*)dout, dhead, head_w, (const bf16_t*)z, mean, rstd, gamma, beta, (const long long*)lens, rng,
               (bf16_t*)dz, (bf16_t*)dy, partials, groups * group_rows, D, seg_len, relu_in, p_pre, p_post, site_pre, site_post,
-              group_rows, nblk, (long long)param_stride, site_stride};
+              group_rows, nblk, (long long)param_stride, site_stride, nullptr, nullptr, 0, 0};
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(groups * nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_layernorm_bwd_slabs(const float* slabs, int nsplit, int64_t slab_stride, const void* R, const void* z,
+                                        const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                        const int64_t* lens, int seg_len, int rows, int D, int relu_in, float p_pre,
+                                        uint32_t site_pre, float p_post, uint32_t site_post, const uint64_t* rng, void* dz, void* dy,
+                                        float* partials, void* stream) {
+  TTSK_REQUIRE(slabs && nsplit > 0 && z && mean && rstd && gamma && partials, "layernorm_bwd_slabs: null pointer");
+  TTSK_REQUIRE(rows > 0 && D >= 256 && D <= 1024 && (D & 255) == 0, "layernorm_bwd_slabs: bad D %d", D);
+  TTSK_REQUIRE((slab_stride & 3) == 0 && slab_stride >= (int64_t)rows * D && (((uintptr_t)slabs) & 15) == 0, "layernorm_bwd_slabs: slabs must be 16-byte aligned [nsplit][rows][D]");
+  TTSK_REQUIRE((p_pre == 0.f && p_post == 0.f) || rng, "layernorm_bwd_slabs: dropout needs rng state");
+  TTSK_REQUIRE(p_post == 0.f || beta, "layernorm_bwd_slabs: post dropout needs beta");
+  const int nblk = ttsk_layernorm_bwd_nblocks(rows);
+  LnBwdArgs a{nullptr, nullptr, nullptr, (const bf16_t*)z, mean, rstd, gamma, beta, (const long long*)lens, rng,
+              (bf16_t*)dz, (bf16_t*)dy, partials, rows, D, seg_len, relu_in, p_pre, p_post, site_pre, site_post, 0, nblk, 0, 0,
+              slabs, (const bf16_t*)R, (long long)slab_stride, nsplit};
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

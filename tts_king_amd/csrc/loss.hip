@@ -23,6 +23,7 @@ struct LossArgs {
   float* partials;       // [nblk][6]
   int B, T, Tt, nm, L;
   float grad_scale;
+  const int* frame_limit;   // device int32[1] or null: the mel means run over B * frame_limit[0] * nm elements (bucketed T)
 };
 
 __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
   float acc[6] = {0, 0, 0, 0, 0, 0};
   const int nm4 = a.nm >> 2;
   const int64_t n4 = (int64_t)a.B * a.T * nm4;
-  const float inv_n = 1.f / ((float)a.B * a.T * a.nm);
+  const float inv_n = 1.f / ((float)a.B * (a.frame_limit ? a.frame_limit[0] : a.T) * a.nm);
   const float gs = a.grad_scale * inv_n;
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const int64_t rt = i / nm4;
@@ -79,7 +80,9 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
 }
 
 __global__ __launch_bounds__(64) void loss_finalize_kernel(const float* __restrict__ partials, int nblk, const long long* __restrict__ src_lens,
-                                                           int B, float n_mel_elems, float* __restrict__ losses) {
+                                                           int B, float n_mel_elems_all, const int* __restrict__ frame_limit, int T,
+                                                           float* __restrict__ losses) {
+  const float n_mel_elems = frame_limit ? n_mel_elems_all / (float)T * (float)frame_limit[0] : n_mel_elems_all;
   // one wave: lane l adds blocks l, l+64, ... of all six quantities (its loads are independent, so they overlap; six lanes
   // walking 256 blocks one dependent load at a time took 22 us), then a butterfly in fixed order: deterministic
   __shared__ double tot[6];
@@ -114,17 +117,17 @@ extern "C" int ttsk_fs2_loss(const float* mel, const float* post, const float* m
                              const float* pitch, const float* energy, const float* logd, const float* pitch_target,
                              const float* energy_target, const int64_t* dur_target, const int64_t* src_lens, int B, int T,
                              int T_target, int n_mel, int L, float grad_scale, float* dmel_sum, float* dpost, float* dpitch,
-                             float* denergy, float* dlogd, float* partials, float* losses, void* stream) {
+                             float* denergy, float* dlogd, float* partials, float* losses, const int32_t* frame_limit, void* stream) {
   TTSK_REQUIRE(mel && post && mel_target && mel_lens && pitch && energy && logd && pitch_target && energy_target && dur_target &&
                    src_lens && dmel_sum && dpost && dpitch && denergy && dlogd && partials && losses, "fs2_loss: null pointer");
   TTSK_REQUIRE(B > 0 && T > 0 && T_target >= T && L > 0 && n_mel > 0 && (n_mel & 3) == 0, "fs2_loss: bad sizes");
   LossArgs a{mel, post, mel_target, (const long long*)mel_lens, pitch, energy, logd, pitch_target, energy_target,
              (const long long*)dur_target, (const long long*)src_lens, dmel_sum, dpost, dpitch, denergy, dlogd, partials,
-             B, T, T_target, n_mel, L, grad_scale};
+             B, T, T_target, n_mel, L, grad_scale, frame_limit};
   const int nblk = ttsk_fs2_loss_nblocks();
   hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, nblk, (const long long*)src_lens, B,
-                     (float)B * T * n_mel, losses);
+                     (float)B * T * n_mel, frame_limit, T, losses);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

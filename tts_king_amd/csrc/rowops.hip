@@ -109,58 +109,85 @@ __global__ __launch_bounds__(256) void gather_add_kernel(const bf16_t* __restric
 __device__ __forceinline__ void scatter_sum_body(const bf16_t* __restrict__ dx, const void* __restrict__ idx, int idx_i64, int idx_div,
                                                  int nidx, float* __restrict__ dtable, int D, int skip, int accumulate, int v, int* hits,
                                                  int& nh) {
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};   // D <= 1024: thread handles channels tid + 256*j
+  float wacc[4][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // D <= 1024: lane owns columns j*256 + 4*lane ..
   if (v != skip) {
     for (int base = 0; base < nidx; base += 1024) {
-      if (threadIdx.x == 0) nh = 0;
+      // every thread tests 4 indices of the chunk (one round trip for the whole chunk; a single wave walking the chunk 64
+      // indices per dependent load took most of the kernel's 59 us), then one wave compacts the flags in ascending order
+      unsigned char* flag = (unsigned char*)(hits + 1024);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + threadIdx.x + 256 * u;
+        flag[threadIdx.x + 256 * u] = (i < nidx && (idx_i64 ? ((const long long*)idx)[i] : ((const int*)idx)[i]) == v) ? 1 : 0;
+      }
       __syncthreads();
-      // ordered compaction of the matching indices in this chunk (single wave does it serially in order)
       if (threadIdx.x < 64) {
         int count = 0;
-        for (int i0 = base; i0 < base + 1024 && i0 < nidx; i0 += 64) {
-          const int i = i0 + threadIdx.x;
-          const bool hit = i < nidx && (idx_i64 ? ((const long long*)idx)[i] : ((const int*)idx)[i]) == v;
+        for (int j0 = 0; j0 < 1024 && base + j0 < nidx; j0 += 64) {
+          const bool hit = flag[j0 + threadIdx.x] != 0;
           const unsigned long long bal = __ballot(hit);
-          if (hit) hits[count + __popcll(bal & ((1ull << threadIdx.x) - 1ull))] = i;
+          if (hit) hits[count + __popcll(bal & ((1ull << threadIdx.x) - 1ull))] = base + j0 + threadIdx.x;
           count += __popcll(bal);
         }
         if (threadIdx.x == 0) nh = count;
       }
       __syncthreads();
-      // the rows a table entry collects: hit h contributes rows hits[h]*idx_div .. +idx_div-1.  Eight row loads are issued
-      // before their (ordered) adds: one dependent load at a time cost 59 us for the speaker table (64 rows per hit)
+      // the rows a table entry collects: hit h contributes rows hits[h]*idx_div .. +idx_div-1 (q = h*idx_div + r, ascending).
+      // Wave w takes rows q = w, w+4, ...; a lane owns 4 columns (8-byte loads), eight row loads in flight per wave.  One
+      // thread per column walking the rows one dependent 2-byte load at a time took 34 us for the speaker table (64 rows
+      // per hit).  Fixed association: per-wave sums in ascending q, then (w0 + w1) + (w2 + w3) — deterministic.
       const int nrow = nh * idx_div;
-      for (int q0 = 0; q0 < nrow; q0 += 8) {
-        float v[8][4];
+      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int q = q0 + u;
-          const int64_t row = q < nrow ? (int64_t)hits[q / idx_div] * idx_div + q % idx_div : 0;
+      for (int j = 0; j < 4; ++j) {
+        const int c = j * 256 + lane * 4;
+        if (c < D)
+        for (int q0 = wave; q0 < nrow; q0 += 32) {
+          uint2 u[8];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int c = threadIdx.x + 256 * j;
-            v[u][j] = (q < nrow && c < D) ? bf2f(dx[row * D + c]) : 0.f;
+          for (int t = 0; t < 8; ++t) {
+            const int q = q0 + 4 * t;
+            u[t] = make_uint2(0u, 0u);
+            if (q < nrow) {
+              const int64_t row = (int64_t)hits[q / idx_div] * idx_div + q % idx_div;
+              u[t] = *(const uint2*)(dx + row * D + c);
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            wacc[j][0] += __uint_as_float(u[t].x << 16); wacc[j][1] += __uint_as_float(u[t].x & 0xFFFF0000u);
+            wacc[j][2] += __uint_as_float(u[t].y << 16); wacc[j][3] += __uint_as_float(u[t].y & 0xFFFF0000u);
           }
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] += v[u][j];
       }
       __syncthreads();
     }
   }
+  // cross-wave combine through LDS (the hit list is dead now): red[wave][column]
+  float* red = (float*)hits;
+  {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = threadIdx.x + 256 * j;
-    if (c < D) dtable[(int64_t)v * D + c] = accumulate ? dtable[(int64_t)v * D + c] + acc[j] : acc[j];
+    for (int j = 0; j < 4; ++j) {
+      if (j * 256 >= D) continue;          // uniform over the workgroup
+      __syncthreads();
+      const int c = lane * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave * 256 + c + e] = wacc[j][e];
+      __syncthreads();
+      const int col = j * 256 + threadIdx.x;
+      if (col < D) {
+        const float t = (red[threadIdx.x] + red[256 + threadIdx.x]) + (red[512 + threadIdx.x] + red[768 + threadIdx.x]);
+        dtable[(int64_t)v * D + col] = accumulate ? dtable[(int64_t)v * D + col] + t : t;
+      }
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void scatter_sum_kernel(const bf16_t* __restrict__ dx, const void* __restrict__ idx,
                                                           int idx_i64, int idx_div, int nidx, float* __restrict__ dtable,
                                                           int D, int skip, int accumulate) {
-  __shared__ int hits[1024];
+  __shared__ int hits[1024 + 256];      // hit list + 1024 flag bytes
   __shared__ int nh;
   scatter_sum_body(dx, idx, idx_i64, idx_div, nidx, dtable, D, skip, accumulate, blockIdx.x, hits, nh);
 }
@@ -170,7 +197,7 @@ struct ScatterBatch {
   ttsk_scatter_item it[8];
 };
 __global__ __launch_bounds__(256) void scatter_sum_batch_kernel(const ScatterBatch sb) {
-  __shared__ int hits[1024];
+  __shared__ int hits[1024 + 256];      // hit list + 1024 flag bytes
   __shared__ int nh;
   const ttsk_scatter_item& it = sb.it[blockIdx.y];
   if ((int)blockIdx.x >= it.n_table_rows) return;
@@ -197,13 +224,18 @@ __global__ __launch_bounds__(256) void va_embed_kernel(const bf16_t* __restrict_
                                                        const float* __restrict__ energy_t, const float* __restrict__ energy_bins,
                                                        const float* __restrict__ energy_table, int nb, bf16_t* __restrict__ x1,
                                                        bf16_t* __restrict__ x2, bf16_t* __restrict__ x3, int* __restrict__ pidx,
-                                                       int* __restrict__ eidx, int rows, int D) {
+                                                       int* __restrict__ eidx, int rows, int D, const long long* __restrict__ row_limit) {
   const int cpr = D >> 2;
   const int64_t n = (int64_t)rows * cpr;
   for (int64_t c = blockIdx.x * 256 + threadIdx.x; c < n; c += (int64_t)gridDim.x * 256) {
     const int row = (int)(c / cpr), ch = (int)(c - (int64_t)row * cpr) * 4;
     const int pi = bucket_of(pitch_bins, nb, pitch_t[row]), ei = bucket_of(energy_bins, nb, energy_t[row]);
     if (ch == 0) { pidx[row] = pi; eidx[row] = ei; }
+    if (row_limit && (row % L) >= row_limit[row / L]) {   // a phoneme position past the batch's own longest text (bucketed L): zero rows
+      const uint2 zz = make_uint2(0u, 0u);
+      *(uint2*)(x1 + (int64_t)row * D + ch) = zz; *(uint2*)(x2 + (int64_t)row * D + ch) = zz; *(uint2*)(x3 + (int64_t)row * D + ch) = zz;
+      continue;
+    }
     const uint2 u = *(const uint2*)(x + (int64_t)row * D + ch);
     f32x4 v = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
     v = round_bf4(v + *(const f32x4*)(spk_table + speakers[row / L] * D + ch));
@@ -222,8 +254,17 @@ __global__ __launch_bounds__(256) void va_embed_kernel(const bf16_t* __restrict_
 //   dx  = dx1 + dxin[0]  (gradient of the encoder output)
 // each rounded to bf16 — the values the step-by-step path's conv dX epilogues (fp32 accumulator + bf16 residual) produce.
 __global__ __launch_bounds__(256) void va_combine_kernel(const bf16_t* __restrict__ dx3, const float* __restrict__ dxin, bf16_t* __restrict__ dx2,
-                                                         bf16_t* __restrict__ dx1, bf16_t* __restrict__ dx, int64_t n4, int64_t gstride) {
+                                                         bf16_t* __restrict__ dx1, bf16_t* __restrict__ dx, int64_t n4, int64_t gstride,
+                                                         int D4, int L, const long long* __restrict__ row_limit) {
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    if (row_limit) {
+      const int row = (int)(i / D4);
+      if ((row % L) >= row_limit[row / L]) {              // no such phoneme position in the reference's batch: no gradient
+        const uint2 zz = make_uint2(0u, 0u);
+        *(uint2*)(dx2 + i * 4) = zz; *(uint2*)(dx1 + i * 4) = zz; *(uint2*)(dx + i * 4) = zz;
+        continue;
+      }
+    }
     const uint2 u = *(const uint2*)(dx3 + i * 4);
     f32x4 v = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
     v = round_bf4(v + *(const f32x4*)(dxin + 2 * gstride + i * 4));
@@ -267,6 +308,16 @@ __global__ __launch_bounds__(256) void to_int16_kernel(const float* __restrict__
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int v = (int)(src[i] * scale);            // trunc toward zero
     dst[i] = (short)v;                              // wraps like numpy's int32->int16 cast path on overflow
+  }
+}
+
+// rows (u, t) with t >= frame_limit[0] := 0 (16-byte pieces; bytes per row a multiple of 16)
+__global__ __launch_bounds__(256) void zero_frames_kernel(uint4* __restrict__ x, int rows, int q_per_row, int seg_len, const int* __restrict__ frame_limit) {
+  const int lim = frame_limit[0];
+  const int64_t n = (int64_t)rows * q_per_row;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / q_per_row);
+    if (r % seg_len >= lim) x[i] = make_uint4(0u, 0u, 0u, 0u);
   }
 }
 
@@ -339,7 +390,7 @@ extern "C" int ttsk_gather_add(const void* in_bf16, const float* table, const vo
 extern "C" int ttsk_scatter_sum(const void* dx_bf16, const void* idx, int idx_is_i64, int idx_div, int n_idx, float* dtable,
                                 int n_table_rows, int D, int skip_row, int accumulate, void* stream) {
   TTSK_REQUIRE(dx_bf16 && idx && dtable && n_idx > 0 && n_table_rows > 0, "scatter_sum: bad arguments");
-  TTSK_REQUIRE(D > 0 && D <= 1024 && idx_div > 0, "scatter_sum: D must be <= 1024");
+  TTSK_REQUIRE(D > 0 && D <= 1024 && (D & 3) == 0 && idx_div > 0, "scatter_sum: D must be a multiple of 4, <= 1024");
   hipLaunchKernelGGL(scatter_sum_kernel, dim3(n_table_rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx_bf16, idx,
                      idx_is_i64, idx_div, n_idx, dtable, D, skip_row, accumulate);
   TTSK_CHECK_LAUNCH();
@@ -355,7 +406,7 @@ extern "C" int ttsk_scatter_sum_batch(const ttsk_scatter_item* items, int n, voi
     for (int i = 0; i < m; ++i) {
       sb.it[i] = items[base + i];
       const ttsk_scatter_item& it = sb.it[i];
-      TTSK_REQUIRE(it.dx && it.idx && it.dtable && it.n_idx > 0 && it.n_table_rows > 0 && it.D > 0 && it.D <= 1024 && it.idx_div > 0,
+      TTSK_REQUIRE(it.dx && it.idx && it.dtable && it.n_idx > 0 && it.n_table_rows > 0 && it.D > 0 && it.D <= 1024 && (it.D & 3) == 0 && it.idx_div > 0,
                    "scatter_sum_batch: bad item %d", base + i);
       if (it.n_table_rows > max_rows) max_rows = it.n_table_rows;
     }
@@ -416,23 +467,36 @@ extern "C" int ttsk_length_mask(const int64_t* lens, uint8_t* mask, int B, int T
 extern "C" int ttsk_va_embed(const void* x_bf16, const float* speaker_table, const int64_t* speakers, int L, const float* pitch_target,
                              const float* pitch_bins, const float* pitch_table, const float* energy_target, const float* energy_bins,
                              const float* energy_table, int n_bins_minus_1, void* x1_bf16, void* x2_bf16, void* x3_bf16, int32_t* pitch_idx,
-                             int32_t* energy_idx, int rows, int D, void* stream) {
+                             int32_t* energy_idx, int rows, int D, const int64_t* row_limit, void* stream) {
   TTSK_REQUIRE(x_bf16 && speaker_table && speakers && pitch_target && pitch_bins && pitch_table && energy_target && energy_bins &&
                    energy_table && x1_bf16 && x2_bf16 && x3_bf16 && pitch_idx && energy_idx, "va_embed: null pointer");
   TTSK_REQUIRE(rows > 0 && L > 0 && rows % L == 0 && D > 0 && (D & 3) == 0 && n_bins_minus_1 > 0, "va_embed: bad sizes");
   hipLaunchKernelGGL(va_embed_kernel, dim3(grid_for((int64_t)rows * (D >> 2))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16,
                      speaker_table, (const long long*)speakers, L, pitch_target, pitch_bins, pitch_table, energy_target, energy_bins,
-                     energy_table, n_bins_minus_1, (bf16_t*)x1_bf16, (bf16_t*)x2_bf16, (bf16_t*)x3_bf16, pitch_idx, energy_idx, rows, D);
+                     energy_table, n_bins_minus_1, (bf16_t*)x1_bf16, (bf16_t*)x2_bf16, (bf16_t*)x3_bf16, pitch_idx, energy_idx, rows, D,
+                     (const long long*)row_limit);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }
 
 extern "C" int ttsk_va_combine(const void* dx3_bf16, const float* dxin, void* dx2_bf16, void* dx1_bf16, void* dx_bf16, int rows, int D,
-                               void* stream) {
+                               int L, const int64_t* row_limit, void* stream) {
   TTSK_REQUIRE(dx3_bf16 && dxin && dx2_bf16 && dx1_bf16 && dx_bf16 && rows > 0 && D > 0 && (D & 3) == 0, "va_combine: bad arguments");
+  TTSK_REQUIRE(!row_limit || (L > 0 && rows % L == 0), "va_combine: row_limit needs rows %% L == 0");
   const int64_t n4 = (int64_t)rows * D / 4;
   hipLaunchKernelGGL(va_combine_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx3_bf16, dxin,
-                     (bf16_t*)dx2_bf16, (bf16_t*)dx1_bf16, (bf16_t*)dx_bf16, n4, (int64_t)rows * D);
+                     (bf16_t*)dx2_bf16, (bf16_t*)dx1_bf16, (bf16_t*)dx_bf16, n4, (int64_t)rows * D, D / 4, L > 0 ? L : 1, (const long long*)row_limit);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_zero_frames_from(void* x, int elem_bytes, int rows, int C, int seg_len, const int32_t* frame_limit, void* stream) {
+  TTSK_REQUIRE(x && frame_limit && rows > 0 && C > 0 && seg_len > 0 && rows % seg_len == 0, "zero_frames_from: bad arguments");
+  TTSK_REQUIRE((elem_bytes == 2 || elem_bytes == 4) && ((int64_t)C * elem_bytes) % 16 == 0 && (((uintptr_t)x) & 15) == 0,
+               "zero_frames_from: rows must be whole 16-byte pieces");
+  const int q = C * elem_bytes / 16;
+  hipLaunchKernelGGL(zero_frames_kernel, dim3(grid_for((int64_t)rows * q)), dim3(256), 0, (hipStream_t)stream, (uint4*)x, rows, q, seg_len,
+                     frame_limit);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

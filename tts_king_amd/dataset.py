@@ -96,27 +96,45 @@ class Dataset(torch.utils.data.Dataset):
 
 class DeviceFeeder:
     """Iterates device batches (the tuple `to_device` returns) over an iterable of numpy 15-tuples, copying one batch
-    ahead on a side stream from pinned memory."""
+    ahead on a side stream from pinned memory.  `bucket` = (l_bucket, t_bucket, max_seq_len): batches are padded to shape
+    buckets on the host first (tts_king_amd.engine.pad_to_bucket) and carry `frame_limit` (device int32[1])."""
 
-    def __init__(self, batches, device):
+    def __init__(self, batches, device, bucket=None):
         self.it, self.device = iter(batches), torch.device(device)
+        self.bucket = bucket
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._next = None
         self._preload()
 
     def _preload(self):
+        from .engine import PaddedBatch, pad_to_bucket
         from .train_step import to_device
         try:
             b = next(self.it)
         except StopIteration:
             self._next = None
             return
+        t_true = l_true = None
+        if self.bucket is not None:
+            b = pad_to_bucket(b, *self.bucket)
+            t_true, l_true = b.t_true, b.l_true
+        nb = len(b[0])
+        fl_host = torch.tensor([t_true], dtype=torch.int32) if t_true is not None else None
+        pl_host = torch.full((nb,), l_true, dtype=torch.int64) if l_true is not None else None
         if self.stream is None:
-            self._next = to_device(b, self.device)
-            return
-        pinned = tuple(torch.as_tensor(x).pin_memory() if isinstance(x, np.ndarray) and x.dtype != object else x for x in b)
-        with torch.cuda.stream(self.stream):
-            self._next = to_device(pinned, self.device, non_blocking=True)
+            dev_b = to_device(b, self.device)
+            fl = fl_host.to(self.device) if fl_host is not None else None
+            pl = pl_host.to(self.device) if pl_host is not None else None
+        else:
+            pinned = tuple(torch.as_tensor(x).pin_memory() if isinstance(x, np.ndarray) and x.dtype != object else x for x in b)
+            with torch.cuda.stream(self.stream):
+                dev_b = to_device(pinned, self.device, non_blocking=True)
+                fl = fl_host.pin_memory().to(self.device, non_blocking=True) if fl_host is not None else None
+                pl = pl_host.pin_memory().to(self.device, non_blocking=True) if pl_host is not None else None
+        if self.bucket is not None:
+            dev_b = PaddedBatch(dev_b)
+            dev_b.t_true, dev_b.l_true, dev_b.frame_limit, dev_b.phoneme_limit = t_true, l_true, fl, pl
+        self._next = dev_b
 
     def __iter__(self):
         return self
@@ -127,7 +145,7 @@ class DeviceFeeder:
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
         batch = self._next
-        for t in batch:
+        for t in tuple(batch) + (getattr(batch, "frame_limit", None), getattr(batch, "phoneme_limit", None)):
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(torch.cuda.current_stream())
         self._preload()

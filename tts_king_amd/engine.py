@@ -1,0 +1,133 @@
+"""The train step as the trainer runs it: shape-bucketed batches, one replayed hipGraph per shape, data-parallel reducer.
+
+reference: train.py:78-235 (`main`: the loop around `main_train_step`).  The reference pads every batch to its own longest
+utterance, so almost every step has a new (L, T); a hipGraph needs static shapes.  Here a batch is padded a little further,
+to the next multiple of `l_bucket` phonemes and `t_bucket` frames (`pad_to_bucket`, host side, before the pinned H2D copy),
+and the sizes the reference would have seen travel along as device scalars.  Most of the model does not notice the extra PAD
+positions (PAD rows are zeroed after every sub-layer, keys are masked, the phoneme losses select valid positions); the places
+that would — PostNet BatchNorm statistics, the PostNet convs' zero padding, the mel-loss denominators (`frame_limit`), and the
+VariancePredictor convs, whose inputs carry the speaker / pitch embeddings at PAD positions too (`phoneme_limit`) — treat
+positions past the batch's own longest utterance as non-existent (include/ttsk.h: BatchNorm, loss, va_embed).  So a bucketed step computes
+what the reference computes on the unpadded batch, and shapes repeat: one graph per (B, L_bucket, T_bucket, update?).
+
+A shape runs eagerly the first time it is seen and is captured the second time; graphs share one memory pool and are kept
+in an LRU list (`mi355x.max_graphs`).  Tensors returned by a replay (the model outputs) live in that pool: they are valid
+until the next step.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from .graph import GraphedTrainStep, make_enqueue
+
+
+class PaddedBatch(tuple):
+    """The 15-tuple batch plus `t_true` / `l_true` (frames / phonemes of the batch's own longest utterance; None when the bucket adds
+    no padding) and, on the device, `frame_limit` (int32[1]) / `phoneme_limit` (int64[B], every entry l_true)."""
+    t_true = None
+    l_true = None
+    frame_limit = None
+    phoneme_limit = None
+
+
+def bucket_up(n, step):
+    return (int(n) + step - 1) // step * step
+
+
+def pad_to_bucket(batch, l_bucket=8, t_bucket=32, max_seq_len=1000):
+    """numpy 15-tuple (fs_two/dataset.py:188-204 layout) -> PaddedBatch with texts / durations / pitch / energy padded to a
+    multiple of `l_bucket` phonemes and mels to a multiple of `t_bucket` frames (zeros = the reference's PAD values).  Batches
+    longer than `max_seq_len` frames keep their length (the train-mode decoder truncation path, Models.py:172-180)."""
+    (ids, raw, spk, texts, src_lens, max_src, mels, mel_lens, max_mel, energies, durations, pitches, cwt, pmean, pstd) = batch
+    Lb = bucket_up(max_src, l_bucket)
+    t_true = int(max_mel)
+    Tb = bucket_up(t_true, t_bucket) if t_true <= max_seq_len else t_true
+    if Tb > max_seq_len >= t_true:
+        Tb = max(t_true, max_seq_len)
+
+    def pad(a, n, axis=1):
+        a = np.asarray(a)
+        if a.shape[axis] == n:
+            return a
+        w = [(0, 0)] * a.ndim
+        w[axis] = (0, n - a.shape[axis])
+        return np.pad(a, w, mode="constant", constant_values=0)
+
+    frame_level_p = np.asarray(pitches).shape[1] == int(max_mel) and int(max_mel) != int(max_src)
+    frame_level_e = np.asarray(energies).shape[1] == int(max_mel) and int(max_mel) != int(max_src)
+    out = PaddedBatch((ids, raw, spk, pad(texts, Lb), src_lens, Lb, pad(mels, Tb), mel_lens, Tb,
+                       pad(energies, Tb if frame_level_e else Lb), pad(durations, Lb), pad(pitches, Tb if frame_level_p else Lb),
+                       pad(cwt, Lb), pmean, pstd))
+    out.t_true = t_true if Tb != t_true else None
+    out.l_true = int(max_src) if Lb != int(max_src) else None
+    return out
+
+
+class TrainEngine:
+    """`step(batch, step_no)` = the device work of `main_train_step` (train.py:24-56), replayed from a hipGraph when the batch's
+    shape has been seen before.  Returns (losses fp32[8] on the device: total, mel, pitch, energy, duration, 0, 0, n_valid —
+    NOT divided by grad_acc_step, the caller does that when it reads them; the model's 9-tuple of outputs)."""
+
+    def __init__(self, model, optimizer, cfg, Loss, reducer=None, hip_graph=None):
+        mi = cfg.get("mi355x", {}) if hasattr(cfg, "get") else {}
+        self.model, self.optimizer, self.cfg, self.Loss, self.reducer = model, optimizer, cfg, Loss, reducer
+        self.use_graph = bool(mi.get("hip_graph", True)) if hip_graph is None else bool(hip_graph)
+        self.max_graphs = int(mi.get("max_graphs", 64))
+        self.grad_acc = int(cfg.train_config["optimizer"]["grad_acc_step"])
+        self.grad_scale = reducer.grad_scale(self.grad_acc) if reducer is not None else None
+        self._graphs = OrderedDict()
+        self._seen = set()
+        self._pool = None
+        self.stats = {"eager": 0, "captured": 0, "replayed": 0}
+
+    @staticmethod
+    def _key(batch, is_update, limited):
+        return tuple(tuple(t.shape) for t in batch if torch.is_tensor(t)) + (int(batch[5]), int(batch[8]), bool(is_update), limited)
+
+    def _enqueue(self, is_update, frame_limit, phoneme_limit):
+        return make_enqueue(self.model, self.optimizer, self.cfg, self.Loss, step_is_update=is_update,
+                            reducer=self.reducer if is_update else None, grad_scale=self.grad_scale, frame_limit=frame_limit,
+                            phoneme_limit=phoneme_limit)
+
+    def step(self, batch, step_no):
+        is_update = step_no % self.grad_acc == 0
+        fl, pl = getattr(batch, "frame_limit", None), getattr(batch, "phoneme_limit", None)
+        self.model.train()
+        if not self.use_graph or int(batch[8]) > self.model.max_seq_len:
+            self.stats["eager"] += 1
+            losses, out = self._enqueue(is_update, fl, pl)(batch)
+            return losses, out
+        key = self._key(batch, is_update, (fl is not None, pl is not None))
+        g = self._graphs.get(key)
+        if g is None and key not in self._seen:
+            self._seen.add(key)                       # first sight of a shape: plain launches (lazy allocations, split-K plans)
+            self.stats["eager"] += 1
+            return self._enqueue(is_update, fl, pl)(batch)
+        if g is None:
+            if len(self._graphs) >= self.max_graphs:
+                self._graphs.popitem(last=False)
+            static = [t.clone() if torch.is_tensor(t) else t for t in batch]
+            static_fl = fl.clone() if fl is not None else None
+            static_pl = pl.clone() if pl is not None else None
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
+            host_step = self.optimizer._host_step
+            torch.cuda.synchronize()
+            g = GraphedTrainStep(self._enqueue(is_update, static_fl, static_pl), static, warmup=0, pool=self._pool)
+            self.optimizer._host_step = host_step     # capture ran the Python of one step without executing it
+            g.frame_limit, g.phoneme_limit = static_fl, static_pl
+            self._graphs[key] = g
+            self.stats["captured"] += 1
+        else:
+            self._graphs.move_to_end(key)
+            self.stats["replayed"] += 1
+        if g.frame_limit is not None:
+            g.frame_limit.copy_(fl, non_blocking=True)
+        if g.phoneme_limit is not None:
+            g.phoneme_limit.copy_(pl, non_blocking=True)
+        losses, out = g.run(batch)
+        if is_update:
+            self.optimizer._host_step += 1
+        return losses.clone(), out

@@ -110,6 +110,7 @@ class FastSpeech2(nn.Module):
         self.fused_attention = True     # one kernel for scores + softmax + P.V (and dP + softmax' + dQ) when d_k = 128
         self.fused_ln = True            # fc / w_2 + dropout + residual + LayerNorm + PAD zeroing in one kernel when d = 256
         self.group_predictors = True    # training with targets: the three VariancePredictors run as grouped launches
+        self.raw_slabs = True           # dX GEMMs that feed a LayerNorm backward leave their split-K tiles for it to sum
         self.group_param_grads = True      # weight-gradient GEMMs of a backward pass share grouped launches (ops.DeferQueue)
         self.overlap_param_grads = False   # measured on MI355X: the branches do overlap under graph replay, but the concurrent
                                            # kernels slow each other by as much (6.39 vs 6.47 ms/step): off by default
@@ -370,7 +371,7 @@ class FastSpeech2(nn.Module):
             ctx[pre] = (x, h1, m1, r1, a1, h2, m2, r2, Bn, Lp, lens, p, site)
         return out.view(Bn, Lp)
 
-    def _predictors_fwd_grouped(self, stack, Bn, Lp, lens, p, rng, ctx):
+    def _predictors_fwd_grouped(self, stack, Bn, Lp, lens, p, rng, ctx, row_limit=None):
         """The duration / pitch / energy VariancePredictors (model/modules.py:255-309) as ONE chain of grouped launches: with
         targets given (training) their inputs x, x + speaker, x + speaker + pitch_emb[target] do not depend on each other's
         outputs (modules.py:158-193).  stack (3, rows, d) bf16 holds the three inputs.  Returns (3, B, L) fp32 = (log-duration,
@@ -384,8 +385,9 @@ class FastSpeech2(nn.Module):
         h1 = torch.empty(3, rows, Fh, dtype=bf16, device=dev)
         ops.conv1d(stack[0].view(Bn, Lp, d), W1, self._m(c + "conv1d_1.conv.bias"), flags=ops.RELU, out=h1[0].view(Bn, Lp, Fh),
                    nz1=3, sA=(rows * d, 0), sB=(ps, 0), sC=(rows * Fh, 0), s_bias1=ps)
+        # row_limit (bucketed L): hidden rows past the batch's own longest text are zero rows — the second conv's zero padding
         a1, m1, r1, _ = ops.layernorm_fwd_grouped(h1.view(3 * rows, Fh), self._m(c + "layer_norm_1.weight"), self._m(c + "layer_norm_1.bias"),
-                                                  3, ps, 2, None, 0, p_post=p, site_post=200, rng=rng)
+                                                  3, ps, 2, row_limit, Lp if row_limit is not None else 0, p_post=p, site_post=200, rng=rng)
         h2 = torch.empty(3, rows, Fh, dtype=bf16, device=dev)
         ops.conv1d(a1[:rows].view(Bn, Lp, Fh), W2, self._m(c + "conv1d_2.conv.bias"), flags=ops.RELU, out=h2[0].view(Bn, Lp, Fh),
                    nz1=3, sA=(rows * Fh, 0), sB=(ps, 0), sC=(rows * Fh, 0), s_bias1=ps)
@@ -393,14 +395,14 @@ class FastSpeech2(nn.Module):
                                                    3, ps, 2, lens, Lp, p_post=p, site_post=201, rng=rng, want_out=False,
                                                    head=(self._m(pre + "linear_layer.weight").view(-1), self._m(pre + "linear_layer.bias")))
         if ctx is not None:
-            ctx["grouped"] = (stack, h1, m1, r1, a1, h2, m2, r2, Bn, Lp, lens, p)
+            ctx["grouped"] = (stack, h1, m1, r1, a1, h2, m2, r2, Bn, Lp, lens, p, row_limit)
         return out.view(3, Bn, Lp)
 
     def _predictors_bwd_grouped(self, saved, dstack, rng, dx3):
         """Backward of _predictors_fwd_grouped; dstack (3, B, L) fp32 = gradients of (log-duration, pitch, energy) predictions,
         dx3 = gradient of the LengthRegulator input.  Returns (dx2, dx1, dx): gradients of x2 (what pitch_embedding collects),
         x1 (speaker_emb) and of the encoder output."""
-        (stack, h1, m1, r1, a1, h2, m2, r2, Bn, Lp, lens, p) = saved
+        (stack, h1, m1, r1, a1, h2, m2, r2, Bn, Lp, lens, p, row_limit) = saved
         d, rows, ps = self.d, Bn * Lp, self._pred_stride
         names = ("duration", "pitch", "energy")
         pre = "variance_adaptor.duration_predictor."
@@ -422,8 +424,8 @@ class FastSpeech2(nn.Module):
         da1 = torch.empty(3, rows, Fh, dtype=bf16, device=dev)
         ops.conv1d_dx(dh2[0].view(Bn, Lp, Fh), W2, out=da1[0].view(Bn, Lp, Fh), nz1=3, sA=(rows * Fh, 0), sB=(ps, 0), sC=(rows * Fh, 0))
         dh1, part, nblk = ops.layernorm_bwd_grouped(da1.view(3 * rows, Fh), h1.view(3 * rows, Fh), m1, r1, self._m(c + "layer_norm_1.weight"),
-                                                    self._m(c + "layer_norm_1.bias"), 3, ps, 2, None, 0, relu_in=True, p_post=p,
-                                                    site_post=200, rng=rng)
+                                                    self._m(c + "layer_norm_1.bias"), 3, ps, 2, row_limit, Lp if row_limit is not None else 0,
+                                                    relu_in=True, p_post=p, site_post=200, rng=rng)
         dh1 = dh1.view(3, rows, Fh)
         with self._side_work(dh1, part, stack):
             for g, n in enumerate(names):
@@ -433,10 +435,15 @@ class FastSpeech2(nn.Module):
                               defer=self._deferred)
         dxin = torch.empty(3, rows, d, dtype=torch.float32, device=dev)
         ops.conv1d_dx(dh1[0].view(Bn, Lp, Fh), W1, out=dxin[0].view(Bn, Lp, d), nz1=3, sA=(rows * Fh, 0), sB=(ps, 0), sC=(rows * d, 0))
-        return ops.va_combine(dx3, dxin)
+        return ops.va_combine(dx3, dxin, Lp, row_limit)
 
     def _forward(self, train, speakers, texts, src_lens, Lp, mel_lens, max_mel_len, e_targets, d_targets, pitches_raw,
-                 p_control, e_control, d_control):
+                 p_control, e_control, d_control, frame_limit=None, phoneme_limit=None):
+        """`phoneme_limit` (device int64[B], every entry = the batch's own longest text, training only): phoneme positions beyond it
+        exist only because the batch was padded to a shape bucket; the predictors treat them as the zero padding the reference's
+        batch has there.  `frame_limit` (device int32[1], training only): the batch was padded to a shape bucket (tts_king_amd/engine.py);
+        frames t >= frame_limit[0] of every utterance do not exist in the reference's batch — the PostNet's BatchNorm statistics,
+        its zero padding and (in the loss) the mel denominators are taken as if the batch ended there."""
         self.sync_shadow()
         dev, d = self.device, self.d
         Bn = texts.shape[0]
@@ -467,8 +474,8 @@ class FastSpeech2(nn.Module):
             x3, pidx, eidx = ops.va_embed(stack, speakers, self._m("speaker_emb.weight"), Lp, pitches_raw.to(dev).float().contiguous(),
                                           self.get(va + "pitch_bins"), self._m(va + "pitch_embedding.weight"),
                                           e_targets.to(dev).float().contiguous(), self.get(va + "energy_bins"),
-                                          self._m(va + "energy_embedding.weight"))
-            pred = self._predictors_fwd_grouped(stack, Bn, Lp, src_lens, p_var, rng, preds)
+                                          self._m(va + "energy_embedding.weight"), row_limit=phoneme_limit)
+            pred = self._predictors_fwd_grouped(stack, Bn, Lp, src_lens, p_var, rng, preds, row_limit=phoneme_limit)
             logd, pitch, energy = pred[0], pred[1], pred[2]
         else:
             logd = self._predictor_fwd(va + "duration_predictor.", x, Bn, Lp, src_lens, p_var, 200, rng, preds)
@@ -512,6 +519,9 @@ class FastSpeech2(nn.Module):
         rows = Bn * T
         mel16 = torch.empty(rows, self.n_mel, dtype=bf16, device=dev)
         mel = ops.linear(y, self._w("mel_linear.weight"), self._m("mel_linear.bias"), out_dtype=torch.float32, C2=mel16)
+        fl = (frame_limit, T) if (frame_limit is not None and train) else None
+        if fl is not None:
+            ops.zero_frames_from(mel16, fl)          # the PostNet's first conv sees zero padding past the batch's own length
         # ---- PostNet: Layers.py:133-143, + mel: fastspeech2.py:104
         pn = []
         xin = mel16.view(Bn, T, self.n_mel)
@@ -522,12 +532,12 @@ class FastSpeech2(nn.Module):
             C = yc.shape[2]
             if train:
                 mean, rstd = ops.bn_train_stats(yc.view(rows, C), self.get(pp + "1.running_mean"), self.get(pp + "1.running_var"),
-                                                self.get(pp + "1.num_batches_tracked").view(1))
+                                                self.get(pp + "1.num_batches_tracked").view(1), frame_limit=fl)
             else:
                 mean, rstd = self.get(pp + "1.running_mean"), ops.rsqrt_eps(self.get(pp + "1.running_var"))
             last = i == 4
             nxt = ops.bn_apply(yc.view(rows, C), mean, rstd, self._m(pp + "1.weight"), self._m(pp + "1.bias"), not last,
-                               p=p_post, site=300 + i, rng=rng, resid=mel if last else None, out_f32=last)
+                               p=p_post, site=300 + i, rng=rng, resid=mel if last else None, out_f32=last, frame_limit=fl)
             pn.append((pp, xin, yc, mean, rstd))
             xin = nxt.view(Bn, T, C) if not last else nxt
         post = xin
@@ -537,6 +547,7 @@ class FastSpeech2(nn.Module):
             ctx.dims = (Bn, Lp, T)
             ctx.texts, ctx.speakers, ctx.pidx, ctx.eidx, ctx.cs = texts, speakers, pidx, eidx, cs
             ctx.dec_out = y
+            ctx.frame_limit = fl
             ctx.used = False
         out = (mel.view(Bn, T, self.n_mel), pitch, energy, logd, d_rounded, src_masks, mel_masks, mel_lens_out,
                post.view(Bn, T, self.n_mel))
@@ -654,29 +665,42 @@ class FastSpeech2(nn.Module):
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
 
-    def _fft_bwd(self, saved, dx2, rng):
+    def _fft_bwd(self, saved, dx2, rng, raw_out=False):
+        """Backward of one FFTBlock.  `dx2`: gradient of the block output — a bf16 tensor, or (Slabs, residual) when the dX GEMM
+        that produced it left its split-K partial tiles un-reduced (the next block's `raw_out`): the LayerNorm backward sums them
+        while it reads its rows, so no reducer launch and no bf16 copy of that gradient exist.  Returns the gradient of the block
+        input in the same two forms."""
         (pre, x, qkv, probs, o, z1, mean1, rstd1, x1, h, z2, mean2, rstd2, Bn, S, lens, H, p, site, o32) = saved
         d, rows = self.d, Bn * S
         dk = d // H
         Sp = probs.shape[2]
         a, f = pre + "slf_attn.", pre + "pos_ffn."
-        dev = dx2.device
+        dev = z2.device
         # ---- FFN tail: LN backward (PAD rows carry no gradient), dropout mask regenerated
-        dz2, dy2, part, nblk = ops.layernorm_bwd(dx2, z2, mean2, rstd2, self._m(f + "layer_norm.weight"), self._m(f + "layer_norm.bias"),
-                                                 lens, S, p_pre=p, site_pre=site + 1, rng=rng)
+        if isinstance(dx2, tuple):
+            dz2, dy2, part, nblk = ops.layernorm_bwd(None, z2, mean2, rstd2, self._m(f + "layer_norm.weight"), self._m(f + "layer_norm.bias"),
+                                                     lens, S, p_pre=p, site_pre=site + 1, rng=rng, slabs=dx2[0], R=dx2[1])
+        else:
+            dz2, dy2, part, nblk = ops.layernorm_bwd(dx2, z2, mean2, rstd2, self._m(f + "layer_norm.weight"), self._m(f + "layer_norm.bias"),
+                                                     lens, S, p_pre=p, site_pre=site + 1, rng=rng)
         # ---- w_2 (k=1): dW, dX gated by the ReLU
         with self._side_work(dy2, part, h):
             self._finalize_ln(part, nblk, 3 * d, f + "w_2.bias")
             ops.conv1d_dw(dy2.view(Bn, S, d), h, self._g(f + "w_2.weight"), k=self.k2, defer=self._deferred)
         dh = ops.conv1d_dx(dy2.view(Bn, S, d), self._w(f + "w_2.weight"), G=h)
-        # ---- w_1 (k=9): bias, dW, dX + residual gradient
+        # ---- w_1 (k=9): bias, dW, dX + residual gradient; the dX stays in split-K form for the attention LayerNorm's backward
         with self._side_work(dh, x1):
             ops.colsum_into(dh.view(rows, -1), self._g(f + "w_1.bias"), defer=self._deferred_fin)
             ops.conv1d_dw(dh, x1.view(Bn, S, d), self._g(f + "w_1.weight"), k=self.k1, defer=self._deferred)
-        dx1 = ops.conv1d_dx(dh, self._w(f + "w_1.weight"), R=dz2.view(Bn, S, d))
         # ---- attention tail
-        dz1, dy1, part, nblk = ops.layernorm_bwd(dx1.view(rows, d), z1, mean1, rstd1, self._m(a + "layer_norm.weight"),
-                                                 self._m(a + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site, rng=rng)
+        if self.raw_slabs:
+            sl = ops.conv1d_dx(dh, self._w(f + "w_1.weight"), raw=True)
+            dz1, dy1, part, nblk = ops.layernorm_bwd(None, z1, mean1, rstd1, self._m(a + "layer_norm.weight"), self._m(a + "layer_norm.bias"),
+                                                     lens, S, p_pre=p, site_pre=site, rng=rng, slabs=sl, R=dz2)
+        else:
+            dx1 = ops.conv1d_dx(dh, self._w(f + "w_1.weight"), R=dz2.view(Bn, S, d))
+            dz1, dy1, part, nblk = ops.layernorm_bwd(dx1.view(rows, d), z1, mean1, rstd1, self._m(a + "layer_norm.weight"),
+                                                     self._m(a + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site, rng=rng)
         with self._side_work(dy1, part, o):
             self._finalize_ln(part, nblk, 3 * d, a + "fc.bias")
             ops.linear_dw(dy1, o, self._g(a + "fc.weight"), defer=self._deferred)
@@ -702,6 +726,8 @@ class FastSpeech2(nn.Module):
         with self._side_work(dqkv, x):
             ops.colsum_into(dqkv, self._g(a + "w_qs.bias", 3 * d), defer=self._deferred_fin)
             ops.linear_dw(dqkv, x, self._g(a + "w_qs.weight", 3 * d * d).view(3 * d, d), defer=self._deferred)
+        if raw_out and self.raw_slabs:
+            return (ops.linear_dx(dqkv, self._w(a + "w_qs.weight", 3 * d), raw=True), dz1)
         return ops.linear_dx(dqkv, self._w(a + "w_qs.weight", 3 * d), R=dz1)
 
     def _predictor_bwd(self, pre, saved, dout, rng, R):
@@ -770,7 +796,8 @@ class FastSpeech2(nn.Module):
             pp, xin, yc, mean, rstd = ctx.pn[i]
             C = yc.shape[2]
             dy = ops.bn_bwd(dout, yc.view(rows, C), mean, rstd, self._m(pp + "1.weight"), self._m(pp + "1.bias"), i < 4,
-                            p=self.p_post, site=300 + i, rng=rng, dgamma=self._g(pp + "1.weight"), dbeta=self._g(pp + "1.bias"))
+                            p=self.p_post, site=300 + i, rng=rng, dgamma=self._g(pp + "1.weight"), dbeta=self._g(pp + "1.bias"),
+                            frame_limit=ctx.frame_limit)
             with self._side_work(dy, xin):
                 ops.colsum_into(dy, self._g(pp + "0.conv.bias"), defer=self._deferred_fin)
                 ops.conv1d_dw(dy.view(Bn, T, C), xin, self._g(pp + "0.conv.weight"), k=5, defer=self._deferred)
@@ -778,6 +805,8 @@ class FastSpeech2(nn.Module):
                 dout = ops.conv1d_dx(dy.view(Bn, T, C), self._w(pp + "0.conv.weight")).view(rows, -1)
             else:
                 dmel_tot = ops.conv1d_dx(dy.view(Bn, T, C), self._w(pp + "0.conv.weight"), R=dmel_sum.view(Bn, T, nm)).view(rows, nm)
+                if ctx.frame_limit is not None:
+                    ops.zero_frames_from(dmel_tot, ctx.frame_limit)      # the conv's reach past the batch's own length is not a frame
         notify("postnet")
         # ---- mel_linear
         with self._side_work(dmel_tot, ctx.dec_out):
@@ -787,7 +816,7 @@ class FastSpeech2(nn.Module):
         notify("mel_linear")
         # ---- decoder
         for i in range(self.n_dec - 1, -1, -1):
-            dx = self._fft_bwd(ctx.blocks[ctx.n_enc_blocks + i], dx, rng)
+            dx = self._fft_bwd(ctx.blocks[ctx.n_enc_blocks + i], dx, rng, raw_out=i > 0)
             notify("decoder.%d" % i)
         # ---- length regulator: segment sums (the position table has no parameters)
         dx3 = ops.length_regulator_bwd(dx.view(Bn, T, d), ctx.cs, Lp).view(Bn * Lp, d)
@@ -812,7 +841,7 @@ class FastSpeech2(nn.Module):
         # ---- encoder
         dx = dxe.view(Bn * Lp, d)
         for i in range(self.n_enc - 1, -1, -1):
-            dx = self._fft_bwd(ctx.blocks[i], dx, rng)
+            dx = self._fft_bwd(ctx.blocks[i], dx, rng, raw_out=i > 0)
             notify("encoder.%d" % i)
         with self._side_work(dx):
             ops.scatter_sum(dx, ctx.texts.view(-1), self._g("encoder.src_word_emb.weight"), skip_row=0, defer=self._deferred_fin)   # padding_idx=0

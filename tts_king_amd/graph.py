@@ -17,7 +17,7 @@ class GraphedTrainStep:
     `enqueue` must only enqueue device work on the current stream (no host reads); it returns device tensors
     (e.g. the losses) that are valid after each replay."""
 
-    def __init__(self, enqueue, example_batch, warmup=2):
+    def __init__(self, enqueue, example_batch, warmup=2, pool=None):
         self.static = [t.clone() if torch.is_tensor(t) else t for t in example_batch]
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
@@ -27,7 +27,7 @@ class GraphedTrainStep:
                 enqueue(self.static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, pool=pool):
             self.outputs = enqueue(self.static)
 
     def key(self):
@@ -42,8 +42,9 @@ class GraphedTrainStep:
         return self.outputs
 
 
-def make_enqueue(model, optimizer, cfg, Loss, step_is_update=True, reducer=None, grad_scale=None):
-    """The device-side part of `main_train_step` (train.py:24-56) as a capturable closure."""
+def make_enqueue(model, optimizer, cfg, Loss, step_is_update=True, reducer=None, grad_scale=None, frame_limit=None, phoneme_limit=None):
+    """The device-side part of `main_train_step` (train.py:24-56) as a capturable closure.  `frame_limit`: device int32[1] holding
+    the batch's own longest utterance when the batch tensors are padded to a shape bucket (see FastSpeech2._forward)."""
     grad_acc = cfg.train_config["optimizer"]["grad_acc_step"]
     gs = (1.0 / grad_acc) if grad_scale is None else grad_scale
 
@@ -51,11 +52,11 @@ def make_enqueue(model, optimizer, cfg, Loss, step_is_update=True, reducer=None,
         dev = model.device
         with torch.no_grad():
             out, ctx = model._forward(True, batch[2], batch[3], batch[4], int(batch[5]), batch[7], batch[8], batch[9],
-                                      batch[10], batch[11], 1.0, 1.0, 1.0)
+                                      batch[10], batch[11], 1.0, 1.0, 1.0, frame_limit=frame_limit, phoneme_limit=phoneme_limit)
             mel, pitch, energy, logd = out[0], out[1], out[2], out[3]
             post = out[8]
             losses, dmel_sum, dpost, dp, de, dd = ops.fs2_loss(mel, post, batch[6], batch[7], pitch, energy, logd, batch[11],
-                                                               batch[9], batch[10], batch[4], grad_scale=gs)
+                                                               batch[9], batch[10], batch[4], grad_scale=gs, frame_limit=None if frame_limit is None else (frame_limit, 0))
             if reducer is not None and step_is_update:
                 model.backward_native(ctx, dmel_sum, dpost, dp, de, dd, on_bucket=reducer.on_group_done)
                 reducer.finish()

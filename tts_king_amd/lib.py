@@ -61,7 +61,7 @@ class FinalizeItem(C.Structure):
 
 
 # flags (include/ttsk.h)
-A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT, F16, C2_LRELU, DEFER_REDUCE = [1 << i for i in range(14)]
+A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT, F16, C2_LRELU, DEFER_REDUCE, RAW_SLABS = [1 << i for i in range(15)]
 
 
 def declared_symbols(header_path=HEADER_PATH):

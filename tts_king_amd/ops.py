@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import (A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT, F16, C2_LRELU, DEFER_REDUCE,  # noqa: F401
+from .lib import (A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT, F16, C2_LRELU, DEFER_REDUCE, RAW_SLABS,  # noqa: F401
                   GemmDesc, check)
 
 bf16 = torch.bfloat16
@@ -32,8 +32,15 @@ def _ptr(t):
 
 import os as _os
 # K steps one workgroup of a grouped weight-gradient launch walks (128x128 tile, 256x128 tile): more steps = fewer split-K slabs
-DW_STEPS_PER_WG = tuple(int(v) for v in _os.environ.get("TTSK_DW_STEPS", "28,36").split(","))
+DW_STEPS_PER_WG = tuple(int(v) for v in _os.environ.get("TTSK_DW_STEPS", "28,72").split(","))
 GEMM_TRACE = None   # bench.py sets this to a list: every ttsk_gemm launch is then bracketed by HIP events on its stream
+
+
+class Slabs:
+    """Raw split-K partial tiles of a GEMM (gemm(raw=True)): fp32 [splits][M*N] in `ws`."""
+
+    def __init__(self, ws, splits, stride):
+        self.ws, self.splits, self.stride = ws, splits, stride
 
 
 class DeferQueue(list):
@@ -115,13 +122,19 @@ def plan(d):
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=None, ldr=0, G=None, ldg=0, C2=None,
          nz1=1, nz2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0), taps=0, seg_len=0, tap_shift0=0, tap_dshift=0,
          b_tap_stride=0, bseg_len=0, bshift0=0, bdshift=0, out_seg=0, out_mul=0, out_add=0, out_add_dz=0, splits=0, kernel=0,
-         in_slope=0.0, out_slope=0.0, defer=None, group=None, s_bias1=0):
+         in_slope=0.0, out_slope=0.0, defer=None, group=None, s_bias1=0, raw=False):
     """Raw descriptor-level call of ttsk_gemm (see include/ttsk.h).  A/B/Cout may be views: the data pointer of
     the view is the operand origin.  splits / kernel = 0 let the library plan (tile configuration, split-K factor);
     the split-K workspace is allocated here (the C library never allocates).  `defer`: a list — a split-K weight-
     gradient GEMM then leaves its slabs un-reduced and appends a reduce item to it (see flush_deferred).  `group`: a
-    GemmGroup — independent problems collected there run as ONE grouped launch at `group.flush()`."""
+    GemmGroup — independent problems collected there run as ONE grouped launch at `group.flush()`.  `raw`: leave the fp32
+    partial tiles [splits][M][N] un-reduced and without epilogue (TTSK_GEMM_RAW_SLABS); returns Slabs(ws, splits, M*N) for
+    layernorm_bwd(slabs=...) — `Cout` may be None."""
     _dev(A, B, Cout, bias, R, G, C2)
+    if raw:
+        flags |= RAW_SLABS | C_F32
+        if Cout is None:
+            Cout = A                  # not written: any valid device pointer
     d = GemmDesc()
     d.A, d.B, d.C, d.C2 = _ptr(A), _ptr(B), _ptr(Cout), _ptr(C2)
     d.bias, d.R, d.G = _ptr(bias), _ptr(R), _ptr(G)
@@ -129,7 +142,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=No
     d.lda, d.ldb, d.ldc, d.ldr, d.ldg = lda, ldb, ldc, ldr, ldg
     if A.dtype == f16:
         flags |= F16
-    if Cout.dtype == torch.float32:
+    if Cout.dtype == torch.float32 and not raw:
         flags |= C_F32
     if R is not None:
         flags |= ADD_R | (R_F32 if R.dtype == torch.float32 else 0)
@@ -170,6 +183,9 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=No
             it.ws, it.C, it.M, it.N, it.ldc, it.nz, it.splits = ws.data_ptr(), Cout.data_ptr(), M, N, ldc, nz2, splits
             it.accumulate, it.sC2, it.alpha = int(bool(flags & ACCUM_C)), sC[1], alpha
             defer.append((it, ws))
+    if raw:
+        check(L.load().ttsk_gemm(C.byref(d), _stream()), "ttsk_gemm")
+        return Slabs(ws, splits, M * N * nz1 * nz2)
     if group is not None:
         group.descs.append(d)
         group.keep.extend(t for t in (A, B, Cout, ws, bias, R, G, C2) if t is not None)
@@ -240,6 +256,8 @@ def linear_dx(dy, W, out=None, R=None, G=None, out_dtype=bf16, **kw):
     """dx[M,K] = dy[M,N] @ W[N,K]   (W read in place through the transposing LDS read)."""
     M, N = dy.shape
     K = W.shape[1]
+    if kw.get("raw"):
+        return gemm(dy, W, None, M, K, N, dy.stride(0), W.stride(0), K, flags=B_TR, **kw)
     if out is None:
         out = torch.empty(M, K, dtype=out_dtype, device=dy.device)
     return gemm(dy, W, out, M, K, N, dy.stride(0), W.stride(0), out.stride(0), flags=B_TR, R=R,
@@ -273,6 +291,9 @@ def conv1d_dx(dy, W, dilation=1, out=None, R=None, G=None, **kw):
     Bsz, T, Cout = dy.shape
     _, k, Cin = W.shape
     pad = dilation * (k - 1) // 2
+    if kw.get("raw"):
+        return gemm(dy, W, None, Bsz * T, Cin, Cout, Cout, k * Cin, Cin, flags=B_TR, taps=k, seg_len=T, tap_shift0=pad,
+                    tap_dshift=-dilation, b_tap_stride=Cin, **kw)
     if out is None:
         out = torch.empty(Bsz, T, Cin, dtype=bf16, device=dy.device)
     gemm(dy, W, out, Bsz * T, Cin, Cout, Cout, k * Cin, Cin, flags=B_TR, R=R, ldr=Cin, G=G, ldg=Cin, taps=k, seg_len=T,
@@ -364,9 +385,11 @@ def gemm_ln_fwd(x, W, bias, res, gamma, beta, lens=None, seg_len=0, p_pre=0.0, s
 
 
 def layernorm_bwd(dout, z, mean, rstd, gamma, beta, lens=None, seg_len=0, relu_in=False, p_pre=0.0, site_pre=0,
-                  p_post=0.0, site_post=0, rng=None, dhead=None, head_w=None, want_dz=True):
-    """Returns (dz, dy, partials, nblk).  dy is dz when p_pre == 0.  partials layout: see include/ttsk.h."""
-    _dev(dout, z, dhead)
+                  p_post=0.0, site_post=0, rng=None, dhead=None, head_w=None, want_dz=True, slabs=None, R=None):
+    """Returns (dz, dy, partials, nblk).  dy is dz when p_pre == 0.  partials layout: see include/ttsk.h.
+    `slabs` (a Slabs from gemm(raw=True)) + `R` (bf16 residual) replace `dout`: dout = sum of the slabs + R, summed in fp32
+    while the rows are read (ttsk_layernorm_bwd_slabs)."""
+    _dev(dout, z, dhead, R)
     rows, D = z.shape
     dev = z.device
     lib = L.load()
@@ -375,6 +398,11 @@ def layernorm_bwd(dout, z, mean, rstd, gamma, beta, lens=None, seg_len=0, relu_i
     partials = _f32(nblk, ncol, device=dev)
     dz = torch.empty(rows, D, dtype=bf16, device=dev) if (want_dz or p_pre == 0.0) else None
     dy = torch.empty(rows, D, dtype=bf16, device=dev) if p_pre > 0.0 else None
+    if slabs is not None:
+        check(lib.ttsk_layernorm_bwd_slabs(_ptr(slabs.ws), slabs.splits, slabs.stride, _ptr(R), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma),
+                                           _ptr(beta), _ptr(lens), seg_len, rows, D, int(relu_in), p_pre, site_pre, p_post, site_post,
+                                           _ptr(rng), _ptr(dz), _ptr(dy), _ptr(partials), _stream()), "ttsk_layernorm_bwd_slabs")
+        return dz, (dy if dy is not None else dz), partials, nblk
     check(lib.ttsk_layernorm_bwd(_ptr(dout), _ptr(dhead), _ptr(head_w), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma),
                                  _ptr(beta), _ptr(lens), seg_len, rows, D, int(relu_in), p_pre, site_pre, p_post,
                                  site_post, _ptr(rng), _ptr(dz), _ptr(dy), _ptr(partials), _stream()), "ttsk_layernorm_bwd")
@@ -417,7 +445,7 @@ def layernorm_bwd_grouped(dout, z, mean, rstd, gamma, beta, groups, param_stride
     return dz, partials, nblk
 
 
-def va_embed(stack, speakers, spk_table, Lp, pitch_t, pitch_bins, pitch_table, energy_t, energy_bins, energy_table):
+def va_embed(stack, speakers, spk_table, Lp, pitch_t, pitch_bins, pitch_table, energy_t, energy_bins, energy_table, row_limit=None):
     """stack (3, rows, D) bf16 with stack[0] = encoder output: fills stack[1] = x + speaker, stack[2] = stack[1] + pitch embedding and
     returns (x3 = stack[2] + energy embedding, pitch bucket indices, energy bucket indices).  reference: modules.py:158-193."""
     _dev(stack, speakers, spk_table, pitch_t, pitch_bins, pitch_table, energy_t, energy_bins, energy_table)
@@ -427,16 +455,16 @@ def va_embed(stack, speakers, spk_table, Lp, pitch_t, pitch_bins, pitch_table, e
     eidx = torch.empty(rows, dtype=torch.int32, device=stack.device)
     check(L.load().ttsk_va_embed(_ptr(stack[0]), _ptr(spk_table), _ptr(speakers), Lp, _ptr(pitch_t), _ptr(pitch_bins), _ptr(pitch_table),
                                  _ptr(energy_t), _ptr(energy_bins), _ptr(energy_table), pitch_bins.numel(), _ptr(stack[1]), _ptr(stack[2]),
-                                 _ptr(x3), _ptr(pidx), _ptr(eidx), rows, D, _stream()), "ttsk_va_embed")
+                                 _ptr(x3), _ptr(pidx), _ptr(eidx), rows, D, _ptr(row_limit), _stream()), "ttsk_va_embed")
     return x3, pidx, eidx
 
 
-def va_combine(dx3, dxin):
+def va_combine(dx3, dxin, Lp=0, row_limit=None):
     """dx3 (rows, D) bf16, dxin (3, rows, D) fp32 -> (dx2, dx1, dx) bf16: see include/ttsk.h."""
-    _dev(dx3, dxin)
+    _dev(dx3, dxin, row_limit)
     rows, D = dx3.shape
     dx2, dx1, dx = torch.empty_like(dx3), torch.empty_like(dx3), torch.empty_like(dx3)
-    check(L.load().ttsk_va_combine(_ptr(dx3), _ptr(dxin), _ptr(dx2), _ptr(dx1), _ptr(dx), rows, D, _stream()), "ttsk_va_combine")
+    check(L.load().ttsk_va_combine(_ptr(dx3), _ptr(dxin), _ptr(dx2), _ptr(dx1), _ptr(dx), rows, D, Lp, _ptr(row_limit), _stream()), "ttsk_va_combine")
     return dx2, dx1, dx
 
 
@@ -619,7 +647,21 @@ def to_int16(x, scale):
 
 # ---------------------------------------------------------------------------------------------------- batch norm
 
-def bn_train_stats(x, running_mean=None, running_var=None, nbt=None, eps=1e-5, momentum=0.1):
+def _lim(frame_limit):
+    """(pointer, seg_len) of a frame limit (None, or (int32[1] device tensor, frames per utterance in the row layout))."""
+    return (None, 0) if frame_limit is None else (frame_limit[0].data_ptr(), int(frame_limit[1]))
+
+
+def zero_frames_from(x, frame_limit):
+    """x (rows, C) bf16/fp32, rows = utterances * seg_len: frames t >= frame_limit of every utterance := 0."""
+    _dev(x)
+    lp, seg = _lim(frame_limit)
+    rows, Cn = x.shape
+    check(L.load().ttsk_zero_frames_from(_ptr(x), x.element_size(), rows, Cn, seg, lp, _stream()), "ttsk_zero_frames_from")
+    return x
+
+
+def bn_train_stats(x, running_mean=None, running_var=None, nbt=None, eps=1e-5, momentum=0.1, frame_limit=None):
     """x (rows, C) bf16 or fp32 -> (mean, rstd) fp32 of the batch; updates the running buffers in place."""
     _dev(x)
     rows, Cn = x.shape
@@ -627,9 +669,10 @@ def bn_train_stats(x, running_mean=None, running_var=None, nbt=None, eps=1e-5, m
     nblk = lib.ttsk_bn_nblocks(rows)
     partials = _f32(nblk, 2 * Cn, device=x.device)
     mean, rstd = _f32(Cn, device=x.device), _f32(Cn, device=x.device)
-    check(lib.ttsk_bn_stats(_ptr(x), int(x.dtype == torch.float32), rows, Cn, _ptr(partials), _stream()), "ttsk_bn_stats")
+    lp, seg = _lim(frame_limit)
+    check(lib.ttsk_bn_stats(_ptr(x), int(x.dtype == torch.float32), rows, Cn, _ptr(partials), lp, seg, _stream()), "ttsk_bn_stats")
     check(lib.ttsk_bn_finalize(_ptr(partials), nblk, Cn, rows, eps, momentum, _ptr(mean), _ptr(rstd), _ptr(running_mean),
-                               _ptr(running_var), _ptr(nbt), _stream()), "ttsk_bn_finalize")
+                               _ptr(running_var), _ptr(nbt), lp, seg, _stream()), "ttsk_bn_finalize")
     return mean, rstd
 
 
@@ -639,16 +682,16 @@ def rsqrt_eps(var, eps=1e-5):
     return out
 
 
-def bn_apply(x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, resid=None, out_f32=False):
+def bn_apply(x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, resid=None, out_f32=False, frame_limit=None):
     rows, Cn = x.shape
     o16 = None if out_f32 else torch.empty(rows, Cn, dtype=bf16, device=x.device)
     o32 = _f32(rows, Cn, device=x.device) if out_f32 else None
     check(L.load().ttsk_bn_apply(_ptr(x), int(x.dtype == torch.float32), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn, int(use_tanh), p, site,
-                                 _ptr(rng), _ptr(resid), _ptr(o16), _ptr(o32), _stream()), "ttsk_bn_apply")
+                                 _ptr(rng), _ptr(resid), _ptr(o16), _ptr(o32), *_lim(frame_limit), _stream()), "ttsk_bn_apply")
     return o32 if out_f32 else o16
 
 
-def bn_bwd(dout, x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, dgamma=None, dbeta=None):
+def bn_bwd(dout, x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, dgamma=None, dbeta=None, frame_limit=None):
     """dx (rows,C) bf16; dgamma/dbeta (fp32, accumulated in place when given)."""
     rows, Cn = x.shape
     lib = L.load()
@@ -657,18 +700,18 @@ def bn_bwd(dout, x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, 
     sums = _f32(2 * Cn, device=x.device)
     f32 = int(dout.dtype == torch.float32)
     check(lib.ttsk_bn_bwd_stats(_ptr(dout), f32, _ptr(x), int(x.dtype == torch.float32), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn,
-                                int(use_tanh), p, site, _ptr(rng), _ptr(partials), _stream()), "ttsk_bn_bwd_stats")
+                                int(use_tanh), p, site, _ptr(rng), _ptr(partials), *_lim(frame_limit), _stream()), "ttsk_bn_bwd_stats")
     colsum_finalize(partials, nblk, 2 * Cn, 2 * Cn, sums, accumulate=False)
     dx = torch.empty(rows, Cn, dtype=bf16, device=x.device)
     check(lib.ttsk_bn_bwd_apply(_ptr(dout), f32, _ptr(x), int(x.dtype == torch.float32), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn,
-                                int(use_tanh), p, site, _ptr(rng), _ptr(sums), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _stream()),
+                                int(use_tanh), p, site, _ptr(rng), _ptr(sums), _ptr(dx), _ptr(dgamma), _ptr(dbeta), *_lim(frame_limit), _stream()),
           "ttsk_bn_bwd_apply")
     return dx
 
 
 # ---------------------------------------------------------------------------------------------------- loss / optimiser
 
-def fs2_loss(mel, post, mel_t, mel_lens, pitch, energy, logd, pitch_t, energy_t, dur_t, src_lens, grad_scale=1.0):
+def fs2_loss(mel, post, mel_t, mel_lens, pitch, energy, logd, pitch_t, energy_t, dur_t, src_lens, grad_scale=1.0, frame_limit=None):
     """Returns (losses[8] fp32 device, dmel_sum, dpost, dpitch, denergy, dlogd).  See include/ttsk.h."""
     _dev(mel, post, mel_t, mel_lens, pitch, energy, logd, pitch_t, energy_t, dur_t, src_lens)
     B, T, nm = mel.shape
@@ -683,7 +726,7 @@ def fs2_loss(mel, post, mel_t, mel_lens, pitch, energy, logd, pitch_t, energy_t,
     losses = _f32(8, device=dev)
     check(lib.ttsk_fs2_loss(_ptr(mel), _ptr(post), _ptr(mel_t), _ptr(mel_lens), _ptr(pitch), _ptr(energy), _ptr(logd),
                             _ptr(pitch_t), _ptr(energy_t), _ptr(dur_t), _ptr(src_lens), B, T, Tt, nm, Lp, grad_scale,
-                            _ptr(dmel), _ptr(dpost), _ptr(dp), _ptr(de), _ptr(dd), _ptr(partials), _ptr(losses), _stream()),
+                            _ptr(dmel), _ptr(dpost), _ptr(dp), _ptr(de), _ptr(dd), _ptr(partials), _ptr(losses), _lim(frame_limit)[0], _stream()),
           "ttsk_fs2_loss")
     return losses, dmel, dpost, dp, de, dd
 

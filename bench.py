@@ -16,6 +16,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -234,7 +235,8 @@ def gemm_roofline(enqueue, batch, steps=3):
         ops.GEMM_TRACE = None
     sym = {"NT1": "gemm_kernel<false, false, false>", "NT_btr1": "gemm_kernel<false, true, false>", "TT1": "gemm_kernel<true, true, false>",
            "NT2": "gemm2_kernel<256, false, false, false>", "NT_btr2": "gemm2_kernel<256, false, true, false>", "TT2": "gemm2_kernel<256, true, true, false>",
-           "TT1g": "gemm_group_kernel<true, true, false>", "TT2g": "gemm2_group_kernel<256, true, true, false>"}
+           "TT1g": "gemm_group_kernel<true, true, false>", "TT2g": "gemm2_group_kernel<256, true, true, false>",
+           "NT3": "gemm64_kernel<false, false>", "NT_btr3": "gemm64_kernel<true, false>"}
     by_sym, by_shape = {}, {}
     for e0, e1, fl, kind, shape in trace:
         ms = e0.elapsed_time(e1)
@@ -243,6 +245,7 @@ def gemm_roofline(enqueue, batch, steps=3):
     tot_ms = sum(v[0] for v in by_sym.values())
     tot_fl = sum(v[1] for v in by_sym.values())
     dk, dv = max(by_sym.items(), key=lambda kv: kv[1][1])      # dominant = most algorithmic FLOPs (decoder FFN / PostNet convs)
+    tk, tv = max(by_sym.items(), key=lambda kv: kv[1][0])      # and the symbol that takes the most TIME (eager brackets incl. reducers)
     sk, sv = max(((k, v) for k, v in by_shape.items() if k[0] == dk), key=lambda kv: kv[1][0])
     ach = dv[1] / (dv[0] * 1e-3) / 1e12
     traffic = pmc_traffic(sym.get(dk, dk))
@@ -252,10 +255,149 @@ def gemm_roofline(enqueue, batch, steps=3):
             "kernel": "%s (tts_king_amd/csrc/gemm%s.hip)" % (sym.get(dk, dk), "2" if "2" in dk else ""),
             "launches_per_step": dv[2] // steps, "avg_launch_us": 1e3 * dv[0] / dv[2], "avg_launch_gflop": dv[1] / dv[2] / 1e9,
             "kernel_ms_per_step": dv[0] / steps,
+            "dominant_by_time": {"kernel": sym.get(tk, tk), "launches_per_step": tv[2] // steps, "ms_per_step": tv[0] / steps,
+                                 "tflops": tv[1] / (tv[0] * 1e-3) / 1e12, "frac_of_peak": tv[1] / (tv[0] * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS},
             "all_gemm": {"launches_per_step": len(trace) // steps, "ms_per_step": tot_ms / steps, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12},
             "largest_shape": ({"grouped_problems": sk[1], "workgroups": sk[6]} if dk.endswith("g") else
                               {"M,N,K,taps,batch,splits": list(sk[1:]), "launches_per_step": sv[2] // steps,
                                "avg_us": 1e3 * sv[0] / sv[2], "tflops": sv[1] / (sv[0] * 1e-3) / 1e12})}
+
+
+def _time_loop(fn, n, sync=True):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / n
+
+
+def extra_train_legs(cfg, dev, B, L, steps=40):
+    """The numbers beside the headline that VERDICT r01 asked for (1 GPU): the same step launched eagerly; the reference's default
+    `grad_acc_step: 4` cycle (three accumulate-only micro-steps + one update, two replayed graphs); and the TRAINER's loop —
+    tts_king_amd.engine.TrainEngine fed by DeviceFeeder with varying-T synthetic batches (shape buckets, graph cache, pinned H2D),
+    i.e. what `python train.py` runs per step."""
+    import copy
+    from tts_king_amd.dataset import DeviceFeeder
+    from tts_king_amd.engine import TrainEngine
+    from tts_king_amd.fastspeech2 import FastSpeech2
+    from tts_king_amd.graph import GraphedTrainStep, make_enqueue
+    from tts_king_amd.loss import FastSpeech2Loss
+    from tts_king_amd.optimizer import ScheduledOptim
+    from tts_king_amd.synthetic import make_batch
+    from tts_king_amd.train_step import to_device
+    out = {}
+    loss_fn = FastSpeech2Loss(cfg.preprocess_config, cfg.model_config)
+    # ---- eager launches of the headline step
+    c1 = copy.deepcopy(cfg)
+    c1.train_config["optimizer"]["grad_acc_step"] = 1
+    model = FastSpeech2(c1.preprocess_config, c1.model_config, 65, device=dev, seed=1234).train()
+    opt = ScheduledOptim(model, c1.train_config, c1.model_config, 0)
+    batch = to_device(make_batch(B, L, seed=1234), dev)
+    enq = make_enqueue(model, opt, c1, loss_fn)
+    for _ in range(3):
+        enq(batch)
+    out["ms_per_step_eager"] = _time_loop(lambda: enq(batch), 20)
+    # ---- grad_acc_step = 4: micro-steps 1-3 accumulate, the 4th also clips / updates (reference default, config.yaml:51)
+    c4 = copy.deepcopy(cfg)
+    c4.train_config["optimizer"]["grad_acc_step"] = 4
+    m4 = FastSpeech2(c4.preprocess_config, c4.model_config, 65, device=dev, seed=1234).train()
+    o4 = ScheduledOptim(m4, c4.train_config, c4.model_config, 0)
+    g_acc = GraphedTrainStep(make_enqueue(m4, o4, c4, loss_fn, step_is_update=False), batch, warmup=2)
+    g_upd = GraphedTrainStep(make_enqueue(m4, o4, c4, loss_fn, step_is_update=True), batch, warmup=0)
+
+    def cycle():
+        g_acc.run(); g_acc.run(); g_acc.run(); g_upd.run()
+    for _ in range(3):
+        cycle()
+    ms_cycle = _time_loop(cycle, max(5, steps // 4))
+    out["ms_per_step_grad_acc4"] = ms_cycle / 4.0
+    out["grad_acc4"] = {"ms_per_optimizer_update": ms_cycle, "micro_steps_per_update": 4,
+                        "valid_mel_frames_per_s": 4 * int(batch[7].sum()) / (ms_cycle * 1e-3)}
+    # ---- the trainer's loop: varying-T batches through the engine (buckets of 8 phonemes / 32 frames), pinned-memory feeder
+    mt = FastSpeech2(c1.preprocess_config, c1.model_config, 65, device=dev, seed=1234).train()
+    ot = ScheduledOptim(mt, c1.train_config, c1.model_config, 0)
+    eng = TrainEngine(mt, ot, c1, loss_fn)
+    mi = cfg.get("mi355x", {})
+    bucket = (int(mi.get("l_bucket", 8)), int(mi.get("t_bucket", 32)), int(cfg.model_config["max_seq_len"]))
+    host = [tuple(x.numpy() if torch.is_tensor(x) else x for x in make_batch(B, L - (i % 3), seed=2000 + i)) for i in range(12)]
+    frames = [int(np.asarray(b[7]).sum()) for b in host]
+    step = [0]
+
+    def run(batches):
+        last = None
+        for b in DeviceFeeder(batches, dev, bucket=bucket):
+            step[0] += 1
+            last, _ = eng.step(b, step[0])
+        return last
+    run(host); run(host)                       # first sight (eager) and second sight (capture) of every shape
+    torch.cuda.synchronize()
+    n_loops = max(1, (max(steps, 50) + len(host) - 1) // len(host))
+    t0 = time.perf_counter()
+    for _ in range(n_loops):
+        last = run(host)
+    last.cpu()
+    dt = time.perf_counter() - t0
+    n = n_loops * len(host)
+    out["ms_per_step_train_loop"] = 1e3 * dt / n
+    out["train_loop"] = {"steps": n, "distinct_batches": len(host), "graphs": len(eng._graphs), "engine": dict(eng.stats),
+                         "T_max_range": [int(min(int(b[8]) for b in host)), int(max(int(b[8]) for b in host))],
+                         "valid_mel_frames_per_s": n_loops * sum(frames) / dt,
+                         "what": "TrainEngine.step over DeviceFeeder (host-side bucket padding, pinned H2D one batch ahead), hipGraph replay per shape"}
+    return out
+
+
+def dp1_leg(cfg, dev, B, L, steps=30):
+    """The data-parallel schedule on ONE GPU: the full step with GradReducer issuing its bucketed all-reduces over RCCL at world
+    size 1 (a collective per gradient bucket on RCCL's stream, backward_native flushing its deferred weight-gradient work whenever
+    a bucket completes) — captured in a hipGraph and eager — beside the plain step, and how many grouped-GEMM / reducer / column-sum
+    flush launches the DP schedule issues per step."""
+    import copy
+    import socket
+    from tts_king_amd import ops
+    from tts_king_amd.fastspeech2 import FastSpeech2
+    from tts_king_amd.graph import GraphedTrainStep, make_enqueue
+    from tts_king_amd.loss import FastSpeech2Loss
+    from tts_king_amd.optimizer import ScheduledOptim
+    from tts_king_amd.parallel import GradReducer
+    from tts_king_amd.synthetic import make_batch
+    from tts_king_amd.train_step import to_device
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        c1 = copy.deepcopy(cfg)
+        c1.train_config["optimizer"]["grad_acc_step"] = 1
+        loss_fn = FastSpeech2Loss(c1.preprocess_config, c1.model_config)
+        model = FastSpeech2(c1.preprocess_config, c1.model_config, 65, device=dev, seed=1234).train()
+        opt = ScheduledOptim(model, c1.train_config, c1.model_config, 0)
+        batch = to_device(make_batch(B, L, seed=1234), dev)
+        buckets = model.grad_buckets(cfg.mi355x.dp_bucket_mb)
+        red = GradReducer(model.flat_buffers()[1], buckets, model.group_offsets(), force_collectives=True)
+        enq = make_enqueue(model, opt, c1, loss_fn, reducer=red, grad_scale=1.0)
+        counts = {}
+        for _ in range(2):
+            enq(batch)
+        torch.cuda.synchronize()
+        ops.LAUNCH_COUNTS = counts
+        enq(batch)
+        torch.cuda.synchronize()
+        ops.LAUNCH_COUNTS = None
+        rec = {"buckets": len(buckets), "bucket_mb": cfg.mi355x.dp_bucket_mb, "launches_per_step": dict(counts),
+               "dp1_reducer_ms_per_step_eager": _time_loop(lambda: enq(batch), 10)}
+        try:
+            g = GraphedTrainStep(enq, batch, warmup=0)
+            for _ in range(3):
+                g.run()
+            rec["dp1_reducer_ms_per_step"] = _time_loop(lambda: g.run(), steps)
+        except Exception as e:          # RCCL refused the capture: the eager number stands
+            rec["dp1_reducer_ms_per_step"] = None
+            rec["graph_capture_error"] = str(e)[:200]
+        return rec
+    finally:
+        if own_pg:
+            dist.destroy_process_group()
 
 
 def main():
@@ -271,6 +413,7 @@ def main():
     ap.add_argument("--no-mel", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the eager / grad_acc_step=4 / trainer-loop / DP-schedule legs")
     args = ap.parse_args()
 
     from tts_king_amd.config import default_config
@@ -369,6 +512,9 @@ def main():
         if not args.no_roofline:
             eager = make_enqueue(model, opt, cfg, loss_fn, reducer=None)
             rec["roofline"] = gemm_roofline(eager, batch)
+        if world == 1 and not args.no_extra:
+            rec.update(extra_train_legs(cfg, dev, B, L, steps=args.steps))
+            rec["dp_schedule_1gpu"] = dp1_leg(cfg, dev, B, L)
         if world == 1 and not args.no_hifi:
             try:
                 from tts_king_amd.hifi_bench import hifi_rtf

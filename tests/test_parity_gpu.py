@@ -96,6 +96,14 @@ def test_full_size_step_vs_oracle(cfg):
         print("  group %-42s |g| HIP %.5f oracle %.5f  (%.2f%%)" % (grp, a, w, 100 * err))
         if err > worst[0]:
             worst = (err, grp)
+    # whole gradient tensors at both ends of the backward chain (direction, not only size)
+    for k in ("postnet.convolutions.4.0.conv.weight", "mel_linear.weight", "decoder.layer_stack.5.pos_ffn.w_1.weight",
+              "decoder.layer_stack.0.slf_attn.w_qs.weight", "variance_adaptor.pitch_predictor.conv_layer.conv1d_1.conv.weight",
+              "variance_adaptor.energy_embedding.weight", "speaker_emb.weight", "encoder.layer_stack.3.pos_ffn.w_2.weight",
+              "encoder.layer_stack.0.slf_attn.fc.weight", "encoder.src_word_emb.weight"):
+        r = rel_rms(named[k].grad.float().cpu(), tr.sd[k].grad)
+        print("  grad %-64s rel-RMS vs oracle %.2f%%" % (k, 100 * r))
+        assert r <= 0.08, (k, r)
     gn, on = math.sqrt(gsq), math.sqrt(osq)
     assert abs(on - tr.grad_norm()) <= 1e-6 * on          # the groups cover every trainable key
     print("global grad norm HIP %.5f oracle %.5f; worst group %s" % (gn, on, worst))

@@ -6,7 +6,7 @@ if [ -n "$1" ]; then
   timeout 900 python -m pytest $1 -m gpu -q -x > $O/pytest_$TAG.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_$TAG.log
   grep -E "passed|failed" $O/pytest_$TAG.log | tail -3
 fi
-timeout 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-e2e --no-mel --no-hifi > $O/bench_$TAG.json 2> $O/bench_$TAG.err; echo "bench rc=$?"
+timeout 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-e2e --no-mel --no-hifi --no-extra > $O/bench_$TAG.json 2> $O/bench_$TAG.err; echo "bench rc=$?"
 python - <<PY
 import json
 try:
@@ -17,7 +17,7 @@ except Exception as e:
 PY
 cd /tmp
 rm -rf $O/prof_$TAG
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o fs2 -- /usr/bin/python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-mel --no-e2e --no-hifi > $O/prof_$TAG.log 2>&1; echo "rocprof rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o fs2 -- /usr/bin/python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-mel --no-e2e --no-hifi --no-extra > $O/prof_$TAG.log 2>&1; echo "rocprof rc=$?"
 T=$(find $O/prof_$TAG -name "*kernel_trace.csv" | head -1)
 python3 $R/tools/timeline.py $T > $O/timeline_$TAG.txt 2>&1; head -45 $O/timeline_$TAG.txt
 python3 $R/tools/timeline.py $T --full > $O/timeline_${TAG}_full.txt 2>&1

@@ -64,6 +64,32 @@ class _Ctx:
     pass
 
 
+class _GroupNotifier:
+    """backward_native's contract with a data-parallel reducer: `done(name)` is called when every gradient of parameter group
+    `name` has been ENQUEUED OR QUEUED; the queued part (grouped dW GEMMs, deferred reducers) must be flushed before the reducer
+    may all-reduce the bucket.  Flushing at every group would cut the step's single grouped weight-gradient launch into 13; the
+    notifier asks the reducer (`ready(name)`) whether a bucket actually completes with this group and only then flushes and
+    announces.  Groups must arrive in `order` (checked: a reordering of backward would silently break the overlap contract)."""
+
+    def __init__(self, order, on_bucket, flush):
+        self.order, self.on_bucket, self.flush = list(order), on_bucket, flush
+        self.ready = getattr(getattr(on_bucket, "__self__", None), "ready", None)
+        self.pos = 0
+        self.flushes = 0
+
+    def done(self, name):
+        if self.pos >= len(self.order) or self.order[self.pos] != name:
+            raise RuntimeError("backward announced group %r, expected %r" % (name, self.order[self.pos] if self.pos < len(self.order) else None))
+        self.pos += 1
+        if self.on_bucket is None:
+            return
+        if self.ready is not None and not self.ready(name):
+            return                      # no gradient bucket completes with this group: keep queueing
+        self.flush()
+        self.flushes += 1
+        self.on_bucket(name)
+
+
 class FastSpeech2(nn.Module):
     def __init__(self, preprocess_config, model_config, n_speakers=None, device=None, seed=1234):
         super().__init__()
@@ -751,6 +777,18 @@ class FastSpeech2(nn.Module):
             ops.conv1d_dw(dh1.view(Bn, Lp, Fh), x.view(Bn, Lp, d), self._g(c + "conv1d_1.conv.weight"), k=self.k_var, defer=self._deferred)
         return ops.conv1d_dx(dh1.view(Bn, Lp, Fh), self._w(c + "conv1d_1.conv.weight"), R=R)
 
+    def backward_group_order(self):
+        """The parameter groups in the order backward_native completes their gradients (= reverse forward order; the flat
+        gradient buffer is laid out in forward order, so everything at or above a finished group's offset is final)."""
+        return (["postnet", "mel_linear"] + ["decoder.%d" % i for i in range(self.n_dec - 1, -1, -1)] + ["variance_adaptor"] +
+                ["encoder.%d" % i for i in range(self.n_enc - 1, -1, -1)] + ["embedding"])
+
+    def _flush_param_grads(self):
+        """Run the queued weight-gradient work (grouped dW GEMMs, split-K reducers, column sums, scatter-sums)."""
+        self._join_side()
+        ops.flush_deferred(self._deferred)
+        ops.flush_finalize(self._deferred_fin)
+
     @staticmethod
     def _stack3(dlogd, dpitch, denergy):
         """(3, B, L) fp32 = (dlogd, dpitch, denergy).  ops.fs2_loss hands them out as the three slices of one buffer (no copy);
@@ -782,14 +820,8 @@ class FastSpeech2(nn.Module):
         self._deferred_fin = []
         if self.overlap_param_grads and self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
-        if on_bucket is not None:
-            def notify(name):
-                self._join_side()
-                ops.flush_deferred(self._deferred)
-                ops.flush_finalize(self._deferred_fin)
-                on_bucket(name)
-        else:
-            notify = lambda name: None
+        notifier = _GroupNotifier(self.backward_group_order(), on_bucket, self._flush_param_grads)
+        notify = notifier.done
         # ---- PostNet (last layer first)
         dout = dpost.view(rows, nm)
         for i in range(4, -1, -1):
@@ -846,7 +878,5 @@ class FastSpeech2(nn.Module):
         with self._side_work(dx):
             ops.scatter_sum(dx, ctx.texts.view(-1), self._g("encoder.src_word_emb.weight"), skip_row=0, defer=self._deferred_fin)   # padding_idx=0
         notify("embedding")
-        self._join_side()
-        ops.flush_deferred(self._deferred)
-        ops.flush_finalize(self._deferred_fin)
+        self._flush_param_grads()
         self._ctx = None

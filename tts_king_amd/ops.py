@@ -33,6 +33,7 @@ def _ptr(t):
 import os as _os
 # K steps one workgroup of a grouped weight-gradient launch walks (128x128 tile, 256x128 tile): more steps = fewer split-K slabs
 DW_STEPS_PER_WG = tuple(int(v) for v in _os.environ.get("TTSK_DW_STEPS", "28,72").split(","))
+LAUNCH_COUNTS = None   # bench.py sets this to a dict: grouped-GEMM / batched-reducer / column-sum launches issued by the flushes
 GEMM_TRACE = None   # bench.py sets this to a list: every ttsk_gemm launch is then bracketed by HIP events on its stream
 
 
@@ -85,6 +86,8 @@ def flush_group(descs, keep):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         check(lib.ttsk_gemm_group_launch(host, C.c_void_p(table.data_ptr()), _stream()), "ttsk_gemm_group_launch")
+        if LAUNCH_COUNTS is not None:
+            LAUNCH_COUNTS["grouped_gemm"] = LAUNCH_COUNTS.get("grouped_gemm", 0) + 1
         if GEMM_TRACE is not None:
             e1.record()
             fl = sum(2.0 * d.M * d.N * d.K * max(d.taps, 1) * d.nz1 * d.nz2 for d in ds)
@@ -107,6 +110,8 @@ def flush_deferred(items):
         return
     arr = (L.ReduceItem * len(items))(*[it for it, _ in items])
     check(L.load().ttsk_gemm_reduce_batch(arr, len(items), _stream()), "ttsk_gemm_reduce_batch")
+    if LAUNCH_COUNTS is not None:
+        LAUNCH_COUNTS["reduce_batch"] = LAUNCH_COUNTS.get("reduce_batch", 0) + 1
     items.clear()
     if group is not None:
         items._keep = []
@@ -485,6 +490,8 @@ def flush_finalize(items):
     finalisations (ttsk_scatter_sum_batch, ttsk_colsum_batch, ttsk_colsum_finalize_batch)."""
     if not items:
         return
+    if LAUNCH_COUNTS is not None:
+        LAUNCH_COUNTS["colsum_flush"] = LAUNCH_COUNTS.get("colsum_flush", 0) + 1
     sc = [it for it, _ in items if isinstance(it, L.ScatterItem)]
     if sc:
         check(L.load().ttsk_scatter_sum_batch((L.ScatterItem * len(sc))(*sc), len(sc), _stream()), "ttsk_scatter_sum_batch")

@@ -36,12 +36,13 @@ class GradReducer:
     `group_offsets`: name -> lowest flat offset of the parameter group whose completion `on_group_done(name)`
     announces (groups complete in reverse forward order, so everything at or above that offset is final)."""
 
-    def __init__(self, flat_grad, buckets, group_offsets, process_group=None):
+    def __init__(self, flat_grad, buckets, group_offsets, process_group=None, force_collectives=False):
         self.flat_grad = flat_grad
         self.buckets = list(buckets)
         self.group_offsets = dict(group_offsets)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.force = bool(force_collectives) and dist.is_initialized()    # issue the all-reduces even at world size 1 (bench: DP schedule cost)
         self._next = 0
         self._handles = []
         self.launched = []          # (start, end) in launch order, for tests / tracing
@@ -49,10 +50,15 @@ class GradReducer:
     def _launch_down_to(self, watermark):
         while self._next < len(self.buckets) and self.buckets[self._next][0] >= watermark:
             s, e = self.buckets[self._next]
-            if self.world > 1:
+            if self.world > 1 or self.force:
                 self._handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
             self.launched.append((s, e))
             self._next += 1
+
+    def ready(self, name):
+        """Would `on_group_done(name)` launch a bucket?  backward_native flushes its deferred weight-gradient work (one grouped
+        launch + reducers) only then: with 24 MB buckets 6 of the 13 group boundaries, instead of a flush at every one."""
+        return self._next < len(self.buckets) and self.buckets[self._next][0] >= self.group_offsets[name]
 
     def on_group_done(self, name):
         self._launch_down_to(self.group_offsets[name])

@@ -76,7 +76,8 @@ def main_train_step(model, batch, step, optimizer, cfg, Loss, reducer=None):
     Everything up to the final read of the loss values is enqueued without host synchronisation; `reducer`
     (tts_king_amd.parallel.GradReducer) all-reduces gradient buckets on a side stream while backward runs."""
     grad_acc_step = cfg.train_config["optimizer"]["grad_acc_step"]
-    model.train()
+    if not model.training:
+        model.train()
     dev = model.device
     with torch.no_grad():
         out, ctx = model._forward(True, batch[2].to(dev).long().contiguous(), batch[3].to(dev).long().contiguous(),

@@ -216,6 +216,22 @@ def pmc_traffic(symbol):
     return None
 
 
+def pmc_mfma_busy(symbol, section="fs2_train_step"):
+    """mfma_busy_frac of `symbol` from the newest committed profiles/r*_mfma_util.json (tools/pmc_mfma.sh: a separate rocprofv3 --pmc
+    pass over this bench command; counters cannot be read from inside the timed process).  None when there is no summary."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_mfma_util.json")), reverse=True):
+        try:
+            doc = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        for r in doc.get(section, []):
+            if symbol in r["kernel"] and r.get("mfma_busy_frac") is not None:
+                return {"mfma_busy_frac": r["mfma_busy_frac"], "source": os.path.relpath(f, here)}
+    return None
+
+
 def gemm_roofline(enqueue, batch, steps=3):
     """Roofline of the dominant kernel of the step.  Every ttsk_gemm launch of `steps` eager train steps is bracketed by
     HIP events on its launch stream (tts_king_amd/ops.py:GEMM_TRACE); launches are grouped by kernel symbol (tile
@@ -252,6 +268,8 @@ def gemm_roofline(enqueue, batch, steps=3):
     return {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_BF16_TFLOPS,
             "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
             "traffic_source": traffic["source"] if traffic else None,
+            "mfma_busy_frac": (pmc_mfma_busy(sym.get(dk, dk)) or {}).get("mfma_busy_frac"),
+            "mfma_busy_source": (pmc_mfma_busy(sym.get(dk, dk)) or {}).get("source"),
             "kernel": "%s (tts_king_amd/csrc/gemm%s.hip)" % (sym.get(dk, dk), "2" if "2" in dk else ""),
             "launches_per_step": dv[2] // steps, "avg_launch_us": 1e3 * dv[0] / dv[2], "avg_launch_gflop": dv[1] / dv[2] / 1e9,
             "kernel_ms_per_step": dv[0] / steps,

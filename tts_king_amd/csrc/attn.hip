@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs a) {
   const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
   const int q0 = blockIdx.x * TQ;
   const int S = a.S, ld = 3 * a.d;
-  const int len = a.lens ? (int)a.lens[b] : S;
+  const int len = a.lens ? min((int)a.lens[b], S) : S;     // (train-mode truncation: mel_len may exceed the S = 1000 rows kept)
   const bf16_t* base = a.qkv + (int64_t)b * S * ld + h * DK;
   const int ntile = (S + TK - 1) / TK;
   const int nblk = (ntile + KBLK - 1) / KBLK;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd1_kernel(const AttnArgs a) {
   const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
   const int q0 = blockIdx.x * TQ;
   const int S = a.S, ld = 3 * a.d;
-  const int len = a.lens ? (int)a.lens[b] : S;
+  const int len = a.lens ? min((int)a.lens[b], S) : S;     // (train-mode truncation: mel_len may exceed the S = 1000 rows kept)
   const bf16_t* base = a.qkv + (int64_t)b * S * ld + h * DK;
   const int ntile = (S + TK - 1) / TK;                 // <= KBLK
   unsigned char* Pw = Ps + wave * 16 * PS_RS;

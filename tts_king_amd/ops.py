@@ -165,6 +165,10 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=No
     d.splits, d.kernel, d.s_bias1 = splits, kernel, s_bias1
     user_splits, user_kernel = splits, kernel
     kernel, splits, ws_bytes = plan(d)
+    if kernel == 3 and group is not None:
+        # grouped launches exist for the 128x128 and 256x128 tiles only: plan again with the 128x128 tile
+        d.kernel, d.splits = 1, user_splits
+        kernel, splits, ws_bytes = plan(d)
     grouped_dw = (defer is not None and getattr(defer, "group", None) is not None and nz1 == 1 and (flags & C_F32)
                   and not (flags & ~(A_TR | B_TR | C_F32 | ACCUM_C)) and bias is None and A.dtype != f16)
     if grouped_dw and user_splits == 0 and user_kernel == 0:

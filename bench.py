@@ -69,7 +69,7 @@ def cpu_baseline(cfg, B, L, n_steps=5):
             "sample": "%d full train steps (dropout on) of the same B=%d, L=%d batch, fp32, %.2f s/step" % (n_steps, B, L, dt)}
 
 
-def hifi_cpu_baseline(cfg, B=8, T=384, runs=1):
+def hifi_cpu_baseline(cfg, B=8, T=384, runs=3):
     """The oracle (CPU fp32 restatement of the reference generator) timed on this box's host cores."""
     import os
     from oracle import hifigan as ohifi
@@ -82,13 +82,15 @@ def hifi_cpu_baseline(cfg, B=8, T=384, runs=1):
     mel = make_mel(B, T, seed=1234)
     with torch.no_grad():
         ohifi.generator(sd, cfg.hifi, mel[:1, :, :32])          # warm-up
-        t0 = time.perf_counter()
+        times = []
         for _ in range(runs):
+            t0 = time.perf_counter()
             ohifi.generator(sd, cfg.hifi, mel)
-        dt = (time.perf_counter() - t0) / runs
+            times.append(time.perf_counter() - t0)
+        dt = sorted(times)[len(times) // 2]                       # median
     audio_s = B * T * 256 / float(cfg.hifi.sampling_rate)
     return {"rtf": dt / audio_s, "seconds_per_batch": dt, "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d run(s) of the same B=%d, T=%d batch, fp32" % (runs, B, T)}
+            "sample": "median of %d runs of the same B=%d, T=%d batch, fp32" % (runs, B, T)}
 
 
 def mel_extraction_leg(cfg, dev, B=16, T=423, iters=20, with_cpu=True):
@@ -433,6 +435,12 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the eager / grad_acc_step=4 / trainer-loop / DP-schedule legs")
     args = ap.parse_args()
+    # ONE JSON line on stdout, nothing else: RCCL prints a version banner to the C-level stdout when a communicator is created
+    # (and flushes it at exit, i.e. AFTER the JSON line).  Everything the process or its libraries print goes to stderr; the
+    # record is written to the original stdout descriptor at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     from tts_king_amd.config import default_config
     from tts_king_amd.fastspeech2 import FastSpeech2
@@ -547,7 +555,8 @@ def main():
             rec["cpu_baseline"] = cpu_baseline(cfg, B, L)
             if rec.get("hifi_gan"):
                 rec["hifi_gan"]["cpu_baseline"] = hifi_cpu_baseline(cfg)
-        print(json.dumps(rec))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(rec) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -12,18 +12,18 @@
 // LDS-DMA into a 4-stage ring (see the comment at the kernel), XOR-swizzled 128-byte rows (conflict-free fragment reads),
 // one barrier per K step.  Epilogue: accumulators -> fp32 LDS tile -> one wave per row (4 columns per
 // lane, exactly ln_fwd_kernel's row code: same Philox indexing, so ln_bwd_kernel regenerates the same dropout mask).
+#include <cstdlib>
 #include "gemm_common.h"
 
 namespace {
 
-constexpr int BM = 32, BN = 256, BK = 64, NT = 256, NSTAGE = 4;
+constexpr int BM = 32, BN = 256, BK = 64, NSTAGE = 4;
 constexpr int A_BYTES = BM * BK * 2;              // 4 KiB  = 4 LDS-DMA pieces (one per wave)
 constexpr int B_BYTES = BN * BK * 2;              // 32 KiB = 32 pieces (eight per wave)
 constexpr int STAGE = A_BYTES + B_BYTES;          // 36 KiB
 constexpr int CS_LD = 260;                        // fp32 epilogue tile leading dimension
 constexpr int SMEM = NSTAGE * STAGE;              // 144 KiB ring (the epilogue tile 32 x 260 x 4 = 33,280 B reuses it)
 constexpr int OOB = 0x7FFFFFFF;
-constexpr int NQ = 9;                             // LDS-DMA pieces per wave per K tile
 
 struct GemmLnArgs {
   const bf16_t* A;        // [M][lda] bf16
@@ -57,7 +57,15 @@ __device__ __forceinline__ void drop4(float v[4], uint64_t seed, uint64_t step, 
 // version: two 36 KiB tiles in flight gave 1.7 us per K step = 21 GB/s).  So: LDS-DMA (buffer_load ... lds, no VGPR round
 // trip, swizzle applied to the SOURCE address) into a 4-stage ring with three tiles in flight, counted vmcnt, one raw
 // s_barrier per K step (the structure of gemm2.hip).  The residual rows are fetched into registers before the K loop.
-__global__ __launch_bounds__(NT, 1) void gemm_ln_kernel(const GemmLnArgs a) {
+// NW waves: wave w owns columns [256/NW * w, +256/NW) of all 32 rows and 32/NW of the workgroup's B pieces per K tile (waves 0-3 also
+// one A piece).  STAGGER: workgroup i starts its K walk at tile (i * 5) % nk and wraps — the workgroups all stream the SAME W, and
+// in lockstep they would all ask L2 for the same 32 KiB at the same time.
+template <int NW, bool STAGGER>
+__global__ __launch_bounds__(NW * 64, 1) void gemm_ln_kernel(const GemmLnArgs a) {
+  constexpr int WC = BN / NW;            // columns per wave: 64 / 32
+  constexpr int NJ = WC / 16;            // MFMA column tiles per wave: 4 / 2
+  constexpr int NBP = 32 / NW;           // B pieces per wave per K tile: 8 / 4
+  constexpr int RW = BM / NW;            // epilogue rows per wave: 8 / 4
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -70,37 +78,42 @@ __global__ __launch_bounds__(NT, 1) void gemm_ln_kernel(const GemmLnArgs a) {
   const int c = lane * 4;
 
   // ---- residual rows of this wave's eight epilogue rows: in flight during the whole K loop
-  uint2 resv[8];
+  uint2 resv[RW];
 #pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {
-    const int row = m0 + wave * 8 + rr;
+  for (int rr = 0; rr < RW; ++rr) {
+    const int row = m0 + wave * RW + rr;
     resv[rr] = (a.res && row < M) ? *(const uint2*)(a.res + (int64_t)row * BN + c) : make_uint2(0u, 0u);
   }
 
   // ---- LDS-DMA source coordinates.  A piece = 1 KiB of the LDS image = 8 tile rows x 128 B; lane -> tile row 8p + lane/8,
   // physical 16-byte chunk lane%8, which must hold logical chunk (lane%8) ^ (row & 7): the XOR swizzle of the fragment reads
   const int prow = lane >> 3, kch = ((lane & 7) ^ (lane >> 3)) * 8;     // row inside the piece, first k of this lane's 16 bytes
-  const int a_row = m0 + wave * 8 + prow;
+  const int a_row = m0 + (wave & 3) * 8 + prow;
   const int a_off = a_row < M ? (a_row * a.lda + kch) * 2 : OOB;
-  int w_off[8];
+  int w_off[NBP];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) w_off[i] = (((i * 4 + wave) * 8 + prow) * a.ldw + kch) * 2;
+  for (int i = 0; i < NBP; ++i) w_off[i] = (((i * NW + wave) * 8 + prow) * a.ldw + kch) * 2;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr)smem + wave * 1024);
+  const bool has_a = wave < 4;           // wave-uniform
+  const int kshift = STAGGER ? (int)((blockIdx.x * 5u) % (unsigned)nk) : 0;
 
+  // tile kt of THIS workgroup's walk is K tile (kt + kshift) % nk; it lives in ring stage kt % NSTAGE
   auto issue_tile = [&](int kt) __attribute__((always_inline)) {
     const unsigned st = lds0 + (kt % NSTAGE) * STAGE;
-    const int kbase = kt * BK;
+    int kk = kt + kshift;
+    if (kk >= nk) kk -= nk;
+    const int kbase = kk * BK;
     const bool kok = kbase + kch < K8;
-    dma16(rsA, st, (kok && a_off != OOB) ? a_off + kbase * 2 : OOB);
+    if (has_a) dma16(rsA, st, (kok && a_off != OOB) ? a_off + kbase * 2 : OOB);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma16(rsW, st + A_BYTES + i * 4096, kok ? w_off[i] + kbase * 2 : OOB);
+    for (int i = 0; i < NBP; ++i) dma16(rsW, st + A_BYTES + i * (NW * 1024), kok ? w_off[i] + kbase * 2 : OOB);
   };
 
-  f32x4 acc[2][4];
+  f32x4 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
   for (int t = 0; t < NSTAGE - 1; ++t)
@@ -109,30 +122,34 @@ __global__ __launch_bounds__(NT, 1) void gemm_ln_kernel(const GemmLnArgs a) {
   for (int kt = 0; kt < nk; ++kt) {
     // this wave's pieces of tile kt have landed when at most the pieces of the (up to two) younger tiles are outstanding
     const int younger = nk - 1 - kt;
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQ) : "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (younger >= 2) {
+      if (has_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NBP + 1)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NBP) : "memory");
+    } else if (younger == 1) {
+      if (has_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP) : "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // everybody's pieces of tile kt landed; everybody is done reading tile kt-1's stage
     if (kt + NSTAGE - 1 < nk) issue_tile(kt + NSTAGE - 1);      // refills the stage tile kt-1 occupied
     const unsigned char* sa = smem + (kt % NSTAGE) * STAGE;
     const unsigned char* sb = sa + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[2], bfr[4];
+      bf16x8 af[2], bfr[NJ];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = i * 16 + l15;
         af[i] = *(const bf16x8*)(sa + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = wave * 64 + j * 16 + l15;
+      for (int j = 0; j < NJ; ++j) {
+        const int row = wave * WC + j * 16 + l15;
         bfr[j] = *(const bf16x8*)(sb + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
   }
   __syncthreads();                         // the last stage has been read by every wave: the ring becomes the epilogue tile
@@ -142,9 +159,9 @@ __global__ __launch_bounds__(NT, 1) void gemm_ln_kernel(const GemmLnArgs a) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cs[(i * 16 + lg * 4 + r) * CS_LD + wave * 64 + j * 16 + l15] = acc[i][j][r];
+      for (int r = 0; r < 4; ++r) cs[(i * 16 + lg * 4 + r) * CS_LD + wave * WC + j * 16 + l15] = acc[i][j][r];
   __syncthreads();
 
   // one wave per row, 8 rows per wave, lane owns columns 4*lane .. 4*lane+3 (ln_fwd_kernel's row code)
@@ -153,11 +170,11 @@ __global__ __launch_bounds__(NT, 1) void gemm_ln_kernel(const GemmLnArgs a) {
   const f32x4 g = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
   const unsigned thr = keep_threshold(a.p_pre);
   const float scale = 1.f / (1.f - a.p_pre);
-  float z[8][4];
-  float s[8];
+  float z[RW][4];
+  float s[RW];
 #pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {
-    const int lr = wave * 8 + rr;
+  for (int rr = 0; rr < RW; ++rr) {
+    const int lr = wave * RW + rr;
     const int row = m0 + lr;
     const bool live = row < M;
     const f32x4 v = *(const f32x4*)(cs + lr * CS_LD + c);
@@ -172,10 +189,10 @@ __global__ __launch_bounds__(NT, 1) void gemm_ln_kernel(const GemmLnArgs a) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) s[rr] += __shfl_xor(s[rr], o, 64);
-  float q[8];
+    for (int rr = 0; rr < RW; ++rr) s[rr] += __shfl_xor(s[rr], o, 64);
+  float q[RW];
 #pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {
+  for (int rr = 0; rr < RW; ++rr) {
     s[rr] *= (1.f / BN);            // mean
     q[rr] = 0.f;
 #pragma unroll
@@ -184,10 +201,10 @@ __global__ __launch_bounds__(NT, 1) void gemm_ln_kernel(const GemmLnArgs a) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) q[rr] += __shfl_xor(q[rr], o, 64);
+    for (int rr = 0; rr < RW; ++rr) q[rr] += __shfl_xor(q[rr], o, 64);
 #pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {
-    const int row = m0 + wave * 8 + rr;
+  for (int rr = 0; rr < RW; ++rr) {
+    const int row = m0 + wave * RW + rr;
     if (row >= M) continue;
     const float mean = s[rr], rstd = rsqrtf(q[rr] * (1.f / BN) + a.eps);
     if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
@@ -216,7 +233,16 @@ extern "C" int ttsk_gemm_ln_fwd(const void* A, int lda, const void* W, int ldw, 
   TTSK_REQUIRE(!lens || (seg_len > 0 && M % seg_len == 0), "ttsk_gemm_ln_fwd: lens needs M %% seg_len == 0");
   GemmLnArgs a{(const bf16_t*)A, (const bf16_t*)W, bias, (const bf16_t*)res, gamma, beta, (bf16_t*)out, (bf16_t*)z_save, mean, rstd,
                (const long long*)lens, (const uint64_t*)rng, M, K, lda, ldw, seg_len > 0 ? seg_len : 1, p_pre, eps, site_pre};
-  hipLaunchKernelGGL(gemm_ln_kernel, dim3((M + BM - 1) / BM), dim3(NT), 0, (hipStream_t)stream, a);
+  static const int variant = [] { const char* e = getenv("TTSK_GEMM_LN_VARIANT"); return e ? atoi(e) : 3; }();   // tuning knob (tools/debug)
+  const dim3 grid((M + BM - 1) / BM);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL((gemm_ln_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 1: hipLaunchKernelGGL((gemm_ln_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL((gemm_ln_kernel<8, false>), grid, dim3(512), 0, (hipStream_t)stream, a); break;
+    case 4: hipLaunchKernelGGL((gemm_ln_kernel<16, false>), grid, dim3(1024), 0, (hipStream_t)stream, a); break;
+    case 5: hipLaunchKernelGGL((gemm_ln_kernel<16, true>), grid, dim3(1024), 0, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL((gemm_ln_kernel<8, true>), grid, dim3(512), 0, (hipStream_t)stream, a); break;
+  }
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

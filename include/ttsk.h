@@ -250,6 +250,20 @@ int ttsk_softmax_fwd(const float* scores, void* probs_bf16, const int64_t* lens,
 int ttsk_softmax_bwd(const void* probs_bf16, const float* dprobs, void* dscores_bf16, int nz, int S, int Sp, float alpha,
                      void* stream);
 
+/* ---------------------------------------------------------------------------- flash attention (d_k = 128), round 2
+ * The same math as ttsk_attention_fwd / _bwd_q below (reference: fs_two/transformer/Modules.py:14-24 + SubLayers.py:44-60)
+ * without any S x S tensor in HBM: the forward keeps a running row max / sum over 64-key tiles and returns O and, for the
+ * backward, lse [B*H][S] = log sum_k exp(score); the backward recomputes P = exp(score - lse) per tile.
+ * bwd: delta_ws [B*H][S] fp32 scratch; writes ALL of dqkv [B*S][3*d] (dQ | dK | dV, head h at columns h*128 of each part),
+ * two launches (query side: dQ; key side: dK, dV), no atomics.
+ * o_f32 [B*S][d] (may be NULL): O before its rounding to bf16.  The backward's delta = rowsum(dO o O) is what dP is cancelled
+ * against; taken from the bf16 O its 2^-9 error dominates small dQ / dK gradients, so a training forward keeps the fp32 copy. */
+int ttsk_flash_attention_fwd(const void* qkv_bf16, void* o_bf16, float* o_f32 /* may be NULL */, float* lse /* may be NULL */,
+                             const int64_t* lens, int B, int H, int S, int d, float scale, void* stream);
+int ttsk_flash_attention_bwd(const void* qkv_bf16, const void* o_bf16, const float* o_f32 /* may be NULL */, const void* dout_bf16,
+                             const float* lse, float* delta_ws, void* dqkv_bf16, const int64_t* lens, int B, int H, int S, int d,
+                             float scale, void* stream);
+
 /* ------------------------------------------------------------------------------------- fused attention (d_k = 128)
  * reference: fs_two/transformer/Modules.py:14-24 + SubLayers.py:44-60.  qkv is the fused projection output
  * [B*S][3*d] (q | k | v, head h = columns h*128.. of each part), o [B*S][d] has the heads merged back.
@@ -317,6 +331,12 @@ int ttsk_pack_conv_weight(const float* src, void* dst16, int f16, int d0, int d1
 int ttsk_hifi_conv_window_supported(int C, int K, int dil);
 int ttsk_hifi_conv_window(const void* x16, const void* w_pack, const float* bias, const void* R16, void* out16, void* out2_16,
                           int f16, int B, int len, int C, int K, int dil, int lrelu_out, float slope, void* stream);
+/* The (c1 dilated -> LeakyReLU -> c2 -> + x) pair of ResBlock1 (hifi/models.py:88-95) as ONE launch at C = 128: x is the raw block
+ * input, out = c2(lrelu(c1(lrelu(x)) + b1)) + b2 + x; lrelu(c1 ..) stays in LDS.  Bit-identical to two ttsk_hifi_conv_window
+ * launches, a third of their HBM traffic.  w*_pack as for ttsk_hifi_conv_window; out must not alias x. */
+int ttsk_hifi_conv_pair_supported(int C, int K, int dil);
+int ttsk_hifi_conv_pair(const void* x16, const void* w1_pack, const float* bias1, const void* w2_pack, const float* bias2, void* out16,
+                        int f16, int B, int len, int C, int K, int dil, float slope, void* stream);
 /* conv_post + tanh (hifi/models.py:198-199): x (B, len, C) 16-bit (already activated), w (1, k, C) tap-major 16-bit,
  * out (B, 1, len) fp32.  A streaming kernel: one output sample per thread. */
 int ttsk_hifi_conv_post(const void* x16, const void* w16, const float* bias, float* out, int f16, int B, int len, int C, int K,

@@ -116,7 +116,10 @@ def test_train_mode_losses_and_gradients(cfg):
     worst = (0.0, None)
     for k, want in gn.items():
         have = float(named[k].grad.norm())
-        err = abs(have - want) / (want + 0.02 * med)
+        # the key-projection bias has a TRUE gradient of zero (a constant added to every key's score cancels in the softmax): what
+        # the bf16 path leaves there is the rounding noise of dS (its rows sum to zero only before rounding) — bounded at 5 % of
+        # the median gradient norm instead of 2 %
+        err = abs(have - want) / (want + (0.05 if k.endswith("slf_attn.w_ks.bias") else 0.02) * med)
         if err > worst[0]:
             worst = (err, k, have, want)
     print("worst grad-norm error", worst)

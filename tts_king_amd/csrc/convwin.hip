@@ -9,6 +9,7 @@
 // 4x fewer fetched bytes per FLOP.  D[cout][frame] orientation, fragment layouts, padding and the weight pipeline are
 // those of resblock.hip.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -167,6 +168,323 @@ __global__ __launch_bounds__(CW_NT, 1) void conv_window_kernel(const CwArgs a) {
   }
 }
 
+// ---- second configuration: 192-frame tiles, four waves, two workgroups per CU.
+// The first one keeps the weights in LDS: every wave reads all 32 KiB of a tap (8 of its 10 fragment reads per MFMA group),
+// the eight waves meet at a barrier per tap, and with 157 KiB of LDS a CU holds one workgroup, so its window load and its
+// epilogue overlap nothing (measured: 24 us per launch + 5.5 us per tap against 3.2 us per tap of MFMA time).  Here a wave
+// owns 32 output channels and all 192 frames of the tile: its weights (8 KiB per tap, fragment-major, so one coalesced
+// 16-byte load per lane and fragment) go straight from L2 to registers two taps ahead, the tap loop has no barrier, LDS holds
+// the window alone (244 rows, 70 KiB) and a second workgroup on the CU computes while this one loads or stores.
+// LDS reads per MFMA: 0.5 (12 activation fragments per 24 MFMAs) against 0.625.
+constexpr int C2_H = 26, C2_NW = 4, C2_NT = C2_NW * 64;
+constexpr int C2_CT = CW_NC / C2_NW;                // 2 cout tiles per wave
+
+template <bool F16, int TT, int OCC>
+__global__ __launch_bounds__(C2_NT, OCC) void conv_window2_kernel(const CwArgs a) {
+  constexpr int C2_LROWS = TT + 2 * C2_H;           // 244 rows at TT = 192
+  constexpr int C2_SMEM = C2_LROWS * CW_RS;         // 70,272 B
+  constexpr int C = CW_C, H = C2_H, RS = CW_RS, NC = CW_NC, KS = CW_KS, NT = C2_NT, CH8 = C / 8, NF = TT / 16, CT = C2_CT;
+  __shared__ __attribute__((aligned(16))) unsigned char XW[C2_SMEM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int bi = blockIdx.y, t0 = blockIdx.x * TT;
+  const int len = a.len, K = a.K, d = a.dil;
+  const int HK = (K - 1) / 2;
+  const bf16_t* __restrict__ xb = a.x + (int64_t)bi * len * C;
+
+  // ---- this wave's weights of one tap: fragments (ks, cout tile wave*CT + cc)
+  bf16x8 wa[KS][CT], wb[KS][CT];
+  const unsigned char* wsrc = (const unsigned char*)a.w + (wave * CT) * 1024 + lane * 16;
+  auto load_w = [&](int g, bf16x8 (&w)[KS][CT]) __attribute__((always_inline)) {
+    const unsigned char* src = wsrc + (int64_t)g * CW_WTAP;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(src + (ks * NC + cc) * 1024);
+  };
+  load_w(0, wa);
+  if (K > 1) load_w(1, wb);
+
+  // ---- activation window, all loads in flight together
+  {
+    constexpr int NCH = (C2_LROWS * CH8 + NT - 1) / NT;     // 16
+    uint4 xv[NCH];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int idx = it * NT + tid;
+      const int row = idx / CH8, ch = idx - row * CH8;
+      const int t = t0 - H + row;
+      xv[it] = make_uint4(0, 0, 0, 0);
+      if (idx < C2_LROWS * CH8 && t >= 0 && t < len) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int idx = it * NT + tid;
+      const int row = idx / CH8, ch = idx - row * CH8;
+      if (idx < C2_LROWS * CH8) *(uint4*)(XW + row * RS + ch * 16) = xv[it];
+    }
+  }
+  f32x4 bv[CT];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc) bv[cc] = *(const f32x4*)(a.bias + (wave * CT + cc) * 16 + q * 4);
+  __syncthreads();
+
+  f32x4 acc[CT][NF];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+    for (int i = 0; i < NF; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned char* inl = XW + (l15 + H) * RS + q * 16;
+  auto tap = [&](int g, const bf16x8 (&w)[KS][CT]) __attribute__((always_inline)) {
+    const unsigned char* inp = inl + (g - HK) * d * RS;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc) acc[cc][i] = mfma16<F16>(w[ks][cc], Bf, acc[cc][i]);
+      }
+    }
+  };
+#pragma unroll 1
+  for (int g = 0; g < K; g += 2) {
+    tap(g, wa);
+    if (g + 2 < K) load_w(g + 2, wa);
+    if (g + 1 < K) {
+      tap(g + 1, wb);
+      if (g + 3 < K) load_w(g + 3, wb);
+    }
+  }
+  __syncthreads();          // every wave is done with the window: its rows become the output staging tile
+
+  const bf16_t* __restrict__ Rb = a.R ? a.R + (int64_t)bi * len * C : nullptr;
+#pragma unroll
+  for (int i = 0; i < NF; ++i) {
+    const int t = t0 + i * 16 + l15;
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc) {
+      const int co = (wave * CT + cc) * 16 + q * 4;
+      f32x4 v = acc[cc][i] + bv[cc];
+      if (Rb && t < len) {
+        const uint2 r = *(const uint2*)(Rb + (int64_t)t * C + co);
+        float r0, r1, r2, r3;
+        unpack2<F16>(r.x, r0, r1); unpack2<F16>(r.y, r2, r3);
+        v += f32x4{r0, r1, r2, r3};
+      }
+      if (a.lrelu_out) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * a.slope);
+      }
+      *(uint2*)(XW + (i * 16 + l15) * RS + co * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+    }
+  }
+  __syncthreads();
+  bf16_t* __restrict__ ob = a.out + (int64_t)bi * len * C;
+  bf16_t* __restrict__ ob2 = a.out2 ? a.out2 + (int64_t)bi * len * C : nullptr;
+  constexpr int NCO = TT * CH8 / NT;     // 12
+#pragma unroll
+  for (int it = 0; it < NCO; ++it) {
+    const int idx = it * NT + tid;
+    const int rr = idx / CH8, ch = idx - rr * CH8;
+    const int t = t0 + rr;
+    if (t >= len) continue;
+    const uint4 v = *(const uint4*)(XW + rr * RS + ch * 16);
+    *(uint4*)(ob + (int64_t)t * C + ch * 8) = v;
+    if (ob2) *(uint4*)(ob2 + (int64_t)t * C + ch * 8) = lrelu8<F16>(v, a.slope);
+  }
+}
+
+// ---- the (dilated conv -> LeakyReLU -> conv -> + x) pair of ResBlock1 in ONE kernel (hifi/models.py:88-95: xt = c1(lrelu(x));
+// xt = c2(lrelu(xt)); x = xt + x).  Measured on the single-conv kernels above: a launch takes (time of its HBM traffic) +
+// (time of its MFMAs) with no overlap between the two however the workgroups are sized or de-phased, and the pair moves
+// 300 MB (x_l in, t out; t in, x in, x' out, lrelu(x') out) for 100 MB of necessary traffic.  Here a workgroup keeps t on
+// chip: it loads x once for 96 + 2*33 frames (LeakyReLU applied on the way into LDS), computes c1 for 112 frames (the 96 of
+// the tile + the halo c2 needs: 7 frame tiles instead of 6, 8 % more MFMAs over the pair), writes lrelu(t) as fp16 rows of
+// a second LDS window (zero outside [0, len): c2's zero padding), runs c2 from there and adds the raw x it re-reads
+// from L2 in the epilogue.  Same fp16 roundings and the same accumulation order as the two-launch path: bit-identical.
+// Wave = 32 output channels x all frames, weights of both convs streamed L2 -> registers as one sequence of 2K taps.
+constexpr int CP_TT = 96, CP_TH = 8, CP_XH = CP_TH + 25;            // t-window starts 8 frames before the tile, x-window 33
+constexpr int CP_TROWS = CP_TT + 2 * CP_TH;                         // 112 = 7 frame tiles of c1 output
+constexpr int CP_XROWS = CP_TROWS + 50;                             // 162
+constexpr int CP_SMEM = (CP_XROWS + CP_TROWS) * CW_RS;              // 78,912 B: two workgroups per CU
+
+struct PairArgs {
+  const bf16_t* x;      // (B, len, C) 16-bit, raw block input
+  const bf16_t* w1;     // fragment-major packs [K][C/32][C/16][64][8]
+  const bf16_t* w2;
+  const float* b1;
+  const float* b2;
+  bf16_t* out;          // (B, len, C) = c2(lrelu(c1(lrelu(x)))) + x
+  int len, K, dil;
+  float slope;
+};
+
+template <bool F16>
+__global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
+  constexpr int C = CW_C, TT = CP_TT, RS = CW_RS, NC = CW_NC, KS = CW_KS, NT = C2_NT, CH8 = C / 8, CT = C2_CT;
+  constexpr int NF1 = CP_TROWS / 16, NF2 = TT / 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CP_SMEM];
+  unsigned char* XW = smem;
+  unsigned char* TW = smem + CP_XROWS * RS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int bi = blockIdx.y, t0 = blockIdx.x * TT;
+  const int len = a.len, K = a.K, d = a.dil;
+  const int HK = (K - 1) / 2;
+  const bf16_t* __restrict__ xb = a.x + (int64_t)bi * len * C;
+
+  bf16x8 wa[KS][CT], wb[KS][CT];
+  const int woff = (wave * CT) * 1024 + lane * 16;
+  auto load_w = [&](int g, bf16x8 (&w)[KS][CT]) __attribute__((always_inline)) {      // tap g of the 2K-tap sequence c1 | c2
+    const unsigned char* src = (const unsigned char*)(g < K ? a.w1 : a.w2) + (int64_t)(g < K ? g : g - K) * CW_WTAP + woff;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(src + (ks * NC + cc) * 1024);
+  };
+  load_w(0, wa);
+  load_w(1, wb);
+
+  {  // ---- x window: lrelu(x) rows t0 - 33 .. t0 + 129, zeros outside the utterance
+    constexpr int NCH = (CP_XROWS * CH8 + NT - 1) / NT;     // 11
+    uint4 xv[NCH];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int idx = it * NT + tid;
+      const int row = idx / CH8, ch = idx - row * CH8;
+      const int t = t0 - CP_XH + row;
+      xv[it] = make_uint4(0, 0, 0, 0);
+      if (idx < CP_XROWS * CH8 && t >= 0 && t < len) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int idx = it * NT + tid;
+      const int row = idx / CH8, ch = idx - row * CH8;
+      if (idx < CP_XROWS * CH8) *(uint4*)(XW + row * RS + ch * 16) = lrelu8<F16>(xv[it], a.slope);
+    }
+  }
+  f32x4 bv1[CT], bv2[CT];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc) {
+    bv1[cc] = *(const f32x4*)(a.b1 + (wave * CT + cc) * 16 + q * 4);
+    bv2[cc] = *(const f32x4*)(a.b2 + (wave * CT + cc) * 16 + q * 4);
+  }
+  __syncthreads();
+
+  // ---- c1 over the 112 frames of the t window
+  f32x4 acc[CT][NF1];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+    for (int i = 0; i < NF1; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const unsigned char* inl = XW + (l15 + CP_XH - CP_TH) * RS + q * 16;      // t-window row r <-> x-window row r + 25
+    auto tap1 = [&](int g, const bf16x8 (&w)[KS][CT]) __attribute__((always_inline)) {
+      const unsigned char* inp = inl + (g - HK) * d * RS;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NF1; ++i) {
+          const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
+#pragma unroll
+          for (int cc = 0; cc < CT; ++cc) acc[cc][i] = mfma16<F16>(w[ks][cc], Bf, acc[cc][i]);
+        }
+      }
+    };
+    // K is odd: taps 0 .. K-2 in pairs, then tap K-1 on set a (c2 starts on set b)
+#pragma unroll 1
+    for (int g = 0; g + 1 < K; g += 2) {
+      tap1(g, wa);
+      load_w(g + 2, wa);
+      tap1(g + 1, wb);
+      load_w(g + 3, wb);
+    }
+    tap1(K - 1, wa);
+    load_w(K + 1, wa);
+  }
+  // t = lrelu(c1 + b1) as fp16 rows of the t window; frames outside [0, len) are c2's zero padding
+#pragma unroll
+  for (int i = 0; i < NF1; ++i) {
+    const int t = t0 - CP_TH + i * 16 + l15;
+    const bool live = t >= 0 && t < len;
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc) {
+      f32x4 v = acc[cc][i] + bv1[cc];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = live ? fmaxf(v[e], v[e] * a.slope) : 0.f;
+      *(uint2*)(TW + (i * 16 + l15) * RS + ((wave * CT + cc) * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+    }
+  }
+  __syncthreads();
+
+  // ---- c2 (dilation 1) over the tile's 96 frames; sequence taps K .. 2K-1: tap K is on set b, K+1 on set a, ...
+  f32x4 acc2[CT][NF2];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+    for (int i = 0; i < NF2; ++i) acc2[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const unsigned char* inl = TW + (l15 + CP_TH) * RS + q * 16;
+    auto tap2 = [&](int g, const bf16x8 (&w)[KS][CT]) __attribute__((always_inline)) {
+      const unsigned char* inp = inl + (g - HK) * RS;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NF2; ++i) {
+          const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
+#pragma unroll
+          for (int cc = 0; cc < CT; ++cc) acc2[cc][i] = mfma16<F16>(w[ks][cc], Bf, acc2[cc][i]);
+        }
+      }
+    };
+#pragma unroll 1
+    for (int g = 0; g + 1 < K; g += 2) {
+      tap2(g, wb);
+      if (g + 2 < K) load_w(K + g + 2, wb);
+      tap2(g + 1, wa);
+      if (g + 3 < K) load_w(K + g + 3, wa);
+    }
+    tap2(K - 1, wb);
+  }
+
+  // ---- epilogue: + b2 + raw x (re-read: the lines are in L2), staged through the x window (dead since the barrier above)
+#pragma unroll
+  for (int i = 0; i < NF2; ++i) {
+    const int t = t0 + i * 16 + l15;
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc) {
+      const int co = (wave * CT + cc) * 16 + q * 4;
+      f32x4 v = acc2[cc][i] + bv2[cc];
+      if (t < len) {
+        const uint2 r = *(const uint2*)(xb + (int64_t)t * C + co);
+        float r0, r1, r2, r3;
+        unpack2<F16>(r.x, r0, r1); unpack2<F16>(r.y, r2, r3);
+        v += f32x4{r0, r1, r2, r3};
+      }
+      *(uint2*)(XW + (i * 16 + l15) * RS + co * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+    }
+  }
+  __syncthreads();
+  bf16_t* __restrict__ ob = a.out + (int64_t)bi * len * C;
+  constexpr int NCO = TT * CH8 / NT;     // 6
+#pragma unroll
+  for (int it = 0; it < NCO; ++it) {
+    const int idx = it * NT + tid;
+    const int rr = idx / CH8, ch = idx - rr * CH8;
+    const int t = t0 + rr;
+    if (t < len) *(uint4*)(ob + (int64_t)t * C + ch * 8) = *(const uint4*)(XW + rr * RS + ch * 16);
+  }
+}
+
+int convwin_variant() {
+  static const int v = [] { const char* e = getenv("TTSK_CONVWIN_VARIANT"); return e ? atoi(e) : 2; }();
+  return v;
+}
+
 }  // namespace
 
 extern "C" int ttsk_hifi_conv_window_supported(int C, int K, int dil) {
@@ -182,9 +500,43 @@ extern "C" int ttsk_hifi_conv_window(const void* x16, const void* w_pack, const 
   TTSK_REQUIRE(((((uintptr_t)x16) | ((uintptr_t)w_pack) | ((uintptr_t)bias) | ((uintptr_t)out16) | ((uintptr_t)R16) | ((uintptr_t)out2_16)) & 15) == 0,
                "ttsk_hifi_conv_window: 16-byte alignment");
   CwArgs a{(const bf16_t*)x16, (const bf16_t*)w_pack, bias, (const bf16_t*)R16, (bf16_t*)out16, (bf16_t*)out2_16, len, K, dil, lrelu_out, slope};
-  dim3 grid((len + CW_TT - 1) / CW_TT, B);
-  if (f16) hipLaunchKernelGGL(conv_window_kernel<true>, grid, dim3(CW_NT), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(conv_window_kernel<false>, grid, dim3(CW_NT), 0, (hipStream_t)stream, a);
+  const int variant = convwin_variant();
+  if (variant >= 2 && dil * ((K - 1) / 2) <= C2_H) {
+#define TTSK_CW2(TT, OCC)                                                                                              \
+  do {                                                                                                                  \
+    dim3 grid((len + TT - 1) / TT, B);                                                                                  \
+    if (f16) hipLaunchKernelGGL((conv_window2_kernel<true, TT, OCC>), grid, dim3(C2_NT), 0, (hipStream_t)stream, a);    \
+    else hipLaunchKernelGGL((conv_window2_kernel<false, TT, OCC>), grid, dim3(C2_NT), 0, (hipStream_t)stream, a);       \
+  } while (0)
+    if (variant == 3) TTSK_CW2(128, 3);
+    else if (variant == 4) TTSK_CW2(96, 3);
+    else if (variant == 5) TTSK_CW2(128, 2);
+    else TTSK_CW2(192, 2);
+#undef TTSK_CW2
+  } else {
+    dim3 grid((len + CW_TT - 1) / CW_TT, B);
+    if (f16) hipLaunchKernelGGL(conv_window_kernel<true>, grid, dim3(CW_NT), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_window_kernel<false>, grid, dim3(CW_NT), 0, (hipStream_t)stream, a);
+  }
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_hifi_conv_pair_supported(int C, int K, int dil) {
+  return C == CW_C && K >= 3 && K <= 11 && (K & 1) == 1 && dil >= 1 && dil * ((K - 1) / 2) <= CP_XH - CP_TH && (K - 1) / 2 <= CP_TH;
+}
+
+extern "C" int ttsk_hifi_conv_pair(const void* x16, const void* w1_pack, const float* bias1, const void* w2_pack, const float* bias2,
+                                   void* out16, int f16, int B, int len, int C, int K, int dil, float slope, void* stream) {
+  TTSK_REQUIRE(x16 && w1_pack && bias1 && w2_pack && bias2 && out16, "ttsk_hifi_conv_pair: null pointer");
+  TTSK_REQUIRE(B > 0 && len > 0 && B <= 65535 && x16 != out16, "ttsk_hifi_conv_pair: bad sizes / in-place output");
+  TTSK_REQUIRE(ttsk_hifi_conv_pair_supported(C, K, dil), "ttsk_hifi_conv_pair: no instance for C=%d K=%d dil=%d", C, K, dil);
+  TTSK_REQUIRE(((((uintptr_t)x16) | ((uintptr_t)w1_pack) | ((uintptr_t)w2_pack) | ((uintptr_t)bias1) | ((uintptr_t)bias2) | ((uintptr_t)out16)) & 15) == 0,
+               "ttsk_hifi_conv_pair: 16-byte alignment");
+  PairArgs a{(const bf16_t*)x16, (const bf16_t*)w1_pack, (const bf16_t*)w2_pack, bias1, bias2, (bf16_t*)out16, len, K, dil, slope};
+  dim3 grid((len + CP_TT - 1) / CP_TT, B);
+  if (f16) hipLaunchKernelGGL(conv_pair_kernel<true>, grid, dim3(C2_NT), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(conv_pair_kernel<false>, grid, dim3(C2_NT), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -134,6 +134,7 @@ class FastSpeech2(nn.Module):
         self._deferred_fin = None       # gradient column-sum partials awaiting the batched finalize
         self._side = None               # second HIP stream for parameter-gradient work (see _SideWork)
         self.fused_attention = True     # one kernel for scores + softmax + P.V (and dP + softmax' + dQ) when d_k = 128
+        self.flash_attention = True     # ... and without the S x S tensors: online softmax forward, recomputing backward (d_k = 128)
         self.fused_ln = True            # fc / w_2 + dropout + residual + LayerNorm + PAD zeroing in one kernel when d = 256
         self.group_predictors = True    # training with targets: the three VariancePredictors run as grouped launches
         self.raw_slabs = True           # dX GEMMs that feed a LayerNorm backward leave their split-K tiles for it to sum
@@ -342,7 +343,11 @@ class FastSpeech2(nn.Module):
         dev = x.device
         # (1) q|k|v projections as one GEMM into a [rows][3d] buffer: SubLayers.py:41-43
         qkv = ops.linear(x, self._w(a + "w_qs.weight", 3 * d), self._m(a + "w_qs.bias", 3 * d))
-        if self.fused_attention and dk == 128:
+        if self.flash_attention and dk == 128:
+            # (2)-(4) one kernel, no S x S tensor: scores, key-padding mask, online softmax, P V, heads merged (Modules.py:15-22,
+            # SubLayers.py:57-60); the backward recomputes P from the per-row log-sum-exp kept in `probs`'s slot
+            o, probs, o32 = ops.flash_attention_fwd(qkv, lens, Bn, H, S, want_lse=ctx_list is not None)
+        elif self.fused_attention and dk == 128:
             # (2)-(4) one kernel: scores, key-padding mask, softmax, P V, heads merged (Modules.py:15-22, SubLayers.py:57-60)
             o, probs, o32 = ops.attention_fwd(qkv, lens, Bn, H, S, want_probs=ctx_list is not None)
         else:
@@ -699,7 +704,8 @@ class FastSpeech2(nn.Module):
         (pre, x, qkv, probs, o, z1, mean1, rstd1, x1, h, z2, mean2, rstd2, Bn, S, lens, H, p, site, o32) = saved
         d, rows = self.d, Bn * S
         dk = d // H
-        Sp = probs.shape[2]
+        flash = probs is not None and probs.dim() == 2       # forward was the flash kernel: `probs` holds the row LSE
+        Sp = 0 if flash else probs.shape[2]
         a, f = pre + "slf_attn.", pre + "pos_ffn."
         dev = z2.device
         # ---- FFN tail: LN backward (PAD rows carry no gradient), dropout mask regenerated
@@ -732,22 +738,25 @@ class FastSpeech2(nn.Module):
             ops.linear_dw(dy1, o, self._g(a + "fc.weight"), defer=self._deferred)
         do = ops.linear_dx(dy1, self._w(a + "fc.weight"))
         # ---- attention core: dP = dO V^T ; dS = softmax'(P, dP)/sqrt(dk) ; dQ = dS K ; dK = dS^T Q ; dV = P^T dO
-        dqkv = torch.empty(rows, 3 * d, dtype=bf16, device=dev)
-        if self.fused_attention and dk == 128:
-            dS = ops.attention_bwd_q(qkv, o32, do, probs, dqkv, Bn, H, S)       # dP, softmax backward and dQ in one kernel
+        if flash:
+            dqkv = ops.flash_attention_bwd(qkv, o, do, probs, lens, Bn, H, S, o32=o32)      # P recomputed per tile; dQ, dK, dV in two launches
         else:
-            dP = torch.empty(Bn * H, S, Sp, dtype=torch.float32, device=dev)
-            ops.gemm(do, qkv[:, 2 * d:], dP, S, S, dk, d, 3 * d, Sp, nz1=Bn, nz2=H, sA=(S * d, dk), sB=(S * 3 * d, dk),
-                     sC=(H * S * Sp, S * Sp))
-            dS = ops.softmax_bwd(probs, dP, dk ** -0.5)
-            ops.gemm(dS, qkv[:, d:], dqkv, S, dk, S, Sp, 3 * d, 3 * d, flags=ops.B_TR, nz1=Bn, nz2=H,
-                     sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * 3 * d, dk))
-        kv = ops.GemmGroup()         # dK and dV are independent: one grouped launch
-        ops.gemm(dS, qkv, dqkv[:, d:], S, dk, S, Sp, 3 * d, 3 * d, flags=ops.A_TR | ops.B_TR, nz1=Bn, nz2=H,
-                 sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * 3 * d, dk), group=kv)
-        ops.gemm(probs, do, dqkv[:, 2 * d:], S, dk, S, Sp, d, 3 * d, flags=ops.A_TR | ops.B_TR, nz1=Bn, nz2=H,
-                 sA=(H * S * Sp, S * Sp), sB=(S * d, dk), sC=(S * 3 * d, dk), group=kv)
-        kv.flush()
+            dqkv = torch.empty(rows, 3 * d, dtype=bf16, device=dev)
+            if self.fused_attention and dk == 128:
+                dS = ops.attention_bwd_q(qkv, o32, do, probs, dqkv, Bn, H, S)       # dP, softmax backward and dQ in one kernel
+            else:
+                dP = torch.empty(Bn * H, S, Sp, dtype=torch.float32, device=dev)
+                ops.gemm(do, qkv[:, 2 * d:], dP, S, S, dk, d, 3 * d, Sp, nz1=Bn, nz2=H, sA=(S * d, dk), sB=(S * 3 * d, dk),
+                         sC=(H * S * Sp, S * Sp))
+                dS = ops.softmax_bwd(probs, dP, dk ** -0.5)
+                ops.gemm(dS, qkv[:, d:], dqkv, S, dk, S, Sp, 3 * d, 3 * d, flags=ops.B_TR, nz1=Bn, nz2=H,
+                         sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * 3 * d, dk))
+            kv = ops.GemmGroup()         # dK and dV are independent: one grouped launch
+            ops.gemm(dS, qkv, dqkv[:, d:], S, dk, S, Sp, 3 * d, 3 * d, flags=ops.A_TR | ops.B_TR, nz1=Bn, nz2=H,
+                     sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * 3 * d, dk), group=kv)
+            ops.gemm(probs, do, dqkv[:, 2 * d:], S, dk, S, Sp, d, 3 * d, flags=ops.A_TR | ops.B_TR, nz1=Bn, nz2=H,
+                     sA=(H * S * Sp, S * Sp), sB=(S * d, dk), sC=(S * 3 * d, dk), group=kv)
+            kv.flush()
         # ---- q|k|v projections
         with self._side_work(dqkv, x):
             ops.colsum_into(dqkv, self._g(a + "w_qs.bias", 3 * d), defer=self._deferred_fin)

@@ -96,6 +96,7 @@ class Generator(nn.Module):
         self._packed_key = None
         self.act_dtype = f16         # storage type of activations and packed weights (fp32 accumulate); bf16 also works
         self.window_conv = True      # window-conv kernel at the C = 128 stage; False = implicit-GEMM convs
+        self.conv_pair = True        # ... with each (c1, c2) pair of a ResBlock1 as one launch (ttsk_hifi_conv_pair)
         self.fused = True            # fused ResBlock1 kernel where an instance exists (C in {32,64}); False = conv-by-conv
         self.stream_upsample = True  # stride-2 upsamplers (128->64, 64->32) on the streaming kernel; False = polyphase implicit GEMMs
         self.group_resblocks = True  # conv m of the three MRF ResBlocks as one grouped launch where they run conv by conv (C = 256)
@@ -166,9 +167,17 @@ class Generator(nn.Module):
         x = block input, xl = lrelu(x).  Every LeakyReLU is applied by the PRODUCING conv's epilogue (LRELU_OUT, or a
         second output C2 = lrelu(v) next to the raw v the residual path needs), the residual add is an epilogue too."""
         nd = len(rb.dilation)
+        pair = rb.kind == "1" and wpacks is not None and self.window_conv and self.conv_pair and \
+            all(ops.hifi_conv_pair_supported(x.shape[2], rb.k, d) for d in rb.dilation)
+        if xl is None and not pair:
+            raise ValueError("_resblock: lrelu(x) is needed unless every dilation runs on the pair kernel")
         for m, d in enumerate(rb.dilation):
             lastp = m == nd - 1
-            xl_next = None if lastp else torch.empty_like(x)
+            xl_next = None if lastp or pair else torch.empty_like(x)
+            if pair:
+                # C = 128: the c1 -> lrelu -> c2 -> + x pair as one launch (lrelu(c1) never leaves the CU); takes the raw x
+                x = ops.hifi_conv_pair(x, wpacks[m], packed[m][1], wpacks[nd + m], packed[nd + m][1], rb.k, d, slope=LRELU_SLOPE)
+                continue
             if rb.kind == "1" and wpacks is not None and self.window_conv:
                 # C = 128: one window-conv launch per conv (activation window in LDS, weights streamed)
                 tl = ops.hifi_conv_window(xl, wpacks[m], packed[m][1], rb.k, d, lrelu_out=True, slope=LRELU_SLOPE)
@@ -239,10 +248,15 @@ class Generator(nn.Module):
                                            scale=1.0 / nk, slope=LRELU_SLOPE, final_slope=nxt_slope if lastb else 1.0)
                     al = out
                     continue
-                axl = torch.empty(al.shape[0], al.shape[1] * u, wu.shape[1], dtype=al.dtype, device=al.device)
-                a = ops.conv_transpose1d(al, wu, bu, u, k, C2=axl, flags=ops.C2_LRELU, out_slope=LRELU_SLOPE)   # x and lrelu(x)
+                windowed = self.window_conv and all(pk["rbw"][i * nk + j] is not None for j in range(nk))
+                if windowed and self.conv_pair and all(ops.hifi_conv_pair_supported(wu.shape[1], rb.k, dd) for rb in rbs for dd in rb.dilation):
+                    axl = None                                                             # the pair kernels activate x themselves
+                    a = ops.conv_transpose1d(al, wu, bu, u, k)
+                else:
+                    axl = torch.empty(al.shape[0], al.shape[1] * u, wu.shape[1], dtype=al.dtype, device=al.device)
+                    a = ops.conv_transpose1d(al, wu, bu, u, k, C2=axl, flags=ops.C2_LRELU, out_slope=LRELU_SLOPE)   # x and lrelu(x)
                 if self.group_resblocks and all(rb.kind == "1" for rb in rbs) and len({len(rb.dilation) for rb in rbs}) == 1 and \
-                        not (self.window_conv and all(pk["rbw"][i * nk + j] is not None for j in range(nk))):
+                        not windowed:
                     outs = self._resblocks_lockstep(rbs, [pk["rb"][i * nk + j] for j in range(nk)], a, axl)
                 else:
                     outs = [self._resblock(rb, pk["rb"][i * nk + j], a, axl, pk["rbw"][i * nk + j]) for j, rb in enumerate(rbs)]

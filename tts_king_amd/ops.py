@@ -550,6 +550,30 @@ def attention_bwd_q(qkv, o32, do, probs, dqkv, Bn, H, S):
     return ds
 
 
+def flash_attention_fwd(qkv, lens, Bn, H, S, want_lse):
+    """softmax(Q K^T / sqrt(128) + key mask) V on the q|k|v buffer (rows, 3d) -> (o (rows, d) bf16, lse (B*H, S) fp32 or None,
+    o32 (rows, d) fp32 or None) with no S x S tensor in HBM (ttsk_flash_attention_fwd); lse and o32 are what the backward needs."""
+    _dev(qkv, lens)
+    d = qkv.shape[1] // 3
+    o = torch.empty(Bn * S, d, dtype=bf16, device=qkv.device)
+    lse = _f32(Bn * H, S, device=qkv.device) if want_lse else None
+    o32 = _f32(Bn * S, d, device=qkv.device) if want_lse else None
+    check(L.load().ttsk_flash_attention_fwd(_ptr(qkv), _ptr(o), _ptr(o32), _ptr(lse), _ptr(lens), Bn, H, S, d, (d // H) ** -0.5, _stream()),
+          "ttsk_flash_attention_fwd")
+    return o, lse, o32
+
+
+def flash_attention_bwd(qkv, o, do, lse, lens, Bn, H, S, o32=None):
+    """dqkv (rows, 3d) bf16 = gradients of q | k | v (ttsk_flash_attention_bwd: two launches, P recomputed from lse)."""
+    _dev(qkv, o, do, lse, lens, o32)
+    d = qkv.shape[1] // 3
+    dqkv = torch.empty(Bn * S, 3 * d, dtype=bf16, device=qkv.device)
+    delta = _f32(Bn * H, S, device=qkv.device)
+    check(L.load().ttsk_flash_attention_bwd(_ptr(qkv), _ptr(o), _ptr(o32), _ptr(do), _ptr(lse), _ptr(delta), _ptr(dqkv), _ptr(lens), Bn, H, S,
+                                            d, (d // H) ** -0.5, _stream()), "ttsk_flash_attention_bwd")
+    return dqkv
+
+
 def softmax_fwd(scores, lens, H):
     """scores (nz,S,Sp) fp32 -> probs (nz,S,Sp) bf16; keys >= lens[z // H] masked."""
     _dev(scores, lens)
@@ -872,6 +896,20 @@ def hifi_conv_post(x, w, bias):
 
 def hifi_conv_window_supported(Cn, K, dil):
     return bool(L.load().ttsk_hifi_conv_window_supported(Cn, K, dil))
+
+
+def hifi_conv_pair_supported(Cn, K, dil):
+    return bool(L.load().ttsk_hifi_conv_pair_supported(Cn, K, dil))
+
+
+def hifi_conv_pair(x, w1_pack, bias1, w2_pack, bias2, K, dilation, slope=0.1):
+    """c2(lrelu(c1_{K,dil}(lrelu(x)) + b1)) + b2 + x in one launch (C = 128; hifi/models.py:88-95, one dilation of ResBlock1)."""
+    _dev(x, w1_pack, bias1, w2_pack, bias2)
+    Bn, ln, Cn = x.shape
+    out = torch.empty_like(x)
+    check(L.load().ttsk_hifi_conv_pair(_ptr(x), _ptr(w1_pack), _ptr(bias1), _ptr(w2_pack), _ptr(bias2), _ptr(out), int(x.dtype == f16), Bn,
+                                       ln, Cn, K, dilation, slope, _stream()), "ttsk_hifi_conv_pair")
+    return out
 
 
 def hifi_conv_window(x, w_pack, bias, K, dilation=1, R=None, out2=None, lrelu_out=False, slope=0.1):

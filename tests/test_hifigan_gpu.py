@@ -235,6 +235,18 @@ def test_conv_pair_equals_two_window_convs(K, dil, B, ln, dt):
     err = float((got.double().cpu() - ref).abs().max())
     eps = 2.0 ** (-10 if dt == torch.float16 else -7)
     assert err <= 4 * eps * float(ref.abs().max()), (err, float(ref.abs().max()))
+    # the MRF average folded into the epilogue (modes 1-3): y*scale, += y*scale, lrelu(out + y*scale) — exact in the 16-bit type's
+    # rounding of the fp32 value.  The fp32 y is not observable, so the check recomputes from the fp64 reference within one ulp.
+    acc = ops.hifi_conv_pair(x, p1, b1, p2, b2, K, dil, mode=1, scale=1.0 / 3.0)
+    assert float((acc.double().cpu() - ref / 3).abs().max()) <= 2 * eps * float(ref.abs().max())
+    prev = acc.clone()
+    ops.hifi_conv_pair(x, p1, b1, p2, b2, K, dil, out=acc, mode=2, scale=1.0 / 3.0)
+    assert float((acc.double().cpu() - (prev.double().cpu() + ref / 3)).abs().max()) <= 2 * eps * float(ref.abs().max())
+    prev = acc.clone()
+    ops.hifi_conv_pair(x, p1, b1, p2, b2, K, dil, out=acc, mode=3, scale=1.0 / 3.0, final_slope=0.01)
+    want3 = prev.double().cpu() + ref / 3
+    want3 = torch.where(want3 > 0, want3, 0.01 * want3)
+    assert float((acc.double().cpu() - want3).abs().max()) <= 2 * eps * float(ref.abs().max())
 
 
 def test_conv_pair_and_window_generators_agree(cfg):

@@ -317,9 +317,13 @@ struct PairArgs {
   const bf16_t* w2;
   const float* b1;
   const float* b2;
-  bf16_t* out;          // (B, len, C) = c2(lrelu(c1(lrelu(x)))) + x
+  bf16_t* out;          // (B, len, C): y = c2(lrelu(c1(lrelu(x)))) + x, stored per `mode`
   int len, K, dil;
   float slope;
+  // MRF average folded into the last pair of each ResBlock (hifi/models.py:190-197: xs = sum_j resblock_j(x); x = xs / 3, then the
+  // consumer's leaky_relu), as in resblock.hip:  0: out = y   1: out = y*scale   2: out += y*scale   3: out = lrelu(out + y*scale, final_slope)
+  int mode;
+  float scale, final_slope;
 };
 
 template <bool F16>
@@ -465,6 +469,19 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
         unpack2<F16>(r.x, r0, r1); unpack2<F16>(r.y, r2, r3);
         v += f32x4{r0, r1, r2, r3};
       }
+      if (a.mode) {
+        v *= a.scale;
+        if (a.mode >= 2 && t < len) {
+          const uint2 o = *(const uint2*)(a.out + ((int64_t)bi * len + t) * C + co);
+          float o0, o1, o2, o3;
+          unpack2<F16>(o.x, o0, o1); unpack2<F16>(o.y, o2, o3);
+          v += f32x4{o0, o1, o2, o3};
+        }
+        if (a.mode == 3) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * a.final_slope);
+        }
+      }
       *(uint2*)(XW + (i * 16 + l15) * RS + co * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
     }
   }
@@ -527,13 +544,16 @@ extern "C" int ttsk_hifi_conv_pair_supported(int C, int K, int dil) {
 }
 
 extern "C" int ttsk_hifi_conv_pair(const void* x16, const void* w1_pack, const float* bias1, const void* w2_pack, const float* bias2,
-                                   void* out16, int f16, int B, int len, int C, int K, int dil, float slope, void* stream) {
+                                   void* out16, int f16, int B, int len, int C, int K, int dil, float slope, int mode, float scale,
+                                   float final_slope, void* stream) {
   TTSK_REQUIRE(x16 && w1_pack && bias1 && w2_pack && bias2 && out16, "ttsk_hifi_conv_pair: null pointer");
   TTSK_REQUIRE(B > 0 && len > 0 && B <= 65535 && x16 != out16, "ttsk_hifi_conv_pair: bad sizes / in-place output");
   TTSK_REQUIRE(ttsk_hifi_conv_pair_supported(C, K, dil), "ttsk_hifi_conv_pair: no instance for C=%d K=%d dil=%d", C, K, dil);
+  TTSK_REQUIRE(mode >= 0 && mode <= 3 && (final_slope > 0.f || mode != 3), "ttsk_hifi_conv_pair: bad mode / final_slope");
   TTSK_REQUIRE(((((uintptr_t)x16) | ((uintptr_t)w1_pack) | ((uintptr_t)w2_pack) | ((uintptr_t)bias1) | ((uintptr_t)bias2) | ((uintptr_t)out16)) & 15) == 0,
                "ttsk_hifi_conv_pair: 16-byte alignment");
-  PairArgs a{(const bf16_t*)x16, (const bf16_t*)w1_pack, (const bf16_t*)w2_pack, bias1, bias2, (bf16_t*)out16, len, K, dil, slope};
+  PairArgs a{(const bf16_t*)x16, (const bf16_t*)w1_pack, (const bf16_t*)w2_pack, bias1, bias2, (bf16_t*)out16, len, K, dil, slope,
+             mode, scale, final_slope};
   dim3 grid((len + CP_TT - 1) / CP_TT, B);
   if (f16) hipLaunchKernelGGL(conv_pair_kernel<true>, grid, dim3(C2_NT), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(conv_pair_kernel<false>, grid, dim3(C2_NT), 0, (hipStream_t)stream, a);

@@ -162,21 +162,22 @@ class Generator(nn.Module):
         return pk
 
     # ------------------------------------------------------------------ forward
-    def _resblock(self, rb, packed, x, xl, wpacks=None):
+    def _resblock(self, rb, packed, x, xl, wpacks=None, acc=None):
         """reference: hifi/models.py:88-95 (ResBlock1) / :136-140 (ResBlock2), conv by conv on the implicit-GEMM kernel.
         x = block input, xl = lrelu(x).  Every LeakyReLU is applied by the PRODUCING conv's epilogue (LRELU_OUT, or a
         second output C2 = lrelu(v) next to the raw v the residual path needs), the residual add is an epilogue too."""
         nd = len(rb.dilation)
         pair = rb.kind == "1" and wpacks is not None and self.window_conv and self.conv_pair and \
             all(ops.hifi_conv_pair_supported(x.shape[2], rb.k, d) for d in rb.dilation)
-        if xl is None and not pair:
-            raise ValueError("_resblock: lrelu(x) is needed unless every dilation runs on the pair kernel")
+        if (xl is None or acc is not None) and not pair:
+            raise ValueError("_resblock: lrelu(x) is needed, and the MRF average cannot be folded, unless every dilation runs on the pair kernel")
         for m, d in enumerate(rb.dilation):
             lastp = m == nd - 1
             xl_next = None if lastp or pair else torch.empty_like(x)
             if pair:
                 # C = 128: the c1 -> lrelu -> c2 -> + x pair as one launch (lrelu(c1) never leaves the CU); takes the raw x
-                x = ops.hifi_conv_pair(x, wpacks[m], packed[m][1], wpacks[nd + m], packed[nd + m][1], rb.k, d, slope=LRELU_SLOPE)
+                kw = dict(out=acc[0], mode=acc[1], scale=acc[2], final_slope=acc[3]) if (acc is not None and lastp) else {}
+                x = ops.hifi_conv_pair(x, wpacks[m], packed[m][1], wpacks[nd + m], packed[nd + m][1], rb.k, d, slope=LRELU_SLOPE, **kw)
                 continue
             if rb.kind == "1" and wpacks is not None and self.window_conv:
                 # C = 128: one window-conv launch per conv (activation window in LDS, weights streamed)
@@ -249,12 +250,16 @@ class Generator(nn.Module):
                     al = out
                     continue
                 windowed = self.window_conv and all(pk["rbw"][i * nk + j] is not None for j in range(nk))
-                if windowed and self.conv_pair and all(ops.hifi_conv_pair_supported(wu.shape[1], rb.k, dd) for rb in rbs for dd in rb.dilation):
-                    axl = None                                                             # the pair kernels activate x themselves
-                    a = ops.conv_transpose1d(al, wu, bu, u, k)
-                else:
-                    axl = torch.empty(al.shape[0], al.shape[1] * u, wu.shape[1], dtype=al.dtype, device=al.device)
-                    a = ops.conv_transpose1d(al, wu, bu, u, k, C2=axl, flags=ops.C2_LRELU, out_slope=LRELU_SLOPE)   # x and lrelu(x)
+                if windowed and self.conv_pair and nk >= 2 and all(ops.hifi_conv_pair_supported(wu.shape[1], rb.k, dd) for rb in rbs for dd in rb.dilation):
+                    a = ops.conv_transpose1d(al, wu, bu, u, k)                             # raw x: the pair kernels activate it themselves
+                    out = torch.empty_like(a)
+                    for j, rb in enumerate(rbs):                                           # each block's last pair adds its share of the MRF average
+                        mode = 1 if j == 0 else (3 if j == nk - 1 else 2)
+                        self._resblock(rb, pk["rb"][i * nk + j], a, None, pk["rbw"][i * nk + j], acc=(out, mode, 1.0 / nk, nxt_slope))
+                    al = out
+                    continue
+                axl = torch.empty(al.shape[0], al.shape[1] * u, wu.shape[1], dtype=al.dtype, device=al.device)
+                a = ops.conv_transpose1d(al, wu, bu, u, k, C2=axl, flags=ops.C2_LRELU, out_slope=LRELU_SLOPE)   # x and lrelu(x)
                 if self.group_resblocks and all(rb.kind == "1" for rb in rbs) and len({len(rb.dilation) for rb in rbs}) == 1 and \
                         not windowed:
                     outs = self._resblocks_lockstep(rbs, [pk["rb"][i * nk + j] for j in range(nk)], a, axl)

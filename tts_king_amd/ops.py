@@ -75,6 +75,10 @@ def flush_group(descs, keep):
         by_layout.setdefault((d.flags & (A_TR | B_TR | F16), d.kernel), []).append(d)
     dev = keep[0].device
     for ds in by_layout.values():
+        # longest workgroups first: a grouped grid is dispatched in workgroup order and its problems differ several-fold in K steps
+        # per workgroup (HiFi-GAN's k = 11 / 7 / 3 convs, a decoder vs an encoder weight gradient), so the short ones should fill the
+        # tail of the launch instead of opening it.  The problems are independent: their order changes no result.
+        ds.sort(key=lambda d: -(d.K * max(d.taps, 1)) // max(d.splits, 1))
         n = len(ds)
         nbytes = int(lib.ttsk_gemm_group_table_bytes(n))
         host = (C.c_ubyte * nbytes)()
@@ -902,13 +906,17 @@ def hifi_conv_pair_supported(Cn, K, dil):
     return bool(L.load().ttsk_hifi_conv_pair_supported(Cn, K, dil))
 
 
-def hifi_conv_pair(x, w1_pack, bias1, w2_pack, bias2, K, dilation, slope=0.1):
-    """c2(lrelu(c1_{K,dil}(lrelu(x)) + b1)) + b2 + x in one launch (C = 128; hifi/models.py:88-95, one dilation of ResBlock1)."""
-    _dev(x, w1_pack, bias1, w2_pack, bias2)
+def hifi_conv_pair(x, w1_pack, bias1, w2_pack, bias2, K, dilation, slope=0.1, out=None, mode=0, scale=1.0, final_slope=1.0):
+    """y = c2(lrelu(c1_{K,dil}(lrelu(x)) + b1)) + b2 + x in one launch (C = 128; hifi/models.py:88-95, one dilation of ResBlock1).
+    mode 0: out = y; 1: out = y*scale; 2: out += y*scale; 3: out = lrelu(out + y*scale, final_slope) (the MRF average, :190-197)."""
+    _dev(x, w1_pack, bias1, w2_pack, bias2, out)
     Bn, ln, Cn = x.shape
-    out = torch.empty_like(x)
+    if out is None:
+        if mode >= 2:
+            raise L.TtskError("hifi_conv_pair: mode %d accumulates into `out`" % mode)
+        out = torch.empty_like(x)
     check(L.load().ttsk_hifi_conv_pair(_ptr(x), _ptr(w1_pack), _ptr(bias1), _ptr(w2_pack), _ptr(bias2), _ptr(out), int(x.dtype == f16), Bn,
-                                       ln, Cn, K, dilation, slope, _stream()), "ttsk_hifi_conv_pair")
+                                       ln, Cn, K, dilation, slope, mode, scale, final_slope, _stream()), "ttsk_hifi_conv_pair")
     return out
 
 

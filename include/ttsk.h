@@ -334,8 +334,9 @@ int ttsk_hifi_conv_window(const void* x16, const void* w_pack, const float* bias
 /* The (c1 dilated -> LeakyReLU -> c2 -> + x) pair of ResBlock1 (hifi/models.py:88-95) as ONE launch at C = 128: x is the raw block
  * input, out = c2(lrelu(c1(lrelu(x)) + b1)) + b2 + x; lrelu(c1 ..) stays in LDS.  Bit-identical to two ttsk_hifi_conv_window
  * launches, a third of their HBM traffic.  w*_pack as for ttsk_hifi_conv_window; out must not alias x.
- * mode folds the MRF average (hifi/models.py:190-197) into a block's last pair, as ttsk_hifi_resblock1 does:
- * 0: out = y   1: out = y*scale   2: out += y*scale   3: out = lrelu(out + y*scale, final_slope). */
+ * mode folds the MRF average (hifi/models.py:190-197) into a block's last pair, with ttsk_hifi_resblock1's meaning:
+ * 0: out = y   1: out += y   2: out = lrelu((out + y) * scale, final_slope).
+ * C = 128: a wave owns 32 output channels; C = 64 / 32 (the last two stages): a wave owns a quarter of the frames. */
 int ttsk_hifi_conv_pair_supported(int C, int K, int dil);
 int ttsk_hifi_conv_pair(const void* x16, const void* w1_pack, const float* bias1, const void* w2_pack, const float* bias2, void* out16,
                         int f16, int B, int len, int C, int K, int dil, float slope, int mode, float scale, float final_slope,

@@ -23,3 +23,20 @@ for K in (3, 7, 11):
         tot1 += t1; tot2 += t2
         print("K=%2d dil=%d: pair %.1f us (%.0f TF/s useful) | two window convs %.1f us" % (K, dil, t1, gf / t1 * 1e3, t2))
 print("total of the 9 pairs: %.1f us vs %.1f us" % (tot1, tot2))
+
+# C = 64 / 32 stages: three pair launches per block vs the six-conv fused kernel
+for C, ln in ((64, 49152), (32, 98304)):
+    x = torch.randn(B, ln, C, device=DEV).half(); out = torch.empty_like(x)
+    b = torch.randn(C, device=DEV)
+    for K in (3, 7, 11):
+        w = (torch.randn(C, C, K, device=DEV) * (C * K) ** -0.5)
+        pack = ops.pack_resblock_weight(w, dtype=torch.float16)
+        def three():
+            y = x
+            for d in (1, 3, 5):
+                y = ops.hifi_conv_pair(y, pack, b, pack, b, K, d)
+            return y
+        t3 = timeit(three, n=5)
+        tf = timeit(lambda: ops.hifi_resblock1(x, [pack] * 6, [b] * 6, (1, 3, 5), out, K), n=5)
+        gf = 6 * 2.0 * B * ln * C * C * K / 1e9
+        print("C=%d K=%2d: three pairs %.1f us (%.0f TF/s useful) | fused six-conv kernel %.1f us" % (C, K, t3, gf / t3 * 1e3, tf))

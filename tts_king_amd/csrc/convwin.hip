@@ -321,7 +321,7 @@ struct PairArgs {
   int len, K, dil;
   float slope;
   // MRF average folded into the last pair of each ResBlock (hifi/models.py:190-197: xs = sum_j resblock_j(x); x = xs / 3, then the
-  // consumer's leaky_relu), as in resblock.hip:  0: out = y   1: out = y*scale   2: out += y*scale   3: out = lrelu(out + y*scale, final_slope)
+  // consumer's leaky_relu), with resblock.hip's modes:  0: out = y   1: out += y   2: out = lrelu((out + y) * scale, final_slope)
   int mode;
   float scale, final_slope;
 };
@@ -470,16 +470,15 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
         v += f32x4{r0, r1, r2, r3};
       }
       if (a.mode) {
-        v *= a.scale;
-        if (a.mode >= 2 && t < len) {
+        if (t < len) {
           const uint2 o = *(const uint2*)(a.out + ((int64_t)bi * len + t) * C + co);
           float o0, o1, o2, o3;
           unpack2<F16>(o.x, o0, o1); unpack2<F16>(o.y, o2, o3);
           v += f32x4{o0, o1, o2, o3};
         }
-        if (a.mode == 3) {
+        if (a.mode == 2) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * a.final_slope);
+          for (int e = 0; e < 4; ++e) { v[e] *= a.scale; v[e] = fmaxf(v[e], v[e] * a.final_slope); }
         }
       }
       *(uint2*)(XW + (i * 16 + l15) * RS + co * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
@@ -494,6 +493,185 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
     const int rr = idx / CH8, ch = idx - rr * CH8;
     const int t = t0 + rr;
     if (t < len) *(uint4*)(ob + (int64_t)t * C + ch * 8) = *(const uint4*)(XW + rr * RS + ch * 16);
+  }
+}
+
+// ---- the same pair at C = 64 and C = 32 (the last two stages).  With 64 or 32 output channels there are not four 32-channel
+// groups to give the waves, so here a wave owns ALL output channels of a quarter of the frames: 48 frames (3 frame tiles) of
+// the 192 the workgroup computes for both convs; the weights of a tap are 8 KiB (C = 64) or 2 KiB per wave, still L2 -> registers.
+// c2 is computed on the same 192 rows as c1 (frames t0 - 8 .. t0 + 184) and only the middle 176 are stored: the t window
+// carries 8 guard rows each side that only those discarded edge rows read.  Against the six-conv fused kernel
+// (resblock.hip): that one reads x once per block but multiplies 1.23-1.45x redundant halo rows and synchronises its eight
+// waves per weight stage; three pair launches move 3x its HBM bytes (still one read + one write of x per pair) and win on the
+// MFMA side.  Row stride C*2 + 16 bytes: 16 consecutive rows start on 16 different 16-byte bank groups.
+template <int C> struct FsGeom {
+  static constexpr int NW = 4, NT = 256, FW = 48, NF = FW / 16, GU = 8;
+  static constexpr int CROWS = NW * FW;                 // 192 rows computed by both convs
+  static constexpr int TT = CROWS - 2 * GU;             // 176 frames stored
+  static constexpr int XROWS = CROWS + 50;              // 242: c1 reaches 25 rows either side
+  static constexpr int TROWS = CROWS + 2 * GU;          // 208
+  static constexpr int RS = C * 2 + 16;
+  static constexpr int NC = C / 16, KS = C / 32, CH8 = C / 8;
+  static constexpr int TAP = NC * KS * 1024;
+  static constexpr int SMEM = (XROWS + TROWS) * RS;     // 64,800 B (C = 64) / 36,000 B (C = 32)
+};
+
+template <int C, bool F16>
+__global__ __launch_bounds__(256, 2) void conv_pair_fs_kernel(const PairArgs a) {
+  using Gm = FsGeom<C>;
+  constexpr int NT = Gm::NT, FW = Gm::FW, NF = Gm::NF, GU = Gm::GU, TT = Gm::TT, XROWS = Gm::XROWS, RS = Gm::RS, NC = Gm::NC, KS = Gm::KS,
+                CH8 = Gm::CH8, TAP = Gm::TAP, XH = GU + 25;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[Gm::SMEM];
+  unsigned char* XW = smem;
+  unsigned char* TW = smem + XROWS * RS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int bi = blockIdx.y, t0 = blockIdx.x * TT;
+  const int len = a.len, K = a.K, d = a.dil;
+  const int HK = (K - 1) / 2;
+  const bf16_t* __restrict__ xb = a.x + (int64_t)bi * len * C;
+
+  bf16x8 wa[KS][NC], wb[KS][NC];
+  auto load_w = [&](int g, bf16x8 (&w)[KS][NC]) __attribute__((always_inline)) {      // tap g of the 2K-tap sequence c1 | c2
+    const unsigned char* src = (const unsigned char*)(g < K ? a.w1 : a.w2) + (int64_t)(g < K ? g : g - K) * TAP + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) w[ks][c] = *(const bf16x8*)(src + (ks * NC + c) * 1024);
+  };
+  load_w(0, wa);
+  load_w(1, wb);
+
+  {  // ---- x window: lrelu(x) rows t0 - 33 .. t0 + 209, zeros outside the utterance
+    constexpr int NCH = (XROWS * CH8 + NT - 1) / NT;
+    uint4 xv[NCH];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int idx = it * NT + tid;
+      const int row = idx / CH8, ch = idx - row * CH8;
+      const int t = t0 - XH + row;
+      xv[it] = make_uint4(0, 0, 0, 0);
+      if (idx < XROWS * CH8 && t >= 0 && t < len) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int idx = it * NT + tid;
+      const int row = idx / CH8, ch = idx - row * CH8;
+      if (idx < XROWS * CH8) *(uint4*)(XW + row * RS + ch * 16) = lrelu8<F16>(xv[it], a.slope);
+    }
+  }
+  f32x4 bv1[NC], bv2[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    bv1[c] = *(const f32x4*)(a.b1 + c * 16 + q * 4);
+    bv2[c] = *(const f32x4*)(a.b2 + c * 16 + q * 4);
+  }
+  __syncthreads();
+
+  f32x4 acc[NC][NF];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int i = 0; i < NF; ++i) acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // one tap of either conv: `inl` = this lane's fragment address at shift 0, rows advance by `step` rows per tap offset
+  auto tap = [&](const unsigned char* inp, const bf16x8 (&w)[KS][NC]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c][i] = mfma16<F16>(w[ks][c], Bf, acc[c][i]);
+      }
+    }
+  };
+
+  // ---- c1: computed row r = wave*48 + i*16 + l15 <-> frame t0 - 8 + r <-> x-window row r + 25
+  zero_acc();
+  {
+    const unsigned char* inl = XW + (wave * FW + l15 + 25) * RS + q * 16;
+#pragma unroll 1
+    for (int g = 0; g + 1 < K; g += 2) {
+      tap(inl + (g - HK) * d * RS, wa);
+      load_w(g + 2, wa);
+      tap(inl + (g + 1 - HK) * d * RS, wb);
+      load_w(g + 3, wb);
+    }
+    tap(inl + (K - 1 - HK) * d * RS, wa);
+    load_w(K + 1, wa);
+  }
+#pragma unroll
+  for (int i = 0; i < NF; ++i) {
+    const int r = wave * FW + i * 16 + l15;
+    const int t = t0 - GU + r;
+    const bool live = t >= 0 && t < len;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      f32x4 v = acc[c][i] + bv1[c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = live ? fmaxf(v[e], v[e] * a.slope) : 0.f;
+      *(uint2*)(TW + (r + GU) * RS + (c * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+    }
+  }
+  __syncthreads();
+
+  // ---- c2 on the same rows (the 8 at either end read guard rows and are dropped)
+  zero_acc();
+  {
+    const unsigned char* inl = TW + (wave * FW + l15 + GU) * RS + q * 16;
+#pragma unroll 1
+    for (int g = 0; g + 1 < K; g += 2) {
+      tap(inl + (g - HK) * RS, wb);
+      if (g + 2 < K) load_w(K + g + 2, wb);
+      tap(inl + (g + 1 - HK) * RS, wa);
+      if (g + 3 < K) load_w(K + g + 3, wa);
+    }
+    tap(inl + (K - 1 - HK) * RS, wb);
+  }
+
+  // ---- epilogue: + b2 + raw x, MRF mode, staged through the x window for full-row stores
+#pragma unroll
+  for (int i = 0; i < NF; ++i) {
+    const int r = wave * FW + i * 16 + l15;
+    const int t = t0 - GU + r;
+    const bool mine = r >= GU && r < GU + TT && t < len;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int co = c * 16 + q * 4;
+      f32x4 v = acc[c][i] + bv2[c];
+      if (mine) {
+        const uint2 rr = *(const uint2*)(xb + (int64_t)t * C + co);
+        float r0, r1, r2, r3;
+        unpack2<F16>(rr.x, r0, r1); unpack2<F16>(rr.y, r2, r3);
+        v += f32x4{r0, r1, r2, r3};
+      }
+      if (a.mode) {
+        if (mine) {
+          const uint2 o = *(const uint2*)(a.out + ((int64_t)bi * len + t) * C + co);
+          float o0, o1, o2, o3;
+          unpack2<F16>(o.x, o0, o1); unpack2<F16>(o.y, o2, o3);
+          v += f32x4{o0, o1, o2, o3};
+        }
+        if (a.mode == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] *= a.scale; v[e] = fmaxf(v[e], v[e] * a.final_slope); }
+        }
+      }
+      if (r >= GU && r < GU + TT) *(uint2*)(XW + (r - GU) * RS + co * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+    }
+  }
+  __syncthreads();
+  bf16_t* __restrict__ ob = a.out + (int64_t)bi * len * C;
+  constexpr int NCO = (TT * CH8 + NT - 1) / NT;
+#pragma unroll
+  for (int it = 0; it < NCO; ++it) {
+    const int idx = it * NT + tid;
+    const int rr = idx / CH8, ch = idx - rr * CH8;
+    const int t = t0 + rr;
+    if (idx < TT * CH8 && t < len) *(uint4*)(ob + (int64_t)t * C + ch * 8) = *(const uint4*)(XW + rr * RS + ch * 16);
   }
 }
 
@@ -540,7 +718,7 @@ extern "C" int ttsk_hifi_conv_window(const void* x16, const void* w_pack, const 
 }
 
 extern "C" int ttsk_hifi_conv_pair_supported(int C, int K, int dil) {
-  return C == CW_C && K >= 3 && K <= 11 && (K & 1) == 1 && dil >= 1 && dil * ((K - 1) / 2) <= CP_XH - CP_TH && (K - 1) / 2 <= CP_TH;
+  return (C == CW_C || C == 64 || C == 32) && K >= 3 && K <= 11 && (K & 1) == 1 && dil >= 1 && dil * ((K - 1) / 2) <= CP_XH - CP_TH && (K - 1) / 2 <= CP_TH;
 }
 
 extern "C" int ttsk_hifi_conv_pair(const void* x16, const void* w1_pack, const float* bias1, const void* w2_pack, const float* bias2,
@@ -549,14 +727,25 @@ extern "C" int ttsk_hifi_conv_pair(const void* x16, const void* w1_pack, const f
   TTSK_REQUIRE(x16 && w1_pack && bias1 && w2_pack && bias2 && out16, "ttsk_hifi_conv_pair: null pointer");
   TTSK_REQUIRE(B > 0 && len > 0 && B <= 65535 && x16 != out16, "ttsk_hifi_conv_pair: bad sizes / in-place output");
   TTSK_REQUIRE(ttsk_hifi_conv_pair_supported(C, K, dil), "ttsk_hifi_conv_pair: no instance for C=%d K=%d dil=%d", C, K, dil);
-  TTSK_REQUIRE(mode >= 0 && mode <= 3 && (final_slope > 0.f || mode != 3), "ttsk_hifi_conv_pair: bad mode / final_slope");
+  TTSK_REQUIRE(mode >= 0 && mode <= 2 && (final_slope > 0.f || mode != 2), "ttsk_hifi_conv_pair: bad mode / final_slope");
   TTSK_REQUIRE(((((uintptr_t)x16) | ((uintptr_t)w1_pack) | ((uintptr_t)w2_pack) | ((uintptr_t)bias1) | ((uintptr_t)bias2) | ((uintptr_t)out16)) & 15) == 0,
                "ttsk_hifi_conv_pair: 16-byte alignment");
   PairArgs a{(const bf16_t*)x16, (const bf16_t*)w1_pack, (const bf16_t*)w2_pack, bias1, bias2, (bf16_t*)out16, len, K, dil, slope,
              mode, scale, final_slope};
-  dim3 grid((len + CP_TT - 1) / CP_TT, B);
-  if (f16) hipLaunchKernelGGL(conv_pair_kernel<true>, grid, dim3(C2_NT), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(conv_pair_kernel<false>, grid, dim3(C2_NT), 0, (hipStream_t)stream, a);
+  if (C == CW_C) {
+    dim3 grid((len + CP_TT - 1) / CP_TT, B);
+    if (f16) hipLaunchKernelGGL(conv_pair_kernel<true>, grid, dim3(C2_NT), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_pair_kernel<false>, grid, dim3(C2_NT), 0, (hipStream_t)stream, a);
+  } else {
+    dim3 grid((len + FsGeom<64>::TT - 1) / FsGeom<64>::TT, B);
+    if (C == 64) {
+      if (f16) hipLaunchKernelGGL((conv_pair_fs_kernel<64, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((conv_pair_fs_kernel<64, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+      if (f16) hipLaunchKernelGGL((conv_pair_fs_kernel<32, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((conv_pair_fs_kernel<32, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
+  }
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -96,7 +96,8 @@ class Generator(nn.Module):
         self._packed_key = None
         self.act_dtype = f16         # storage type of activations and packed weights (fp32 accumulate); bf16 also works
         self.window_conv = True      # window-conv kernel at the C = 128 stage; False = implicit-GEMM convs
-        self.conv_pair = True        # ... with each (c1, c2) pair of a ResBlock1 as one launch (ttsk_hifi_conv_pair)
+        self.conv_pair = True        # each (c1, c2) pair of a ResBlock1 as one launch (ttsk_hifi_conv_pair) at C = 128 ...
+        self.conv_pair_small = True  # ... and at C = 64 / 32, instead of the six-conv fused kernel
         self.fused = True            # fused ResBlock1 kernel where an instance exists (C in {32,64}); False = conv-by-conv
         self.stream_upsample = True  # stride-2 upsamplers (128->64, 64->32) on the streaming kernel; False = polyphase implicit GEMMs
         self.group_resblocks = True  # conv m of the three MRF ResBlocks as one grouped launch where they run conv by conv (C = 256)
@@ -162,23 +163,14 @@ class Generator(nn.Module):
         return pk
 
     # ------------------------------------------------------------------ forward
-    def _resblock(self, rb, packed, x, xl, wpacks=None, acc=None):
+    def _resblock(self, rb, packed, x, xl, wpacks=None):
         """reference: hifi/models.py:88-95 (ResBlock1) / :136-140 (ResBlock2), conv by conv on the implicit-GEMM kernel.
         x = block input, xl = lrelu(x).  Every LeakyReLU is applied by the PRODUCING conv's epilogue (LRELU_OUT, or a
         second output C2 = lrelu(v) next to the raw v the residual path needs), the residual add is an epilogue too."""
         nd = len(rb.dilation)
-        pair = rb.kind == "1" and wpacks is not None and self.window_conv and self.conv_pair and \
-            all(ops.hifi_conv_pair_supported(x.shape[2], rb.k, d) for d in rb.dilation)
-        if (xl is None or acc is not None) and not pair:
-            raise ValueError("_resblock: lrelu(x) is needed, and the MRF average cannot be folded, unless every dilation runs on the pair kernel")
         for m, d in enumerate(rb.dilation):
             lastp = m == nd - 1
-            xl_next = None if lastp or pair else torch.empty_like(x)
-            if pair:
-                # C = 128: the c1 -> lrelu -> c2 -> + x pair as one launch (lrelu(c1) never leaves the CU); takes the raw x
-                kw = dict(out=acc[0], mode=acc[1], scale=acc[2], final_slope=acc[3]) if (acc is not None and lastp) else {}
-                x = ops.hifi_conv_pair(x, wpacks[m], packed[m][1], wpacks[nd + m], packed[nd + m][1], rb.k, d, slope=LRELU_SLOPE, **kw)
-                continue
+            xl_next = None if lastp else torch.empty_like(x)
             if rb.kind == "1" and wpacks is not None and self.window_conv:
                 # C = 128: one window-conv launch per conv (activation window in LDS, weights streamed)
                 tl = ops.hifi_conv_window(xl, wpacks[m], packed[m][1], rb.k, d, lrelu_out=True, slope=LRELU_SLOPE)
@@ -193,6 +185,43 @@ class Generator(nn.Module):
                 x = ops.conv1d(xl, w, b, dilation=d, R=x, C2=xl_next, flags=0 if lastp else ops.C2_LRELU, out_slope=LRELU_SLOPE)
             xl = xl_next
         return x
+
+    def _pair_blocks(self, rbs, packs, a, nxt_slope, fused_for=()):
+        """The stage's ResBlock1s on the pair kernel (hifi/models.py:88-95, :190-197): per block three launches, each one
+        (c1 dilated -> lrelu -> c2 -> + x); every block's last launch adds into `out` and the last block's scales by 1/num_kernels and
+        applies the consumer's LeakyReLU (the MRF average).  packs[j] = (weight packs, biases), both in the order c1_0, c2_0, c1_1,
+        c2_1, ...; blocks whose kernel size is in `fused_for` run on the six-conv fused kernel instead (same packs, same modes)."""
+        nk = len(rbs)
+        out = torch.empty_like(a)
+        for j, rb in enumerate(rbs):
+            ws, bs = packs[j]
+            mode = 0 if j == 0 else (2 if j == nk - 1 else 1)
+            fs = nxt_slope if j == nk - 1 else 1.0
+            if rb.k in fused_for:
+                ops.hifi_resblock1(a, ws, bs, rb.dilation, out, rb.k, mode=mode, scale=1.0 / nk, slope=LRELU_SLOPE, final_slope=fs)
+                continue
+            x, nd = a, len(rb.dilation)
+            for m, d in enumerate(rb.dilation):
+                kw = dict(out=out, mode=mode, scale=1.0 / nk, final_slope=fs) if m == nd - 1 else {}
+                x = ops.hifi_conv_pair(x, ws[2 * m], bs[2 * m], ws[2 * m + 1], bs[2 * m + 1], rb.k, d, slope=LRELU_SLOPE, **kw)
+        return out
+
+    def _pair_packs(self, pk, i, nk, rbs, C):
+        """Weight packs / biases of stage i in `_pair_blocks` order, or None when the pair kernel does not cover the stage."""
+        if nk < 2 or not all(rb.kind == "1" and all(ops.hifi_conv_pair_supported(C, rb.k, d) for d in rb.dilation) for rb in rbs):
+            return None
+        packs = []
+        for j, rb in enumerate(rbs):
+            n = len(rb.dilation)
+            if pk["rbf"][i * nk + j] is not None:                      # packed for the fused kernel: already in pair order
+                packs.append(pk["rbf"][i * nk + j])
+            elif pk["rbw"][i * nk + j] is not None:                    # window packs: convs1 then convs2
+                w, b = pk["rbw"][i * nk + j], [p[1] for p in pk["rb"][i * nk + j]]
+                order = [m // 2 + (n if m % 2 else 0) for m in range(2 * n)]
+                packs.append(([w[o] for o in order], [b[o] for o in order]))
+            else:
+                return None
+        return packs
 
     def _resblocks_lockstep(self, rbs, packs, x, xl):
         """The stage's ResBlock1s (one per MRF kernel size, hifi/models.py:190-196) advanced conv by conv TOGETHER: they read
@@ -235,6 +264,21 @@ class Generator(nn.Module):
                 # F.leaky_relu's default 0.01 before conv_post (hifi/models.py:197)
                 nxt_slope = LRELU_SLOPE if i + 1 < self.num_upsamples else 0.01
                 rbs = [self.resblocks[i * nk + j] for j in range(nk)]
+                C_out = wu.shape[1]
+                # C = 32: the fused kernel is as fast or faster for every kernel size (86 / 143 / 181 us against 102 / 139 / 178)
+                want_pair = (self.conv_pair and self.window_conv) if C_out >= 128 else (self.conv_pair_small and self.fused and C_out == 64)
+                ppacks = self._pair_packs(pk, i, nk, rbs, C_out) if want_pair else None
+                if ppacks is not None:
+                    if self.stream_upsample and ops.hifi_upsample2_supported(wu.shape[2], wu.shape[1], u, k) and al.is_contiguous():
+                        a = ops.hifi_upsample2(al, wu, bu)
+                    else:
+                        a = ops.conv_transpose1d(al, wu, bu, u, k)                         # raw x: the pair kernels activate it themselves
+                    # measured per block at the bench shape (tools/debug/convpair_micro.py): three pair launches beat the six-conv
+                    # fused kernel at C = 64 for k = 7, 11 (228 vs 242 us, 290 vs 370 us) and lose at k = 3 (158 vs 141 us: the block is
+                    # then bound by its HBM passes, and the fused kernel makes one instead of three)
+                    fused_for = (3,) if C_out == 64 and all(pk["rbf"][i * nk + j] is not None for j in range(nk)) else ()
+                    al = self._pair_blocks(rbs, ppacks, a, nxt_slope, fused_for)
+                    continue
                 fused = self.fused and all(pk["rbf"][i * nk + j] is not None for j in range(nk)) and nk >= 2
                 if fused:
                     if self.stream_upsample and ops.hifi_upsample2_supported(wu.shape[2], wu.shape[1], u, k) and al.is_contiguous():
@@ -250,14 +294,6 @@ class Generator(nn.Module):
                     al = out
                     continue
                 windowed = self.window_conv and all(pk["rbw"][i * nk + j] is not None for j in range(nk))
-                if windowed and self.conv_pair and nk >= 2 and all(ops.hifi_conv_pair_supported(wu.shape[1], rb.k, dd) for rb in rbs for dd in rb.dilation):
-                    a = ops.conv_transpose1d(al, wu, bu, u, k)                             # raw x: the pair kernels activate it themselves
-                    out = torch.empty_like(a)
-                    for j, rb in enumerate(rbs):                                           # each block's last pair adds its share of the MRF average
-                        mode = 1 if j == 0 else (3 if j == nk - 1 else 2)
-                        self._resblock(rb, pk["rb"][i * nk + j], a, None, pk["rbw"][i * nk + j], acc=(out, mode, 1.0 / nk, nxt_slope))
-                    al = out
-                    continue
                 axl = torch.empty(al.shape[0], al.shape[1] * u, wu.shape[1], dtype=al.dtype, device=al.device)
                 a = ops.conv_transpose1d(al, wu, bu, u, k, C2=axl, flags=ops.C2_LRELU, out_slope=LRELU_SLOPE)   # x and lrelu(x)
                 if self.group_resblocks and all(rb.kind == "1" for rb in rbs) and len({len(rb.dilation) for rb in rbs}) == 1 and \

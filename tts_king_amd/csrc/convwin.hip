@@ -425,6 +425,21 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
   }
   __syncthreads();
 
+  // raw x (residual) and, in the accumulating modes, the current `out`: requested now, consumed after c2's taps
+  uint2 rres[CT][NF2], rout[CT][NF2];
+#pragma unroll
+  for (int i = 0; i < NF2; ++i) {
+    const int t = t0 + i * 16 + l15;
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc) {
+      const int co = (wave * CT + cc) * 16 + q * 4;
+      rres[cc][i] = rout[cc][i] = make_uint2(0u, 0u);
+      if (t < len) {
+        rres[cc][i] = *(const uint2*)(xb + (int64_t)t * C + co);
+        if (a.mode) rout[cc][i] = *(const uint2*)(a.out + ((int64_t)bi * len + t) * C + co);
+      }
+    }
+  }
   // ---- c2 (dilation 1) over the tile's 96 frames; sequence taps K .. 2K-1: tap K is on set b, K+1 on set a, ...
   f32x4 acc2[CT][NF2];
 #pragma unroll
@@ -463,17 +478,15 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
     for (int cc = 0; cc < CT; ++cc) {
       const int co = (wave * CT + cc) * 16 + q * 4;
       f32x4 v = acc2[cc][i] + bv2[cc];
-      if (t < len) {
-        const uint2 r = *(const uint2*)(xb + (int64_t)t * C + co);
+      {
         float r0, r1, r2, r3;
-        unpack2<F16>(r.x, r0, r1); unpack2<F16>(r.y, r2, r3);
+        unpack2<F16>(rres[cc][i].x, r0, r1); unpack2<F16>(rres[cc][i].y, r2, r3);
         v += f32x4{r0, r1, r2, r3};
       }
       if (a.mode) {
-        if (t < len) {
-          const uint2 o = *(const uint2*)(a.out + ((int64_t)bi * len + t) * C + co);
+        {
           float o0, o1, o2, o3;
-          unpack2<F16>(o.x, o0, o1); unpack2<F16>(o.y, o2, o3);
+          unpack2<F16>(rout[cc][i].x, o0, o1); unpack2<F16>(rout[cc][i].y, o2, o3);
           v += f32x4{o0, o1, o2, o3};
         }
         if (a.mode == 2) {
@@ -618,6 +631,22 @@ __global__ __launch_bounds__(256, 2) void conv_pair_fs_kernel(const PairArgs a) 
   }
   __syncthreads();
 
+  // raw x (residual) and, in the accumulating modes, the current `out`: requested now, consumed after c2's taps
+  uint2 rres[NC][NF], rout[NC][NF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) {
+    const int r = wave * FW + i * 16 + l15;
+    const int t = t0 - GU + r;
+    const bool mine = r >= GU && r < GU + TT && t < len;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      rres[c][i] = rout[c][i] = make_uint2(0u, 0u);
+      if (mine) {
+        rres[c][i] = *(const uint2*)(xb + (int64_t)t * C + c * 16 + q * 4);
+        if (a.mode) rout[c][i] = *(const uint2*)(a.out + ((int64_t)bi * len + t) * C + c * 16 + q * 4);
+      }
+    }
+  }
   // ---- c2 on the same rows (the 8 at either end read guard rows and are dropped)
   zero_acc();
   {
@@ -642,17 +671,15 @@ __global__ __launch_bounds__(256, 2) void conv_pair_fs_kernel(const PairArgs a) 
     for (int c = 0; c < NC; ++c) {
       const int co = c * 16 + q * 4;
       f32x4 v = acc[c][i] + bv2[c];
-      if (mine) {
-        const uint2 rr = *(const uint2*)(xb + (int64_t)t * C + co);
+      {
         float r0, r1, r2, r3;
-        unpack2<F16>(rr.x, r0, r1); unpack2<F16>(rr.y, r2, r3);
+        unpack2<F16>(rres[c][i].x, r0, r1); unpack2<F16>(rres[c][i].y, r2, r3);
         v += f32x4{r0, r1, r2, r3};
       }
       if (a.mode) {
-        if (mine) {
-          const uint2 o = *(const uint2*)(a.out + ((int64_t)bi * len + t) * C + co);
+        {
           float o0, o1, o2, o3;
-          unpack2<F16>(o.x, o0, o1); unpack2<F16>(o.y, o2, o3);
+          unpack2<F16>(rout[c][i].x, o0, o1); unpack2<F16>(rout[c][i].y, o2, o3);
           v += f32x4{o0, o1, o2, o3};
         }
         if (a.mode == 2) {

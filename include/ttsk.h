@@ -129,6 +129,11 @@ int ttsk_gemm_reduce_batch(const ttsk_reduce_item* items, int n, void* stream);
 int64_t ttsk_gemm_group_table_bytes(int n);
 int ttsk_gemm_group_build(const ttsk_gemm_desc* descs, int n, void* host_table, int32_t* total_wgs);
 int ttsk_gemm_group_launch(const void* host_table, void* dev_table, void* stream);
+/* The same with the grid capped at max_wgs workgroups (0 = no cap; honoured by the 256x128 configuration, kernel = 2): each
+ * workgroup walks the table's tiles in steps of the grid size.  A grid of fewer workgroups than CUs (that configuration holds one
+ * per CU) leaves the remaining CUs to kernels of a concurrent stream: the FS2 backward runs its weight-gradient group beside the
+ * encoder-side dX chain this way. */
+int ttsk_gemm_group_launch_capped(const void* host_table, void* dev_table, int max_wgs, void* stream);
 
 /* Fused sub-layer tail of an FFT block (reference: fs_two/transformer/SubLayers.py:62-63 and :96-99 + Layers.py:29,32):
  *   out = zero_PAD_rows( LayerNorm( dropout_{p_pre, site_pre}( A[M,K] @ W[D,K]^T + bias ) + res ) ),  D = 256 only.

@@ -764,8 +764,14 @@ extern "C" int ttsk_gemm_group_build(const ttsk_gemm_desc* descs, int n, void* h
   return TTSK_OK;
 }
 
+extern "C" int ttsk_gemm_group_launch_capped(const void* host_table, void* dev_table, int max_wgs, void* stream);
 extern "C" int ttsk_gemm_group_launch(const void* host_table, void* dev_table, void* stream) {
+  return ttsk_gemm_group_launch_capped(host_table, dev_table, 0, stream);
+}
+
+extern "C" int ttsk_gemm_group_launch_capped(const void* host_table, void* dev_table, int max_wgs, void* stream) {
   TTSK_REQUIRE(host_table && dev_table && (((uintptr_t)dev_table) & 15) == 0, "ttsk_gemm_group_launch: bad table pointers");
+  TTSK_REQUIRE(max_wgs >= 0, "ttsk_gemm_group_launch_capped: max_wgs < 0");
   const GroupHeader* h = (const GroupHeader*)host_table;
   TTSK_REQUIRE(h->n > 0 && h->total > 0, "ttsk_gemm_group_launch: empty table (call ttsk_gemm_group_build first)");
   const bool inline_table = h->n <= 2 && !h->f16 && h->kernel == 1;      // bf16 pairs: table in the kernel arguments
@@ -786,7 +792,7 @@ extern "C" int ttsk_gemm_group_launch(const void* host_table, void* dev_table, v
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(h->total), block(NTHREADS);
   if (h->kernel == 2) {
-    ttsk_launch_gemm2_group(prefix, args, h->n, h->total, h->atr, h->btr, h->f16, s);
+    ttsk_launch_gemm2_group(prefix, args, h->n, h->total, max_wgs, h->atr, h->btr, h->f16, s);
   } else if (inline_table) {
     GroupInline<2> t;
     const int32_t* hp = (const int32_t*)((const unsigned char*)host_table + h->prefix_off);

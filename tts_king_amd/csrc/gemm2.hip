@@ -344,25 +344,31 @@ template <int BM_, bool ATR, bool BTR, bool F16>
 __global__ __launch_bounds__(Cfg<BM_>::NTHREADS, 1) void gemm2_group_kernel(const int* __restrict__ prefix, const GemmArgs* __restrict__ args,
                                                                            int n) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg<BM_>::SMEM_BYTES];
-  const int wg = blockIdx.x;
-  int lo = 0, hi = n;                 // invariant: prefix[lo] <= wg < prefix[hi]
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (prefix[mid] <= wg) lo = mid; else hi = mid;
+  // The grid may be smaller than the table's workgroup count (ttsk_gemm_group_launch_capped): a workgroup then walks the tiles
+  // blockIdx.x, blockIdx.x + gridDim.x, ...  A capped grid of one workgroup per CU leaves the other CUs to a concurrent stream.
+  const int total = prefix[n];
+  for (int wg = blockIdx.x; wg < total; wg += gridDim.x) {
+    int lo = 0, hi = n;                 // invariant: prefix[lo] <= wg < prefix[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (prefix[mid] <= wg) lo = mid; else hi = mid;
+    }
+    const int p = __builtin_amdgcn_readfirstlane(lo);
+    const GemmArgs& g = args[p];
+    const int local = wg - prefix[p];
+    const int tiles = g.tiles_m * g.tiles_n, nz = g.d.nz1 * g.d.nz2;
+    const int tile = local % tiles, rest = local / tiles;
+    gemm2_tile<BM_, ATR, BTR, F16>(g, tile, rest % nz, rest / nz, nz, smem);
+    __syncthreads();                    // the epilogue's staging tile is the next tile's operand ring
   }
-  const int p = __builtin_amdgcn_readfirstlane(lo);
-  const GemmArgs& g = args[p];
-  const int local = wg - prefix[p];
-  const int tiles = g.tiles_m * g.tiles_n, nz = g.d.nz1 * g.d.nz2;
-  const int tile = local % tiles, rest = local / tiles;
-  gemm2_tile<BM_, ATR, BTR, F16>(g, tile, rest % nz, rest / nz, nz, smem);
 }
 
 }  // namespace
 
-int ttsk_launch_gemm2_group(const int* prefix, const GemmArgs* args, int n, int total_wgs, bool atr, bool btr, bool f16, hipStream_t s) {
+int ttsk_launch_gemm2_group(const int* prefix, const GemmArgs* args, int n, int total_wgs, int max_wgs, bool atr, bool btr, bool f16,
+                            hipStream_t s) {
   constexpr int BM = 256;
-  dim3 grid(total_wgs), block(Cfg<BM>::NTHREADS);
+  dim3 grid(max_wgs > 0 && max_wgs < total_wgs ? max_wgs : total_wgs), block(Cfg<BM>::NTHREADS);
   if (atr) hipLaunchKernelGGL((gemm2_group_kernel<BM, true, true, false>), grid, block, 0, s, prefix, args, n);
   else if (btr) {
     if (f16) hipLaunchKernelGGL((gemm2_group_kernel<BM, false, true, true>), grid, block, 0, s, prefix, args, n);

@@ -259,4 +259,5 @@ __device__ __forceinline__ void tile_epilogue(const ttsk_gemm_desc& d, unsigned 
 // gemm2.hip
 int ttsk_launch_gemm2(const GemmArgs& g, bool atr, bool btr, bool f16, hipStream_t s);
 // grouped launch of the 256x128 configuration: prefix / args live in device memory (see gemm.hip: ttsk_gemm_group_*)
-int ttsk_launch_gemm2_group(const int* prefix, const GemmArgs* args, int n, int total_wgs, bool atr, bool btr, bool f16, hipStream_t s);
+int ttsk_launch_gemm2_group(const int* prefix, const GemmArgs* args, int n, int total_wgs, int max_wgs, bool atr, bool btr, bool f16,
+                            hipStream_t s);

@@ -141,6 +141,13 @@ class FastSpeech2(nn.Module):
         self.group_param_grads = True      # weight-gradient GEMMs of a backward pass share grouped launches (ops.DeferQueue)
         self.overlap_param_grads = False   # measured on MI355X: the branches do overlap under graph replay, but the concurrent
                                            # kernels slow each other by as much (6.39 vs 6.47 ms/step): off by default
+        # The weight-gradient GEMMs of PostNet + decoder (88 % of the step's dW FLOPs) are complete once the decoder's backward is;
+        # what follows on the dX path (length regulator, variance adaptor, encoder: ~0.5 ms of 32-128-workgroup kernels) fills a
+        # fraction of the chip.  So that group is launched there on a second stream with its grid capped at `dw_side_wgs` workgroups
+        # (one per CU: the other CUs stay free for the dX chain) and joined before the optimizer.  0 = launch it at the end instead.
+        self.dw_side_wgs = int(os.environ.get("TTSK_DW_SIDE_WGS", "192"))
+        self._dw_side = None
+        self._dw_side_pending = False
         self._rng_state = None          # device block shared with the optimizer (ops.optim_state)
         self._seed = seed
         self._modules_by_key = {}
@@ -792,9 +799,21 @@ class FastSpeech2(nn.Module):
         return (["postnet", "mel_linear"] + ["decoder.%d" % i for i in range(self.n_dec - 1, -1, -1)] + ["variance_adaptor"] +
                 ["encoder.%d" % i for i in range(self.n_enc - 1, -1, -1)] + ["embedding"])
 
+    def _launch_dw_side(self):
+        """The grouped dW GEMMs queued so far, on the side stream with a capped grid (see `dw_side_wgs`)."""
+        if self._dw_side is None:
+            self._dw_side = torch.cuda.Stream(device=self.device)
+        self._dw_side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._dw_side):
+            ops.flush_deferred_gemms(self._deferred, max_wgs=self.dw_side_wgs)
+        self._dw_side_pending = True
+
     def _flush_param_grads(self):
         """Run the queued weight-gradient work (grouped dW GEMMs, split-K reducers, column sums, scatter-sums)."""
         self._join_side()
+        if self._dw_side_pending:
+            torch.cuda.current_stream().wait_stream(self._dw_side)
+            self._dw_side_pending = False
         ops.flush_deferred(self._deferred)
         ops.flush_finalize(self._deferred_fin)
 
@@ -859,6 +878,8 @@ class FastSpeech2(nn.Module):
         for i in range(self.n_dec - 1, -1, -1):
             dx = self._fft_bwd(ctx.blocks[ctx.n_enc_blocks + i], dx, rng, raw_out=i > 0)
             notify("decoder.%d" % i)
+        if self.dw_side_wgs > 0 and on_bucket is None and self.group_param_grads and not self.overlap_param_grads:
+            self._launch_dw_side()
         # ---- length regulator: segment sums (the position table has no parameters)
         dx3 = ops.length_regulator_bwd(dx.view(Bn, T, d), ctx.cs, Lp).view(Bn * Lp, d)
         # ---- variance adaptor, reverse order of modules.py:158-193

@@ -65,8 +65,9 @@ class GemmGroup:
         self.keep = []
 
 
-def flush_group(descs, keep):
-    """Grouped launches (ttsk_gemm_group_*) of the queued descriptors, one per operand layout; `keep` holds their tensors."""
+def flush_group(descs, keep, max_wgs=0):
+    """Grouped launches (ttsk_gemm_group_*) of the queued descriptors, one per operand layout; `keep` holds their tensors.
+    max_wgs > 0 caps the grid of the 256x128 configuration (ttsk_gemm_group_launch_capped)."""
     if not descs:
         return
     lib = L.load()
@@ -89,7 +90,7 @@ def flush_group(descs, keep):
         if GEMM_TRACE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        check(lib.ttsk_gemm_group_launch(host, C.c_void_p(table.data_ptr()), _stream()), "ttsk_gemm_group_launch")
+        check(lib.ttsk_gemm_group_launch_capped(host, C.c_void_p(table.data_ptr()), int(max_wgs), _stream()), "ttsk_gemm_group_launch")
         if LAUNCH_COUNTS is not None:
             LAUNCH_COUNTS["grouped_gemm"] = LAUNCH_COUNTS.get("grouped_gemm", 0) + 1
         if GEMM_TRACE is not None:
@@ -99,6 +100,14 @@ def flush_group(descs, keep):
             GEMM_TRACE.append((e0, e1, fl, kind + "%dg" % ds[0].kernel, (n, 0, 0, 1, 1, int(total.value))))
         keep.append(table)
     descs.clear()
+
+
+def flush_deferred_gemms(items, max_wgs=0):
+    """Only the grouped weight-gradient GEMMs queued in `items` so far, as grouped launches on the current stream (grid capped at
+    max_wgs workgroups when > 0); their split-K slabs stay queued for `flush_deferred`'s reducer launch."""
+    group = getattr(items, "group", None)
+    if group:
+        flush_group(group, getattr(items, "_keep"), max_wgs)
 
 
 def flush_deferred(items):

@@ -538,6 +538,19 @@ def main():
         if not args.no_roofline:
             eager = make_enqueue(model, opt, cfg, loss_fn, reducer=None)
             rec["roofline"] = gemm_roofline(eager, batch)
+            if model.dw_side_wgs > 0:
+                # The shipped step runs this kernel on a second stream with its grid capped (192 of 256 CUs) beside the encoder-side
+                # dX chain: its launch is longer than on the whole chip and the step shorter.  `achieved` / `frac` above are what runs
+                # (and what rocprofv3 shows); `whole_chip` is the same kernel uncapped, alone, for the kernel's own quality.
+                cap = model.dw_side_wgs
+                rec["roofline"]["grid_cap"] = {"workgroups": cap, "cus": 256, "frac_of_peak_on_its_cus": rec["roofline"]["frac"] * 256.0 / cap,
+                                               "concurrent_with": "length regulator, variance adaptor and encoder backward (main stream)"}
+                model.dw_side_wgs = 0
+                try:
+                    whole = gemm_roofline(eager, batch)
+                finally:
+                    model.dw_side_wgs = cap
+                rec["roofline"]["whole_chip"] = {k: whole[k] for k in ("achieved", "frac", "avg_launch_us", "kernel_ms_per_step", "kernel")}
         if world == 1 and not args.no_extra:
             rec.update(extra_train_legs(cfg, dev, B, L, steps=args.steps))
             rec["dp_schedule_1gpu"] = dp1_leg(cfg, dev, B, L)

@@ -315,6 +315,28 @@ def test_grouped_launch_equals_individual_launches(kern):
         ops.flush_deferred(q)
         torch.cuda.synchronize()
         outs[mode] = [r.cpu() for r in res]
+    # the same group with its grid capped at 5 workgroups (ttsk_gemm_group_launch_capped: each workgroup walks tiles wg, wg + 5, ...;
+    # honoured by the 256x128 configuration) on a second stream, then the reducers on the first: bit-identical again
+    q = ops.DeferQueue(group_gemms=True)
+    res = []
+    for dy, x, cout, cin, k, sp in tensors:
+        dst = torch.full((cout, k, cin), 0.5, dtype=torch.float32, device=DEV)
+        kw = dict(defer=q, kernel=kern, splits=sp)
+        if k == 1:
+            ops.linear_dw(dy.view(-1, cout), x.view(-1, cin), dst.view(cout, cin), **kw)
+        else:
+            ops.conv1d_dw(dy, x, dst, k=k, **kw)
+        res.append(dst)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.flush_deferred_gemms(q, max_wgs=5)
+    assert not q.group and len(q) > 0                      # the GEMMs went out, their split-K slabs still wait for the reducer
+    torch.cuda.current_stream().wait_stream(side)
+    ops.flush_deferred(q)
+    torch.cuda.synchronize()
+    for a, r in zip(outs["single"], res):
+        assert torch.equal(a, r.cpu())
     for a, b, c, (dy, x, cout, cin, k, sp) in zip(outs["single"], outs["grouped"], outs["grouped-auto"], tensors):
         assert torch.equal(a, b)
         if k == 1:

@@ -367,6 +367,26 @@ def extra_train_legs(cfg, dev, B, L, steps=40):
     return out
 
 
+def dp1_leg_isolated(args):
+    """`dp1_leg` in a child process, started before this process initialises the GPU.  The leg creates an RCCL communicator and
+    captures collectives into a hipGraph; ProcessGroupNCCL's watchdog thread aborted the whole process once while doing that (a HIP
+    event query during the capture, see tts_king_amd/graph.py), and an abort here would cost the bench line.  Under rocprofv3 the
+    profiler's preload has already initialised the GPU in this process, and starting another program from such a process is not
+    allowed on this pool: the leg is skipped there."""
+    import subprocess
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+        return {"skipped": "running under rocprofv3: no child process may be started"}
+    cmd = [sys.executable, os.path.abspath(__file__), "--dp1-child", "--batch", str(args.batch), "--phonemes", str(args.phonemes)]
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if p.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"error": "child exited with %d" % p.returncode, "stderr_tail": p.stderr.decode(errors="replace")[-400:]}
+    except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def dp1_leg(cfg, dev, B, L, steps=30):
     """The data-parallel schedule on ONE GPU: the full step with GradReducer issuing its bucketed all-reduces over RCCL at world
     size 1 (a collective per gradient bucket on RCCL's stream, backward_native flushing its deferred weight-gradient work whenever
@@ -434,7 +454,19 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the eager / grad_acc_step=4 / trainer-loop / DP-schedule legs")
+    ap.add_argument("--dp1-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.dp1_child:            # the DP-schedule leg in a process of its own (see dp1_leg_isolated)
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
+        from tts_king_amd.config import default_config
+        torch.cuda.set_device(0)
+        rec = dp1_leg(default_config(), "cuda:0", args.batch, args.phonemes)
+        os.write(real_stdout, (json.dumps(rec) + "\n").encode())
+        return
+    dp1_rec = None
+    if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_extra:
+        dp1_rec = dp1_leg_isolated(args)          # before this process touches the GPU
     # ONE JSON line on stdout, nothing else: RCCL prints a version banner to the C-level stdout when a communicator is created
     # (and flushes it at exit, i.e. AFTER the JSON line).  Everything the process or its libraries print goes to stderr; the
     # record is written to the original stdout descriptor at the very end.
@@ -553,7 +585,7 @@ def main():
                 rec["roofline"]["whole_chip"] = {k: whole[k] for k in ("achieved", "frac", "avg_launch_us", "kernel_ms_per_step", "kernel")}
         if world == 1 and not args.no_extra:
             rec.update(extra_train_legs(cfg, dev, B, L, steps=args.steps))
-            rec["dp_schedule_1gpu"] = dp1_leg(cfg, dev, B, L)
+            rec["dp_schedule_1gpu"] = dp1_rec
         if world == 1 and not args.no_hifi:
             try:
                 from tts_king_amd.hifi_bench import hifi_rtf

@@ -6,6 +6,8 @@ running statistics) lives in device memory and is advanced by kernels, so a capt
 no host work besides copying the next batch into the static input buffers.  Shapes are static per graph: batches
 are bucketed by (B, L, T) and one graph is kept per bucket (T varies per batch in real training).
 """
+import time
+
 import torch
 
 from . import ops
@@ -27,6 +29,12 @@ class GraphedTrainStep:
                 enqueue(self.static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # ProcessGroupNCCL's watchdog thread polls the end events of the eager collectives it has not reaped yet (every 100 ms).
+            # Once RCCL's stream has joined this capture HIP answers such a query with hipErrorCapturedEvent ("event last recorded
+            # in a capturing stream") and the watchdog aborts the process — seen once in bench.py's 1-GPU DP leg.  Everything is
+            # complete after the synchronize above; give the watchdog time to drop those works before the capture begins.
+            time.sleep(0.5)
         with torch.cuda.graph(self.graph, pool=pool):
             self.outputs = enqueue(self.static)
 

@@ -324,7 +324,13 @@ struct PairArgs {
   // consumer's leaky_relu), with resblock.hip's modes:  0: out = y   1: out += y   2: out = lrelu((out + y) * scale, final_slope)
   int mode;
   float scale, final_slope;
+  unsigned long long* stamps;   // diagnostic (ttsk_hifi_conv_pair_set_stamps): 8 x s_memrealtime per workgroup, null in the product path
 };
+#define TTSK_STAMP(i)                                                                                            \
+  do {                                                                                                            \
+    if (a.stamps && threadIdx.x == 0)                                                                             \
+      a.stamps[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();      \
+  } while (0)
 
 template <bool F16>
 __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
@@ -350,6 +356,7 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
 #pragma unroll
       for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(src + (ks * NC + cc) * 1024);
   };
+  TTSK_STAMP(0);
   load_w(0, wa);
   load_w(1, wb);
 
@@ -377,7 +384,9 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
     bv1[cc] = *(const f32x4*)(a.b1 + (wave * CT + cc) * 16 + q * 4);
     bv2[cc] = *(const f32x4*)(a.b2 + (wave * CT + cc) * 16 + q * 4);
   }
+  TTSK_STAMP(1);
   __syncthreads();
+  TTSK_STAMP(2);
 
   // ---- c1 over the 112 frames of the t window
   f32x4 acc[CT][NF1];
@@ -410,6 +419,7 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
     tap1(K - 1, wa);
     load_w(K + 1, wa);
   }
+  TTSK_STAMP(3);
   // t = lrelu(c1 + b1) as fp16 rows of the t window; frames outside [0, len) are c2's zero padding
 #pragma unroll
   for (int i = 0; i < NF1; ++i) {
@@ -425,6 +435,7 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
   }
   __syncthreads();
 
+  TTSK_STAMP(4);
   // raw x (residual) and, in the accumulating modes, the current `out`: requested now, consumed after c2's taps
   uint2 rres[CT][NF2], rout[CT][NF2];
 #pragma unroll
@@ -470,6 +481,7 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
     tap2(K - 1, wb);
   }
 
+  TTSK_STAMP(5);
   // ---- epilogue: + b2 + raw x (re-read: the lines are in L2), staged through the x window (dead since the barrier above)
 #pragma unroll
   for (int i = 0; i < NF2; ++i) {
@@ -498,6 +510,7 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
     }
   }
   __syncthreads();
+  TTSK_STAMP(6);
   bf16_t* __restrict__ ob = a.out + (int64_t)bi * len * C;
   constexpr int NCO = TT * CH8 / NT;     // 6
 #pragma unroll
@@ -507,6 +520,7 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
     const int t = t0 + rr;
     if (t < len) *(uint4*)(ob + (int64_t)t * C + ch * 8) = *(const uint4*)(XW + rr * RS + ch * 16);
   }
+  TTSK_STAMP(7);
 }
 
 // ---- the same pair at C = 64 and C = 32 (the last two stages).  With 64 or 32 output channels there are not four 32-channel
@@ -744,6 +758,14 @@ extern "C" int ttsk_hifi_conv_window(const void* x16, const void* w_pack, const 
   return TTSK_OK;
 }
 
+static unsigned long long* g_pair_stamps = nullptr;
+// diagnostic only (tools/debug/pair_stamps.py; not declared in ttsk.h): device buffer of 8 x uint64 per workgroup of the C = 128
+// kernel for the launches that follow; null switches the stamps off again
+extern "C" int ttsk_hifi_conv_pair_set_stamps(void* dev_buffer) {
+  g_pair_stamps = (unsigned long long*)dev_buffer;
+  return TTSK_OK;
+}
+
 extern "C" int ttsk_hifi_conv_pair_supported(int C, int K, int dil) {
   return (C == CW_C || C == 64 || C == 32) && K >= 3 && K <= 11 && (K & 1) == 1 && dil >= 1 && dil * ((K - 1) / 2) <= CP_XH - CP_TH && (K - 1) / 2 <= CP_TH;
 }
@@ -758,7 +780,7 @@ extern "C" int ttsk_hifi_conv_pair(const void* x16, const void* w1_pack, const f
   TTSK_REQUIRE(((((uintptr_t)x16) | ((uintptr_t)w1_pack) | ((uintptr_t)w2_pack) | ((uintptr_t)bias1) | ((uintptr_t)bias2) | ((uintptr_t)out16)) & 15) == 0,
                "ttsk_hifi_conv_pair: 16-byte alignment");
   PairArgs a{(const bf16_t*)x16, (const bf16_t*)w1_pack, (const bf16_t*)w2_pack, bias1, bias2, (bf16_t*)out16, len, K, dil, slope,
-             mode, scale, final_slope};
+             mode, scale, final_slope, g_pair_stamps};
   if (C == CW_C) {
     dim3 grid((len + CP_TT - 1) / CP_TT, B);
     if (f16) hipLaunchKernelGGL(conv_pair_kernel<true>, grid, dim3(C2_NT), 0, (hipStream_t)stream, a);

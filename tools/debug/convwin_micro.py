@@ -1,4 +1,4 @@
-"""Window conv (C = 128 HiFi-GAN stage) timing at the bench shape: B = 8, 24,576 frames.  TTSK_CONVWIN_VARIANT selects the kernel."""
+"""Window conv (C = 128 HiFi-GAN stage) timing at the bench shape: B = 8, 24,576 frames.  the shipped kernel (conv_window2_kernel)."""
 import os, sys
 import torch
 sys.path.insert(0, os.getcwd())

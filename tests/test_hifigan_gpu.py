@@ -211,7 +211,8 @@ def test_window_conv_vs_fp64(K, dil, B, ln, res):
                                              (128, 11, 1, 1, 5, torch.float16), (128, 7, 5, 3, 257, torch.bfloat16), (128, 3, 5, 1, 193, torch.float16),
                                              (64, 11, 5, 2, 1000, torch.float16), (64, 3, 1, 1, 176, torch.float16), (64, 7, 3, 2, 353, torch.bfloat16),
                                              (64, 11, 3, 1, 7, torch.float16), (32, 11, 5, 2, 900, torch.float16), (32, 7, 1, 1, 177, torch.float16),
-                                             (32, 3, 3, 3, 40, torch.bfloat16)])
+                                             (32, 3, 3, 3, 40, torch.bfloat16), (256, 11, 5, 2, 500, torch.float16), (256, 3, 1, 1, 96, torch.float16),
+                                             (256, 7, 3, 2, 201, torch.bfloat16), (256, 11, 3, 1, 9, torch.float16)])
 def test_conv_pair_equals_two_window_convs(C, K, dil, B, ln, dt):
     """ttsk_hifi_conv_pair (c1 dilated -> lrelu -> c2 -> + x in one launch, lrelu(c1) kept in LDS; hifi/models.py:88-95) is
     bit-identical to the two window-conv launches it replaces (same fp16 roundings, same accumulation order), at tile-multiple,
@@ -223,7 +224,7 @@ def test_conv_pair_equals_two_window_convs(C, K, dil, B, ln, dt):
     w2 = torch.randn(C, C, K, generator=g) * (C * K) ** -0.5
     b1, b2 = (0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
     p1, p2 = ops.pack_resblock_weight(w1.to(DEV), dtype=dt), ops.pack_resblock_weight(w2.to(DEV), dtype=dt)
-    assert ops.hifi_conv_pair_supported(C, K, dil) and not ops.hifi_conv_pair_supported(256, K, dil) and not ops.hifi_conv_pair_supported(C, 13, 1)
+    assert ops.hifi_conv_pair_supported(C, K, dil) and not ops.hifi_conv_pair_supported(512, K, dil) and not ops.hifi_conv_pair_supported(C, 13, 1)
     got = ops.hifi_conv_pair(x, p1, b1, p2, b2, K, dil)
     xl = torch.where(x.float() > 0, x.float(), 0.1 * x.float()).to(dt)
     if C == 128:                      # the two launches the pair replaces exist at C = 128 only (C = 64 / 32: the frame-split kernel)

@@ -40,3 +40,23 @@ for C, ln in ((64, 49152), (32, 98304)):
         tf = timeit(lambda: ops.hifi_resblock1(x, [pack] * 6, [b] * 6, (1, 3, 5), out, K), n=5)
         gf = 6 * 2.0 * B * ln * C * C * K / 1e9
         print("C=%d K=%2d: three pairs %.1f us (%.0f TF/s useful) | fused six-conv kernel %.1f us" % (C, K, t3, gf / t3 * 1e3, tf))
+
+# C = 256 stage: a pair launch vs the two implicit-GEMM convs it replaces (single launches here; the generator groups three blocks)
+C, ln = 256, 3072
+x = torch.randn(B, ln, C, device=DEV).half(); xl = torch.randn(B, ln, C, device=DEV).half(); c2 = torch.empty_like(x)
+b = torch.randn(C, device=DEV)
+tp = tg = 0.0
+for K in (3, 7, 11):
+    w = (torch.randn(C, C, K, device=DEV) * (C * K) ** -0.5)
+    pack = ops.pack_resblock_weight(w, dtype=torch.float16)
+    wg = ops.pack_conv_weight(w, dtype=torch.float16)
+    for dil in (1, 3, 5):
+        def two():
+            tl = ops.conv1d(xl, wg, b, dilation=dil, flags=ops.LRELU_OUT, out_slope=0.1)
+            return ops.conv1d(tl, wg, b, R=x, C2=c2, flags=ops.C2_LRELU, out_slope=0.1)
+        t2 = timeit(two)
+        t1 = timeit(lambda: ops.hifi_conv_pair(x, pack, b, pack, b, K, dil))
+        gf = 2 * 2.0 * B * ln * C * C * K / 1e9
+        tp += t1; tg += t2
+        print("C=256 K=%2d dil=%d: pair %.1f us (%.0f TF/s useful) | two implicit-GEMM convs %.1f us" % (K, dil, t1, gf / t1 * 1e3, t2))
+print("C=256 total of the 9 pairs: %.1f us vs %.1f us" % (tp, tg))

@@ -383,6 +383,196 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
   TTSK_STAMP(7);
 }
 
+// ---- the same pair at C = 256 (the first MRF stage: 3,072 frames per utterance).  Eight waves, each 32 output channels x all
+// frames; the 256 input channels of a tap are taken as two halves of 128 so that a wave's weights of one step stay 8 KiB = 32
+// VGPRs (two register sets): the tap loop of the C = 128 kernel over 2K half-taps per conv.  LDS: x window 162 rows + t window
+// 112 rows of 544 B = 149 KiB, one workgroup per CU; 32 tiles x 8 utterances = 256 workgroups = one per CU.  Replaces two grouped
+// implicit-GEMM launches per dilation (48 KiB of operand fetch per 4.2 MFLOP there, 128 KiB of weights per tap and 96 frames
+// = 25 MFLOP here).
+constexpr int C256 = 256, C256_NW = 8, C256_NT = C256_NW * 64;
+constexpr int C256_RS = C256 * 2 + 32;                               // 544 B per row
+constexpr int C256_NC = C256 / 16, C256_KH = 4;                      // 16 cout tiles; 4 k-steps per 128-channel half
+constexpr int C256_TAP = C256_NC * (C256 / 32) * 1024;               // 128 KiB per tap
+constexpr int C256_SMEM = (CP_XROWS + CP_TROWS) * C256_RS;           // 149,056 B
+
+template <bool F16>
+__global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs a) {
+  constexpr int C = C256, TT = CP_TT, RS = C256_RS, NC = C256_NC, KH = C256_KH, NT = C256_NT, CH8 = C / 8, CT = 2;
+  constexpr int NF1 = CP_TROWS / 16, NF2 = TT / 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C256_SMEM];
+  unsigned char* XW = smem;
+  unsigned char* TW = smem + CP_XROWS * RS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int bi = blockIdx.y, t0 = blockIdx.x * TT;
+  const int len = a.len, K = a.K, d = a.dil;
+  const int HK = (K - 1) / 2, K2 = 2 * K;
+  const bf16_t* __restrict__ xb = a.x + (int64_t)bi * len * C;
+
+  // half-tap g of the sequence c1 (2K half-taps) | c2 (2K): tap (g mod 2K) / 2, channel half g & 1
+  bf16x8 wa[KH][CT], wb[KH][CT];
+  const int woff = (wave * CT) * 1024 + lane * 16;
+  auto load_w = [&](int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
+    const int gl = g < K2 ? g : g - K2;
+    const unsigned char* src = (const unsigned char*)(g < K2 ? a.w1 : a.w2) + (int64_t)(gl >> 1) * C256_TAP + (gl & 1) * (KH * NC * 1024) + woff;
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(src + (ks * NC + cc) * 1024);
+  };
+  load_w(0, wa);
+  load_w(1, wb);
+
+  {  // ---- x window: lrelu(x) rows t0 - 33 .. t0 + 129, zeros outside the utterance
+    constexpr int NCH = (CP_XROWS * CH8 + NT - 1) / NT;     // 11
+    uint4 xv[NCH];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int idx = it * NT + tid;
+      const int row = idx / CH8, ch = idx - row * CH8;
+      const int t = t0 - CP_XH + row;
+      xv[it] = make_uint4(0, 0, 0, 0);
+      if (idx < CP_XROWS * CH8 && t >= 0 && t < len) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int idx = it * NT + tid;
+      const int row = idx / CH8, ch = idx - row * CH8;
+      if (idx < CP_XROWS * CH8) *(uint4*)(XW + row * RS + ch * 16) = lrelu8<F16>(xv[it], a.slope);
+    }
+  }
+  f32x4 bv1[CT], bv2[CT];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc) {
+    bv1[cc] = *(const f32x4*)(a.b1 + (wave * CT + cc) * 16 + q * 4);
+    bv2[cc] = *(const f32x4*)(a.b2 + (wave * CT + cc) * 16 + q * 4);
+  }
+  __syncthreads();
+
+  // ---- c1 over the 112 frames of the t window
+  f32x4 acc[CT][NF1];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+    for (int i = 0; i < NF1; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const unsigned char* inl = XW + (l15 + CP_XH - CP_TH) * RS + q * 16;
+    auto tap1 = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
+      const unsigned char* inp = inl + ((g >> 1) - HK) * d * RS + (g & 1) * (KH * 64);
+#pragma unroll
+      for (int ks = 0; ks < KH; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NF1; ++i) {
+          const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
+#pragma unroll
+          for (int cc = 0; cc < CT; ++cc) acc[cc][i] = mfma16<F16>(w[ks][cc], Bf, acc[cc][i]);
+        }
+      }
+    };
+#pragma unroll 1
+    for (int g = 0; g < K2; g += 2) {      // the last two loads are c2's first two half-taps
+      tap1(g, wa);
+      load_w(g + 2, wa);
+      tap1(g + 1, wb);
+      load_w(g + 3, wb);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NF1; ++i) {
+    const int t = t0 - CP_TH + i * 16 + l15;
+    const bool live = t >= 0 && t < len;
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc) {
+      f32x4 v = acc[cc][i] + bv1[cc];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = live ? fmaxf(v[e], v[e] * a.slope) : 0.f;
+      *(uint2*)(TW + (i * 16 + l15) * RS + ((wave * CT + cc) * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+    }
+  }
+  __syncthreads();
+
+  // raw x (residual): requested now, consumed after c2's taps (the accumulate operand of modes 1 / 2 is read in the epilogue:
+  // its registers would spill here)
+  uint2 rres[CT][NF2];
+#pragma unroll
+  for (int i = 0; i < NF2; ++i) {
+    const int t = t0 + i * 16 + l15;
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc) {
+      rres[cc][i] = make_uint2(0u, 0u);
+      if (t < len) rres[cc][i] = *(const uint2*)(xb + (int64_t)t * C + (wave * CT + cc) * 16 + q * 4);
+    }
+  }
+  // ---- c2 (dilation 1) over the tile's 96 frames
+  f32x4 acc2[CT][NF2];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+    for (int i = 0; i < NF2; ++i) acc2[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const unsigned char* inl = TW + (l15 + CP_TH) * RS + q * 16;
+    auto tap2 = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
+      const unsigned char* inp = inl + ((g >> 1) - HK) * RS + (g & 1) * (KH * 64);
+#pragma unroll
+      for (int ks = 0; ks < KH; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NF2; ++i) {
+          const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
+#pragma unroll
+          for (int cc = 0; cc < CT; ++cc) acc2[cc][i] = mfma16<F16>(w[ks][cc], Bf, acc2[cc][i]);
+        }
+      }
+    };
+#pragma unroll 1
+    for (int g = 0; g < K2; g += 2) {
+      tap2(g, wa);
+      if (g + 2 < K2) load_w(K2 + g + 2, wa);
+      tap2(g + 1, wb);
+      if (g + 3 < K2) load_w(K2 + g + 3, wb);
+    }
+  }
+  __syncthreads();          // every wave is done with the t window; the x window has been dead since c1: the output is staged there
+
+#pragma unroll
+  for (int i = 0; i < NF2; ++i) {
+    const int t = t0 + i * 16 + l15;
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc) {
+      const int co = (wave * CT + cc) * 16 + q * 4;
+      f32x4 v = acc2[cc][i] + bv2[cc];
+      {
+        float r0, r1, r2, r3;
+        unpack2<F16>(rres[cc][i].x, r0, r1); unpack2<F16>(rres[cc][i].y, r2, r3);
+        v += f32x4{r0, r1, r2, r3};
+      }
+      if (a.mode) {
+        if (t < len) {
+          const uint2 o = *(const uint2*)(a.out + ((int64_t)bi * len + t) * C + co);
+          float o0, o1, o2, o3;
+          unpack2<F16>(o.x, o0, o1); unpack2<F16>(o.y, o2, o3);
+          v += f32x4{o0, o1, o2, o3};
+        }
+        if (a.mode == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] *= a.scale; v[e] = fmaxf(v[e], v[e] * a.final_slope); }
+        }
+      }
+      *(uint2*)(XW + (i * 16 + l15) * RS + co * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+    }
+  }
+  __syncthreads();
+  bf16_t* __restrict__ ob = a.out + (int64_t)bi * len * C;
+  constexpr int NCO = TT * CH8 / NT;     // 6
+#pragma unroll
+  for (int it = 0; it < NCO; ++it) {
+    const int idx = it * NT + tid;
+    const int rr = idx / CH8, ch = idx - rr * CH8;
+    const int t = t0 + rr;
+    if (t < len) *(uint4*)(ob + (int64_t)t * C + ch * 8) = *(const uint4*)(XW + rr * RS + ch * 16);
+  }
+}
+
 // ---- the same pair at C = 64 and C = 32 (the last two stages).  With 64 or 32 output channels there are not four 32-channel
 // groups to give the waves, so here a wave owns ALL output channels of a quarter of the frames: 48 frames (3 frame tiles) of
 // the 192 the workgroup computes for both convs; the weights of a tap are 8 KiB (C = 64) or 2 KiB per wave, still L2 -> registers.
@@ -608,7 +798,7 @@ extern "C" int ttsk_hifi_conv_pair_set_stamps(void* dev_buffer) {
 }
 
 extern "C" int ttsk_hifi_conv_pair_supported(int C, int K, int dil) {
-  return (C == CW_C || C == 64 || C == 32) && K >= 3 && K <= 11 && (K & 1) == 1 && dil >= 1 && dil * ((K - 1) / 2) <= CP_XH - CP_TH && (K - 1) / 2 <= CP_TH;
+  return (C == CW_C || C == C256 || C == 64 || C == 32) && K >= 3 && K <= 11 && (K & 1) == 1 && dil >= 1 && dil * ((K - 1) / 2) <= CP_XH - CP_TH && (K - 1) / 2 <= CP_TH;
 }
 
 extern "C" int ttsk_hifi_conv_pair(const void* x16, const void* w1_pack, const float* bias1, const void* w2_pack, const float* bias2,
@@ -622,7 +812,11 @@ extern "C" int ttsk_hifi_conv_pair(const void* x16, const void* w1_pack, const f
                "ttsk_hifi_conv_pair: 16-byte alignment");
   PairArgs a{(const bf16_t*)x16, (const bf16_t*)w1_pack, (const bf16_t*)w2_pack, bias1, bias2, (bf16_t*)out16, len, K, dil, slope,
              mode, scale, final_slope, g_pair_stamps};
-  if (C == CW_C) {
+  if (C == C256) {
+    dim3 grid((len + CP_TT - 1) / CP_TT, B);
+    if (f16) hipLaunchKernelGGL(conv_pair256_kernel<true>, grid, dim3(C256_NT), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_pair256_kernel<false>, grid, dim3(C256_NT), 0, (hipStream_t)stream, a);
+  } else if (C == CW_C) {
     dim3 grid((len + CP_TT - 1) / CP_TT, B);
     if (f16) hipLaunchKernelGGL(conv_pair_kernel<true>, grid, dim3(C2_NT), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(conv_pair_kernel<false>, grid, dim3(C2_NT), 0, (hipStream_t)stream, a);

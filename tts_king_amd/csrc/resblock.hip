@@ -333,7 +333,7 @@ int launch_rb(const RbArgs& a, int B, int f16, hipStream_t s) {
 extern "C" int64_t ttsk_resblock_pack_elems(int C, int K) { return (int64_t)C * C * rb_kpad(C, K); }
 
 extern "C" int ttsk_pack_resblock_weight(const float* src, void* dst16, int f16, int C, int K, void* stream) {
-  TTSK_REQUIRE(src && dst16 && (C == 32 || C == 64 || C == 128) && K >= 1, "ttsk_pack_resblock_weight: C must be 32, 64 or 128");
+  TTSK_REQUIRE(src && dst16 && (C == 32 || C == 64 || C == 128 || C == 256) && K >= 1, "ttsk_pack_resblock_weight: C must be 32, 64, 128 or 256");
   const int Kpad = rb_kpad(C, K);
   const int64_t n = (int64_t)C * C * Kpad;
   int blocks = (int)((n + 255) / 256);

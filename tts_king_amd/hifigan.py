@@ -153,7 +153,8 @@ class Generator(nn.Module):
                 pk["rbf"].append(([ops.pack_resblock_weight(c.folded_weight(), dtype=dt) for c in order], [c.bias.data for c in order]))
             else:
                 pk["rbf"].append(None)
-            if rb.kind == "1" and pk["rbf"][-1] is None and all(ops.hifi_conv_window_supported(ch, rb.k, dd) for dd in rb.dilation):
+            if rb.kind == "1" and pk["rbf"][-1] is None and (all(ops.hifi_conv_window_supported(ch, rb.k, dd) for dd in rb.dilation) or
+                                                             all(ops.hifi_conv_pair_supported(ch, rb.k, dd) for dd in rb.dilation)):
                 pk["rbw"].append([ops.pack_resblock_weight(c.folded_weight(), dtype=dt) for c in convs])     # window-conv packs
             else:
                 pk["rbw"].append(None)
@@ -293,7 +294,8 @@ class Generator(nn.Module):
                                            scale=1.0 / nk, slope=LRELU_SLOPE, final_slope=nxt_slope if lastb else 1.0)
                     al = out
                     continue
-                windowed = self.window_conv and all(pk["rbw"][i * nk + j] is not None for j in range(nk))
+                windowed = self.window_conv and all(pk["rbw"][i * nk + j] is not None and ops.hifi_conv_window_supported(C_out, rbs[j].k, dd)
+                                                    for j in range(nk) for dd in rbs[j].dilation)
                 axl = torch.empty(al.shape[0], al.shape[1] * u, wu.shape[1], dtype=al.dtype, device=al.device)
                 a = ops.conv_transpose1d(al, wu, bu, u, k, C2=axl, flags=ops.C2_LRELU, out_slope=LRELU_SLOPE)   # x and lrelu(x)
                 if self.group_resblocks and all(rb.kind == "1" for rb in rbs) and len({len(rb.dilation) for rb in rbs}) == 1 and \

@@ -135,6 +135,19 @@ int ttsk_gemm_group_launch(const void* host_table, void* dev_table, void* stream
  * encoder-side dX chain this way. */
 int ttsk_gemm_group_launch_capped(const void* host_table, void* dev_table, int max_wgs, void* stream);
 
+/* The FFT block's first position-wise conv, forward: out = [relu](Conv1d(256 -> Cout, k)(x) + bias), 'same' zero padding per
+ * utterance.  reference: fs_two/transformer/SubLayers.py:93-101 (w_1 + relu).  x [B*S][256] bf16 (row = utterance*S + frame), w the
+ * tap-major bf16 weight (Cout, k, 256) as ttsk_gemm's conv takes it, out [B*S][Cout] bf16.  A window kernel (activation window of
+ * 112 frames in LDS, weights L2 -> registers, no barrier in the tap loop) for Cin = 256, Cout % 256 == 0, odd k <= 9; same result
+ * as the implicit-GEMM conv up to the order of the fp32 accumulation. */
+int ttsk_ffn_conv_supported(int Cin, int Cout, int K);
+int ttsk_ffn_conv_fwd(const void* x_bf16, const void* w_bf16, const float* bias, void* out_bf16, int B, int S, int Cin, int Cout, int K,
+                      int relu, int packed, void* stream);
+/* packed = 1: w is the fragment-major repack [k][8][Cout/16][64][8] written by ttsk_ffn_pack_weight from the tap-major weight (a
+ * wave's fragment is then 1 KiB contiguous instead of 16 rows x 64 B). */
+int ttsk_ffn_pack_weight(const void* w_bf16, void* packed_bf16, int Cout, int K, void* stream);
+int ttsk_ffn_pack_weight_batch(const void* const* w_bf16, void* const* packed_bf16, int n /* <= 16 */, int Cout, int K, void* stream);
+
 /* Fused sub-layer tail of an FFT block (reference: fs_two/transformer/SubLayers.py:62-63 and :96-99 + Layers.py:29,32):
  *   out = zero_PAD_rows( LayerNorm( dropout_{p_pre, site_pre}( A[M,K] @ W[D,K]^T + bias ) + res ) ),  D = 256 only.
  * A, W, res, out, z_save bf16; z_save (may be NULL) receives the LayerNorm input, mean / rstd [M] its statistics (what

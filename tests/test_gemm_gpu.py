@@ -468,3 +468,32 @@ def test_raw_slabs_sum_to_the_product_and_feed_layernorm_bwd(M, N, K, kern, spli
     err = float((dz_a.float() - dz_b.float()).abs().max())
     assert err <= 2 ** -6 * float(dz_a.float().abs().max()) + 1e-3, err
     torch.testing.assert_close(part_a.sum(0), part_b.sum(0), rtol=2e-2, atol=0.5)
+
+
+@pytest.mark.parametrize("B,S,Cout,K", [(16, 423, 1024, 9), (16, 64, 1024, 9), (2, 112, 256, 9), (3, 113, 512, 3), (1, 5, 256, 9), (2, 500, 1024, 1)])
+def test_ffn_conv_window_kernel(B, S, Cout, K):
+    """ttsk_ffn_conv_fwd (window kernel for the FFT block's w_1: SubLayers.py:93-101) against fp64 conv1d on the same bf16 operands
+    and against the implicit-GEMM conv it replaces (same operands, another accumulation order), zero padding per utterance, tile
+    multiples / ragged / shorter-than-a-tile lengths, with and without ReLU."""
+    from tts_king_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(S * 7 + K)
+    x = bf(torch.randn(B, S, 256, generator=g)).to(DEV)
+    W = bf(torch.randn(Cout, K, 256, generator=g) * (256 * K) ** -0.5).to(DEV)
+    bias = (0.1 * torch.randn(Cout, generator=g)).to(DEV)
+    assert ops.ffn_conv_supported(256, Cout, K) and not ops.ffn_conv_supported(128, Cout, K) and not ops.ffn_conv_supported(256, Cout, 11)
+    ref = F.conv1d(x.double().cpu().transpose(1, 2), W.double().cpu().permute(0, 2, 1), bias.double().cpu(), padding=(K - 1) // 2).transpose(1, 2)
+    for relu in (True, False):
+        got = ops.ffn_conv_fwd(x, W, bias, relu=relu)
+        want = ref.clamp(min=0) if relu else ref
+        err = float((got.double().cpu() - want).abs().max())
+        assert err <= 2 ** -8 * float(want.abs().max()) + 1e-3, (relu, err, float(want.abs().max()))
+        old = ops.conv1d(x, W, bias, flags=ops.RELU if relu else 0)
+        d = float((got.float() - old.float()).abs().max())
+        assert d <= 2 ** -7 * float(want.abs().max()), (relu, d)          # both round the same fp32 sums (up to their order) to bf16
+        # fragment-major repack of the weights (what the model feeds the kernel): bit-identical result
+        pk = ops.ffn_pack_weight(W)
+        assert torch.equal(ops.ffn_conv_fwd(x, W, bias, relu=relu, packed=pk), got)
+    pk2 = torch.empty(2 * W.numel(), dtype=torch.bfloat16, device=DEV)
+    ops.ffn_pack_weight_batch([W, W], [pk2[:W.numel()], pk2[W.numel():]])
+    assert torch.equal(pk2[:W.numel()], pk) and torch.equal(pk2[W.numel():], pk)

@@ -134,6 +134,12 @@ class FastSpeech2(nn.Module):
         self._deferred_fin = None       # gradient column-sum partials awaiting the batched finalize
         self._side = None               # second HIP stream for parameter-gradient work (see _SideWork)
         self.fused_attention = True     # one kernel for scores + softmax + P.V (and dP + softmax' + dQ) when d_k = 128
+        # w_1 forward of the DECODER blocks on the window kernel (csrc/ffn_conv.hip; d = 256, d_ff % 256 == 0, k <= 9).  It wants the
+        # weights in MFMA-fragment order (1 KiB contiguous per fragment; from the tap-major shadow it is no faster than the
+        # implicit GEMM): `_w1_packed` holds such a copy per decoder block, rewritten by one batched launch whenever the bf16 shadow is
+        # (sync_shadow, the optimizer step).  At the encoder's 1024 rows the two kernels tie, so the encoder keeps the GEMM.
+        self.window_ffn = os.environ.get("TTSK_WINDOW_FFN", "1") != "0"
+        self._w1_packed = None
         self.flash_attention = True     # ... and without the S x S tensors: online softmax forward, recomputing backward (d_k = 128)
         self.fused_ln = True            # fc / w_2 + dropout + residual + LayerNorm + PAD zeroing in one kernel when d = 256
         self.group_predictors = True    # training with targets: the three VariancePredictors run as grouped launches
@@ -215,6 +221,8 @@ class FastSpeech2(nn.Module):
         super()._apply(fn, recurse)
         self._flat, self._flat_grad = flat, grad
         self._shadow = shadow.to(bf16) if shadow.dtype != bf16 else shadow
+        self._w1_packed = None
+        self._shadow_version = -1
         self._rng_state = None
         self._side = None
         self._rebind()
@@ -297,6 +305,24 @@ class FastSpeech2(nn.Module):
         if force or self._shadow_version != self._flat._version:
             ops.cast_bf16(self._flat, self._shadow)
             self._shadow_version = self._flat._version
+            self.refresh_packed()
+
+    def refresh_packed(self):
+        """Rewrite the fragment-major copies of the decoder blocks' w_1 from the bf16 shadow (one launch).  Called by everything that
+        writes the shadow: `sync_shadow` and `ScheduledOptim.step_and_update_lr`."""
+        if not self.window_ffn:
+            return
+        if self._w1_packed is None:
+            keys = ["decoder.layer_stack.%d.pos_ffn.w_1.weight" % i for i in range(self.n_dec)]
+            keys = [k for k in keys if k in self._table and ops.ffn_conv_supported(self.d, *self._table[k].storage_shape[:2])]
+            if len({self._table[k].storage_shape for k in keys}) > 1 or len(keys) > 16:
+                keys = []
+            n = self._table[keys[0]].numel if keys else 0
+            buf = torch.empty(len(keys) * n, dtype=bf16, device=self._shadow.device)
+            self._w1_packed = {k: buf[i * n:(i + 1) * n] for i, k in enumerate(keys)}
+        if self._w1_packed:
+            keys = list(self._w1_packed)
+            ops.ffn_pack_weight_batch([self._w(k) for k in keys], [self._w1_packed[k] for k in keys])
 
     # views into the flat buffers ------------------------------------------------------------------
     def _w(self, key, rows=None):
@@ -380,7 +406,12 @@ class FastSpeech2(nn.Module):
             x1, z1, mean1, rstd1, _ = ops.layernorm_fwd(y, x, self._m(a + "layer_norm.weight"), self._m(a + "layer_norm.bias"),
                                                         lens, S, p_pre=p, site_pre=site, rng=rng, save_z=ctx_list is not None)
         # (6) FFN: Conv1d(k=9)+ReLU, Conv1d(k=1), dropout, +residual, LayerNorm, zero PAD rows: SubLayers.py:96-99, Layers.py:32
-        h = ops.conv1d(x1.view(Bn, S, d), self._w(f + "w_1.weight"), self._m(f + "w_1.bias"), flags=ops.RELU)
+        W1 = self._w(f + "w_1.weight")
+        pk = self._w1_packed.get(f + "w_1.weight") if (self.window_ffn and self._w1_packed) else None
+        if pk is not None and x1.dtype == bf16:
+            h = ops.ffn_conv_fwd(x1.view(Bn, S, d), W1, self._m(f + "w_1.bias"), relu=True, packed=pk)      # window kernel (csrc/ffn_conv.hip)
+        else:
+            h = ops.conv1d(x1.view(Bn, S, d), W1, self._m(f + "w_1.bias"), flags=ops.RELU)
         if fuse and self.k2 == 1:
             x2, z2, mean2, rstd2 = ops.gemm_ln_fwd(h.view(rows, -1), self._w(f + "w_2.weight"), self._m(f + "w_2.bias"), x1,
                                                    self._m(f + "layer_norm.weight"), self._m(f + "layer_norm.bias"), lens, S, p_pre=p,

@@ -308,6 +308,42 @@ def conv1d(x, W, bias, dilation=1, out=None, flags=0, out_dtype=None, R=None, C2
     return out
 
 
+def ffn_conv_supported(Cin, Cout, k):
+    return bool(L.load().ttsk_ffn_conv_supported(Cin, Cout, k))
+
+
+def ffn_pack_weight(W, out=None):
+    """Tap-major (Cout,k,256) bf16 -> fragment-major pack for ffn_conv_fwd(packed=...) (ttsk_ffn_pack_weight)."""
+    _dev(W, out)
+    Cout, k, _ = W.shape
+    if out is None:
+        out = torch.empty(W.numel(), dtype=bf16, device=W.device)
+    check(L.load().ttsk_ffn_pack_weight(_ptr(W), _ptr(out), Cout, k, _stream()), "ttsk_ffn_pack_weight")
+    return out
+
+
+def ffn_pack_weight_batch(Ws, outs):
+    """ffn_pack_weight for up to 16 weights of one shape in one launch (ttsk_ffn_pack_weight_batch)."""
+    _dev(*Ws, *outs)
+    n = len(Ws)
+    Cout, k, _ = Ws[0].shape
+    src = (C.c_void_p * n)(*[w.data_ptr() for w in Ws])
+    dst = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+    check(L.load().ttsk_ffn_pack_weight_batch(C.cast(src, C.c_void_p), C.cast(dst, C.c_void_p), n, Cout, k, _stream()), "ttsk_ffn_pack_weight_batch")
+
+
+def ffn_conv_fwd(x, W, bias, relu=True, packed=None):
+    """relu(Conv1d(256 -> Cout, k)(x) + bias) on the window kernel (ttsk_ffn_conv_fwd; SubLayers.py:93-101, w_1).
+    x (B,S,256) bf16, W (Cout,k,256) bf16 tap-major -> (B,S,Cout) bf16; `packed`: ffn_pack_weight(W), read instead of W."""
+    _dev(x, W, bias, packed)
+    Bsz, S, Cin = x.shape
+    Cout, k, _ = W.shape
+    out = torch.empty(Bsz, S, Cout, dtype=bf16, device=x.device)
+    check(L.load().ttsk_ffn_conv_fwd(_ptr(x), _ptr(W if packed is None else packed), _ptr(bias), _ptr(out), Bsz, S, Cin, Cout, k, int(relu),
+                                     int(packed is not None), _stream()), "ttsk_ffn_conv_fwd")
+    return out
+
+
 def conv1d_dx(dy, W, dilation=1, out=None, R=None, G=None, **kw):
     """dx (B,T,Cin) = sum_j dy[t + pad - j*dil] @ W[:, j, :]."""
     Bsz, T, Cout = dy.shape

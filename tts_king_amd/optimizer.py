@@ -55,6 +55,7 @@ class ScheduledOptim:
         ops.optim_step(flat, grad, self.exp_avg, self.exp_avg_sq, shadow, self.state, self._partials, self.grad_clip_thresh,
                        self.betas[0], self.betas[1], self.eps, self.d_model, self.n_warmup_steps, self.anneal_steps, self.anneal_rate,
                        zero_grad=True, advance_rng=advance_rng)
+        self.model.refresh_packed()          # the step rewrote the bf16 shadow: so are the fragment-major copies read by the window conv
         self._host_step += 1
 
     def zero_grad(self):

@@ -147,6 +147,16 @@ int ttsk_ffn_conv_fwd(const void* x_bf16, const void* w_bf16, const float* bias,
  * wave's fragment is then 1 KiB contiguous instead of 16 rows x 64 B). */
 int ttsk_ffn_pack_weight(const void* w_bf16, void* packed_bf16, int Cout, int K, void* stream);
 int ttsk_ffn_pack_weight_batch(const void* const* w_bf16, void* const* packed_bf16, int n /* <= 16 */, int Cout, int K, void* stream);
+/* The same window kernel for Cin = 256 or 512 (the PostNet's Conv1d(512 -> 512, k = 5), fs_two/transformer/Layers.py:85-129): out =
+ * [relu](conv(x) + bias), bias may be NULL, out bf16 or (out_f32 = 1, Cin = 512 only: the PostNet keeps its conv outputs in fp32 for
+ * BatchNorm) fp32.  The weights are always the fragment-major pack written by ttsk_win_conv_pack_batch from the tap-major storage
+ * (Cs, K, Ds): transpose = 0 packs the conv's own weights (Cout = Cs, Cin = Ds); transpose = 1 packs the weights of the conv's INPUT
+ * GRADIENT seen as a forward conv on dy with flipped taps (Cout = Ds, Cin = Cs), so that ttsk_win_conv(dy, that pack) = dx. */
+int ttsk_win_conv_supported(int Cin, int Cout, int K);
+int ttsk_win_conv_pack_batch(const void* const* w_bf16, void* const* packed_bf16, int n /* <= 16 */, int Cs, int K, int Ds, int transpose,
+                             void* stream);
+int ttsk_win_conv(const void* x_bf16, const void* w_packed, const float* bias /* may be NULL */, void* out, int out_f32, int B, int S,
+                  int Cin, int Cout, int K, int relu, void* stream);
 
 /* Fused sub-layer tail of an FFT block (reference: fs_two/transformer/SubLayers.py:62-63 and :96-99 + Layers.py:29,32):
  *   out = zero_PAD_rows( LayerNorm( dropout_{p_pre, site_pre}( A[M,K] @ W[D,K]^T + bias ) + res ) ),  D = 256 only.

@@ -497,3 +497,32 @@ def test_ffn_conv_window_kernel(B, S, Cout, K):
     pk2 = torch.empty(2 * W.numel(), dtype=torch.bfloat16, device=DEV)
     ops.ffn_pack_weight_batch([W, W], [pk2[:W.numel()], pk2[W.numel():]])
     assert torch.equal(pk2[:W.numel()], pk) and torch.equal(pk2[W.numel():], pk)
+
+
+@pytest.mark.parametrize("B,S,K", [(16, 423, 5), (2, 64, 5), (3, 65, 3), (1, 7, 5)])
+def test_win_conv_postnet_shapes(B, S, K):
+    """ttsk_win_conv at Cin = Cout = 512 (PostNet convs, Layers.py:85-129): forward with fp32 output against fp64 and against the
+    implicit-GEMM conv; the input gradient as a forward conv on the transposed, tap-flipped pack against conv1d_dx and fp64."""
+    from tts_king_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(S * 11 + K)
+    x = bf(torch.randn(B, S, 512, generator=g)).to(DEV)
+    W = bf(torch.randn(512, K, 512, generator=g) * (512 * K) ** -0.5).to(DEV)
+    bias = (0.1 * torch.randn(512, generator=g)).to(DEV)
+    pk, pkt = torch.empty(W.numel(), dtype=torch.bfloat16, device=DEV), torch.empty(W.numel(), dtype=torch.bfloat16, device=DEV)
+    ops.win_conv_pack_batch([W], [pk])
+    ops.win_conv_pack_batch([W], [pkt], transpose=True)
+    Wt = W.double().cpu().permute(0, 2, 1)                                  # torch layout (Cout, Cin, k)
+    ref = F.conv1d(x.double().cpu().transpose(1, 2), Wt, bias.double().cpu(), padding=(K - 1) // 2).transpose(1, 2)
+    got = ops.win_conv(x, pk, 512, K, bias=bias, out_dtype=torch.float32)
+    assert got.dtype == torch.float32
+    assert float((got.double().cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-4          # fp32 accumulate of bf16 products
+    old = ops.conv1d(x, W, bias, out_dtype=torch.float32)
+    assert float((got - old).abs().max()) <= 1e-4 * float(ref.abs().max())
+    # input gradient: dx = conv_transpose of dy with W = forward conv of dy with the flipped, channel-swapped weights
+    dref = F.conv_transpose1d(x.double().cpu().transpose(1, 2), Wt, padding=(K - 1) // 2).transpose(1, 2)
+    dgot = ops.win_conv(x, pkt, 512, K)
+    assert dgot.dtype == torch.bfloat16
+    assert float((dgot.double().cpu() - dref).abs().max()) <= 2 ** -8 * float(dref.abs().max()) + 1e-3
+    dold = ops.conv1d_dx(x, W)
+    assert float((dgot.float() - dold.float()).abs().max()) <= 2 ** -7 * float(dref.abs().max())

@@ -18,3 +18,18 @@ for B, S in ((16, 423), (16, 64), (16, 448)):
     t2 = timeit(lambda: ops.conv1d(x, W, b, flags=ops.RELU))
     gf = 2.0 * B * S * 1024 * 256 * 9 / 1e9
     print("B=%d S=%d: window kernel %.1f us (%.0f TF/s) | implicit GEMM %.1f us (%.0f TF/s)" % (B, S, t1, gf / t1 * 1e3, t2, gf / t2 * 1e3))
+
+# PostNet Conv1d(512 -> 512, k = 5): forward (fp32 out for BatchNorm) and input gradient, window kernel vs implicit GEMM
+B, S = 16, 423
+x = torch.randn(B, S, 512, device=DEV).bfloat16()
+W = (torch.randn(512, 5, 512, device=DEV) * 0.02).bfloat16()
+b = torch.randn(512, device=DEV)
+pk, pkt = torch.empty(W.numel(), dtype=torch.bfloat16, device=DEV), torch.empty(W.numel(), dtype=torch.bfloat16, device=DEV)
+ops.win_conv_pack_batch([W], [pk]); ops.win_conv_pack_batch([W], [pkt], transpose=True)
+f1 = ops.win_conv(x, pk, 512, 5, bias=b, out_dtype=torch.float32); f2 = ops.conv1d(x, W, b, out_dtype=torch.float32)
+g1 = ops.win_conv(x, pkt, 512, 5); g2 = ops.conv1d_dx(x, W)
+print("PostNet fwd max diff %.3g of %.3g; dX max diff %.3g of %.3g" % (float((f1 - f2).abs().max()), float(f2.abs().max()), float((g1.float() - g2.float()).abs().max()), float(g2.float().abs().max())))
+t1 = timeit(lambda: ops.win_conv(x, pk, 512, 5, bias=b, out_dtype=torch.float32)); t2 = timeit(lambda: ops.conv1d(x, W, b, out_dtype=torch.float32))
+t3 = timeit(lambda: ops.win_conv(x, pkt, 512, 5)); t4 = timeit(lambda: ops.conv1d_dx(x, W))
+t5 = timeit(lambda: ops.win_conv_pack_batch([W, W, W], [pk, pk, pk])); t6 = timeit(lambda: ops.win_conv_pack_batch([W, W, W], [pkt, pkt, pkt], transpose=True))
+print("B=16 S=423 PostNet 512->512 k5: fwd window %.1f us | GEMM %.1f us || dX window %.1f us | GEMM %.1f us || packs of 3 weights: %.1f us, transposed %.1f us" % (t1, t2, t3, t4, t5, t6))

@@ -1,64 +1,81 @@
-// ffn_conv.hip — the FFT block's first position-wise conv, forward: h = relu(Conv1d(256 -> d_ff, k = 9)(x)).
+// ffn_conv.hip — window kernels for the two wide Conv1d families of the FS2 step, forward (and, through a transposed weight pack,
+// input gradient):  the FFT block's first position-wise conv  h = relu(Conv1d(256 -> d_ff, k = 9)(x))  and the PostNet's
+// Conv1d(512 -> 512, k = 5).
 // reference: fs_two/transformer/SubLayers.py:93-101 (PositionwiseFeedForward.forward: w_1 on x^T, relu), called once per
-// FFTBlock (Layers.py:25-34); 62.6 % of the step's FLOPs sit in this conv and its two gradients.
+// FFTBlock (Layers.py:25-34); fs_two/transformer/Layers.py:85-129,133-143 (PostNet convolutions).  62.6 % + 17.4 % of the step's
+// FLOPs sit in these convs and their gradients.
 //
 // The implicit-GEMM kernels re-fetch the activation rows of a tile for every tap and synchronise their eight waves per K step
 // (0.9-1.3 us per step against 0.55 us of MFMA time; 45 us for the decoder's 31.9 GFLOP).  This kernel is the HiFi-GAN window
-// kernel's layout (convwin.hip) for this shape: a workgroup owns 112 frames of one utterance x 256 of the output channels; the
-// 120-row activation window (all 256 input channels, 65 KiB) is loaded into LDS once; each of the eight waves owns 32 output
-// channels and streams its weights L2 -> registers, one (tap, 128-channel half) step = 8 fragments = 32 VGPRs, requested two steps ahead (three register sets);
-// no barrier inside the tap loop.  T = 423: 4 tiles x 16 utterances x 4 channel groups = 256 workgroups, one per CU.
-// The weights are read from the tap-major bf16 shadow (Cout, k, 256) as it is: a fragment is 16 rows x 64 contiguous bytes.
+// kernel's layout (convwin.hip) for these shapes: a workgroup owns TT frames of one utterance x 256 of the output channels; the
+// activation window (TT + 8 rows, all input channels) is loaded into LDS once; each of the eight waves owns 32 output channels and
+// streams its weights L2 -> registers, one step = a tap x a 128-channel part of the input = 8 fragments = 32 VGPRs, requested two
+// steps ahead (three register sets); no barrier inside the tap loop.  w_1 at T = 423: 112-frame tiles, 4 x 16 x 4 = 256
+// workgroups, one per CU.  PostNet: 64-frame tiles (66 KiB window of 512 channels), 7 x 16 x 2 = 224 workgroups.
+// The weights come in MFMA-fragment order ([tap][k-step][cout tile][lane][8], ttsk_win_conv_pack_batch): a fragment is 1 KiB
+// contiguous; from the tap-major shadow (16 rows x 64 B per fragment) the kernel only ties the GEMM (kept for Cin = 256 as the
+// unpacked variant of ttsk_ffn_conv_fwd).
 #include "common.h"
 
 namespace {
 
-constexpr int FC_CIN = 256, FC_TT = 112, FC_H = 4, FC_NW = 8, FC_NT = FC_NW * 64;
-constexpr int FC_RS = FC_CIN * 2 + 32;                 // 544 B per window row
-constexpr int FC_XROWS = FC_TT + 2 * FC_H;             // 120
-constexpr int FC_SMEM = FC_XROWS * FC_RS;              // 65,280 B
-constexpr int FC_NF = FC_TT / 16, FC_KH = 4, FC_CT = 2, FC_COUT = FC_NW * FC_CT * 16;   // 7 frame tiles; 256 output channels per workgroup
+constexpr int WC_H = 4, WC_NW = 8, WC_NT = WC_NW * 64, WC_KH = 4, WC_CT = 2, WC_COUT = WC_NW * WC_CT * 16;   // 256 output channels per workgroup
 
-struct FfnArgs {
-  const bf16_t* x;      // [B*S][256] bf16 (PAD rows are zeros)
-  const bf16_t* w;      // (Cout, K, 256) bf16, tap-major
-  const float* bias;    // [Cout]
-  bf16_t* out;          // [B*S][Cout]
+struct WcArgs {
+  const bf16_t* x;      // [B*S][CIN] bf16 (PAD rows are zeros)
+  const bf16_t* w;      // fragment-major pack, or (Cout, K, CIN) tap-major when !PACKED
+  const float* bias;    // [Cout] or null
+  void* out;            // [B*S][Cout] bf16, or fp32 when OUT32
   int S, K, Cout, relu;
   int B, tiles_per_utt;
 };
 
-// (Cout, K, 256) tap-major -> [K][8][Cout/16][64][8] fragment-major, up to 16 weights of one shape per launch (blockIdx.y)
+// Weight packs.  src = storage (Cs, K, Ds) bf16 tap-major.
+//   transpose = 0: the conv's own weights, W'[co][tap][ci] = src[co][tap][ci]                   (Cout' = Cs, Cin' = Ds)
+//   transpose = 1: the weights of its input gradient seen as a forward conv on dy, taps flipped:
+//                  W'[co' = ci][tap][ci' = co] = src[co][K-1-tap][ci]                            (Cout' = Ds, Cin' = Cs)
+// dst = [K][Cin'/32][Cout'/16][64][8]: lane l of a fragment holds W'[c*16 + (l & 15)][tap][ks*32 + (l >> 4)*8 + j], j = 0..7.
 struct PackBatch {
   const bf16_t* src[16];
   bf16_t* dst[16];
 };
-__global__ __launch_bounds__(256) void ffn_pack_kernel(const PackBatch pb, int Cout, int K) {
+__global__ __launch_bounds__(256) void win_pack_kernel(const PackBatch pb, int Cs, int K, int Ds, int transpose) {
   const bf16_t* __restrict__ src = pb.src[blockIdx.y];
   bf16_t* __restrict__ dst = pb.dst[blockIdx.y];
-  const int64_t n8 = (int64_t)Cout * K * (FC_CIN / 8);           // 16-byte pieces
+  const int Co = transpose ? Ds : Cs, Ci = transpose ? Cs : Ds;
+  const int64_t n8 = (int64_t)Co * K * (Ci / 8);                 // 16-byte pieces of the pack
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
     const int l = (int)(i & 63);
     int64_t f = i >> 6;
-    const int c = (int)(f % (Cout / 16)); f /= (Cout / 16);
-    const int ks = (int)(f % (FC_CIN / 32));
-    const int tap = (int)(f / (FC_CIN / 32));
+    const int c = (int)(f % (Co / 16)); f /= (Co / 16);
+    const int ks = (int)(f % (Ci / 32));
+    const int tap = (int)(f / (Ci / 32));
     const int co = c * 16 + (l & 15), ci = ks * 32 + (l >> 4) * 8;
-    *(uint4*)(dst + i * 8) = *(const uint4*)(src + ((int64_t)co * K + tap) * FC_CIN + ci);
+    if (!transpose) {
+      *(uint4*)(dst + i * 8) = *(const uint4*)(src + ((int64_t)co * K + tap) * Ds + ci);
+    } else {
+      unsigned short v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[((int64_t)(ci + j) * K + (K - 1 - tap)) * Ds + co];
+      *(uint4*)(dst + i * 8) = make_uint4(v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16),
+                                          v[6] | ((unsigned)v[7] << 16));
+    }
   }
 }
 
-template <bool PACKED>
-__global__ __launch_bounds__(FC_NT, 1) void ffn_conv_fwd_kernel(const FfnArgs a) {
-  constexpr int C = FC_CIN, TT = FC_TT, RS = FC_RS, NT = FC_NT, CH8 = C / 8, KH = FC_KH, CT = FC_CT, NF = FC_NF;
-  __shared__ __attribute__((aligned(16))) unsigned char XW[FC_SMEM];
+template <int CIN, int TT, bool OUT32, bool PACKED>
+__global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
+  constexpr int C = CIN, RS = CIN * 2 + 32, NT = WC_NT, CH8 = C / 8, KH = WC_KH, CT = WC_CT, NF = TT / 16, NP = CIN / 128;
+  constexpr int XROWS = TT + 2 * WC_H;
+  static_assert(!OUT32 || WC_COUT * 4 + 32 <= RS, "fp32 staging rows must fit the window's row stride");
+  __shared__ __attribute__((aligned(16))) unsigned char XW[XROWS * RS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, q = lane >> 4;
   // XCD-aware mapping: consecutive workgroup ids go round the 8 XCDs, and a channel group's weights (1.2 MB at d_ff = 1024, k = 9) should
-  // stay in ONE XCD's 4 MiB L2 instead of all four groups (4.7 MB) in every L2: channel group = f(id % 8), tile = the rest.
+  // stay in ONE XCD's 4 MiB L2 instead of all groups in every L2: channel group = f(id % 8), tile = the rest.
   int bi, t0, cg;
   {
-    const int id = blockIdx.x, ncg = a.Cout / FC_COUT, ntile = a.tiles_per_utt * a.B;
+    const int id = blockIdx.x, ncg = a.Cout / WC_COUT, ntile = a.tiles_per_utt * a.B;
     const int xcd = id & 7, per = 8 / (ncg < 8 ? ncg : 8);        // XCDs per channel group (ncg = 1, 2, 4, 8); other counts: plain order
     int tile;
     if ((8 % (ncg < 8 ? ncg : 8)) == 0 && ncg <= 8 && (ntile * ncg) % 8 == 0 && ntile % per == 0) {
@@ -71,28 +88,26 @@ __global__ __launch_bounds__(FC_NT, 1) void ffn_conv_fwd_kernel(const FfnArgs a)
     bi = tile / a.tiles_per_utt;
     t0 = (tile - bi * a.tiles_per_utt) * TT;
   }
-  const int S = a.S, K = a.K, HK = (K - 1) / 2, K2 = 2 * K;
+  const int S = a.S, K = a.K, HK = (K - 1) / 2, NS = NP * K;       // NS steps: tap g / NP, 128-channel part g % NP
   const bf16_t* __restrict__ xb = a.x + (int64_t)bi * S * C;
 
-  // step g of the 2K-step sequence: tap g / 2, input-channel half g & 1
-  // tap-major weights (Cout, K, 256): a fragment is 16 rows x 64 B, 4,608 B apart (half of every 128-B line fetched is used);
-  // PACKED: fragment-major [tap][k-step][cout tile][lane][8] (ttsk_ffn_pack_weight): a fragment is 1 KiB contiguous
   const bf16_t* wrow[CT];
 #pragma unroll
   for (int cc = 0; cc < CT; ++cc)
-    wrow[cc] = PACKED ? a.w + ((int64_t)(cg * (FC_COUT / 16) + wave * CT + cc) * 64 + lane) * 8
-                      : a.w + ((int64_t)(cg * FC_COUT + (wave * CT + cc) * 16 + l15) * K) * C + q * 8;
+    wrow[cc] = PACKED ? a.w + ((int64_t)(cg * (WC_COUT / 16) + wave * CT + cc) * 64 + lane) * 8
+                      : a.w + ((int64_t)(cg * WC_COUT + (wave * CT + cc) * 16 + l15) * K) * C + q * 8;
   const int64_t kstep_stride = (int64_t)(a.Cout / 16) * 512;     // PACKED: elements per (tap, k-step)
   bf16x8 wa[KH][CT], wb[KH][CT], wc[KH][CT];      // three register sets: a step's weights are requested two steps (>= 1 us) ahead
   auto load_w = [&](int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
+    const int tap = g / NP, part = g - tap * NP;
     if (PACKED) {
-      const int64_t off = (int64_t)((g >> 1) * (C / 32) + (g & 1) * KH) * kstep_stride;
+      const int64_t off = (int64_t)(tap * (C / 32) + part * KH) * kstep_stride;
 #pragma unroll
       for (int ks = 0; ks < KH; ++ks)
 #pragma unroll
         for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(wrow[cc] + off + ks * kstep_stride);
     } else {
-      const int off = (g >> 1) * C + (g & 1) * (KH * 32);
+      const int off = tap * C + part * (KH * 32);
 #pragma unroll
       for (int ks = 0; ks < KH; ++ks)
 #pragma unroll
@@ -100,30 +115,31 @@ __global__ __launch_bounds__(FC_NT, 1) void ffn_conv_fwd_kernel(const FfnArgs a)
     }
   };
   load_w(0, wa);
-  load_w(1, wb);
-  if (2 < K2) load_w(2, wc);
+  if (1 < NS) load_w(1, wb);
+  if (2 < NS) load_w(2, wc);
 
-  {  // ---- activation window: rows t0 - 4 .. t0 + 116 of the utterance, zeros outside it (the conv's zero padding)
-    constexpr int NCH = (FC_XROWS * CH8 + NT - 1) / NT;     // 8
+  {  // ---- activation window: rows t0 - 4 .. t0 + TT + 4 of the utterance, zeros outside it (the conv's zero padding)
+    constexpr int NCH = (XROWS * CH8 + NT - 1) / NT;
     uint4 xv[NCH];
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
       const int idx = it * NT + tid;
       const int row = idx / CH8, ch = idx - row * CH8;
-      const int t = t0 - FC_H + row;
+      const int t = t0 - WC_H + row;
       xv[it] = make_uint4(0, 0, 0, 0);
-      if (idx < FC_XROWS * CH8 && t >= 0 && t < S) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
+      if (idx < XROWS * CH8 && t >= 0 && t < S) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
     }
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
       const int idx = it * NT + tid;
       const int row = idx / CH8, ch = idx - row * CH8;
-      if (idx < FC_XROWS * CH8) *(uint4*)(XW + row * RS + ch * 16) = xv[it];
+      if (idx < XROWS * CH8) *(uint4*)(XW + row * RS + ch * 16) = xv[it];
     }
   }
   f32x4 bv[CT];
 #pragma unroll
-  for (int cc = 0; cc < CT; ++cc) bv[cc] = *(const f32x4*)(a.bias + cg * FC_COUT + (wave * CT + cc) * 16 + q * 4);
+  for (int cc = 0; cc < CT; ++cc)
+    bv[cc] = a.bias ? *(const f32x4*)(a.bias + cg * WC_COUT + (wave * CT + cc) * 16 + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
   f32x4 acc[CT][NF];
@@ -132,9 +148,10 @@ __global__ __launch_bounds__(FC_NT, 1) void ffn_conv_fwd_kernel(const FfnArgs a)
 #pragma unroll
     for (int i = 0; i < NF; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
-    const unsigned char* inl = XW + (l15 + FC_H) * RS + q * 16;
+    const unsigned char* inl = XW + (l15 + WC_H) * RS + q * 16;
     auto step = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
-      const unsigned char* inp = inl + ((g >> 1) - HK) * RS + (g & 1) * (KH * 64);
+      const int tap = g / NP, part = g - tap * NP;
+      const unsigned char* inp = inl + (tap - HK) * RS + part * (KH * 64);
 #pragma unroll
       for (int ks = 0; ks < KH; ++ks) {
 #pragma unroll
@@ -146,16 +163,16 @@ __global__ __launch_bounds__(FC_NT, 1) void ffn_conv_fwd_kernel(const FfnArgs a)
       }
     };
 #pragma unroll 1
-    for (int g = 0; g < K2; g += 3) {
+    for (int g = 0; g < NS; g += 3) {
       step(g, wa);
-      if (g + 3 < K2) load_w(g + 3, wa);
-      if (g + 1 < K2) {
+      if (g + 3 < NS) load_w(g + 3, wa);
+      if (g + 1 < NS) {
         step(g + 1, wb);
-        if (g + 4 < K2) load_w(g + 4, wb);
+        if (g + 4 < NS) load_w(g + 4, wb);
       }
-      if (g + 2 < K2) {
+      if (g + 2 < NS) {
         step(g + 2, wc);
-        if (g + 5 < K2) load_w(g + 5, wc);
+        if (g + 5 < NS) load_w(g + 5, wc);
       }
     }
   }
@@ -170,46 +187,84 @@ __global__ __launch_bounds__(FC_NT, 1) void ffn_conv_fwd_kernel(const FfnArgs a)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
-      *(uint2*)(XW + (i * 16 + l15) * RS + ((wave * CT + cc) * 16 + q * 4) * 2) = make_uint2(pack2<false>(v[0], v[1]), pack2<false>(v[2], v[3]));
+      const int col = (wave * CT + cc) * 16 + q * 4;
+      if (OUT32) *(f32x4*)(XW + (i * 16 + l15) * RS + col * 4) = v;
+      else *(uint2*)(XW + (i * 16 + l15) * RS + col * 2) = make_uint2(pack2<false>(v[0], v[1]), pack2<false>(v[2], v[3]));
     }
   }
   __syncthreads();
-  bf16_t* __restrict__ ob = a.out + (int64_t)bi * S * a.Cout + cg * FC_COUT;
-  constexpr int OCH = FC_COUT / 8;                       // 32 16-byte chunks per output row of this channel group
-  constexpr int NCO = TT * OCH / NT;                     // 7
+  constexpr int ESZ = OUT32 ? 4 : 2;
+  constexpr int OCH = WC_COUT * ESZ / 16;                // 16-byte chunks per output row of this channel group
+  constexpr int NCO = (TT * OCH + NT - 1) / NT;
+  unsigned char* __restrict__ ob = (unsigned char*)a.out + ((int64_t)bi * S * a.Cout + cg * WC_COUT) * ESZ;
 #pragma unroll
   for (int it = 0; it < NCO; ++it) {
     const int idx = it * NT + tid;
     const int rr = idx / OCH, ch = idx - rr * OCH;
     const int t = t0 + rr;
-    if (t < S) *(uint4*)(ob + (int64_t)t * a.Cout + ch * 8) = *(const uint4*)(XW + rr * RS + ch * 16);
+    if (idx < TT * OCH && t < S) *(uint4*)(ob + (int64_t)t * a.Cout * ESZ + ch * 16) = *(const uint4*)(XW + rr * RS + ch * 16);
   }
+}
+
+int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int packed, hipStream_t s) {
+  WcArgs a = a0;
+  const int TT = Cin == 256 ? 112 : 64;
+  a.B = B;
+  a.tiles_per_utt = (S + TT - 1) / TT;
+  dim3 grid(a.tiles_per_utt * B * (a.Cout / WC_COUT));
+  if (Cin == 256) {
+    if (packed) hipLaunchKernelGGL((win_conv_kernel<256, 112, false, true>), grid, dim3(WC_NT), 0, s, a);
+    else hipLaunchKernelGGL((win_conv_kernel<256, 112, false, false>), grid, dim3(WC_NT), 0, s, a);
+  } else {
+    if (out_f32) hipLaunchKernelGGL((win_conv_kernel<512, 64, true, true>), grid, dim3(WC_NT), 0, s, a);
+    else hipLaunchKernelGGL((win_conv_kernel<512, 64, false, true>), grid, dim3(WC_NT), 0, s, a);
+  }
+  return 0;
 }
 
 }  // namespace
 
-extern "C" int ttsk_ffn_conv_supported(int Cin, int Cout, int K) {
-  return Cin == FC_CIN && Cout > 0 && Cout % FC_COUT == 0 && K >= 1 && K <= 2 * FC_H + 1 && (K & 1) == 1;
+extern "C" int ttsk_win_conv_supported(int Cin, int Cout, int K) {
+  return (Cin == 256 || Cin == 512) && Cout > 0 && Cout % WC_COUT == 0 && K >= 1 && K <= 2 * WC_H + 1 && (K & 1) == 1;
 }
+extern "C" int ttsk_ffn_conv_supported(int Cin, int Cout, int K) { return Cin == 256 && ttsk_win_conv_supported(Cin, Cout, K); }
 
-extern "C" int ttsk_ffn_pack_weight_batch(const void* const* w_bf16, void* const* packed_bf16, int n, int Cout, int K, void* stream) {
-  TTSK_REQUIRE(w_bf16 && packed_bf16 && n > 0 && n <= 16 && Cout > 0 && Cout % 16 == 0 && K >= 1, "ttsk_ffn_pack_weight_batch: bad arguments");
+extern "C" int ttsk_win_conv_pack_batch(const void* const* w_bf16, void* const* packed_bf16, int n, int Cs, int K, int Ds, int transpose,
+                                        void* stream) {
+  TTSK_REQUIRE(w_bf16 && packed_bf16 && n > 0 && n <= 16 && Cs > 0 && Cs % 32 == 0 && Ds > 0 && Ds % 32 == 0 && K >= 1,
+               "ttsk_win_conv_pack_batch: bad arguments");
   PackBatch pb;
   for (int i = 0; i < 16; ++i) {
     pb.src[i] = (const bf16_t*)w_bf16[i < n ? i : 0];
     pb.dst[i] = (bf16_t*)packed_bf16[i < n ? i : 0];
-    TTSK_REQUIRE(pb.src[i] && pb.dst[i] && ((((uintptr_t)pb.src[i]) | ((uintptr_t)pb.dst[i])) & 15) == 0, "ttsk_ffn_pack_weight_batch: null / unaligned pointer");
+    TTSK_REQUIRE(pb.src[i] && pb.dst[i] && ((((uintptr_t)pb.src[i]) | ((uintptr_t)pb.dst[i])) & 15) == 0, "ttsk_win_conv_pack_batch: null / unaligned pointer");
   }
-  const int64_t n8 = (int64_t)Cout * K * (FC_CIN / 8);
+  const int64_t n8 = (int64_t)Cs * K * (Ds / 8);
   int blocks = (int)((n8 + 255) / 256);
   if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL(ffn_pack_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, pb, Cout, K);
+  hipLaunchKernelGGL(win_pack_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, pb, Cs, K, Ds, transpose);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }
-
+extern "C" int ttsk_ffn_pack_weight_batch(const void* const* w_bf16, void* const* packed_bf16, int n, int Cout, int K, void* stream) {
+  return ttsk_win_conv_pack_batch(w_bf16, packed_bf16, n, Cout, K, 256, 0, stream);
+}
 extern "C" int ttsk_ffn_pack_weight(const void* w_bf16, void* packed_bf16, int Cout, int K, void* stream) {
-  return ttsk_ffn_pack_weight_batch(&w_bf16, &packed_bf16, 1, Cout, K, stream);
+  return ttsk_win_conv_pack_batch(&w_bf16, &packed_bf16, 1, Cout, K, 256, 0, stream);
+}
+
+extern "C" int ttsk_win_conv(const void* x_bf16, const void* w_packed, const float* bias, void* out, int out_f32, int B, int S, int Cin,
+                             int Cout, int K, int relu, void* stream) {
+  TTSK_REQUIRE(x_bf16 && w_packed && out, "ttsk_win_conv: null pointer");
+  TTSK_REQUIRE(B > 0 && S > 0 && B <= 65535, "ttsk_win_conv: bad sizes B=%d S=%d", B, S);
+  TTSK_REQUIRE(ttsk_win_conv_supported(Cin, Cout, K) && !(out_f32 && Cin != 512), "ttsk_win_conv: no instance for Cin=%d Cout=%d K=%d out_f32=%d", Cin,
+               Cout, K, out_f32);
+  TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_packed) | ((uintptr_t)bias) | ((uintptr_t)out)) & 15) == 0, "ttsk_win_conv: 16-byte alignment");
+  TTSK_REQUIRE((int64_t)B * S * (Cout > Cin ? Cout : Cin) * 4 < ((int64_t)1 << 40), "ttsk_win_conv: sizes out of range");
+  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, bias, out, S, K, Cout, relu, 0, 0};
+  launch_win_conv(a, B, S, Cin, out_f32, 1, (hipStream_t)stream);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
 }
 
 extern "C" int ttsk_ffn_conv_fwd(const void* x_bf16, const void* w_bf16, const float* bias, void* out_bf16, int B, int S, int Cin, int Cout,
@@ -219,11 +274,8 @@ extern "C" int ttsk_ffn_conv_fwd(const void* x_bf16, const void* w_bf16, const f
   TTSK_REQUIRE(ttsk_ffn_conv_supported(Cin, Cout, K), "ttsk_ffn_conv_fwd: no instance for Cin=%d Cout=%d K=%d", Cin, Cout, K);
   TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_bf16) | ((uintptr_t)bias) | ((uintptr_t)out_bf16)) & 15) == 0, "ttsk_ffn_conv_fwd: 16-byte alignment");
   TTSK_REQUIRE((int64_t)B * S * (Cout > Cin ? Cout : Cin) * 2 < ((int64_t)1 << 40), "ttsk_ffn_conv_fwd: sizes out of range");
-  const int tpu = (S + FC_TT - 1) / FC_TT;
-  FfnArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_bf16, bias, (bf16_t*)out_bf16, S, K, Cout, relu, B, tpu};
-  dim3 grid(tpu * B * (Cout / FC_COUT));
-  if (packed) hipLaunchKernelGGL(ffn_conv_fwd_kernel<true>, grid, dim3(FC_NT), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(ffn_conv_fwd_kernel<false>, grid, dim3(FC_NT), 0, (hipStream_t)stream, a);
+  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_bf16, bias, out_bf16, S, K, Cout, relu, 0, 0};
+  launch_win_conv(a, B, S, Cin, 0, packed, (hipStream_t)stream);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

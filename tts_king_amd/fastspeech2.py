@@ -134,10 +134,10 @@ class FastSpeech2(nn.Module):
         self._deferred_fin = None       # gradient column-sum partials awaiting the batched finalize
         self._side = None               # second HIP stream for parameter-gradient work (see _SideWork)
         self.fused_attention = True     # one kernel for scores + softmax + P.V (and dP + softmax' + dQ) when d_k = 128
-        # w_1 forward of the DECODER blocks on the window kernel (csrc/ffn_conv.hip; d = 256, d_ff % 256 == 0, k <= 9).  It wants the
-        # weights in MFMA-fragment order (1 KiB contiguous per fragment; from the tap-major shadow it is no faster than the
-        # implicit GEMM): `_w1_packed` holds such a copy per decoder block, rewritten by one batched launch whenever the bf16 shadow is
-        # (sync_shadow, the optimizer step).  At the encoder's 1024 rows the two kernels tie, so the encoder keeps the GEMM.
+        # w_1 forward of the DECODER blocks and the PostNet's 512 -> 512 convs (forward and input gradient) on the window kernel
+        # (csrc/ffn_conv.hip).  It wants the weights in MFMA-fragment order (1 KiB contiguous per fragment; from the tap-major shadow it
+        # is no faster than the implicit GEMM): `_w1_packed` holds such copies, rewritten by one batched launch per group whenever the
+        # bf16 shadow is (sync_shadow, the optimizer step).  At the encoder's 1024 rows the two kernels tie, so the encoder keeps the GEMM.
         self.window_ffn = os.environ.get("TTSK_WINDOW_FFN", "1") != "0"
         self._w1_packed = None
         self.flash_attention = True     # ... and without the S x S tensors: online softmax forward, recomputing backward (d_k = 128)
@@ -308,21 +308,33 @@ class FastSpeech2(nn.Module):
             self.refresh_packed()
 
     def refresh_packed(self):
-        """Rewrite the fragment-major copies of the decoder blocks' w_1 from the bf16 shadow (one launch).  Called by everything that
-        writes the shadow: `sync_shadow` and `ScheduledOptim.step_and_update_lr`."""
+        """Rewrite the fragment-major weight copies the window conv kernel reads (csrc/ffn_conv.hip) from the bf16 shadow: the decoder
+        blocks' w_1, and the PostNet's three 512 -> 512 convs both as they are (forward) and transposed with flipped taps (input
+        gradient).  One launch per group.  Called by everything that writes the shadow: `sync_shadow` and
+        `ScheduledOptim.step_and_update_lr`."""
         if not self.window_ffn:
             return
         if self._w1_packed is None:
-            keys = ["decoder.layer_stack.%d.pos_ffn.w_1.weight" % i for i in range(self.n_dec)]
-            keys = [k for k in keys if k in self._table and ops.ffn_conv_supported(self.d, *self._table[k].storage_shape[:2])]
-            if len({self._table[k].storage_shape for k in keys}) > 1 or len(keys) > 16:
-                keys = []
-            n = self._table[keys[0]].numel if keys else 0
-            buf = torch.empty(len(keys) * n, dtype=bf16, device=self._shadow.device)
-            self._w1_packed = {k: buf[i * n:(i + 1) * n] for i, k in enumerate(keys)}
-        if self._w1_packed:
-            keys = list(self._w1_packed)
-            ops.ffn_pack_weight_batch([self._w(k) for k in keys], [self._w1_packed[k] for k in keys])
+            groups = [("w1", ["decoder.layer_stack.%d.pos_ffn.w_1.weight" % i for i in range(self.n_dec)], False),
+                      ("pn", ["postnet.convolutions.%d.0.conv.weight" % i for i in range(1, 4)], False),
+                      ("pnT", ["postnet.convolutions.%d.0.conv.weight" % i for i in range(1, 4)], True)]
+            self._w1_packed, self._pack_groups = {}, []
+            for tag, keys, tr in groups:
+                keys = [k for k in keys if k in self._table]
+                shapes = {self._table[k].storage_shape for k in keys}
+                if not keys or len(shapes) != 1 or len(keys) > 16:
+                    continue
+                cs, kk, ds = next(iter(shapes))
+                if not ops.win_conv_supported(cs if tr else ds, ds if tr else cs, kk) or (tag == "w1" and ds != 256):
+                    continue
+                n = self._table[keys[0]].numel
+                buf = torch.empty(len(keys) * n, dtype=bf16, device=self._shadow.device)
+                views = [buf[i * n:(i + 1) * n] for i in range(len(keys))]
+                for k, v in zip(keys, views):
+                    self._w1_packed[(tag, k)] = v
+                self._pack_groups.append((keys, views, tr))
+        for keys, views, tr in self._pack_groups:
+            ops.win_conv_pack_batch([self._w(k) for k in keys], views, transpose=tr)
 
     # views into the flat buffers ------------------------------------------------------------------
     def _w(self, key, rows=None):
@@ -407,7 +419,7 @@ class FastSpeech2(nn.Module):
                                                         lens, S, p_pre=p, site_pre=site, rng=rng, save_z=ctx_list is not None)
         # (6) FFN: Conv1d(k=9)+ReLU, Conv1d(k=1), dropout, +residual, LayerNorm, zero PAD rows: SubLayers.py:96-99, Layers.py:32
         W1 = self._w(f + "w_1.weight")
-        pk = self._w1_packed.get(f + "w_1.weight") if (self.window_ffn and self._w1_packed) else None
+        pk = self._w1_packed.get(("w1", f + "w_1.weight")) if (self.window_ffn and self._w1_packed) else None
         if pk is not None and x1.dtype == bf16:
             h = ops.ffn_conv_fwd(x1.view(Bn, S, d), W1, self._m(f + "w_1.bias"), relu=True, packed=pk)      # window kernel (csrc/ffn_conv.hip)
         else:
@@ -597,7 +609,12 @@ class FastSpeech2(nn.Module):
         for i in range(5):
             pp = "postnet.convolutions.%d." % i
             # conv output stays fp32: BatchNorm divides by the batch std, which amplifies a bf16 rounding of it
-            yc = ops.conv1d(xin, self._w(pp + "0.conv.weight"), self._m(pp + "0.conv.bias"), out_dtype=torch.float32)
+            pk = self._w1_packed.get(("pn", pp + "0.conv.weight")) if (self.window_ffn and self._w1_packed) else None
+            if pk is not None and xin.dtype == bf16:
+                cw = self._table[pp + "0.conv.weight"].storage_shape
+                yc = ops.win_conv(xin, pk, cw[0], cw[1], bias=self._m(pp + "0.conv.bias"), out_dtype=torch.float32)   # window kernel
+            else:
+                yc = ops.conv1d(xin, self._w(pp + "0.conv.weight"), self._m(pp + "0.conv.bias"), out_dtype=torch.float32)
             C = yc.shape[2]
             if train:
                 mean, rstd = ops.bn_train_stats(yc.view(rows, C), self.get(pp + "1.running_mean"), self.get(pp + "1.running_var"),
@@ -666,7 +683,12 @@ class FastSpeech2(nn.Module):
         xin = mel16.view(Bn, T, self.n_mel)
         for i in range(5):
             pp = "postnet.convolutions.%d." % i
-            yc = ops.conv1d(xin, self._w(pp + "0.conv.weight"), self._m(pp + "0.conv.bias"), out_dtype=torch.float32)
+            pk = self._w1_packed.get(("pn", pp + "0.conv.weight")) if (self.window_ffn and self._w1_packed) else None
+            if pk is not None and xin.dtype == bf16:
+                cw = self._table[pp + "0.conv.weight"].storage_shape
+                yc = ops.win_conv(xin, pk, cw[0], cw[1], bias=self._m(pp + "0.conv.bias"), out_dtype=torch.float32)   # window kernel
+            else:
+                yc = ops.conv1d(xin, self._w(pp + "0.conv.weight"), self._m(pp + "0.conv.bias"), out_dtype=torch.float32)
             C = yc.shape[2]
             last = i == 4
             nxt = ops.bn_apply(yc.view(rows, C), self.get(pp + "1.running_mean"), ops.rsqrt_eps(self.get(pp + "1.running_var")),
@@ -892,7 +914,11 @@ class FastSpeech2(nn.Module):
             with self._side_work(dy, xin):
                 ops.colsum_into(dy, self._g(pp + "0.conv.bias"), defer=self._deferred_fin)
                 ops.conv1d_dw(dy.view(Bn, T, C), xin, self._g(pp + "0.conv.weight"), k=5, defer=self._deferred)
-            if i > 0:
+            pkt = self._w1_packed.get(("pnT", pp + "0.conv.weight")) if (self.window_ffn and self._w1_packed) else None
+            if i > 0 and pkt is not None:
+                cw = self._table[pp + "0.conv.weight"].storage_shape
+                dout = ops.win_conv(dy.view(Bn, T, C), pkt, cw[2], cw[1]).view(rows, -1)       # dX as a forward conv on the transposed pack
+            elif i > 0:
                 dout = ops.conv1d_dx(dy.view(Bn, T, C), self._w(pp + "0.conv.weight")).view(rows, -1)
             else:
                 dmel_tot = ops.conv1d_dx(dy.view(Bn, T, C), self._w(pp + "0.conv.weight"), R=dmel_sum.view(Bn, T, nm)).view(rows, nm)

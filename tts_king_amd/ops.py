@@ -332,6 +332,33 @@ def ffn_pack_weight_batch(Ws, outs):
     check(L.load().ttsk_ffn_pack_weight_batch(C.cast(src, C.c_void_p), C.cast(dst, C.c_void_p), n, Cout, k, _stream()), "ttsk_ffn_pack_weight_batch")
 
 
+def win_conv_supported(Cin, Cout, k):
+    return bool(L.load().ttsk_win_conv_supported(Cin, Cout, k))
+
+
+def win_conv_pack_batch(Ws, outs, transpose=False):
+    """Fragment-major packs of up to 16 tap-major weights (Cs, k, Ds) of one shape in one launch (ttsk_win_conv_pack_batch);
+    transpose: the pack of the conv's input gradient as a forward conv (taps flipped, channels swapped)."""
+    _dev(*Ws, *outs)
+    n = len(Ws)
+    Cs, k, Ds = Ws[0].shape
+    src = (C.c_void_p * n)(*[w.data_ptr() for w in Ws])
+    dst = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+    check(L.load().ttsk_win_conv_pack_batch(C.cast(src, C.c_void_p), C.cast(dst, C.c_void_p), n, Cs, k, Ds, int(transpose), _stream()),
+          "ttsk_win_conv_pack_batch")
+
+
+def win_conv(x, packed, Cout, k, bias=None, relu=False, out_dtype=None):
+    """[relu](Conv1d(Cin -> Cout, k)(x) + bias) on the window kernel, weights = a win_conv_pack_batch pack (ttsk_win_conv).
+    x (B,S,Cin) bf16 -> (B,S,Cout) bf16 or fp32."""
+    _dev(x, packed, bias)
+    Bsz, S, Cin = x.shape
+    out = torch.empty(Bsz, S, Cout, dtype=out_dtype or bf16, device=x.device)
+    check(L.load().ttsk_win_conv(_ptr(x), _ptr(packed), _ptr(bias), _ptr(out), int(out.dtype == torch.float32), Bsz, S, Cin, Cout, k,
+                                 int(relu), _stream()), "ttsk_win_conv")
+    return out
+
+
 def ffn_conv_fwd(x, W, bias, relu=True, packed=None):
     """relu(Conv1d(256 -> Cout, k)(x) + bias) on the window kernel (ttsk_ffn_conv_fwd; SubLayers.py:93-101, w_1).
     x (B,S,256) bf16, W (Cout,k,256) bf16 tap-major -> (B,S,Cout) bf16; `packed`: ffn_pack_weight(W), read instead of W."""

@@ -152,11 +152,20 @@ int ttsk_ffn_pack_weight_batch(const void* const* w_bf16, void* const* packed_bf
  * BatchNorm) fp32.  The weights are always the fragment-major pack written by ttsk_win_conv_pack_batch from the tap-major storage
  * (Cs, K, Ds): transpose = 0 packs the conv's own weights (Cout = Cs, Cin = Ds); transpose = 1 packs the weights of the conv's INPUT
  * GRADIENT seen as a forward conv on dy with flipped taps (Cout = Ds, Cin = Cs), so that ttsk_win_conv(dy, that pack) = dx. */
+typedef struct ttsk_pack_item {
+  const void* src;     /* tap-major bf16 weight (Cs, K, Ds) */
+  void* dst;           /* fragment-major pack, Cs*K*Ds elements */
+  int32_t Cs, K, Ds, transpose;
+} ttsk_pack_item;
 int ttsk_win_conv_supported(int Cin, int Cout, int K);
+/* up to 32 packs of any shapes in ONE launch (the model rewrites all its packs after every optimizer step) */
+int ttsk_win_conv_pack_items(const ttsk_pack_item* items, int n, void* stream);
 int ttsk_win_conv_pack_batch(const void* const* w_bf16, void* const* packed_bf16, int n /* <= 16 */, int Cs, int K, int Ds, int transpose,
                              void* stream);
-int ttsk_win_conv(const void* x_bf16, const void* w_packed, const float* bias /* may be NULL */, void* out, int out_f32, int B, int S,
-                  int Cin, int Cout, int K, int relu, void* stream);
+/* gate_bf16 [B*S][Cout] (may be NULL; bf16 output only): out = gate > 0 ? out : 0 — the ReLU backward of SubLayers.py:96 folded into
+ * the w_2 input-gradient conv. */
+int ttsk_win_conv(const void* x_bf16, const void* w_packed, const float* bias /* may be NULL */, const void* gate_bf16 /* may be NULL */,
+                  void* out, int out_f32, int B, int S, int Cin, int Cout, int K, int relu, void* stream);
 
 /* Fused sub-layer tail of an FFT block (reference: fs_two/transformer/SubLayers.py:62-63 and :96-99 + Layers.py:29,32):
  *   out = zero_PAD_rows( LayerNorm( dropout_{p_pre, site_pre}( A[M,K] @ W[D,K]^T + bias ) + res ) ),  D = 256 only.

@@ -526,3 +526,30 @@ def test_win_conv_postnet_shapes(B, S, K):
     assert float((dgot.double().cpu() - dref).abs().max()) <= 2 ** -8 * float(dref.abs().max()) + 1e-3
     dold = ops.conv1d_dx(x, W)
     assert float((dgot.float() - dold.float()).abs().max()) <= 2 ** -7 * float(dref.abs().max())
+
+
+def test_win_conv_k1_projections_gate_and_item_packs():
+    """The k = 1 uses of the window kernel in the decoder blocks: q|k|v projection (256 -> 768, bias), fc input gradient (transposed
+    pack) and w_2 input gradient (256 -> 1024, transposed pack, zeroed where the saved ReLU output is <= 0: SubLayers.py:96) against
+    the GEMM paths; all three packs written by ONE ttsk_win_conv_pack_items launch."""
+    from tts_king_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, S, d, Fh = 3, 130, 256, 1024
+    x = bf(torch.randn(B, S, d, generator=g)).to(DEV)
+    Wq = bf(torch.randn(3 * d, 1, d, generator=g) * d ** -0.5).to(DEV)
+    bq = (0.1 * torch.randn(3 * d, generator=g)).to(DEV)
+    Wf = bf(torch.randn(d, 1, d, generator=g) * d ** -0.5).to(DEV)
+    W2 = bf(torch.randn(d, 1, Fh, generator=g) * Fh ** -0.5).to(DEV)            # storage (Cout = 256, 1, Cin = 1024)
+    h = bf(torch.randn(B, S, Fh, generator=g)).clamp(min=0).to(DEV)             # a ReLU output: zeros and positives
+    pq, pf, p2 = (torch.empty(w.numel(), dtype=torch.bfloat16, device=DEV) for w in (Wq, Wf, W2))
+    ops.win_conv_pack_items([(Wq, pq, False), (Wf, pf, True), (W2, p2, True)])
+    qkv = ops.win_conv(x, pq, 3 * d, 1, bias=bq)
+    assert torch.equal(qkv.view(-1, 3 * d), ops.linear(x.view(-1, d), Wq.view(3 * d, d), bq))
+    do = ops.win_conv(x, pf, d, 1)
+    ref = ops.linear_dx(x.view(-1, d), Wf.view(d, d))
+    assert float((do.view(-1, d).float() - ref.float()).abs().max()) <= 2 ** -7 * float(ref.float().abs().max())
+    dh = ops.win_conv(x, p2, Fh, 1, gate=h)
+    ref = ops.conv1d_dx(x, W2, G=h)
+    assert float((dh.float() - ref.float()).abs().max()) <= 2 ** -7 * float(ref.float().abs().max())
+    assert torch.equal(dh == 0, (ref == 0)) or float(((dh == 0) != (ref == 0)).float().mean()) < 1e-3
+    assert bool((dh[h <= 0] == 0).all())

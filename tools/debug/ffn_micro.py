@@ -33,3 +33,15 @@ t1 = timeit(lambda: ops.win_conv(x, pk, 512, 5, bias=b, out_dtype=torch.float32)
 t3 = timeit(lambda: ops.win_conv(x, pkt, 512, 5)); t4 = timeit(lambda: ops.conv1d_dx(x, W))
 t5 = timeit(lambda: ops.win_conv_pack_batch([W, W, W], [pk, pk, pk])); t6 = timeit(lambda: ops.win_conv_pack_batch([W, W, W], [pkt, pkt, pkt], transpose=True))
 print("B=16 S=423 PostNet 512->512 k5: fwd window %.1f us | GEMM %.1f us || dX window %.1f us | GEMM %.1f us || packs of 3 weights: %.1f us, transposed %.1f us" % (t1, t2, t3, t4, t5, t6))
+
+# decoder-side k = 1 projections on the window kernel: QKV (256 -> 768) and fc dX (256 -> 256, transposed pack)
+x = torch.randn(16, 423, 256, device=DEV).bfloat16()
+Wq = (torch.randn(768, 1, 256, device=DEV) * 0.05).bfloat16(); bq = torch.randn(768, device=DEV)
+pq = torch.empty(Wq.numel(), dtype=torch.bfloat16, device=DEV); ops.win_conv_pack_batch([Wq], [pq])
+a = ops.win_conv(x, pq, 768, 1, bias=bq); b2 = ops.linear(x.view(-1, 256), Wq.view(768, 256), bq)
+print("QKV max diff %.3g" % float((a.view(-1, 768).float() - b2.float()).abs().max()))
+t1 = timeit(lambda: ops.win_conv(x, pq, 768, 1, bias=bq)); t2 = timeit(lambda: ops.linear(x.view(-1, 256), Wq.view(768, 256), bq))
+Wf = (torch.randn(256, 1, 256, device=DEV) * 0.05).bfloat16()
+pf = torch.empty(Wf.numel(), dtype=torch.bfloat16, device=DEV); ops.win_conv_pack_batch([Wf], [pf], transpose=True)
+t3 = timeit(lambda: ops.win_conv(x, pf, 256, 1)); t4 = timeit(lambda: ops.linear_dx(x.view(-1, 256), Wf.view(256, 256)))
+print("B=16 S=423 QKV 256->768: window %.1f us | GEMM %.1f us || fc dX 256->256: window %.1f us | GEMM %.1f us" % (t1, t2, t3, t4))

@@ -28,6 +28,7 @@ struct WcArgs {
   void* out;            // [B*S][Cout] bf16, or fp32 when OUT32
   int S, K, Cout, relu;
   int B, tiles_per_utt;
+  const bf16_t* gate;   // [B*S][Cout] bf16 or null: out = gate > 0 ? out : 0 (a ReLU's backward on the way out; bf16 output only)
 };
 
 // Weight packs.  src = storage (Cs, K, Ds) bf16 tap-major.
@@ -36,12 +37,15 @@ struct WcArgs {
 //                  W'[co' = ci][tap][ci' = co] = src[co][K-1-tap][ci]                            (Cout' = Ds, Cin' = Cs)
 // dst = [K][Cin'/32][Cout'/16][64][8]: lane l of a fragment holds W'[c*16 + (l & 15)][tap][ks*32 + (l >> 4)*8 + j], j = 0..7.
 struct PackBatch {
-  const bf16_t* src[16];
-  bf16_t* dst[16];
+  const bf16_t* src[32];
+  bf16_t* dst[32];
+  int Cs[32], K[32], Ds[32], transpose[32];
 };
-__global__ __launch_bounds__(256) void win_pack_kernel(const PackBatch pb, int Cs, int K, int Ds, int transpose) {
-  const bf16_t* __restrict__ src = pb.src[blockIdx.y];
-  bf16_t* __restrict__ dst = pb.dst[blockIdx.y];
+__global__ __launch_bounds__(256) void win_pack_kernel(const PackBatch pb) {
+  const int it = blockIdx.y;
+  const bf16_t* __restrict__ src = pb.src[it];
+  bf16_t* __restrict__ dst = pb.dst[it];
+  const int Cs = pb.Cs[it], K = pb.K[it], Ds = pb.Ds[it], transpose = pb.transpose[it];
   const int Co = transpose ? Ds : Cs, Ci = transpose ? Cs : Ds;
   const int64_t n8 = (int64_t)Co * K * (Ci / 8);                 // 16-byte pieces of the pack
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
@@ -202,7 +206,18 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
     const int idx = it * NT + tid;
     const int rr = idx / OCH, ch = idx - rr * OCH;
     const int t = t0 + rr;
-    if (idx < TT * OCH && t < S) *(uint4*)(ob + (int64_t)t * a.Cout * ESZ + ch * 16) = *(const uint4*)(XW + rr * RS + ch * 16);
+    if (idx < TT * OCH && t < S) {
+      uint4 v = *(const uint4*)(XW + rr * RS + ch * 16);
+      if (!OUT32 && a.gate) {
+        const uint4 g = *(const uint4*)(a.gate + ((int64_t)bi * S + t) * a.Cout + cg * WC_COUT + ch * 8);
+        auto keep = [](unsigned w) {      // 0xFFFF per bf16 half that is > 0 (sign clear, not zero)
+          const unsigned lo = w & 0xFFFFu, hi = w >> 16;
+          return ((lo - 1u) < 0x7FFFu ? 0xFFFFu : 0u) | ((hi - 1u) < 0x7FFFu ? 0xFFFF0000u : 0u);
+        };
+        v.x &= keep(g.x); v.y &= keep(g.y); v.z &= keep(g.z); v.w &= keep(g.w);
+      }
+      *(uint4*)(ob + (int64_t)t * a.Cout * ESZ + ch * 16) = v;
+    }
   }
 }
 
@@ -229,22 +244,32 @@ extern "C" int ttsk_win_conv_supported(int Cin, int Cout, int K) {
 }
 extern "C" int ttsk_ffn_conv_supported(int Cin, int Cout, int K) { return Cin == 256 && ttsk_win_conv_supported(Cin, Cout, K); }
 
-extern "C" int ttsk_win_conv_pack_batch(const void* const* w_bf16, void* const* packed_bf16, int n, int Cs, int K, int Ds, int transpose,
-                                        void* stream) {
-  TTSK_REQUIRE(w_bf16 && packed_bf16 && n > 0 && n <= 16 && Cs > 0 && Cs % 32 == 0 && Ds > 0 && Ds % 32 == 0 && K >= 1,
-               "ttsk_win_conv_pack_batch: bad arguments");
+extern "C" int ttsk_win_conv_pack_items(const ttsk_pack_item* items, int n, void* stream) {
+  TTSK_REQUIRE(items && n > 0 && n <= 32, "ttsk_win_conv_pack_items: 1..32 items");
   PackBatch pb;
-  for (int i = 0; i < 16; ++i) {
-    pb.src[i] = (const bf16_t*)w_bf16[i < n ? i : 0];
-    pb.dst[i] = (bf16_t*)packed_bf16[i < n ? i : 0];
-    TTSK_REQUIRE(pb.src[i] && pb.dst[i] && ((((uintptr_t)pb.src[i]) | ((uintptr_t)pb.dst[i])) & 15) == 0, "ttsk_win_conv_pack_batch: null / unaligned pointer");
+  int64_t nmax = 0;
+  for (int i = 0; i < 32; ++i) {
+    const ttsk_pack_item& it = items[i < n ? i : 0];
+    TTSK_REQUIRE(it.src && it.dst && ((((uintptr_t)it.src) | ((uintptr_t)it.dst)) & 15) == 0, "ttsk_win_conv_pack_items: null / unaligned pointer");
+    TTSK_REQUIRE(it.Cs > 0 && it.Cs % 32 == 0 && it.Ds > 0 && it.Ds % 32 == 0 && it.K >= 1, "ttsk_win_conv_pack_items: bad shape (%d, %d, %d)", it.Cs, it.K, it.Ds);
+    pb.src[i] = (const bf16_t*)it.src; pb.dst[i] = (bf16_t*)it.dst;
+    pb.Cs[i] = it.Cs; pb.K[i] = it.K; pb.Ds[i] = it.Ds; pb.transpose[i] = it.transpose;
+    const int64_t n8 = (int64_t)it.Cs * it.K * (it.Ds / 8);
+    if (n8 > nmax) nmax = n8;
   }
-  const int64_t n8 = (int64_t)Cs * K * (Ds / 8);
-  int blocks = (int)((n8 + 255) / 256);
-  if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL(win_pack_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, pb, Cs, K, Ds, transpose);
+  int blocks = (int)((nmax + 255) / 256);
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(win_pack_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, pb);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
+}
+
+extern "C" int ttsk_win_conv_pack_batch(const void* const* w_bf16, void* const* packed_bf16, int n, int Cs, int K, int Ds, int transpose,
+                                        void* stream) {
+  TTSK_REQUIRE(w_bf16 && packed_bf16 && n > 0 && n <= 16, "ttsk_win_conv_pack_batch: bad arguments");
+  ttsk_pack_item items[16];
+  for (int i = 0; i < n; ++i) items[i] = ttsk_pack_item{w_bf16[i], packed_bf16[i], Cs, K, Ds, transpose};
+  return ttsk_win_conv_pack_items(items, n, stream);
 }
 extern "C" int ttsk_ffn_pack_weight_batch(const void* const* w_bf16, void* const* packed_bf16, int n, int Cout, int K, void* stream) {
   return ttsk_win_conv_pack_batch(w_bf16, packed_bf16, n, Cout, K, 256, 0, stream);
@@ -253,15 +278,16 @@ extern "C" int ttsk_ffn_pack_weight(const void* w_bf16, void* packed_bf16, int C
   return ttsk_win_conv_pack_batch(&w_bf16, &packed_bf16, 1, Cout, K, 256, 0, stream);
 }
 
-extern "C" int ttsk_win_conv(const void* x_bf16, const void* w_packed, const float* bias, void* out, int out_f32, int B, int S, int Cin,
-                             int Cout, int K, int relu, void* stream) {
+extern "C" int ttsk_win_conv(const void* x_bf16, const void* w_packed, const float* bias, const void* gate_bf16, void* out, int out_f32, int B,
+                             int S, int Cin, int Cout, int K, int relu, void* stream) {
   TTSK_REQUIRE(x_bf16 && w_packed && out, "ttsk_win_conv: null pointer");
   TTSK_REQUIRE(B > 0 && S > 0 && B <= 65535, "ttsk_win_conv: bad sizes B=%d S=%d", B, S);
   TTSK_REQUIRE(ttsk_win_conv_supported(Cin, Cout, K) && !(out_f32 && Cin != 512), "ttsk_win_conv: no instance for Cin=%d Cout=%d K=%d out_f32=%d", Cin,
                Cout, K, out_f32);
   TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_packed) | ((uintptr_t)bias) | ((uintptr_t)out)) & 15) == 0, "ttsk_win_conv: 16-byte alignment");
   TTSK_REQUIRE((int64_t)B * S * (Cout > Cin ? Cout : Cin) * 4 < ((int64_t)1 << 40), "ttsk_win_conv: sizes out of range");
-  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, bias, out, S, K, Cout, relu, 0, 0};
+  TTSK_REQUIRE(!(gate_bf16 && out_f32) && (((uintptr_t)gate_bf16) & 15) == 0, "ttsk_win_conv: the gate goes with bf16 output, 16-byte aligned");
+  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, bias, out, S, K, Cout, relu, 0, 0, (const bf16_t*)gate_bf16};
   launch_win_conv(a, B, S, Cin, out_f32, 1, (hipStream_t)stream);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
@@ -274,7 +300,7 @@ extern "C" int ttsk_ffn_conv_fwd(const void* x_bf16, const void* w_bf16, const f
   TTSK_REQUIRE(ttsk_ffn_conv_supported(Cin, Cout, K), "ttsk_ffn_conv_fwd: no instance for Cin=%d Cout=%d K=%d", Cin, Cout, K);
   TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_bf16) | ((uintptr_t)bias) | ((uintptr_t)out_bf16)) & 15) == 0, "ttsk_ffn_conv_fwd: 16-byte alignment");
   TTSK_REQUIRE((int64_t)B * S * (Cout > Cin ? Cout : Cin) * 2 < ((int64_t)1 << 40), "ttsk_ffn_conv_fwd: sizes out of range");
-  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_bf16, bias, out_bf16, S, K, Cout, relu, 0, 0};
+  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_bf16, bias, out_bf16, S, K, Cout, relu, 0, 0, nullptr};
   launch_win_conv(a, B, S, Cin, 0, packed, (hipStream_t)stream);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;

@@ -315,26 +315,37 @@ class FastSpeech2(nn.Module):
         if not self.window_ffn:
             return
         if self._w1_packed is None:
-            groups = [("w1", ["decoder.layer_stack.%d.pos_ffn.w_1.weight" % i for i in range(self.n_dec)], False),
-                      ("pn", ["postnet.convolutions.%d.0.conv.weight" % i for i in range(1, 4)], False),
-                      ("pnT", ["postnet.convolutions.%d.0.conv.weight" % i for i in range(1, 4)], True)]
-            self._w1_packed, self._pack_groups = {}, []
-            for tag, keys, tr in groups:
-                keys = [k for k in keys if k in self._table]
-                shapes = {self._table[k].storage_shape for k in keys}
-                if not keys or len(shapes) != 1 or len(keys) > 16:
+            d, dec = self.d, ["decoder.layer_stack.%d." % i for i in range(self.n_dec)]
+            # (tag, key, rows of a fused view or None, transpose)
+            want = [("w1", p + "pos_ffn.w_1.weight", None, False) for p in dec] + \
+                   [("qkv", p + "slf_attn.w_qs.weight", 3 * d, False) for p in dec] + \
+                   [("fcT", p + "slf_attn.fc.weight", None, True) for p in dec] + \
+                   [("w2T", p + "pos_ffn.w_2.weight", None, True) for p in dec] + \
+                   [("pn", "postnet.convolutions.%d.0.conv.weight" % i, None, False) for i in range(1, 4)] + \
+                   [("pnT", "postnet.convolutions.%d.0.conv.weight" % i, None, True) for i in range(1, 4)]
+            items = []
+            for tag, key, fused_rows, tr in want:
+                if key not in self._table:
                     continue
-                cs, kk, ds = next(iter(shapes))
-                if not ops.win_conv_supported(cs if tr else ds, ds if tr else cs, kk) or (tag == "w1" and ds != 256):
+                W = self._pack_source(key, fused_rows)
+                cs, kk, ds = W.shape
+                if W.dim() != 3 or not ops.win_conv_supported(cs if tr else ds, ds if tr else cs, kk):
                     continue
-                n = self._table[keys[0]].numel
-                buf = torch.empty(len(keys) * n, dtype=bf16, device=self._shadow.device)
-                views = [buf[i * n:(i + 1) * n] for i in range(len(keys))]
-                for k, v in zip(keys, views):
-                    self._w1_packed[(tag, k)] = v
-                self._pack_groups.append((keys, views, tr))
-        for keys, views, tr in self._pack_groups:
-            ops.win_conv_pack_batch([self._w(k) for k in keys], views, transpose=tr)
+                items.append((tag, key, fused_rows, tr, W.numel()))
+            items = items[:32]
+            buf = torch.empty(sum(it[4] for it in items), dtype=bf16, device=self._shadow.device)
+            self._w1_packed, self._pack_items, off = {}, [], 0
+            for tag, key, fused_rows, tr, n in items:
+                self._w1_packed[(tag, key)] = buf[off:off + n]
+                self._pack_items.append((key, fused_rows, buf[off:off + n], tr))
+                off += n
+        if self._pack_items:
+            ops.win_conv_pack_items([(self._pack_source(key, fr), out, tr) for key, fr, out, tr in self._pack_items])
+
+    def _pack_source(self, key, fused_rows=None):
+        """The tap-major bf16 shadow of `key` as a (Cs, k, Ds) tensor (a Linear weight is k = 1; `fused_rows`: the q|k|v rows as one)."""
+        W = self._w(key, fused_rows) if fused_rows is not None else self._w(key)
+        return W.view(W.shape[0], 1, W.shape[1]) if W.dim() == 2 else W
 
     # views into the flat buffers ------------------------------------------------------------------
     def _w(self, key, rows=None):
@@ -387,7 +398,11 @@ class FastSpeech2(nn.Module):
         Sp = (S + 7) // 8 * 8
         dev = x.device
         # (1) q|k|v projections as one GEMM into a [rows][3d] buffer: SubLayers.py:41-43
-        qkv = ops.linear(x, self._w(a + "w_qs.weight", 3 * d), self._m(a + "w_qs.bias", 3 * d))
+        pkq = self._w1_packed.get(("qkv", a + "w_qs.weight")) if (self.window_ffn and self._w1_packed) else None
+        if pkq is not None and x.dtype == bf16:
+            qkv = ops.win_conv(x.view(Bn, S, d), pkq, 3 * d, 1, bias=self._m(a + "w_qs.bias", 3 * d)).view(rows, 3 * d)   # window kernel, k = 1
+        else:
+            qkv = ops.linear(x, self._w(a + "w_qs.weight", 3 * d), self._m(a + "w_qs.bias", 3 * d))
         if self.flash_attention and dk == 128:
             # (2)-(4) one kernel, no S x S tensor: scores, key-padding mask, online softmax, P V, heads merged (Modules.py:15-22,
             # SubLayers.py:57-60); the backward recomputes P from the per-row log-sum-exp kept in `probs`'s slot
@@ -779,7 +794,11 @@ class FastSpeech2(nn.Module):
         with self._side_work(dy2, part, h):
             self._finalize_ln(part, nblk, 3 * d, f + "w_2.bias")
             ops.conv1d_dw(dy2.view(Bn, S, d), h, self._g(f + "w_2.weight"), k=self.k2, defer=self._deferred)
-        dh = ops.conv1d_dx(dy2.view(Bn, S, d), self._w(f + "w_2.weight"), G=h)
+        pk2 = self._w1_packed.get(("w2T", f + "w_2.weight")) if (self.window_ffn and self._w1_packed) else None
+        if pk2 is not None and self.k2 == 1:
+            dh = ops.win_conv(dy2.view(Bn, S, d), pk2, h.shape[-1], 1, gate=h)         # dX as a forward conv on the transposed pack, ReLU gate on the way out
+        else:
+            dh = ops.conv1d_dx(dy2.view(Bn, S, d), self._w(f + "w_2.weight"), G=h)
         # ---- w_1 (k=9): bias, dW, dX + residual gradient; the dX stays in split-K form for the attention LayerNorm's backward
         with self._side_work(dh, x1):
             ops.colsum_into(dh.view(rows, -1), self._g(f + "w_1.bias"), defer=self._deferred_fin)
@@ -796,7 +815,11 @@ class FastSpeech2(nn.Module):
         with self._side_work(dy1, part, o):
             self._finalize_ln(part, nblk, 3 * d, a + "fc.bias")
             ops.linear_dw(dy1, o, self._g(a + "fc.weight"), defer=self._deferred)
-        do = ops.linear_dx(dy1, self._w(a + "fc.weight"))
+        pkf = self._w1_packed.get(("fcT", a + "fc.weight")) if (self.window_ffn and self._w1_packed) else None
+        if pkf is not None:
+            do = ops.win_conv(dy1.view(Bn, S, d), pkf, d, 1).view(rows, d)
+        else:
+            do = ops.linear_dx(dy1, self._w(a + "fc.weight"))
         # ---- attention core: dP = dO V^T ; dS = softmax'(P, dP)/sqrt(dk) ; dQ = dS K ; dK = dS^T Q ; dV = P^T dO
         if flash:
             dqkv = ops.flash_attention_bwd(qkv, o, do, probs, lens, Bn, H, S, o32=o32)      # P recomputed per tile; dQ, dK, dV in two launches

@@ -348,14 +348,25 @@ def win_conv_pack_batch(Ws, outs, transpose=False):
           "ttsk_win_conv_pack_batch")
 
 
-def win_conv(x, packed, Cout, k, bias=None, relu=False, out_dtype=None):
-    """[relu](Conv1d(Cin -> Cout, k)(x) + bias) on the window kernel, weights = a win_conv_pack_batch pack (ttsk_win_conv).
-    x (B,S,Cin) bf16 -> (B,S,Cout) bf16 or fp32."""
-    _dev(x, packed, bias)
+def win_conv_pack_items(items):
+    """items: [(W (Cs,k,Ds) bf16 tap-major, out flat bf16, transpose)], up to 32 of any shapes, one launch (ttsk_win_conv_pack_items)."""
+    n = len(items)
+    arr = (L.PackItem * n)()
+    for i, (W, out, tr) in enumerate(items):
+        _dev(W, out)
+        arr[i].src, arr[i].dst = W.data_ptr(), out.data_ptr()
+        arr[i].Cs, arr[i].K, arr[i].Ds, arr[i].transpose = W.shape[0], W.shape[1], W.shape[2], int(tr)
+    check(L.load().ttsk_win_conv_pack_items(arr, n, _stream()), "ttsk_win_conv_pack_items")
+
+
+def win_conv(x, packed, Cout, k, bias=None, relu=False, out_dtype=None, gate=None):
+    """[relu](Conv1d(Cin -> Cout, k)(x) + bias) on the window kernel, weights = a win_conv_pack_batch pack (ttsk_win_conv); `gate`
+    (B,S,Cout) bf16: result zeroed where gate <= 0.  x (B,S,Cin) bf16 -> (B,S,Cout) bf16 or fp32."""
+    _dev(x, packed, bias, gate)
     Bsz, S, Cin = x.shape
     out = torch.empty(Bsz, S, Cout, dtype=out_dtype or bf16, device=x.device)
-    check(L.load().ttsk_win_conv(_ptr(x), _ptr(packed), _ptr(bias), _ptr(out), int(out.dtype == torch.float32), Bsz, S, Cin, Cout, k,
-                                 int(relu), _stream()), "ttsk_win_conv")
+    check(L.load().ttsk_win_conv(_ptr(x), _ptr(packed), _ptr(bias), _ptr(gate), _ptr(out), int(out.dtype == torch.float32), Bsz, S, Cin, Cout,
+                                 k, int(relu), _stream()), "ttsk_win_conv")
     return out
 
 

@@ -158,7 +158,7 @@ typedef struct ttsk_pack_item {
   int32_t Cs, K, Ds, transpose;
 } ttsk_pack_item;
 int ttsk_win_conv_supported(int Cin, int Cout, int K);
-/* up to 32 packs of any shapes in ONE launch (the model rewrites all its packs after every optimizer step) */
+/* up to 48 packs of any shapes in ONE launch (the model rewrites all its packs after every optimizer step) */
 int ttsk_win_conv_pack_items(const ttsk_pack_item* items, int n, void* stream);
 int ttsk_win_conv_pack_batch(const void* const* w_bf16, void* const* packed_bf16, int n /* <= 16 */, int Cs, int K, int Ds, int transpose,
                              void* stream);

@@ -37,9 +37,9 @@ struct WcArgs {
 //                  W'[co' = ci][tap][ci' = co] = src[co][K-1-tap][ci]                            (Cout' = Ds, Cin' = Cs)
 // dst = [K][Cin'/32][Cout'/16][64][8]: lane l of a fragment holds W'[c*16 + (l & 15)][tap][ks*32 + (l >> 4)*8 + j], j = 0..7.
 struct PackBatch {
-  const bf16_t* src[32];
-  bf16_t* dst[32];
-  int Cs[32], K[32], Ds[32], transpose[32];
+  const bf16_t* src[48];
+  bf16_t* dst[48];
+  int Cs[48], K[48], Ds[48], transpose[48];
 };
 __global__ __launch_bounds__(256) void win_pack_kernel(const PackBatch pb) {
   const int it = blockIdx.y;
@@ -223,11 +223,14 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
 
 int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int packed, hipStream_t s) {
   WcArgs a = a0;
-  const int TT = Cin == 256 ? 112 : 64;
+  const bool short_seq = Cin == 256 && packed && (S <= 64 || (S > 112 && S <= 128));      // phoneme-side sequences: 64-frame tiles waste less
+  const int TT = Cin == 256 && !short_seq ? 112 : 64;
   a.B = B;
   a.tiles_per_utt = (S + TT - 1) / TT;
   dim3 grid(a.tiles_per_utt * B * (a.Cout / WC_COUT));
-  if (Cin == 256) {
+  if (short_seq) {
+    hipLaunchKernelGGL((win_conv_kernel<256, 64, false, true>), grid, dim3(WC_NT), 0, s, a);
+  } else if (Cin == 256) {
     if (packed) hipLaunchKernelGGL((win_conv_kernel<256, 112, false, true>), grid, dim3(WC_NT), 0, s, a);
     else hipLaunchKernelGGL((win_conv_kernel<256, 112, false, false>), grid, dim3(WC_NT), 0, s, a);
   } else {
@@ -245,10 +248,10 @@ extern "C" int ttsk_win_conv_supported(int Cin, int Cout, int K) {
 extern "C" int ttsk_ffn_conv_supported(int Cin, int Cout, int K) { return Cin == 256 && ttsk_win_conv_supported(Cin, Cout, K); }
 
 extern "C" int ttsk_win_conv_pack_items(const ttsk_pack_item* items, int n, void* stream) {
-  TTSK_REQUIRE(items && n > 0 && n <= 32, "ttsk_win_conv_pack_items: 1..32 items");
+  TTSK_REQUIRE(items && n > 0 && n <= 48, "ttsk_win_conv_pack_items: 1..48 items");
   PackBatch pb;
   int64_t nmax = 0;
-  for (int i = 0; i < 32; ++i) {
+  for (int i = 0; i < 48; ++i) {
     const ttsk_pack_item& it = items[i < n ? i : 0];
     TTSK_REQUIRE(it.src && it.dst && ((((uintptr_t)it.src) | ((uintptr_t)it.dst)) & 15) == 0, "ttsk_win_conv_pack_items: null / unaligned pointer");
     TTSK_REQUIRE(it.Cs > 0 && it.Cs % 32 == 0 && it.Ds > 0 && it.Ds % 32 == 0 && it.K >= 1, "ttsk_win_conv_pack_items: bad shape (%d, %d, %d)", it.Cs, it.K, it.Ds);

@@ -134,10 +134,11 @@ class FastSpeech2(nn.Module):
         self._deferred_fin = None       # gradient column-sum partials awaiting the batched finalize
         self._side = None               # second HIP stream for parameter-gradient work (see _SideWork)
         self.fused_attention = True     # one kernel for scores + softmax + P.V (and dP + softmax' + dQ) when d_k = 128
-        # w_1 forward of the DECODER blocks and the PostNet's 512 -> 512 convs (forward and input gradient) on the window kernel
-        # (csrc/ffn_conv.hip).  It wants the weights in MFMA-fragment order (1 KiB contiguous per fragment; from the tap-major shadow it
-        # is no faster than the implicit GEMM): `_w1_packed` holds such copies, rewritten by one batched launch per group whenever the
-        # bf16 shadow is (sync_shadow, the optimizer step).  At the encoder's 1024 rows the two kernels tie, so the encoder keeps the GEMM.
+        # The FFT blocks' w_1 forward, q|k|v projection, fc and w_2 input gradients, and the PostNet's 512 -> 512 convs (forward and
+        # input gradient) run on the window kernel (csrc/ffn_conv.hip).  It wants the weights in MFMA-fragment order (1 KiB contiguous
+        # per fragment; from the tap-major shadow it is no faster than the implicit GEMM): `_w1_packed` holds such copies — for an input
+        # gradient the transposed, tap-flipped weight — all rewritten by ONE launch whenever the bf16 shadow is (sync_shadow, the
+        # optimizer step).
         self.window_ffn = os.environ.get("TTSK_WINDOW_FFN", "1") != "0"
         self._w1_packed = None
         self.flash_attention = True     # ... and without the S x S tensors: online softmax forward, recomputing backward (d_k = 128)
@@ -316,11 +317,12 @@ class FastSpeech2(nn.Module):
             return
         if self._w1_packed is None:
             d, dec = self.d, ["decoder.layer_stack.%d." % i for i in range(self.n_dec)]
+            enc = ["encoder.layer_stack.%d." % i for i in range(self.n_enc)]
             # (tag, key, rows of a fused view or None, transpose)
-            want = [("w1", p + "pos_ffn.w_1.weight", None, False) for p in dec] + \
-                   [("qkv", p + "slf_attn.w_qs.weight", 3 * d, False) for p in dec] + \
-                   [("fcT", p + "slf_attn.fc.weight", None, True) for p in dec] + \
-                   [("w2T", p + "pos_ffn.w_2.weight", None, True) for p in dec] + \
+            want = [("w1", p + "pos_ffn.w_1.weight", None, False) for p in dec + enc] + \
+                   [("qkv", p + "slf_attn.w_qs.weight", 3 * d, False) for p in dec + enc] + \
+                   [("fcT", p + "slf_attn.fc.weight", None, True) for p in dec + enc] + \
+                   [("w2T", p + "pos_ffn.w_2.weight", None, True) for p in dec + enc] + \
                    [("pn", "postnet.convolutions.%d.0.conv.weight" % i, None, False) for i in range(1, 4)] + \
                    [("pnT", "postnet.convolutions.%d.0.conv.weight" % i, None, True) for i in range(1, 4)]
             items = []
@@ -332,7 +334,7 @@ class FastSpeech2(nn.Module):
                 if W.dim() != 3 or not ops.win_conv_supported(cs if tr else ds, ds if tr else cs, kk):
                     continue
                 items.append((tag, key, fused_rows, tr, W.numel()))
-            items = items[:32]
+            items = items[:48]
             buf = torch.empty(sum(it[4] for it in items), dtype=bf16, device=self._shadow.device)
             self._w1_packed, self._pack_items, off = {}, [], 0
             for tag, key, fused_rows, tr, n in items:

@@ -349,7 +349,7 @@ def win_conv_pack_batch(Ws, outs, transpose=False):
 
 
 def win_conv_pack_items(items):
-    """items: [(W (Cs,k,Ds) bf16 tap-major, out flat bf16, transpose)], up to 32 of any shapes, one launch (ttsk_win_conv_pack_items)."""
+    """items: [(W (Cs,k,Ds) bf16 tap-major, out flat bf16, transpose)], up to 48 of any shapes, one launch (ttsk_win_conv_pack_items)."""
     n = len(items)
     arr = (L.PackItem * n)()
     for i, (W, out, tr) in enumerate(items):

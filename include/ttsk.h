@@ -162,6 +162,12 @@ int ttsk_win_conv_supported(int Cin, int Cout, int K);
 int ttsk_win_conv_pack_items(const ttsk_pack_item* items, int n, void* stream);
 int ttsk_win_conv_pack_batch(const void* const* w_bf16, void* const* packed_bf16, int n /* <= 16 */, int Cs, int K, int Ds, int transpose,
                              void* stream);
+/* An input gradient whose contraction is wide (w_1: 1024 channels x 9 taps; q|k|v: 768), as nsplit window convs over 256-channel slices
+ * of x [B*S][nsplit*256] in ONE launch: w_packed is the whole transposed pack (Cout, K, nsplit*256), slice sp takes its k-steps of every
+ * tap and writes the fp32 slab slabs + sp*B*S*Cout — the raw split-K slabs that ttsk_layernorm_bwd_slabs sums (splits = nsplit,
+ * stride = B*S*Cout). */
+int ttsk_win_conv_split(const void* x_bf16, const void* w_packed, float* slabs, int nsplit, int B, int S, int Cin_total, int Cout, int K,
+                        void* stream);
 /* gate_bf16 [B*S][Cout] (may be NULL; bf16 output only): out = gate > 0 ? out : 0 — the ReLU backward of SubLayers.py:96 folded into
  * the w_2 input-gradient conv. */
 int ttsk_win_conv(const void* x_bf16, const void* w_packed, const float* bias /* may be NULL */, const void* gate_bf16 /* may be NULL */,

@@ -553,3 +553,23 @@ def test_win_conv_k1_projections_gate_and_item_packs():
     assert float((dh.float() - ref.float()).abs().max()) <= 2 ** -7 * float(ref.float().abs().max())
     assert torch.equal(dh == 0, (ref == 0)) or float(((dh == 0) != (ref == 0)).float().mean()) < 1e-3
     assert bool((dh[h <= 0] == 0).all())
+
+
+@pytest.mark.parametrize("B,S,Cin,K", [(16, 423, 1024, 9), (16, 64, 1024, 9), (2, 130, 768, 1), (1, 9, 512, 3)])
+def test_win_conv_split_slabs(B, S, Cin, K):
+    """ttsk_win_conv_split: the input gradient of a conv with a wide contraction (w_1: 1024 channels x 9 taps; q|k|v: 768) as 256-channel
+    slices into fp32 slabs; their sum against conv1d_dx's fp32 result and fp64, and through ttsk_layernorm_bwd_slabs' consumer path."""
+    from tts_king_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(S + Cin + K)
+    dy = bf(torch.randn(B, S, Cin, generator=g)).to(DEV)
+    W = bf(torch.randn(Cin, K, 256, generator=g) * (Cin * K) ** -0.5).to(DEV)          # storage of the forward conv 256 -> Cin
+    pk = torch.empty(W.numel(), dtype=torch.bfloat16, device=DEV)
+    ops.win_conv_pack_items([(W, pk, True)])
+    sl = ops.win_conv_split(dy, pk, 256, K)
+    assert sl.splits == Cin // 256 and sl.stride == B * S * 256
+    got = sl.ws.view(sl.splits, B * S, 256).double().sum(0).cpu()
+    ref = F.conv_transpose1d(dy.double().cpu().transpose(1, 2), W.double().cpu().permute(0, 2, 1), padding=(K - 1) // 2).transpose(1, 2).reshape(B * S, 256)
+    assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-4
+    old = ops.conv1d_dx(dy, W, out_dtype=torch.float32) if False else ops.conv1d_dx(dy, W)
+    assert float((got.float() - old.view(B * S, 256).float().cpu()).abs().max()) <= 2 ** -7 * float(ref.abs().max())

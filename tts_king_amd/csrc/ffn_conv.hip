@@ -29,6 +29,12 @@ struct WcArgs {
   int S, K, Cout, relu;
   int B, tiles_per_utt;
   const bf16_t* gate;   // [B*S][Cout] bf16 or null: out = gate > 0 ? out : 0 (a ReLU's backward on the way out; bf16 output only)
+  // Contraction split over the input channels (an input gradient whose "input" is wide: w_1's dX has 1024, q|k|v's 768): workgroup
+  // group `sp` of nsplit reads channels [sp*CIN, (sp+1)*CIN) of rows `ldx` = nsplit*CIN elements long, the k-steps
+  // sp*CIN/32 .. of every tap of the pack (whose taps hold ldx/32 k-steps) and writes its own fp32 slab (out + sp*out_split): the raw
+  // split-K slabs ttsk_layernorm_bwd_slabs sums.  nsplit = 1: ldx = CIN.
+  int nsplit, ldx;
+  int64_t out_split;
 };
 
 // Weight packs.  src = storage (Cs, K, Ds) bf16 tap-major.
@@ -71,15 +77,16 @@ template <int CIN, int TT, bool OUT32, bool PACKED>
 __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
   constexpr int C = CIN, RS = CIN * 2 + 32, NT = WC_NT, CH8 = C / 8, KH = WC_KH, CT = WC_CT, NF = TT / 16, NP = CIN / 128;
   constexpr int XROWS = TT + 2 * WC_H;
-  static_assert(!OUT32 || WC_COUT * 4 + 32 <= RS, "fp32 staging rows must fit the window's row stride");
-  __shared__ __attribute__((aligned(16))) unsigned char XW[XROWS * RS];
+  constexpr int SRS = OUT32 ? WC_COUT * 4 + 32 : RS;               // row stride of the output staging tile (fp32 rows are 1 KiB)
+  constexpr int SMEM = XROWS * RS > TT * SRS ? XROWS * RS : TT * SRS;
+  __shared__ __attribute__((aligned(16))) unsigned char XW[SMEM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, q = lane >> 4;
   // XCD-aware mapping: consecutive workgroup ids go round the 8 XCDs, and a channel group's weights (1.2 MB at d_ff = 1024, k = 9) should
   // stay in ONE XCD's 4 MiB L2 instead of all groups in every L2: channel group = f(id % 8), tile = the rest.
-  int bi, t0, cg;
+  int bi, t0, cg, sp;
   {
-    const int id = blockIdx.x, ncg = a.Cout / WC_COUT, ntile = a.tiles_per_utt * a.B;
+    const int id = blockIdx.x, ncg = (a.Cout / WC_COUT) * a.nsplit, ntile = a.tiles_per_utt * a.B;
     const int xcd = id & 7, per = 8 / (ncg < 8 ? ncg : 8);        // XCDs per channel group (ncg = 1, 2, 4, 8); other counts: plain order
     int tile;
     if ((8 % (ncg < 8 ? ncg : 8)) == 0 && ncg <= 8 && (ntile * ncg) % 8 == 0 && ntile % per == 0) {
@@ -91,21 +98,26 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
     }
     bi = tile / a.tiles_per_utt;
     t0 = (tile - bi * a.tiles_per_utt) * TT;
+    sp = cg % a.nsplit;            // group = (channel group, contraction split)
+    cg = cg / a.nsplit;
   }
   const int S = a.S, K = a.K, HK = (K - 1) / 2, NS = NP * K;       // NS steps: tap g / NP, 128-channel part g % NP
-  const bf16_t* __restrict__ xb = a.x + (int64_t)bi * S * C;
+  const int ldx = a.ldx;
+  const bf16_t* __restrict__ xb = a.x + (int64_t)bi * S * ldx + sp * C;
+  const bf16_t* __restrict__ wbase = a.w;
+  const int ks_total = ldx / 32, ks_base = sp * (C / 32);
 
   const bf16_t* wrow[CT];
 #pragma unroll
   for (int cc = 0; cc < CT; ++cc)
-    wrow[cc] = PACKED ? a.w + ((int64_t)(cg * (WC_COUT / 16) + wave * CT + cc) * 64 + lane) * 8
-                      : a.w + ((int64_t)(cg * WC_COUT + (wave * CT + cc) * 16 + l15) * K) * C + q * 8;
+    wrow[cc] = PACKED ? wbase + ((int64_t)(cg * (WC_COUT / 16) + wave * CT + cc) * 64 + lane) * 8
+                      : wbase + ((int64_t)(cg * WC_COUT + (wave * CT + cc) * 16 + l15) * K) * C + q * 8;
   const int64_t kstep_stride = (int64_t)(a.Cout / 16) * 512;     // PACKED: elements per (tap, k-step)
   bf16x8 wa[KH][CT], wb[KH][CT], wc[KH][CT];      // three register sets: a step's weights are requested two steps (>= 1 us) ahead
   auto load_w = [&](int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
     const int tap = g / NP, part = g - tap * NP;
     if (PACKED) {
-      const int64_t off = (int64_t)(tap * (C / 32) + part * KH) * kstep_stride;
+      const int64_t off = (int64_t)(tap * ks_total + ks_base + part * KH) * kstep_stride;
 #pragma unroll
       for (int ks = 0; ks < KH; ++ks)
 #pragma unroll
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
       const int row = idx / CH8, ch = idx - row * CH8;
       const int t = t0 - WC_H + row;
       xv[it] = make_uint4(0, 0, 0, 0);
-      if (idx < XROWS * CH8 && t >= 0 && t < S) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
+      if (idx < XROWS * CH8 && t >= 0 && t < S) xv[it] = *(const uint4*)(xb + (int64_t)t * ldx + ch * 8);
     }
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
@@ -192,22 +204,22 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
       const int col = (wave * CT + cc) * 16 + q * 4;
-      if (OUT32) *(f32x4*)(XW + (i * 16 + l15) * RS + col * 4) = v;
-      else *(uint2*)(XW + (i * 16 + l15) * RS + col * 2) = make_uint2(pack2<false>(v[0], v[1]), pack2<false>(v[2], v[3]));
+      if (OUT32) *(f32x4*)(XW + (i * 16 + l15) * SRS + col * 4) = v;
+      else *(uint2*)(XW + (i * 16 + l15) * SRS + col * 2) = make_uint2(pack2<false>(v[0], v[1]), pack2<false>(v[2], v[3]));
     }
   }
   __syncthreads();
   constexpr int ESZ = OUT32 ? 4 : 2;
   constexpr int OCH = WC_COUT * ESZ / 16;                // 16-byte chunks per output row of this channel group
   constexpr int NCO = (TT * OCH + NT - 1) / NT;
-  unsigned char* __restrict__ ob = (unsigned char*)a.out + ((int64_t)bi * S * a.Cout + cg * WC_COUT) * ESZ;
+  unsigned char* __restrict__ ob = (unsigned char*)a.out + (sp * a.out_split + (int64_t)bi * S * a.Cout + cg * WC_COUT) * ESZ;
 #pragma unroll
   for (int it = 0; it < NCO; ++it) {
     const int idx = it * NT + tid;
     const int rr = idx / OCH, ch = idx - rr * OCH;
     const int t = t0 + rr;
     if (idx < TT * OCH && t < S) {
-      uint4 v = *(const uint4*)(XW + rr * RS + ch * 16);
+      uint4 v = *(const uint4*)(XW + rr * SRS + ch * 16);
       if (!OUT32 && a.gate) {
         const uint4 g = *(const uint4*)(a.gate + ((int64_t)bi * S + t) * a.Cout + cg * WC_COUT + ch * 8);
         auto keep = [](unsigned w) {      // 0xFFFF per bf16 half that is > 0 (sign clear, not zero)
@@ -227,8 +239,11 @@ int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int pa
   const int TT = Cin == 256 && !short_seq ? 112 : 64;
   a.B = B;
   a.tiles_per_utt = (S + TT - 1) / TT;
-  dim3 grid(a.tiles_per_utt * B * (a.Cout / WC_COUT));
-  if (short_seq) {
+  dim3 grid(a.tiles_per_utt * B * (a.Cout / WC_COUT) * a.nsplit);
+  if (Cin == 256 && out_f32) {
+    if (short_seq) hipLaunchKernelGGL((win_conv_kernel<256, 64, true, true>), grid, dim3(WC_NT), 0, s, a);
+    else hipLaunchKernelGGL((win_conv_kernel<256, 112, true, true>), grid, dim3(WC_NT), 0, s, a);
+  } else if (short_seq) {
     hipLaunchKernelGGL((win_conv_kernel<256, 64, false, true>), grid, dim3(WC_NT), 0, s, a);
   } else if (Cin == 256) {
     if (packed) hipLaunchKernelGGL((win_conv_kernel<256, 112, false, true>), grid, dim3(WC_NT), 0, s, a);
@@ -285,12 +300,11 @@ extern "C" int ttsk_win_conv(const void* x_bf16, const void* w_packed, const flo
                              int S, int Cin, int Cout, int K, int relu, void* stream) {
   TTSK_REQUIRE(x_bf16 && w_packed && out, "ttsk_win_conv: null pointer");
   TTSK_REQUIRE(B > 0 && S > 0 && B <= 65535, "ttsk_win_conv: bad sizes B=%d S=%d", B, S);
-  TTSK_REQUIRE(ttsk_win_conv_supported(Cin, Cout, K) && !(out_f32 && Cin != 512), "ttsk_win_conv: no instance for Cin=%d Cout=%d K=%d out_f32=%d", Cin,
-               Cout, K, out_f32);
+  TTSK_REQUIRE(ttsk_win_conv_supported(Cin, Cout, K), "ttsk_win_conv: no instance for Cin=%d Cout=%d K=%d", Cin, Cout, K);
   TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_packed) | ((uintptr_t)bias) | ((uintptr_t)out)) & 15) == 0, "ttsk_win_conv: 16-byte alignment");
   TTSK_REQUIRE((int64_t)B * S * (Cout > Cin ? Cout : Cin) * 4 < ((int64_t)1 << 40), "ttsk_win_conv: sizes out of range");
   TTSK_REQUIRE(!(gate_bf16 && out_f32) && (((uintptr_t)gate_bf16) & 15) == 0, "ttsk_win_conv: the gate goes with bf16 output, 16-byte aligned");
-  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, bias, out, S, K, Cout, relu, 0, 0, (const bf16_t*)gate_bf16};
+  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, bias, out, S, K, Cout, relu, 0, 0, (const bf16_t*)gate_bf16, 1, Cin, 0};
   launch_win_conv(a, B, S, Cin, out_f32, 1, (hipStream_t)stream);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
@@ -303,8 +317,20 @@ extern "C" int ttsk_ffn_conv_fwd(const void* x_bf16, const void* w_bf16, const f
   TTSK_REQUIRE(ttsk_ffn_conv_supported(Cin, Cout, K), "ttsk_ffn_conv_fwd: no instance for Cin=%d Cout=%d K=%d", Cin, Cout, K);
   TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_bf16) | ((uintptr_t)bias) | ((uintptr_t)out_bf16)) & 15) == 0, "ttsk_ffn_conv_fwd: 16-byte alignment");
   TTSK_REQUIRE((int64_t)B * S * (Cout > Cin ? Cout : Cin) * 2 < ((int64_t)1 << 40), "ttsk_ffn_conv_fwd: sizes out of range");
-  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_bf16, bias, out_bf16, S, K, Cout, relu, 0, 0, nullptr};
+  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_bf16, bias, out_bf16, S, K, Cout, relu, 0, 0, nullptr, 1, Cin, 0};
   launch_win_conv(a, B, S, Cin, 0, packed, (hipStream_t)stream);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_win_conv_split(const void* x_bf16, const void* w_packed, float* slabs, int nsplit, int B, int S, int Cin_total, int Cout,
+                                   int K, void* stream) {
+  TTSK_REQUIRE(x_bf16 && w_packed && slabs && nsplit >= 1 && nsplit <= 8, "ttsk_win_conv_split: bad arguments");
+  TTSK_REQUIRE(B > 0 && S > 0 && B <= 65535 && Cin_total == nsplit * 256, "ttsk_win_conv_split: Cin must be nsplit * 256 (got %d, nsplit %d)", Cin_total, nsplit);
+  TTSK_REQUIRE(ttsk_win_conv_supported(256, Cout, K), "ttsk_win_conv_split: no instance for Cout=%d K=%d", Cout, K);
+  TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_packed) | ((uintptr_t)slabs)) & 15) == 0, "ttsk_win_conv_split: 16-byte alignment");
+  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, nullptr, slabs, S, K, Cout, 0, 0, 0, nullptr, nsplit, Cin_total, (int64_t)B * S * Cout};
+  launch_win_conv(a, B, S, 256, 1, 1, (hipStream_t)stream);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -323,6 +323,8 @@ class FastSpeech2(nn.Module):
                    [("qkv", p + "slf_attn.w_qs.weight", 3 * d, False) for p in dec + enc] + \
                    [("fcT", p + "slf_attn.fc.weight", None, True) for p in dec + enc] + \
                    [("w2T", p + "pos_ffn.w_2.weight", None, True) for p in dec + enc] + \
+                   [("w1T", p + "pos_ffn.w_1.weight", None, True) for p in dec + enc] + \
+                   [("qkvT", p + "slf_attn.w_qs.weight", 3 * d, True) for p in dec + enc] + \
                    [("pn", "postnet.convolutions.%d.0.conv.weight" % i, None, False) for i in range(1, 4)] + \
                    [("pnT", "postnet.convolutions.%d.0.conv.weight" % i, None, True) for i in range(1, 4)]
             items = []
@@ -331,18 +333,19 @@ class FastSpeech2(nn.Module):
                     continue
                 W = self._pack_source(key, fused_rows)
                 cs, kk, ds = W.shape
-                if W.dim() != 3 or not ops.win_conv_supported(cs if tr else ds, ds if tr else cs, kk):
+                cin, cout = (cs, ds) if tr else (ds, cs)
+                split = tag in ("w1T", "qkvT")                 # wide contraction: 256-channel slices into fp32 slabs (ops.win_conv_split)
+                if not ops.win_conv_supported(256 if split else cin, cout, kk) or (split and cin % 256):
                     continue
                 items.append((tag, key, fused_rows, tr, W.numel()))
-            items = items[:48]
             buf = torch.empty(sum(it[4] for it in items), dtype=bf16, device=self._shadow.device)
             self._w1_packed, self._pack_items, off = {}, [], 0
             for tag, key, fused_rows, tr, n in items:
                 self._w1_packed[(tag, key)] = buf[off:off + n]
                 self._pack_items.append((key, fused_rows, buf[off:off + n], tr))
                 off += n
-        if self._pack_items:
-            ops.win_conv_pack_items([(self._pack_source(key, fr), out, tr) for key, fr, out, tr in self._pack_items])
+        for i in range(0, len(self._pack_items), 48):
+            ops.win_conv_pack_items([(self._pack_source(key, fr), out, tr) for key, fr, out, tr in self._pack_items[i:i + 48]])
 
     def _pack_source(self, key, fused_rows=None):
         """The tap-major bf16 shadow of `key` as a (Cs, k, Ds) tensor (a Linear weight is k = 1; `fused_rows`: the q|k|v rows as one)."""
@@ -807,7 +810,11 @@ class FastSpeech2(nn.Module):
             ops.conv1d_dw(dh, x1.view(Bn, S, d), self._g(f + "w_1.weight"), k=self.k1, defer=self._deferred)
         # ---- attention tail
         if self.raw_slabs:
-            sl = ops.conv1d_dx(dh, self._w(f + "w_1.weight"), raw=True)
+            pk1 = self._w1_packed.get(("w1T", f + "w_1.weight")) if (self.window_ffn and self._w1_packed) else None
+            if pk1 is not None:
+                sl = ops.win_conv_split(dh, pk1, d, self.k1)       # four 256-channel slices of the 1024-channel contraction, one launch
+            else:
+                sl = ops.conv1d_dx(dh, self._w(f + "w_1.weight"), raw=True)
             dz1, dy1, part, nblk = ops.layernorm_bwd(None, z1, mean1, rstd1, self._m(a + "layer_norm.weight"), self._m(a + "layer_norm.bias"),
                                                      lens, S, p_pre=p, site_pre=site, rng=rng, slabs=sl, R=dz2)
         else:
@@ -847,6 +854,9 @@ class FastSpeech2(nn.Module):
             ops.colsum_into(dqkv, self._g(a + "w_qs.bias", 3 * d), defer=self._deferred_fin)
             ops.linear_dw(dqkv, x, self._g(a + "w_qs.weight", 3 * d * d).view(3 * d, d), defer=self._deferred)
         if raw_out and self.raw_slabs:
+            pkq = self._w1_packed.get(("qkvT", a + "w_qs.weight")) if (self.window_ffn and self._w1_packed) else None
+            if pkq is not None:
+                return (ops.win_conv_split(dqkv.view(Bn, S, 3 * d), pkq, d, 1), dz1)
             return (ops.linear_dx(dqkv, self._w(a + "w_qs.weight", 3 * d), raw=True), dz1)
         return ops.linear_dx(dqkv, self._w(a + "w_qs.weight", 3 * d), R=dz1)
 

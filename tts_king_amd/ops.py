@@ -370,6 +370,17 @@ def win_conv(x, packed, Cout, k, bias=None, relu=False, out_dtype=None, gate=Non
     return out
 
 
+def win_conv_split(x, packed, Cout, k):
+    """An input-gradient conv with a wide contraction (x (B,S,n*256) bf16) as n window convs over 256-channel slices in one launch:
+    fp32 Slabs (n, B*S*Cout) for layernorm_bwd(slabs=...) (ttsk_win_conv_split).  `packed`: the whole transposed pack."""
+    _dev(x, packed)
+    Bsz, S, Cin = x.shape
+    n = Cin // 256
+    ws = _f32(n, Bsz * S * Cout, device=x.device)
+    check(L.load().ttsk_win_conv_split(_ptr(x), _ptr(packed), _ptr(ws), n, Bsz, S, Cin, Cout, k, _stream()), "ttsk_win_conv_split")
+    return Slabs(ws, n, Bsz * S * Cout)
+
+
 def ffn_conv_fwd(x, W, bias, relu=True, packed=None):
     """relu(Conv1d(256 -> Cout, k)(x) + bias) on the window kernel (ttsk_ffn_conv_fwd; SubLayers.py:93-101, w_1).
     x (B,S,256) bf16, W (Cout,k,256) bf16 tap-major -> (B,S,Cout) bf16; `packed`: ffn_pack_weight(W), read instead of W."""

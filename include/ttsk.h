@@ -158,8 +158,11 @@ typedef struct ttsk_pack_item {
   int32_t Cs, K, Ds, transpose;
 } ttsk_pack_item;
 int ttsk_win_conv_supported(int Cin, int Cout, int K);
-/* up to 48 packs of any shapes in ONE launch (the model rewrites all its packs after every optimizer step) */
+/* up to 48 packs of any shapes from a HOST item list (handed over through the kernel's arguments: capturable), one launch */
 int ttsk_win_conv_pack_items(const ttsk_pack_item* items, int n, void* stream);
+/* the same from an item table that already lives in DEVICE memory (8-byte aligned), any n: what a model with fixed weight and pack
+ * addresses calls after every optimizer step (one launch, no upload) */
+int ttsk_win_conv_pack_table(const ttsk_pack_item* dev_items, int n, void* stream);
 int ttsk_win_conv_pack_batch(const void* const* w_bf16, void* const* packed_bf16, int n /* <= 16 */, int Cs, int K, int Ds, int transpose,
                              void* stream);
 /* An input gradient whose contraction is wide (w_1: 1024 channels x 9 taps; q|k|v: 768), as nsplit window convs over 256-channel slices

@@ -45,3 +45,14 @@ Wf = (torch.randn(256, 1, 256, device=DEV) * 0.05).bfloat16()
 pf = torch.empty(Wf.numel(), dtype=torch.bfloat16, device=DEV); ops.win_conv_pack_batch([Wf], [pf], transpose=True)
 t3 = timeit(lambda: ops.win_conv(x, pf, 256, 1)); t4 = timeit(lambda: ops.linear_dx(x.view(-1, 256), Wf.view(256, 256)))
 print("B=16 S=423 QKV 256->768: window %.1f us | GEMM %.1f us || fc dX 256->256: window %.1f us | GEMM %.1f us" % (t1, t2, t3, t4))
+
+# pack kernel: the model's full item list (one launch from a device table)
+from tts_king_amd.config import default_config
+from tts_king_amd.fastspeech2 import FastSpeech2
+cfg = default_config()
+m = FastSpeech2(cfg.preprocess_config, cfg.model_config, 65, device=DEV, seed=1).train()
+m.sync_shadow(force=True)
+tb, n = m._pack_table
+nbytes = sum(o.numel() * 2 for _, _, o, _ in m._pack_items)
+t = timeit(lambda: ops.win_conv_pack_run(tb, n))
+print("pack table: %d items, %.1f MB of packs, %.1f us per launch (%.2f TB/s read + write)" % (n, nbytes / 1e6, t, 2 * nbytes / t / 1e6))

@@ -42,36 +42,61 @@ struct WcArgs {
 //   transpose = 1: the weights of its input gradient seen as a forward conv on dy, taps flipped:
 //                  W'[co' = ci][tap][ci' = co] = src[co][K-1-tap][ci]                            (Cout' = Ds, Cin' = Cs)
 // dst = [K][Cin'/32][Cout'/16][64][8]: lane l of a fragment holds W'[c*16 + (l & 15)][tap][ks*32 + (l >> 4)*8 + j], j = 0..7.
-struct PackBatch {
-  const bf16_t* src[48];
-  bf16_t* dst[48];
-  int Cs[48], K[48], Ds[48], transpose[48];
-};
-__global__ __launch_bounds__(256) void win_pack_kernel(const PackBatch pb) {
-  const int it = blockIdx.y;
-  const bf16_t* __restrict__ src = pb.src[it];
-  bf16_t* __restrict__ dst = pb.dst[it];
-  const int Cs = pb.Cs[it], K = pb.K[it], Ds = pb.Ds[it], transpose = pb.transpose[it];
-  const int Co = transpose ? Ds : Cs, Ci = transpose ? Cs : Ds;
-  const int64_t n8 = (int64_t)Co * K * (Ci / 8);                 // 16-byte pieces of the pack
-  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
-    const int l = (int)(i & 63);
-    int64_t f = i >> 6;
-    const int c = (int)(f % (Co / 16)); f /= (Co / 16);
-    const int ks = (int)(f % (Ci / 32));
-    const int tap = (int)(f / (Ci / 32));
-    const int co = c * 16 + (l & 15), ci = ks * 32 + (l >> 4) * 8;
-    if (!transpose) {
+// One workgroup row (blockIdx.y) per item; the item table lives in device memory (the model's packs have fixed addresses, so it
+// is built once), any number of items per launch.
+__device__ __forceinline__ void pack_one(const ttsk_pack_item& it) {
+  const bf16_t* __restrict__ src = (const bf16_t*)it.src;
+  bf16_t* __restrict__ dst = (bf16_t*)it.dst;
+  const int Cs = it.Cs, K = it.K, Ds = it.Ds;
+  if (!it.transpose) {
+    const int Co = Cs, Ci = Ds;
+    const int64_t n8 = (int64_t)Co * K * (Ci / 8);                 // 16-byte pieces of the pack
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+      const int l = (int)(i & 63);
+      int64_t f = i >> 6;
+      const int c = (int)(f % (Co / 16)); f /= (Co / 16);
+      const int ks = (int)(f % (Ci / 32));
+      const int tap = (int)(f / (Ci / 32));
+      const int co = c * 16 + (l & 15), ci = ks * 32 + (l >> 4) * 8;
       *(uint4*)(dst + i * 8) = *(const uint4*)(src + ((int64_t)co * K + tap) * Ds + ci);
-    } else {
-      unsigned short v[8];
+    }
+  } else {
+    // W'[co' = ci_s][tap][ci' = co_s] = src[co_s][K-1-tap][ci_s]: a thread takes an 8 x 8 block (8 storage rows co_s = 8 consecutive
+    // ci' of one piece, 8 consecutive ci_s = co' of 8 neighbouring lanes' pieces): eight 16-byte loads, transposed in registers, eight
+    // 16-byte stores
+    const int Co = Ds, Ci = Cs;
+    const int64_t nb = (int64_t)(Co / 8) * K * (Ci / 8);
+    for (int64_t b = blockIdx.x * 256ll + threadIdx.x; b < nb; b += (int64_t)gridDim.x * 256) {
+      const int co8 = (int)(b % (Co / 8));
+      int64_t f = b / (Co / 8);
+      const int ci8 = (int)(f % (Ci / 8));
+      const int tap = (int)(f / (Ci / 8));
+      uint4 r[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = src[((int64_t)(ci + j) * K + (K - 1 - tap)) * Ds + co];
-      *(uint4*)(dst + i * 8) = make_uint4(v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16),
-                                          v[6] | ((unsigned)v[7] << 16));
+      for (int j = 0; j < 8; ++j) r[j] = *(const uint4*)(src + ((int64_t)(ci8 * 8 + j) * K + (K - 1 - tap)) * Ds + co8 * 8);
+      const int ks = (ci8 * 8) / 32, lhi = ((ci8 * 8) % 32) / 8;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {            // output piece of co' = co8*8 + m: elements j = r[j] half m
+        unsigned short v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned w = m < 2 ? r[j].x : (m < 4 ? r[j].y : (m < 6 ? r[j].z : r[j].w));
+          v[j] = (unsigned short)((m & 1) ? (w >> 16) : (w & 0xFFFFu));
+        }
+        const int co = co8 * 8 + m;
+        const int64_t piece = ((int64_t)(tap * (Ci / 32) + ks) * (Co / 16) + co / 16) * 64 + lhi * 16 + (co & 15);
+        *(uint4*)(dst + piece * 8) = make_uint4(v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16),
+                                                v[6] | ((unsigned)v[7] << 16));
+      }
     }
   }
 }
+
+struct ItemChunk {
+  ttsk_pack_item it[48];
+};
+__global__ __launch_bounds__(256) void win_pack_kernel(const ttsk_pack_item* __restrict__ items) { pack_one(items[blockIdx.y]); }
+__global__ __launch_bounds__(256) void win_pack_args_kernel(const ItemChunk c) { pack_one(c.it[blockIdx.y]); }
 
 template <int CIN, int TT, bool OUT32, bool PACKED>
 __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
@@ -262,22 +287,24 @@ extern "C" int ttsk_win_conv_supported(int Cin, int Cout, int K) {
 }
 extern "C" int ttsk_ffn_conv_supported(int Cin, int Cout, int K) { return Cin == 256 && ttsk_win_conv_supported(Cin, Cout, K); }
 
+extern "C" int ttsk_win_conv_pack_table(const ttsk_pack_item* dev_items, int n, void* stream) {
+  TTSK_REQUIRE(dev_items && n > 0 && n <= 65535 && (((uintptr_t)dev_items) & 7) == 0, "ttsk_win_conv_pack_table: bad arguments");
+  hipLaunchKernelGGL(win_pack_kernel, dim3(256, n), dim3(256), 0, (hipStream_t)stream, dev_items);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+// host items: checked, handed to the kernel through its arguments (capturable, no device table needed)
 extern "C" int ttsk_win_conv_pack_items(const ttsk_pack_item* items, int n, void* stream) {
   TTSK_REQUIRE(items && n > 0 && n <= 48, "ttsk_win_conv_pack_items: 1..48 items");
-  PackBatch pb;
-  int64_t nmax = 0;
+  ItemChunk c;
   for (int i = 0; i < 48; ++i) {
     const ttsk_pack_item& it = items[i < n ? i : 0];
     TTSK_REQUIRE(it.src && it.dst && ((((uintptr_t)it.src) | ((uintptr_t)it.dst)) & 15) == 0, "ttsk_win_conv_pack_items: null / unaligned pointer");
     TTSK_REQUIRE(it.Cs > 0 && it.Cs % 32 == 0 && it.Ds > 0 && it.Ds % 32 == 0 && it.K >= 1, "ttsk_win_conv_pack_items: bad shape (%d, %d, %d)", it.Cs, it.K, it.Ds);
-    pb.src[i] = (const bf16_t*)it.src; pb.dst[i] = (bf16_t*)it.dst;
-    pb.Cs[i] = it.Cs; pb.K[i] = it.K; pb.Ds[i] = it.Ds; pb.transpose[i] = it.transpose;
-    const int64_t n8 = (int64_t)it.Cs * it.K * (it.Ds / 8);
-    if (n8 > nmax) nmax = n8;
+    c.it[i] = it;
   }
-  int blocks = (int)((nmax + 255) / 256);
-  if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(win_pack_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, pb);
+  hipLaunchKernelGGL(win_pack_args_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, c);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

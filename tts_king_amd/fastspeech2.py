@@ -344,8 +344,11 @@ class FastSpeech2(nn.Module):
                 self._w1_packed[(tag, key)] = buf[off:off + n]
                 self._pack_items.append((key, fused_rows, buf[off:off + n], tr))
                 off += n
-        for i in range(0, len(self._pack_items), 48):
-            ops.win_conv_pack_items([(self._pack_source(key, fr), out, tr) for key, fr, out, tr in self._pack_items[i:i + 48]])
+            # the shadow views and the packs keep their addresses until _apply: a device-resident item table, one pack launch per step
+            self._pack_table = ops.win_conv_pack_table([(self._pack_source(key, fr), out, tr) for key, fr, out, tr in self._pack_items],
+                                                       self._shadow.device) if self._pack_items else None
+        if self._pack_table is not None:
+            ops.win_conv_pack_run(*self._pack_table)
 
     def _pack_source(self, key, fused_rows=None):
         """The tap-major bf16 shadow of `key` as a (Cs, k, Ds) tensor (a Linear weight is k = 1; `fused_rows`: the q|k|v rows as one)."""

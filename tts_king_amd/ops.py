@@ -359,6 +359,24 @@ def win_conv_pack_items(items):
     check(L.load().ttsk_win_conv_pack_items(arr, n, _stream()), "ttsk_win_conv_pack_items")
 
 
+def win_conv_pack_table(items, device):
+    """A device-resident item table for win_conv_pack_run: int32 tensor holding n `ttsk_pack_item`s (the tensors must stay where
+    they are).  items as for win_conv_pack_items, any number."""
+    n = len(items)
+    arr = (L.PackItem * n)()
+    for i, (W, out, tr) in enumerate(items):
+        _dev(W, out)
+        arr[i].src, arr[i].dst = W.data_ptr(), out.data_ptr()
+        arr[i].Cs, arr[i].K, arr[i].Ds, arr[i].transpose = W.shape[0], W.shape[1], W.shape[2], int(tr)
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.int32).clone()
+    return host.to(device), n
+
+
+def win_conv_pack_run(table, n):
+    """Rewrite every pack of a win_conv_pack_table in one launch (ttsk_win_conv_pack_table)."""
+    check(L.load().ttsk_win_conv_pack_table(_ptr(table), n, _stream()), "ttsk_win_conv_pack_table")
+
+
 def win_conv(x, packed, Cout, k, bias=None, relu=False, out_dtype=None, gate=None):
     """[relu](Conv1d(Cin -> Cout, k)(x) + bias) on the window kernel, weights = a win_conv_pack_batch pack (ttsk_win_conv); `gate`
     (B,S,Cout) bf16: result zeroed where gate <= 0.  x (B,S,Cin) bf16 -> (B,S,Cout) bf16 or fp32."""

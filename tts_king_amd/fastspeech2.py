@@ -167,6 +167,8 @@ class FastSpeech2(nn.Module):
         o = [self._table[va + n + "_predictor.conv_layer.conv1d_1.conv.weight"].offset for n in ("duration", "pitch", "energy")]
         self._pred_stride = o[1] - o[0]
         assert o[2] - o[1] == self._pred_stride and self._pred_stride % 8 == 0
+        if self.window_ffn and self._shadow.is_cuda:
+            self._build_packs()
 
     # ------------------------------------------------------------------ parameter plumbing
     def _register(self, en, device):
@@ -227,6 +229,8 @@ class FastSpeech2(nn.Module):
         self._rng_state = None
         self._side = None
         self._rebind()
+        if self.window_ffn and self._shadow.is_cuda:
+            self._build_packs()
         return self
 
     def get(self, key):
@@ -309,46 +313,51 @@ class FastSpeech2(nn.Module):
             self.refresh_packed()
 
     def refresh_packed(self):
-        """Rewrite the fragment-major weight copies the window conv kernel reads (csrc/ffn_conv.hip) from the bf16 shadow: the decoder
-        blocks' w_1, and the PostNet's three 512 -> 512 convs both as they are (forward) and transposed with flipped taps (input
-        gradient).  One launch per group.  Called by everything that writes the shadow: `sync_shadow` and
+        """Rewrite the fragment-major weight copies the window conv kernel reads (csrc/ffn_conv.hip) from the bf16 shadow — one launch
+        over a device-resident item table.  Called by everything that writes the shadow: `sync_shadow` and
         `ScheduledOptim.step_and_update_lr`."""
         if not self.window_ffn:
             return
         if self._w1_packed is None:
-            d, dec = self.d, ["decoder.layer_stack.%d." % i for i in range(self.n_dec)]
-            enc = ["encoder.layer_stack.%d." % i for i in range(self.n_enc)]
-            # (tag, key, rows of a fused view or None, transpose)
-            want = [("w1", p + "pos_ffn.w_1.weight", None, False) for p in dec + enc] + \
-                   [("qkv", p + "slf_attn.w_qs.weight", 3 * d, False) for p in dec + enc] + \
-                   [("fcT", p + "slf_attn.fc.weight", None, True) for p in dec + enc] + \
-                   [("w2T", p + "pos_ffn.w_2.weight", None, True) for p in dec + enc] + \
-                   [("w1T", p + "pos_ffn.w_1.weight", None, True) for p in dec + enc] + \
-                   [("qkvT", p + "slf_attn.w_qs.weight", 3 * d, True) for p in dec + enc] + \
-                   [("pn", "postnet.convolutions.%d.0.conv.weight" % i, None, False) for i in range(1, 4)] + \
-                   [("pnT", "postnet.convolutions.%d.0.conv.weight" % i, None, True) for i in range(1, 4)]
-            items = []
-            for tag, key, fused_rows, tr in want:
-                if key not in self._table:
-                    continue
-                W = self._pack_source(key, fused_rows)
-                cs, kk, ds = W.shape
-                cin, cout = (cs, ds) if tr else (ds, cs)
-                split = tag in ("w1T", "qkvT")                 # wide contraction: 256-channel slices into fp32 slabs (ops.win_conv_split)
-                if not ops.win_conv_supported(256 if split else cin, cout, kk) or (split and cin % 256):
-                    continue
-                items.append((tag, key, fused_rows, tr, W.numel()))
-            buf = torch.empty(sum(it[4] for it in items), dtype=bf16, device=self._shadow.device)
-            self._w1_packed, self._pack_items, off = {}, [], 0
-            for tag, key, fused_rows, tr, n in items:
-                self._w1_packed[(tag, key)] = buf[off:off + n]
-                self._pack_items.append((key, fused_rows, buf[off:off + n], tr))
-                off += n
-            # the shadow views and the packs keep their addresses until _apply: a device-resident item table, one pack launch per step
-            self._pack_table = ops.win_conv_pack_table([(self._pack_source(key, fr), out, tr) for key, fr, out, tr in self._pack_items],
-                                                       self._shadow.device) if self._pack_items else None
+            self._build_packs()
         if self._pack_table is not None:
             ops.win_conv_pack_run(*self._pack_table)
+
+    def _build_packs(self):
+        """Allocate the packs and their item table (host -> device copy: not capturable, so this runs at construction and after
+        `_apply`, never inside a forward).  Packs: the FFT blocks' w_1 and q|k|v as they are (forward), fc / w_2 / w_1 / q|k|v transposed
+        with flipped taps (input gradients), the PostNet's three 512 -> 512 convs both ways."""
+        d, dec = self.d, ["decoder.layer_stack.%d." % i for i in range(self.n_dec)]
+        enc = ["encoder.layer_stack.%d." % i for i in range(self.n_enc)]
+        # (tag, key, rows of a fused view or None, transpose)
+        want = [("w1", p + "pos_ffn.w_1.weight", None, False) for p in dec + enc] + \
+               [("qkv", p + "slf_attn.w_qs.weight", 3 * d, False) for p in dec + enc] + \
+               [("fcT", p + "slf_attn.fc.weight", None, True) for p in dec + enc] + \
+               [("w2T", p + "pos_ffn.w_2.weight", None, True) for p in dec + enc] + \
+               [("w1T", p + "pos_ffn.w_1.weight", None, True) for p in dec + enc] + \
+               [("qkvT", p + "slf_attn.w_qs.weight", 3 * d, True) for p in dec + enc] + \
+               [("pn", "postnet.convolutions.%d.0.conv.weight" % i, None, False) for i in range(1, 4)] + \
+               [("pnT", "postnet.convolutions.%d.0.conv.weight" % i, None, True) for i in range(1, 4)]
+        items = []
+        for tag, key, fused_rows, tr in want:
+            if key not in self._table:
+                continue
+            W = self._pack_source(key, fused_rows)
+            cs, kk, ds = W.shape
+            cin, cout = (cs, ds) if tr else (ds, cs)
+            split = tag in ("w1T", "qkvT")                 # wide contraction: 256-channel slices into fp32 slabs (ops.win_conv_split)
+            if not ops.win_conv_supported(256 if split else cin, cout, kk) or (split and cin % 256):
+                continue
+            items.append((tag, key, fused_rows, tr, W.numel()))
+        buf = torch.empty(sum(it[4] for it in items), dtype=bf16, device=self._shadow.device)
+        self._w1_packed, self._pack_items, off = {}, [], 0
+        for tag, key, fused_rows, tr, n in items:
+            self._w1_packed[(tag, key)] = buf[off:off + n]
+            self._pack_items.append((key, fused_rows, buf[off:off + n], tr))
+            off += n
+        # the shadow views and the packs keep their addresses until _apply: a device-resident item table, one pack launch per step
+        self._pack_table = ops.win_conv_pack_table([(self._pack_source(key, fr), out, tr) for key, fr, out, tr in self._pack_items],
+                                                   self._shadow.device) if self._pack_items else None
 
     def _pack_source(self, key, fused_rows=None):
         """The tap-major bf16 shadow of `key` as a (Cs, k, Ds) tensor (a Linear weight is k = 1; `fused_rows`: the q|k|v rows as one)."""
@@ -903,7 +912,15 @@ class FastSpeech2(nn.Module):
         """Run the queued weight-gradient work (grouped dW GEMMs, split-K reducers, column sums, scatter-sums)."""
         self._join_side()
         if self._dw_side_pending:
-            torch.cuda.current_stream().wait_stream(self._dw_side)
+            # The main stream gets here ~0.1 ms before the capped dW group on the side stream ends.  The column sums / scatter-sums read
+            # only activations and gradients the main chain produced: they run now, beside the side stream; the encoder-side dW group
+            # queues behind the first one on the side stream; the join comes last, before the split-K reducer.
+            cur = torch.cuda.current_stream()
+            self._dw_side.wait_stream(cur)
+            with torch.cuda.stream(self._dw_side):
+                ops.flush_deferred_gemms(self._deferred, max_wgs=0)
+            ops.flush_finalize(self._deferred_fin)
+            cur.wait_stream(self._dw_side)
             self._dw_side_pending = False
         ops.flush_deferred(self._deferred)
         ops.flush_finalize(self._deferred_fin)

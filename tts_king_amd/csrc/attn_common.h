@@ -64,29 +64,6 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned char* base, int nblk, i
       (__attribute__((address_space(3))) bf16x4*)(base + k1 * 256 + ((nblk ^ tr_sw(k1)) << 5) + ((l15 & 3) << 3)));
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
-// Reductions over the 16 lanes that share lane >> 4 (one MFMA output row lives in such a group = one DPP row).  Four DPP steps
-// on the VALU — xor 1, xor 2 inside the quad, then row_half_mirror (quads 0<->1, 2<->3) and row_mirror (halves) — instead of
-// four ds_bpermute round trips through the LDS (the online softmax runs two of these per row and key tile, back to back on the
-// wave's critical path).  max / + are commutative, so the mirrored pairings reduce like the xor butterfly; every lane ends with
-// the group's result.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float quad16_max(float v) {
-  v = fmaxf(v, dpp_f32<0xB1>(v));      // quad_perm [1,0,3,2]
-  v = fmaxf(v, dpp_f32<0x4E>(v));      // quad_perm [2,3,0,1]
-  v = fmaxf(v, dpp_f32<0x141>(v));     // row_half_mirror
-  v = fmaxf(v, dpp_f32<0x140>(v));     // row_mirror
-  return v;
-}
-__device__ __forceinline__ float quad16_sum(float v) {
-  v += dpp_f32<0xB1>(v);
-  v += dpp_f32<0x4E>(v);
-  v += dpp_f32<0x141>(v);
-  v += dpp_f32<0x140>(v);
-  return v;
-}
 
 
 }  // namespace

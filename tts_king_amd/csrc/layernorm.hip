@@ -320,11 +320,7 @@ __device__ __forceinline__ void unpack8(uint4 u, float* v) {
 __device__ __forceinline__ uint4 pack8f(const float* v) {
   return make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
 }
-__device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ float group16_sum(float v) { return quad16_sum(v); }     // DPP, no LDS round trips (common.h)
 
 __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd256_kernel(const LnBwdArgs a) {
   constexpr int D = 256;

@@ -187,9 +187,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ln_kernel(const GemmLnArgs a)
     s[rr] = z[rr][0] + z[rr][1] + z[rr][2] + z[rr][3];
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-    for (int rr = 0; rr < RW; ++rr) s[rr] += __shfl_xor(s[rr], o, 64);
+  for (int rr = 0; rr < RW; ++rr) s[rr] = wave_sum(s[rr]);       // independent chains: DPP inside the 16-lane rows, two permutes across
   float q[RW];
 #pragma unroll
   for (int rr = 0; rr < RW; ++rr) {
@@ -199,9 +197,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ln_kernel(const GemmLnArgs a)
     for (int e = 0; e < 4; ++e) { const float d = z[rr][e] - s[rr]; q[rr] += d * d; }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-    for (int rr = 0; rr < RW; ++rr) q[rr] += __shfl_xor(q[rr], o, 64);
+  for (int rr = 0; rr < RW; ++rr) q[rr] = wave_sum(q[rr]);
 #pragma unroll
   for (int rr = 0; rr < RW; ++rr) {
     const int row = m0 + wave * RW + rr;

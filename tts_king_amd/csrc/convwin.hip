@@ -574,16 +574,19 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
 }
 
 // ---- the same pair at C = 64 and C = 32 (the last two stages).  With 64 or 32 output channels there are not four 32-channel
-// groups to give the waves, so here a wave owns ALL output channels of a quarter of the frames: 48 frames (3 frame tiles) of
-// the 192 the workgroup computes for both convs; the weights of a tap are 8 KiB (C = 64) or 2 KiB per wave, still L2 -> registers.
+// groups to give the waves, so the four waves split the 192 frames the workgroup computes for both convs as well: C = 64: two
+// 32-channel groups x two 96-frame halves, C = 32: all channels x four 48-frame quarters; weights still L2 -> registers.
 // c2 is computed on the same 192 rows as c1 (frames t0 - 8 .. t0 + 184) and only the middle 176 are stored: the t window
 // carries 8 guard rows each side that only those discarded edge rows read.  Against the six-conv fused kernel
 // (resblock.hip): that one reads x once per block but multiplies 1.23-1.45x redundant halo rows and synchronises its eight
 // waves per weight stage; three pair launches move 3x its HBM bytes (still one read + one write of x per pair) and win on the
 // MFMA side.  Row stride C*2 + 16 bytes: 16 consecutive rows start on 16 different 16-byte bank groups.
 template <int C> struct FsGeom {
-  static constexpr int NW = 4, NT = 256, FW = 48, NF = FW / 16, GU = 8;
-  static constexpr int CROWS = NW * FW;                 // 192 rows computed by both convs
+  static constexpr int NW = 4, NT = 256, GU = 8, CROWS = 192;       // 192 rows computed by both convs
+  // wave = (cout group, frame group): C = 64: 2 x 2 — 32 output channels x 96 frames per wave (6 MFMAs per weight fragment loaded, the
+  // weights of a tap fetched twice per workgroup); all 64 channels x 48 frames per wave measured 29 % MFMA busy (3 MFMAs per fragment,
+  // four fetches).  C = 32: one cout group, four frame groups of 48.
+  static constexpr int CG = C == 64 ? 2 : 1, FG = NW / CG, FW = CROWS / FG, NF = FW / 16;
   static constexpr int TT = CROWS - 2 * GU;             // 176 frames stored
   static constexpr int XROWS = CROWS + 50;              // 242: c1 reaches 25 rows either side
   static constexpr int TROWS = CROWS + 2 * GU;          // 208
@@ -597,25 +600,26 @@ template <int C, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_pair_fs_kernel(const PairArgs a) {
   using Gm = FsGeom<C>;
   constexpr int NT = Gm::NT, FW = Gm::FW, NF = Gm::NF, GU = Gm::GU, TT = Gm::TT, XROWS = Gm::XROWS, RS = Gm::RS, NC = Gm::NC, KS = Gm::KS,
-                CH8 = Gm::CH8, TAP = Gm::TAP, XH = GU + 25;
+                CH8 = Gm::CH8, TAP = Gm::TAP, XH = GU + 25, CG = Gm::CG, CT = NC / CG;
   __shared__ __attribute__((aligned(16))) unsigned char smem[Gm::SMEM];
   unsigned char* XW = smem;
   unsigned char* TW = smem + XROWS * RS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, q = lane >> 4;
+  const int cgi = wave % CG, fg = wave / CG;             // this wave's output-channel group and frame group
   const int bi = blockIdx.y, t0 = blockIdx.x * TT;
   const int len = a.len, K = a.K, d = a.dil;
   const int HK = (K - 1) / 2;
   const bf16_t* __restrict__ xb = a.x + (int64_t)bi * len * C;
 
-  bf16x8 wa[KS][NC], wb[KS][NC];
-  auto load_w = [&](int g, bf16x8 (&w)[KS][NC]) __attribute__((always_inline)) {      // tap g of the 2K-tap sequence c1 | c2
-    const unsigned char* src = (const unsigned char*)(g < K ? a.w1 : a.w2) + (int64_t)(g < K ? g : g - K) * TAP + lane * 16;
+  bf16x8 wa[KS][CT], wb[KS][CT];
+  auto load_w = [&](int g, bf16x8 (&w)[KS][CT]) __attribute__((always_inline)) {      // tap g of the 2K-tap sequence c1 | c2
+    const unsigned char* src = (const unsigned char*)(g < K ? a.w1 : a.w2) + (int64_t)(g < K ? g : g - K) * TAP + (cgi * CT) * 1024 + lane * 16;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int c = 0; c < NC; ++c) w[ks][c] = *(const bf16x8*)(src + (ks * NC + c) * 1024);
+      for (int c = 0; c < CT; ++c) w[ks][c] = *(const bf16x8*)(src + (ks * NC + c) * 1024);
   };
   load_w(0, wa);
   load_w(1, wb);
@@ -638,30 +642,30 @@ __global__ __launch_bounds__(256, 2) void conv_pair_fs_kernel(const PairArgs a) 
       if (idx < XROWS * CH8) *(uint4*)(XW + row * RS + ch * 16) = lrelu8<F16>(xv[it], a.slope);
     }
   }
-  f32x4 bv1[NC], bv2[NC];
+  f32x4 bv1[CT], bv2[CT];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    bv1[c] = *(const f32x4*)(a.b1 + c * 16 + q * 4);
-    bv2[c] = *(const f32x4*)(a.b2 + c * 16 + q * 4);
+  for (int c = 0; c < CT; ++c) {
+    bv1[c] = *(const f32x4*)(a.b1 + (cgi * CT + c) * 16 + q * 4);
+    bv2[c] = *(const f32x4*)(a.b2 + (cgi * CT + c) * 16 + q * 4);
   }
   __syncthreads();
 
-  f32x4 acc[NC][NF];
+  f32x4 acc[CT][NF];
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int i = 0; i < NF; ++i) acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
   // one tap of either conv: `inl` = this lane's fragment address at shift 0, rows advance by `step` rows per tap offset
-  auto tap = [&](const unsigned char* inp, const bf16x8 (&w)[KS][NC]) __attribute__((always_inline)) {
+  auto tap = [&](const unsigned char* inp, const bf16x8 (&w)[KS][CT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
         const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c][i] = mfma16<F16>(w[ks][c], Bf, acc[c][i]);
+        for (int c = 0; c < CT; ++c) acc[c][i] = mfma16<F16>(w[ks][c], Bf, acc[c][i]);
       }
     }
   };
@@ -669,7 +673,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_fs_kernel(const PairArgs a) 
   // ---- c1: computed row r = wave*48 + i*16 + l15 <-> frame t0 - 8 + r <-> x-window row r + 25
   zero_acc();
   {
-    const unsigned char* inl = XW + (wave * FW + l15 + 25) * RS + q * 16;
+    const unsigned char* inl = XW + (fg * FW + l15 + 25) * RS + q * 16;
 #pragma unroll 1
     for (int g = 0; g + 1 < K; g += 2) {
       tap(inl + (g - HK) * d * RS, wa);
@@ -682,39 +686,39 @@ __global__ __launch_bounds__(256, 2) void conv_pair_fs_kernel(const PairArgs a) 
   }
 #pragma unroll
   for (int i = 0; i < NF; ++i) {
-    const int r = wave * FW + i * 16 + l15;
+    const int r = fg * FW + i * 16 + l15;
     const int t = t0 - GU + r;
     const bool live = t >= 0 && t < len;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
+    for (int c = 0; c < CT; ++c) {
       f32x4 v = acc[c][i] + bv1[c];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = live ? fmaxf(v[e], v[e] * a.slope) : 0.f;
-      *(uint2*)(TW + (r + GU) * RS + (c * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+      *(uint2*)(TW + (r + GU) * RS + ((cgi * CT + c) * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
     }
   }
   __syncthreads();
 
   // raw x (residual) and, in the accumulating modes, the current `out`: requested now, consumed after c2's taps
-  uint2 rres[NC][NF], rout[NC][NF];
+  uint2 rres[CT][NF], rout[CT][NF];
 #pragma unroll
   for (int i = 0; i < NF; ++i) {
-    const int r = wave * FW + i * 16 + l15;
+    const int r = fg * FW + i * 16 + l15;
     const int t = t0 - GU + r;
     const bool mine = r >= GU && r < GU + TT && t < len;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
+    for (int c = 0; c < CT; ++c) {
       rres[c][i] = rout[c][i] = make_uint2(0u, 0u);
       if (mine) {
-        rres[c][i] = *(const uint2*)(xb + (int64_t)t * C + c * 16 + q * 4);
-        if (a.mode) rout[c][i] = *(const uint2*)(a.out + ((int64_t)bi * len + t) * C + c * 16 + q * 4);
+        rres[c][i] = *(const uint2*)(xb + (int64_t)t * C + (cgi * CT + c) * 16 + q * 4);
+        if (a.mode) rout[c][i] = *(const uint2*)(a.out + ((int64_t)bi * len + t) * C + (cgi * CT + c) * 16 + q * 4);
       }
     }
   }
   // ---- c2 on the same rows (the 8 at either end read guard rows and are dropped)
   zero_acc();
   {
-    const unsigned char* inl = TW + (wave * FW + l15 + GU) * RS + q * 16;
+    const unsigned char* inl = TW + (fg * FW + l15 + GU) * RS + q * 16;
 #pragma unroll 1
     for (int g = 0; g + 1 < K; g += 2) {
       tap(inl + (g - HK) * RS, wb);
@@ -728,12 +732,12 @@ __global__ __launch_bounds__(256, 2) void conv_pair_fs_kernel(const PairArgs a) 
   // ---- epilogue: + b2 + raw x, MRF mode, staged through the x window for full-row stores
 #pragma unroll
   for (int i = 0; i < NF; ++i) {
-    const int r = wave * FW + i * 16 + l15;
+    const int r = fg * FW + i * 16 + l15;
     const int t = t0 - GU + r;
     const bool mine = r >= GU && r < GU + TT && t < len;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int co = c * 16 + q * 4;
+    for (int c = 0; c < CT; ++c) {
+      const int co = (cgi * CT + c) * 16 + q * 4;
       f32x4 v = acc[c][i] + bv2[c];
       {
         float r0, r1, r2, r3;

@@ -301,7 +301,7 @@ int ttsk_softmax_bwd(const void* probs_bf16, const float* dprobs, void* dscores_
  * without any S x S tensor in HBM: the forward keeps a running row max / sum over 64-key tiles and returns O and, for the
  * backward, lse [B*H][S] = log sum_k exp(score); the backward recomputes P = exp(score - lse) per tile.
  * bwd: delta_ws [B*H][S] fp32 scratch; writes ALL of dqkv [B*S][3*d] (dQ | dK | dV, head h at columns h*128 of each part),
- * two launches (query side: dQ; key side: dK, dV), no atomics.
+ * two launches (delta = rowsum(dO o O); then the query side (dQ) and the key side (dK, dV) as one grid), no atomics.
  * o_f32 [B*S][d] (may be NULL): O before its rounding to bf16.  The backward's delta = rowsum(dO o O) is what dP is cancelled
  * against; taken from the bf16 O its 2^-9 error dominates small dQ / dK gradients, so a training forward keeps the fp32 copy. */
 int ttsk_flash_attention_fwd(const void* qkv_bf16, void* o_bf16, float* o_f32 /* may be NULL */, float* lse /* may be NULL */,

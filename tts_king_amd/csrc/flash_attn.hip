@@ -162,8 +162,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const FlashArgs a) {
 
 // ------------------------------------------------------------------------------------------------ backward, query side
 // per (utterance, head, 64 queries): delta, then over the key tiles  P, dP -> dS -> dQ += dS K
-__global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(const FlashArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[KS_BYTES + VS_BYTES + KS_BYTES + PS_BYTES];   // 58,368 B
+__device__ __forceinline__ void flash_bwd_q_body(const FlashArgs& a, unsigned char* smem) {      // uses 58,368 B of smem
   unsigned char* Kr = smem;                          // K tile, row-major image  (B operand of S = Q K^T)
   unsigned char* Kt = smem + KS_BYTES;               // K tile, contraction-major image (B operand of dQ = dS K)
   unsigned char* Vr = Kt + VS_BYTES;                 // V tile, row-major image  (B operand of dP = dO V^T)
@@ -189,31 +188,13 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(const FlashArgs a) 
     store_rows(Kr, rq, tid);
     store_rows(Vr, rd, tid);
   }
-  // delta[q] = sum_d dO[q][d] * O[q][d] and LSE for rows lg*4 + r of the wave (16 lanes x 8 columns each)
+  // delta[q] = sum_d dO[q][d] * O[q][d] (flash_delta_kernel) and LSE for rows lg*4 + r of the wave
   float delta[4], lse[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int q = q0 + wave * 16 + lg * 4 + r;
-    float acc = 0.f;
-    lse[r] = 0.f;
-    if (q < S && a.o32) {
-      const uint4 x = *(const uint4*)(dob + (int64_t)q * a.d + l15 * 8);
-      const float* op = a.o32 + ((int64_t)b * S + q) * a.d + h * DK + l15 * 8;
-      const f32x4 y0 = *(const f32x4*)op, y1 = *(const f32x4*)(op + 4);
-      acc = __uint_as_float(x.x << 16) * y0[0] + __uint_as_float(x.x & 0xFFFF0000u) * y0[1] + __uint_as_float(x.y << 16) * y0[2] +
-            __uint_as_float(x.y & 0xFFFF0000u) * y0[3] + __uint_as_float(x.z << 16) * y1[0] + __uint_as_float(x.z & 0xFFFF0000u) * y1[1] +
-            __uint_as_float(x.w << 16) * y1[2] + __uint_as_float(x.w & 0xFFFF0000u) * y1[3];
-      lse[r] = a.lse[(int64_t)z * S + q];
-    } else if (q < S) {
-      const uint4 x = *(const uint4*)(dob + (int64_t)q * a.d + l15 * 8), y = *(const uint4*)(ob + (int64_t)q * a.d + l15 * 8);
-      acc = __uint_as_float(x.x << 16) * __uint_as_float(y.x << 16) + __uint_as_float(x.x & 0xFFFF0000u) * __uint_as_float(y.x & 0xFFFF0000u) +
-            __uint_as_float(x.y << 16) * __uint_as_float(y.y << 16) + __uint_as_float(x.y & 0xFFFF0000u) * __uint_as_float(y.y & 0xFFFF0000u) +
-            __uint_as_float(x.z << 16) * __uint_as_float(y.z << 16) + __uint_as_float(x.z & 0xFFFF0000u) * __uint_as_float(y.z & 0xFFFF0000u) +
-            __uint_as_float(x.w << 16) * __uint_as_float(y.w << 16) + __uint_as_float(x.w & 0xFFFF0000u) * __uint_as_float(y.w & 0xFFFF0000u);
-      lse[r] = a.lse[(int64_t)z * S + q];
-    }
-    delta[r] = quad16_sum(acc);
-    if (q < S && l15 == 0) a.delta[(int64_t)z * S + q] = delta[r];
+    delta[r] = q < S ? a.delta[(int64_t)z * S + q] : 0.f;
+    lse[r] = q < S ? a.lse[(int64_t)z * S + q] : 0.f;
   }
   __syncthreads();
   bf16x8 qa[4], da[4];
@@ -276,8 +257,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(const FlashArgs a) 
 // per (utterance, head, 64 keys): over the query tiles, with keys on the MFMA rows:
 //   S^T = K Q^T, dP^T = V dO^T  ->  P^T = exp(S^T * scale - LSE[query]),  dS^T = P^T o (dP^T - delta[query]) * scale
 //   dV += P^T dO,  dK += dS^T Q          (dO and Q as contraction-major images: the contraction index is the query row)
-__global__ __launch_bounds__(256, 2) void flash_bwd_kv_kernel(const FlashArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KS_BYTES + 2 * VS_BYTES + PS_BYTES];      // 74,752 B
+__device__ __forceinline__ void flash_bwd_kv_body(const FlashArgs& a, unsigned char* smem) {     // uses 74,752 B of smem
   unsigned char* Qr = smem;                          // Q tile, row-major image           (B operand of S^T = K Q^T)
   unsigned char* Dr = smem + KS_BYTES;               // dO tile, row-major image          (B operand of dP^T = V dO^T)
   unsigned char* Qt = Dr + KS_BYTES;                 // Q tile, contraction-major image   (B operand of dK += dS^T Q)
@@ -396,6 +376,42 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kv_kernel(const FlashArgs a)
   }
 }
 
+// delta[z][q] = sum_d dO[q][h*128 + d] * O[q][h*128 + d] (O in fp32 when kept): a 16-lane group per (row, head), 16 rows per workgroup
+__global__ __launch_bounds__(256) void flash_delta_kernel(const FlashArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
+  const int q = blockIdx.x * 16 + wave * 4 + lg;
+  const int S = a.S;
+  float acc = 0.f;
+  if (q < S) {
+    const uint4 x = *(const uint4*)(a.dout + ((int64_t)b * S + q) * a.d + h * DK + l15 * 8);
+    if (a.o32) {
+      const float* op = a.o32 + ((int64_t)b * S + q) * a.d + h * DK + l15 * 8;
+      const f32x4 y0 = *(const f32x4*)op, y1 = *(const f32x4*)(op + 4);
+      acc = __uint_as_float(x.x << 16) * y0[0] + __uint_as_float(x.x & 0xFFFF0000u) * y0[1] + __uint_as_float(x.y << 16) * y0[2] +
+            __uint_as_float(x.y & 0xFFFF0000u) * y0[3] + __uint_as_float(x.z << 16) * y1[0] + __uint_as_float(x.z & 0xFFFF0000u) * y1[1] +
+            __uint_as_float(x.w << 16) * y1[2] + __uint_as_float(x.w & 0xFFFF0000u) * y1[3];
+    } else {
+      const uint4 y = *(const uint4*)(a.o + ((int64_t)b * S + q) * a.d + h * DK + l15 * 8);
+      acc = __uint_as_float(x.x << 16) * __uint_as_float(y.x << 16) + __uint_as_float(x.x & 0xFFFF0000u) * __uint_as_float(y.x & 0xFFFF0000u) +
+            __uint_as_float(x.y << 16) * __uint_as_float(y.y << 16) + __uint_as_float(x.y & 0xFFFF0000u) * __uint_as_float(y.y & 0xFFFF0000u) +
+            __uint_as_float(x.z << 16) * __uint_as_float(y.z << 16) + __uint_as_float(x.z & 0xFFFF0000u) * __uint_as_float(y.z & 0xFFFF0000u) +
+            __uint_as_float(x.w << 16) * __uint_as_float(y.w << 16) + __uint_as_float(x.w & 0xFFFF0000u) * __uint_as_float(y.w & 0xFFFF0000u);
+    }
+  }
+  acc = quad16_sum(acc);
+  if (q < S && l15 == 0) a.delta[(int64_t)z * S + q] = acc;
+}
+
+// The query side (dQ) and the key side (dK, dV) as ONE grid (blockIdx.z = side): with delta precomputed neither needs the other, and a
+// side alone is 7 x 32 workgroups for the decoder — one per CU, a single wave per SIMD on a chain of dependent loads, LDS round trips
+// and VALU work; together two workgroups share a CU and fill each other's stalls.
+__global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KS_BYTES + 2 * VS_BYTES + PS_BYTES];      // 74,752 B (the key side's)
+  if (blockIdx.z == 0) flash_bwd_q_body(a, smem);
+  else flash_bwd_kv_body(a, smem);
+}
+
 }  // namespace
 
 extern "C" int ttsk_flash_attention_fwd(const void* qkv_bf16, void* o_bf16, float* o_f32, float* lse, const int64_t* lens, int B, int H,
@@ -417,9 +433,8 @@ extern "C" int ttsk_flash_attention_bwd(const void* qkv_bf16, const void* o_bf16
   TTSK_REQUIRE(B * H <= 65535 && (int64_t)S * 3 * d * 2 < ((int64_t)1 << 31), "flash_attention_bwd: sizes out of range");
   FlashArgs a{(const bf16_t*)qkv_bf16, (bf16_t*)o_bf16, (float*)o_f32, (float*)lse, (const bf16_t*)dout_bf16, delta_ws, (bf16_t*)dqkv_bf16,
               (const long long*)lens, S, H, d, scale};
-  const dim3 grid((S + TQ - 1) / TQ, B * H);
-  hipLaunchKernelGGL(flash_bwd_q_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(flash_bwd_kv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(flash_delta_kernel, dim3((S + 15) / 16, B * H), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(flash_bwd_kernel, dim3((S + TQ - 1) / TQ, B * H, 2), dim3(256), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

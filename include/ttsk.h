@@ -173,8 +173,12 @@ int ttsk_win_conv_split(const void* x_bf16, const void* w_packed, float* slabs, 
                         void* stream);
 /* gate_bf16 [B*S][Cout] (may be NULL; bf16 output only): out = gate > 0 ? out : 0 — the ReLU backward of SubLayers.py:96 folded into
  * the w_2 input-gradient conv. */
+/* delta_out [B*(Cout/128)][S] with delta_o32 [B*S][Cout] fp32 (both may be NULL; bf16 output, Cout = heads*128): the attention
+ * backward's delta = rowsum over a head's 128 columns of out (as stored) * delta_o32, written while the rows are stored — out is then
+ * the dO of ttsk_flash_attention_bwd(delta_ready = 1). */
 int ttsk_win_conv(const void* x_bf16, const void* w_packed, const float* bias /* may be NULL */, const void* gate_bf16 /* may be NULL */,
-                  void* out, int out_f32, int B, int S, int Cin, int Cout, int K, int relu, void* stream);
+                  const float* delta_o32 /* may be NULL */, float* delta_out /* may be NULL */, void* out, int out_f32, int B, int S, int Cin,
+                  int Cout, int K, int relu, void* stream);
 
 /* Fused sub-layer tail of an FFT block (reference: fs_two/transformer/SubLayers.py:62-63 and :96-99 + Layers.py:29,32):
  *   out = zero_PAD_rows( LayerNorm( dropout_{p_pre, site_pre}( A[M,K] @ W[D,K]^T + bias ) + res ) ),  D = 256 only.
@@ -306,9 +310,10 @@ int ttsk_softmax_bwd(const void* probs_bf16, const float* dprobs, void* dscores_
  * against; taken from the bf16 O its 2^-9 error dominates small dQ / dK gradients, so a training forward keeps the fp32 copy. */
 int ttsk_flash_attention_fwd(const void* qkv_bf16, void* o_bf16, float* o_f32 /* may be NULL */, float* lse /* may be NULL */,
                              const int64_t* lens, int B, int H, int S, int d, float scale, void* stream);
+/* delta_ready = 1: delta_ws already holds delta (the producer of dout wrote it: ttsk_win_conv with delta_out), no delta launch. */
 int ttsk_flash_attention_bwd(const void* qkv_bf16, const void* o_bf16, const float* o_f32 /* may be NULL */, const void* dout_bf16,
-                             const float* lse, float* delta_ws, void* dqkv_bf16, const int64_t* lens, int B, int H, int S, int d,
-                             float scale, void* stream);
+                             const float* lse, float* delta_ws, int delta_ready, void* dqkv_bf16, const int64_t* lens, int B, int H, int S,
+                             int d, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------- fused attention (d_k = 128)
  * reference: fs_two/transformer/Modules.py:14-24 + SubLayers.py:44-60.  qkv is the fused projection output

@@ -548,6 +548,13 @@ def test_win_conv_k1_projections_gate_and_item_packs():
     do = ops.win_conv(x, pf, d, 1)
     ref = ops.linear_dx(x.view(-1, d), Wf.view(d, d))
     assert float((do.view(-1, d).float() - ref.float()).abs().max()) <= 2 ** -7 * float(ref.float().abs().max())
+    # the attention backward's delta written by the fc input-gradient conv: rowsum per 128-column head of (stored dO) * o32
+    o32 = torch.randn(B * S, d, generator=g).to(DEV)
+    delta = torch.empty(B * 2, S, dtype=torch.float32, device=DEV)
+    do2 = ops.win_conv(x, pf, d, 1, delta_o32=o32, delta_out=delta)
+    assert torch.equal(do2, do)
+    want = (do.view(B, S, 2, 128).float() * o32.view(B, S, 2, 128)).sum(-1).permute(0, 2, 1).reshape(B * 2, S)
+    assert float((delta - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-5
     dh = ops.win_conv(x, p2, Fh, 1, gate=h)
     ref = ops.conv1d_dx(x, W2, G=h)
     assert float((dh.float() - ref.float()).abs().max()) <= 2 ** -7 * float(ref.float().abs().max())

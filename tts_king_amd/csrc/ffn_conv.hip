@@ -35,6 +35,10 @@ struct WcArgs {
   // split-K slabs ttsk_layernorm_bwd_slabs sums.  nsplit = 1: ldx = CIN.
   int nsplit, ldx;
   int64_t out_split;
+  // attention backward's delta folded into the fc input-gradient conv (bf16 output, Cout = H*128): delta[(b*H + h)*S + t] =
+  // sum over head h's 128 columns of out[t][.] (as stored, bf16) * o32[t][.]  — what flash_delta_kernel computes from the same operands
+  const float* o32;     // [B*S][Cout] fp32 or null
+  float* delta;         // [B*H][S]
 };
 
 // Weight packs.  src = storage (Cs, K, Ds) bf16 tap-major.
@@ -243,6 +247,7 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
     const int idx = it * NT + tid;
     const int rr = idx / OCH, ch = idx - rr * OCH;
     const int t = t0 + rr;
+    float dacc = 0.f;
     if (idx < TT * OCH && t < S) {
       uint4 v = *(const uint4*)(XW + rr * SRS + ch * 16);
       if (!OUT32 && a.gate) {
@@ -254,6 +259,18 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
         v.x &= keep(g.x); v.y &= keep(g.y); v.z &= keep(g.z); v.w &= keep(g.w);
       }
       *(uint4*)(ob + (int64_t)t * a.Cout * ESZ + ch * 16) = v;
+      if (!OUT32 && a.delta) {
+        const float* op = a.o32 + ((int64_t)bi * S + t) * a.Cout + cg * WC_COUT + ch * 8;
+        const f32x4 y0 = *(const f32x4*)op, y1 = *(const f32x4*)(op + 4);
+        dacc = __uint_as_float(v.x << 16) * y0[0] + __uint_as_float(v.x & 0xFFFF0000u) * y0[1] + __uint_as_float(v.y << 16) * y0[2] +
+               __uint_as_float(v.y & 0xFFFF0000u) * y0[3] + __uint_as_float(v.z << 16) * y1[0] + __uint_as_float(v.z & 0xFFFF0000u) * y1[1] +
+               __uint_as_float(v.w << 16) * y1[2] + __uint_as_float(v.w & 0xFFFF0000u) * y1[3];
+      }
+    }
+    if (!OUT32 && a.delta) {          // 16 consecutive lanes hold one (row, head): 16 chunks of 8 columns
+      dacc = quad16_sum(dacc);
+      const int hd = (cg * WC_COUT + ch * 8) / 128, nh = a.Cout / 128;
+      if (idx < TT * OCH && t < S && (ch & 15) == 0) a.delta[((int64_t)bi * nh + hd) * S + t] = dacc;
     }
   }
 }
@@ -323,15 +340,17 @@ extern "C" int ttsk_ffn_pack_weight(const void* w_bf16, void* packed_bf16, int C
   return ttsk_win_conv_pack_batch(&w_bf16, &packed_bf16, 1, Cout, K, 256, 0, stream);
 }
 
-extern "C" int ttsk_win_conv(const void* x_bf16, const void* w_packed, const float* bias, const void* gate_bf16, void* out, int out_f32, int B,
-                             int S, int Cin, int Cout, int K, int relu, void* stream) {
+extern "C" int ttsk_win_conv(const void* x_bf16, const void* w_packed, const float* bias, const void* gate_bf16, const float* delta_o32,
+                             float* delta_out, void* out, int out_f32, int B, int S, int Cin, int Cout, int K, int relu, void* stream) {
   TTSK_REQUIRE(x_bf16 && w_packed && out, "ttsk_win_conv: null pointer");
   TTSK_REQUIRE(B > 0 && S > 0 && B <= 65535, "ttsk_win_conv: bad sizes B=%d S=%d", B, S);
   TTSK_REQUIRE(ttsk_win_conv_supported(Cin, Cout, K), "ttsk_win_conv: no instance for Cin=%d Cout=%d K=%d", Cin, Cout, K);
   TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_packed) | ((uintptr_t)bias) | ((uintptr_t)out)) & 15) == 0, "ttsk_win_conv: 16-byte alignment");
   TTSK_REQUIRE((int64_t)B * S * (Cout > Cin ? Cout : Cin) * 4 < ((int64_t)1 << 40), "ttsk_win_conv: sizes out of range");
   TTSK_REQUIRE(!(gate_bf16 && out_f32) && (((uintptr_t)gate_bf16) & 15) == 0, "ttsk_win_conv: the gate goes with bf16 output, 16-byte aligned");
-  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, bias, out, S, K, Cout, relu, 0, 0, (const bf16_t*)gate_bf16, 1, Cin, 0};
+  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, bias, out, S, K, Cout, relu, 0, 0, (const bf16_t*)gate_bf16, 1, Cin, 0, delta_o32, delta_out};
+  TTSK_REQUIRE(!delta_out || (delta_o32 && !out_f32 && Cout % 128 == 0 && (((uintptr_t)delta_o32) & 15) == 0),
+               "ttsk_win_conv: delta needs o32 (16-byte aligned), bf16 output and Cout = heads * 128");
   launch_win_conv(a, B, S, Cin, out_f32, 1, (hipStream_t)stream);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
@@ -344,7 +363,7 @@ extern "C" int ttsk_ffn_conv_fwd(const void* x_bf16, const void* w_bf16, const f
   TTSK_REQUIRE(ttsk_ffn_conv_supported(Cin, Cout, K), "ttsk_ffn_conv_fwd: no instance for Cin=%d Cout=%d K=%d", Cin, Cout, K);
   TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_bf16) | ((uintptr_t)bias) | ((uintptr_t)out_bf16)) & 15) == 0, "ttsk_ffn_conv_fwd: 16-byte alignment");
   TTSK_REQUIRE((int64_t)B * S * (Cout > Cin ? Cout : Cin) * 2 < ((int64_t)1 << 40), "ttsk_ffn_conv_fwd: sizes out of range");
-  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_bf16, bias, out_bf16, S, K, Cout, relu, 0, 0, nullptr, 1, Cin, 0};
+  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_bf16, bias, out_bf16, S, K, Cout, relu, 0, 0, nullptr, 1, Cin, 0, nullptr, nullptr};
   launch_win_conv(a, B, S, Cin, 0, packed, (hipStream_t)stream);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
@@ -356,7 +375,8 @@ extern "C" int ttsk_win_conv_split(const void* x_bf16, const void* w_packed, flo
   TTSK_REQUIRE(B > 0 && S > 0 && B <= 65535 && Cin_total == nsplit * 256, "ttsk_win_conv_split: Cin must be nsplit * 256 (got %d, nsplit %d)", Cin_total, nsplit);
   TTSK_REQUIRE(ttsk_win_conv_supported(256, Cout, K), "ttsk_win_conv_split: no instance for Cout=%d K=%d", Cout, K);
   TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_packed) | ((uintptr_t)slabs)) & 15) == 0, "ttsk_win_conv_split: 16-byte alignment");
-  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, nullptr, slabs, S, K, Cout, 0, 0, 0, nullptr, nsplit, Cin_total, (int64_t)B * S * Cout};
+  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, nullptr, slabs, S, K, Cout, 0, 0, 0, nullptr, nsplit, Cin_total, (int64_t)B * S * Cout,
+           nullptr, nullptr};
   launch_win_conv(a, B, S, 256, 1, 1, (hipStream_t)stream);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;

@@ -426,14 +426,14 @@ extern "C" int ttsk_flash_attention_fwd(const void* qkv_bf16, void* o_bf16, floa
 }
 
 extern "C" int ttsk_flash_attention_bwd(const void* qkv_bf16, const void* o_bf16, const float* o_f32, const void* dout_bf16, const float* lse,
-                                        float* delta_ws, void* dqkv_bf16, const int64_t* lens, int B, int H, int S, int d, float scale,
-                                        void* stream) {
+                                        float* delta_ws, int delta_ready, void* dqkv_bf16, const int64_t* lens, int B, int H, int S, int d,
+                                        float scale, void* stream) {
   TTSK_REQUIRE(qkv_bf16 && o_bf16 && dout_bf16 && lse && delta_ws && dqkv_bf16, "flash_attention_bwd: null pointer");
   TTSK_REQUIRE(B > 0 && H > 0 && S > 0 && d == H * DK, "flash_attention_bwd: head size must be 128");
   TTSK_REQUIRE(B * H <= 65535 && (int64_t)S * 3 * d * 2 < ((int64_t)1 << 31), "flash_attention_bwd: sizes out of range");
   FlashArgs a{(const bf16_t*)qkv_bf16, (bf16_t*)o_bf16, (float*)o_f32, (float*)lse, (const bf16_t*)dout_bf16, delta_ws, (bf16_t*)dqkv_bf16,
               (const long long*)lens, S, H, d, scale};
-  hipLaunchKernelGGL(flash_delta_kernel, dim3((S + 15) / 16, B * H), dim3(256), 0, (hipStream_t)stream, a);
+  if (!delta_ready) hipLaunchKernelGGL(flash_delta_kernel, dim3((S + 15) / 16, B * H), dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(flash_bwd_kernel, dim3((S + TQ - 1) / TQ, B * H, 2), dim3(256), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;

@@ -837,13 +837,17 @@ class FastSpeech2(nn.Module):
             self._finalize_ln(part, nblk, 3 * d, a + "fc.bias")
             ops.linear_dw(dy1, o, self._g(a + "fc.weight"), defer=self._deferred)
         pkf = self._w1_packed.get(("fcT", a + "fc.weight")) if (self.window_ffn and self._w1_packed) else None
+        delta = None
         if pkf is not None:
-            do = ops.win_conv(dy1.view(Bn, S, d), pkf, d, 1).view(rows, d)
+            if flash and o32 is not None:
+                # the attention backward's delta = rowsum(dO o O) per head, written by this conv's epilogue while it stores dO
+                delta = torch.empty(Bn * H, S, dtype=torch.float32, device=dev)
+            do = ops.win_conv(dy1.view(Bn, S, d), pkf, d, 1, delta_o32=o32 if delta is not None else None, delta_out=delta).view(rows, d)
         else:
             do = ops.linear_dx(dy1, self._w(a + "fc.weight"))
         # ---- attention core: dP = dO V^T ; dS = softmax'(P, dP)/sqrt(dk) ; dQ = dS K ; dK = dS^T Q ; dV = P^T dO
         if flash:
-            dqkv = ops.flash_attention_bwd(qkv, o, do, probs, lens, Bn, H, S, o32=o32)      # P recomputed per tile; dQ, dK, dV in two launches
+            dqkv = ops.flash_attention_bwd(qkv, o, do, probs, lens, Bn, H, S, o32=o32, delta=delta)      # P recomputed per tile; dQ, dK, dV in two launches
         else:
             dqkv = torch.empty(rows, 3 * d, dtype=bf16, device=dev)
             if self.fused_attention and dk == 128:

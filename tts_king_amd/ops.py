@@ -377,14 +377,15 @@ def win_conv_pack_run(table, n):
     check(L.load().ttsk_win_conv_pack_table(_ptr(table), n, _stream()), "ttsk_win_conv_pack_table")
 
 
-def win_conv(x, packed, Cout, k, bias=None, relu=False, out_dtype=None, gate=None):
+def win_conv(x, packed, Cout, k, bias=None, relu=False, out_dtype=None, gate=None, delta_o32=None, delta_out=None):
     """[relu](Conv1d(Cin -> Cout, k)(x) + bias) on the window kernel, weights = a win_conv_pack_batch pack (ttsk_win_conv); `gate`
     (B,S,Cout) bf16: result zeroed where gate <= 0.  x (B,S,Cin) bf16 -> (B,S,Cout) bf16 or fp32."""
     _dev(x, packed, bias, gate)
     Bsz, S, Cin = x.shape
     out = torch.empty(Bsz, S, Cout, dtype=out_dtype or bf16, device=x.device)
-    check(L.load().ttsk_win_conv(_ptr(x), _ptr(packed), _ptr(bias), _ptr(gate), _ptr(out), int(out.dtype == torch.float32), Bsz, S, Cin, Cout,
-                                 k, int(relu), _stream()), "ttsk_win_conv")
+    _dev(delta_o32, delta_out)
+    check(L.load().ttsk_win_conv(_ptr(x), _ptr(packed), _ptr(bias), _ptr(gate), _ptr(delta_o32), _ptr(delta_out), _ptr(out),
+                                 int(out.dtype == torch.float32), Bsz, S, Cin, Cout, k, int(relu), _stream()), "ttsk_win_conv")
     return out
 
 
@@ -679,14 +680,17 @@ def flash_attention_fwd(qkv, lens, Bn, H, S, want_lse):
     return o, lse, o32
 
 
-def flash_attention_bwd(qkv, o, do, lse, lens, Bn, H, S, o32=None):
-    """dqkv (rows, 3d) bf16 = gradients of q | k | v (ttsk_flash_attention_bwd: two launches, P recomputed from lse)."""
-    _dev(qkv, o, do, lse, lens, o32)
+def flash_attention_bwd(qkv, o, do, lse, lens, Bn, H, S, o32=None, delta=None):
+    """dqkv (rows, 3d) bf16 = gradients of q | k | v (ttsk_flash_attention_bwd: delta, then dQ and dK/dV sides as one grid; P
+    recomputed from lse).  `delta` (B*H, S) fp32: already computed by the producer of `do` (win_conv(delta_out=...)): no delta launch."""
+    _dev(qkv, o, do, lse, lens, o32, delta)
     d = qkv.shape[1] // 3
     dqkv = torch.empty(Bn * S, 3 * d, dtype=bf16, device=qkv.device)
-    delta = _f32(Bn * H, S, device=qkv.device)
-    check(L.load().ttsk_flash_attention_bwd(_ptr(qkv), _ptr(o), _ptr(o32), _ptr(do), _ptr(lse), _ptr(delta), _ptr(dqkv), _ptr(lens), Bn, H, S,
-                                            d, (d // H) ** -0.5, _stream()), "ttsk_flash_attention_bwd")
+    ready = delta is not None
+    if delta is None:
+        delta = _f32(Bn * H, S, device=qkv.device)
+    check(L.load().ttsk_flash_attention_bwd(_ptr(qkv), _ptr(o), _ptr(o32), _ptr(do), _ptr(lse), _ptr(delta), int(ready), _ptr(dqkv), _ptr(lens),
+                                            Bn, H, S, d, (d // H) ** -0.5, _stream()), "ttsk_flash_attention_bwd")
     return dqkv
 
 

@@ -189,6 +189,12 @@ int ttsk_win_conv(const void* x_bf16, const void* w_packed, const float* bias /*
 int ttsk_gemm_ln_fwd(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res, const float* gamma,
                      const float* beta, void* out, void* z_save, float* mean, float* rstd, const int64_t* lens, int seg_len,
                      int M, int K, int D, float eps, float p_pre, uint32_t site_pre, const void* rng, void* stream);
+/* The same fused op on the window-conv data path: W_packed is the MFMA-fragment-major pack of the (256, K) weight
+ * (ttsk_win_conv_pack_* with (Cs, K, Ds) = (256, 1, K), transpose = 0); K = 256 or 1024.  Same row code, same dropout mask. */
+int ttsk_win_ln_supported(int K, int D);
+int ttsk_win_ln_fwd(const void* A, int lda, const void* W_packed, const float* bias, const void* res, const float* gamma, const float* beta,
+                    void* out, void* z_save, float* mean, float* rstd, const int64_t* lens, int seg_len, int M, int K, int D, float eps,
+                    float p_pre, uint32_t site_pre, const void* rng, void* stream);
 
 /* what ttsk_gemm will run for `d` (with d->kernel / d->splits as constraints when non-zero) and the workspace it needs */
 int ttsk_gemm_plan(const ttsk_gemm_desc* d, int32_t* kernel, int32_t* splits, int64_t* workspace_bytes);

@@ -421,6 +421,17 @@ def test_gemm_ln_fwd_matches_reference(M, K, seg):
     # the conv-layout weight (256, 1, K) of w_2 is accepted as is
     out2, *_ = ops.gemm_ln_fwd(a.to(DEV), w.view(D, 1, K).to(DEV), b.to(DEV), res.to(DEV), gamma.to(DEV), beta.to(DEV), lens.to(DEV), seg)
     assert torch.equal(out2, out)
+    # the window-path kernel (weights as a fragment-major pack, K = 256 / 1024): same fp32 sums in the same order, same row code
+    assert ops.win_ln_supported(K, D) == (K in (256, 1024))
+    if ops.win_ln_supported(K, D):
+        pk = torch.empty(D * K, dtype=torch.bfloat16, device=DEV)
+        ops.win_conv_pack_items([(w.view(D, 1, K).to(DEV), pk, False)])
+        out3, z3, mean3, rstd3 = ops.win_ln_fwd(a.to(DEV), pk, b.to(DEV), res.to(DEV), gamma.to(DEV), beta.to(DEV), lens.to(DEV), seg)
+        assert float((out3.float() - out.float()).abs().max()) <= 2 ** -7 * float(ref.abs().max()) + 2e-3
+        assert float((z3.float().cpu().double() - z_ref).abs().max()) <= 2 ** -8 * float(z_ref.abs().max()) + 1e-3
+        torch.testing.assert_close(mean3, mean, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(rstd3, rstd, rtol=1e-3, atol=1e-4)
+        assert float(out3.float().cpu()[pad].abs().max() if bool(pad.any()) else 0.0) == 0.0
 
 
 def test_gemm_ln_fwd_dropout_matches_unfused_masks():
@@ -436,6 +447,10 @@ def test_gemm_ln_fwd_dropout_matches_unfused_masks():
     _, z_f, mean_f, rstd_f = ops.gemm_ln_fwd(a.to(DEV), w.to(DEV), b.to(DEV), None, gamma.to(DEV), beta.to(DEV), None, 0, p_pre=p, site_pre=9, rng=rng)
     y = ops.linear(a.to(DEV), w.to(DEV), b.to(DEV))
     _, z_u, mean_u, rstd_u, _ = ops.layernorm_fwd(y, None, gamma.to(DEV), beta.to(DEV), None, 0, p_pre=p, site_pre=9, rng=rng)
+    pk = torch.empty(D * K, dtype=torch.bfloat16, device=DEV)
+    ops.win_conv_pack_items([(w.view(D, 1, K).to(DEV), pk, False)])
+    _, z_w, _, _ = ops.win_ln_fwd(a.to(DEV), pk, b.to(DEV), None, gamma.to(DEV), beta.to(DEV), None, 0, p_pre=p, site_pre=9, rng=rng)
+    assert torch.equal(z_w == 0, z_f == 0)                  # the window-path kernel drops the same elements
     zf, zu = z_f.float().cpu(), z_u.float().cpu()
     assert torch.equal(zf == 0, zu == 0)
     keep = zu != 0

@@ -52,6 +52,59 @@ __device__ __forceinline__ void drop4(float v[4], uint64_t seed, uint64_t step, 
   v[3] = b.w >= thr ? v[3] * scale : 0.f;
 }
 
+// The LayerNorm rows of a 32 x 256 fp32 tile `cs` (leading dimension CS_LD): one wave per row, RW rows per wave, lane owns columns
+// 4*lane .. 4*lane+3 (ln_fwd_kernel's row code: same Philox indexing, so ln_bwd_kernel regenerates the same dropout mask).
+template <int RW>
+__device__ __forceinline__ void ln_rows_epilogue(const GemmLnArgs& a, const float* cs, int m0, int wave, int lane, const uint2 (&resv)[RW]) {
+  const int M = a.M, c = lane * 4;
+  const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
+  const f32x4 bi = *(const f32x4*)(a.bias + c);
+  const f32x4 g = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
+  const unsigned thr = keep_threshold(a.p_pre);
+  const float scale = 1.f / (1.f - a.p_pre);
+  float z[RW][4];
+  float s[RW];
+#pragma unroll
+  for (int rr = 0; rr < RW; ++rr) {
+    const int lr = wave * RW + rr;
+    const int row = m0 + lr;
+    const bool live = row < M;
+    const f32x4 v = *(const f32x4*)(cs + lr * CS_LD + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[rr][e] = v[e] + bi[e];
+    if (a.p_pre > 0.f) drop4(z[rr], seed, step, a.site_pre, (unsigned)(((int64_t)row * BN + c) >> 2), thr, scale);
+    z[rr][0] += __uint_as_float(resv[rr].x << 16); z[rr][1] += __uint_as_float(resv[rr].x & 0xFFFF0000u);
+    z[rr][2] += __uint_as_float(resv[rr].y << 16); z[rr][3] += __uint_as_float(resv[rr].y & 0xFFFF0000u);
+    if (a.z_save && live) *(uint2*)(a.z_save + (int64_t)row * BN + c) = make_uint2(pack_bf2(z[rr][0], z[rr][1]), pack_bf2(z[rr][2], z[rr][3]));
+    s[rr] = z[rr][0] + z[rr][1] + z[rr][2] + z[rr][3];
+  }
+#pragma unroll
+  for (int rr = 0; rr < RW; ++rr) s[rr] = wave_sum(s[rr]);       // independent chains: DPP inside the 16-lane rows, two permutes across
+  float q[RW];
+#pragma unroll
+  for (int rr = 0; rr < RW; ++rr) {
+    s[rr] *= (1.f / BN);            // mean
+    q[rr] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = z[rr][e] - s[rr]; q[rr] += d * d; }
+  }
+#pragma unroll
+  for (int rr = 0; rr < RW; ++rr) q[rr] = wave_sum(q[rr]);
+#pragma unroll
+  for (int rr = 0; rr < RW; ++rr) {
+    const int row = m0 + wave * RW + rr;
+    if (row >= M) continue;
+    const float mean = s[rr], rstd = rsqrtf(q[rr] * (1.f / BN) + a.eps);
+    if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+    bool masked = false;
+    if (a.lens) { const int b = row / a.seg_len, t = row - b * a.seg_len; masked = t >= a.lens[b]; }
+    float o4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o4[e] = masked ? 0.f : (z[rr][e] - mean) * rstd * g[e] + bt[e];
+    *(uint2*)(a.out + (int64_t)row * BN + c) = make_uint2(pack_bf2(o4[0], o4[1]), pack_bf2(o4[2], o4[3]));
+  }
+}
+
 // The kernel streams W (256 x K, the same for every workgroup: L2-resident) and its 32 rows of A through LDS; one CU pulls
 // about 70-90 GB/s from L2 into LDS, and only with ~100 KB of requests in flight (measured with the register-staged first
 // version: two 36 KiB tiles in flight gave 1.7 us per K step = 21 GB/s).  So: LDS-DMA (buffer_load ... lds, no VGPR round
@@ -164,53 +217,103 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ln_kernel(const GemmLnArgs a)
       for (int r = 0; r < 4; ++r) cs[(i * 16 + lg * 4 + r) * CS_LD + wave * WC + j * 16 + l15] = acc[i][j][r];
   __syncthreads();
 
-  // one wave per row, 8 rows per wave, lane owns columns 4*lane .. 4*lane+3 (ln_fwd_kernel's row code)
-  const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
-  const f32x4 bi = *(const f32x4*)(a.bias + c);
-  const f32x4 g = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
-  const unsigned thr = keep_threshold(a.p_pre);
-  const float scale = 1.f / (1.f - a.p_pre);
-  float z[RW][4];
-  float s[RW];
-#pragma unroll
-  for (int rr = 0; rr < RW; ++rr) {
-    const int lr = wave * RW + rr;
-    const int row = m0 + lr;
-    const bool live = row < M;
-    const f32x4 v = *(const f32x4*)(cs + lr * CS_LD + c);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) z[rr][e] = v[e] + bi[e];
-    if (a.p_pre > 0.f) drop4(z[rr], seed, step, a.site_pre, (unsigned)(((int64_t)row * BN + c) >> 2), thr, scale);
-    z[rr][0] += __uint_as_float(resv[rr].x << 16); z[rr][1] += __uint_as_float(resv[rr].x & 0xFFFF0000u);
-    z[rr][2] += __uint_as_float(resv[rr].y << 16); z[rr][3] += __uint_as_float(resv[rr].y & 0xFFFF0000u);
-    if (a.z_save && live) *(uint2*)(a.z_save + (int64_t)row * BN + c) = make_uint2(pack_bf2(z[rr][0], z[rr][1]), pack_bf2(z[rr][2], z[rr][3]));
-    s[rr] = z[rr][0] + z[rr][1] + z[rr][2] + z[rr][3];
-  }
-#pragma unroll
-  for (int rr = 0; rr < RW; ++rr) s[rr] = wave_sum(s[rr]);       // independent chains: DPP inside the 16-lane rows, two permutes across
-  float q[RW];
-#pragma unroll
-  for (int rr = 0; rr < RW; ++rr) {
-    s[rr] *= (1.f / BN);            // mean
-    q[rr] = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { const float d = z[rr][e] - s[rr]; q[rr] += d * d; }
-  }
-#pragma unroll
-  for (int rr = 0; rr < RW; ++rr) q[rr] = wave_sum(q[rr]);
+  ln_rows_epilogue<RW>(a, cs, m0, wave, lane, resv);
+}
+
+
+// ---- the same fused op with the window-conv data path (csrc/ffn_conv.hip): the 32 rows of A (all K channels, K = 256 or 1024) go into
+// LDS once, each of the eight waves owns 32 of the 256 output columns and streams its weights L2 -> registers from the MFMA-fragment-
+// major pack (ttsk_win_conv_pack_*: [k-step][cout tile][lane][8]), one step = 128 input channels = 8 fragments, three register sets, no
+// barrier in the loop; then the fp32 tile and ln_rows_epilogue as above.  W still crosses L2 -> CU once per workgroup (128 / 512 KiB), but
+// as 1 KiB contiguous fragments into registers instead of through the LDS ring with a barrier per 64 channels.
+template <int CIN>
+__global__ __launch_bounds__(512, CIN == 256 ? 2 : 1) void win_ln_kernel(const GemmLnArgs a) {
+  constexpr int TT = BM, RS = CIN * 2 + 32, NT = 512, CH8 = CIN / 8, KH = 4, CT = 2, NF = TT / 16, NS = CIN / 128, RW = BM / 8;
+  constexpr int XBYTES = TT * RS, CBYTES = BM * CS_LD * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[XBYTES > CBYTES ? XBYTES : CBYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.x * BM;
+  const int M = a.M;
+  uint2 resv[RW];
 #pragma unroll
   for (int rr = 0; rr < RW; ++rr) {
     const int row = m0 + wave * RW + rr;
-    if (row >= M) continue;
-    const float mean = s[rr], rstd = rsqrtf(q[rr] * (1.f / BN) + a.eps);
-    if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
-    bool masked = false;
-    if (a.lens) { const int b = row / a.seg_len, t = row - b * a.seg_len; masked = t >= a.lens[b]; }
-    float o4[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o4[e] = masked ? 0.f : (z[rr][e] - mean) * rstd * g[e] + bt[e];
-    *(uint2*)(a.out + (int64_t)row * BN + c) = make_uint2(pack_bf2(o4[0], o4[1]), pack_bf2(o4[2], o4[3]));
+    resv[rr] = (a.res && row < M) ? *(const uint2*)(a.res + (int64_t)row * BN + lane * 4) : make_uint2(0u, 0u);
   }
+  const bf16_t* wrow[CT];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc) wrow[cc] = a.W + ((int64_t)(wave * CT + cc) * 64 + lane) * 8;
+  constexpr int64_t kstep_stride = (BN / 16) * 512;            // elements per k-step of the pack
+  bf16x8 wa[KH][CT], wb[KH][CT], wc[KH][CT];
+  auto load_w = [&](int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(wrow[cc] + (int64_t)(g * KH + ks) * kstep_stride);
+  };
+  load_w(0, wa);
+  if (1 < NS) load_w(1, wb);
+  if (2 < NS) load_w(2, wc);
+  {
+    constexpr int NCH = (TT * CH8 + NT - 1) / NT;
+    uint4 xv[NCH];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int idx = it * NT + tid;
+      const int row = idx / CH8, ch = idx - row * CH8;
+      xv[it] = make_uint4(0, 0, 0, 0);
+      if (idx < TT * CH8 && m0 + row < M) xv[it] = *(const uint4*)(a.A + (int64_t)(m0 + row) * a.lda + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int idx = it * NT + tid;
+      const int row = idx / CH8, ch = idx - row * CH8;
+      if (idx < TT * CH8) *(uint4*)(smem + row * RS + ch * 16) = xv[it];
+    }
+  }
+  __syncthreads();
+  f32x4 acc[CT][NF];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+    for (int i = 0; i < NF; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const unsigned char* inl = smem + l15 * RS + q * 16;
+    auto step = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
+      const unsigned char* inp = inl + g * (KH * 64);
+#pragma unroll
+      for (int ks = 0; ks < KH; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
+#pragma unroll
+          for (int cc = 0; cc < CT; ++cc) acc[cc][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][cc], Bf, acc[cc][i], 0, 0, 0);
+        }
+      }
+    };
+#pragma unroll 1
+    for (int g = 0; g < NS; g += 3) {
+      step(g, wa);
+      if (g + 3 < NS) load_w(g + 3, wa);
+      if (g + 1 < NS) {
+        step(g + 1, wb);
+        if (g + 4 < NS) load_w(g + 4, wb);
+      }
+      if (g + 2 < NS) {
+        step(g + 2, wc);
+        if (g + 5 < NS) load_w(g + 5, wc);
+      }
+    }
+  }
+  __syncthreads();                         // every wave is done with the rows of A: they become the fp32 tile
+  float* cs = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < NF; ++i)
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc) *(f32x4*)(cs + (i * 16 + l15) * CS_LD + (wave * CT + cc) * 16 + q * 4) = acc[cc][i];
+  __syncthreads();
+  ln_rows_epilogue<RW>(a, cs, m0, wave, lane, resv);
 }
 
 }  // namespace
@@ -239,6 +342,27 @@ extern "C" int ttsk_gemm_ln_fwd(const void* A, int lda, const void* W, int ldw, 
     case 5: hipLaunchKernelGGL((gemm_ln_kernel<16, true>), grid, dim3(1024), 0, (hipStream_t)stream, a); break;
     default: hipLaunchKernelGGL((gemm_ln_kernel<8, true>), grid, dim3(512), 0, (hipStream_t)stream, a); break;
   }
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_win_ln_supported(int K, int D) { return D == BN && (K == 256 || K == 1024); }
+
+extern "C" int ttsk_win_ln_fwd(const void* A, int lda, const void* W_packed, const float* bias, const void* res, const float* gamma,
+                               const float* beta, void* out, void* z_save, float* mean, float* rstd, const int64_t* lens, int seg_len, int M,
+                               int K, int D, float eps, float p_pre, uint32_t site_pre, const void* rng, void* stream) {
+  TTSK_REQUIRE(A && W_packed && bias && gamma && beta && out && mean && rstd, "ttsk_win_ln_fwd: null pointer");
+  TTSK_REQUIRE(ttsk_win_ln_supported(K, D), "ttsk_win_ln_fwd: built for D = 256, K = 256 or 1024 (got K=%d D=%d)", K, D);
+  TTSK_REQUIRE(M > 0 && (lda & 7) == 0 && lda >= K, "ttsk_win_ln_fwd: bad M / lda");
+  TTSK_REQUIRE((((uintptr_t)A | (uintptr_t)W_packed | (uintptr_t)out | (uintptr_t)res | (uintptr_t)z_save) & 15) == 0, "ttsk_win_ln_fwd: operands must be 16-byte aligned");
+  TTSK_REQUIRE(!(p_pre > 0.f) || rng, "ttsk_win_ln_fwd: dropout needs the rng state");
+  TTSK_REQUIRE(p_pre >= 0.f && p_pre < 1.f, "ttsk_win_ln_fwd: p_pre must be in [0, 1)");
+  TTSK_REQUIRE(!lens || (seg_len > 0 && M % seg_len == 0), "ttsk_win_ln_fwd: lens needs M %% seg_len == 0");
+  GemmLnArgs a{(const bf16_t*)A, (const bf16_t*)W_packed, bias, (const bf16_t*)res, gamma, beta, (bf16_t*)out, (bf16_t*)z_save, mean, rstd,
+               (const long long*)lens, (const uint64_t*)rng, M, K, lda, 0, seg_len > 0 ? seg_len : 1, p_pre, eps, site_pre};
+  const dim3 grid((M + BM - 1) / BM);
+  if (K == 256) hipLaunchKernelGGL(win_ln_kernel<256>, grid, dim3(512), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(win_ln_kernel<1024>, grid, dim3(512), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -335,6 +335,8 @@ class FastSpeech2(nn.Module):
                [("fcT", p + "slf_attn.fc.weight", None, True) for p in dec + enc] + \
                [("w2T", p + "pos_ffn.w_2.weight", None, True) for p in dec + enc] + \
                [("w1T", p + "pos_ffn.w_1.weight", None, True) for p in dec + enc] + \
+               [("fc", p + "slf_attn.fc.weight", None, False) for p in dec + enc] + \
+               [("w2", p + "pos_ffn.w_2.weight", None, False) for p in dec + enc] + \
                [("qkvT", p + "slf_attn.w_qs.weight", 3 * d, True) for p in dec + enc] + \
                [("pn", "postnet.convolutions.%d.0.conv.weight" % i, None, False) for i in range(1, 4)] + \
                [("pnT", "postnet.convolutions.%d.0.conv.weight" % i, None, True) for i in range(1, 4)]
@@ -346,7 +348,10 @@ class FastSpeech2(nn.Module):
             cs, kk, ds = W.shape
             cin, cout = (cs, ds) if tr else (ds, cs)
             split = tag in ("w1T", "qkvT")                 # wide contraction: 256-channel slices into fp32 slabs (ops.win_conv_split)
-            if not ops.win_conv_supported(256 if split else cin, cout, kk) or (split and cin % 256):
+            if tag in ("fc", "w2"):                        # the fused projection + LayerNorm kernel's weights (ops.win_ln_fwd)
+                if kk != 1 or not ops.win_ln_supported(cin, cout):
+                    continue
+            elif not ops.win_conv_supported(256 if split else cin, cout, kk) or (split and cin % 256):
                 continue
             items.append((tag, key, fused_rows, tr, W.numel()))
         buf = torch.empty(sum(it[4] for it in items), dtype=bf16, device=self._shadow.device)
@@ -442,9 +447,15 @@ class FastSpeech2(nn.Module):
         fuse = self.fused_ln and d == 256
         # (5) fc, dropout, +residual, LayerNorm, zero PAD rows: SubLayers.py:62-63, Layers.py:29 — one kernel when d = 256
         if fuse:
-            x1, z1, mean1, rstd1 = ops.gemm_ln_fwd(o, self._w(a + "fc.weight"), self._m(a + "fc.bias"), x, self._m(a + "layer_norm.weight"),
-                                                   self._m(a + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site, rng=rng,
-                                                   save_z=ctx_list is not None)
+            pkl = self._w1_packed.get(("fc", a + "fc.weight")) if (self.window_ffn and self._w1_packed) else None
+            if pkl is not None:
+                x1, z1, mean1, rstd1 = ops.win_ln_fwd(o, pkl, self._m(a + "fc.bias"), x, self._m(a + "layer_norm.weight"),
+                                                      self._m(a + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site, rng=rng,
+                                                      save_z=ctx_list is not None)
+            else:
+                x1, z1, mean1, rstd1 = ops.gemm_ln_fwd(o, self._w(a + "fc.weight"), self._m(a + "fc.bias"), x, self._m(a + "layer_norm.weight"),
+                                                       self._m(a + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site, rng=rng,
+                                                       save_z=ctx_list is not None)
         else:
             y = ops.linear(o, self._w(a + "fc.weight"), self._m(a + "fc.bias"))
             x1, z1, mean1, rstd1, _ = ops.layernorm_fwd(y, x, self._m(a + "layer_norm.weight"), self._m(a + "layer_norm.bias"),
@@ -457,9 +468,15 @@ class FastSpeech2(nn.Module):
         else:
             h = ops.conv1d(x1.view(Bn, S, d), W1, self._m(f + "w_1.bias"), flags=ops.RELU)
         if fuse and self.k2 == 1:
-            x2, z2, mean2, rstd2 = ops.gemm_ln_fwd(h.view(rows, -1), self._w(f + "w_2.weight"), self._m(f + "w_2.bias"), x1,
-                                                   self._m(f + "layer_norm.weight"), self._m(f + "layer_norm.bias"), lens, S, p_pre=p,
-                                                   site_pre=site + 1, rng=rng, save_z=ctx_list is not None, out=out)
+            pkl = self._w1_packed.get(("w2", f + "w_2.weight")) if (self.window_ffn and self._w1_packed) else None
+            if pkl is not None:
+                x2, z2, mean2, rstd2 = ops.win_ln_fwd(h.view(rows, -1), pkl, self._m(f + "w_2.bias"), x1, self._m(f + "layer_norm.weight"),
+                                                      self._m(f + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site + 1, rng=rng,
+                                                      save_z=ctx_list is not None, out=out)
+            else:
+                x2, z2, mean2, rstd2 = ops.gemm_ln_fwd(h.view(rows, -1), self._w(f + "w_2.weight"), self._m(f + "w_2.bias"), x1,
+                                                       self._m(f + "layer_norm.weight"), self._m(f + "layer_norm.bias"), lens, S, p_pre=p,
+                                                       site_pre=site + 1, rng=rng, save_z=ctx_list is not None, out=out)
         else:
             y2 = ops.conv1d(h, self._w(f + "w_2.weight"), self._m(f + "w_2.bias"))
             x2, z2, mean2, rstd2, _ = ops.layernorm_fwd(y2.view(rows, d), x1, self._m(f + "layer_norm.weight"),

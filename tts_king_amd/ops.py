@@ -510,6 +510,26 @@ def gemm_ln_fwd(x, W, bias, res, gamma, beta, lens=None, seg_len=0, p_pre=0.0, s
     return out, z, mean, rstd
 
 
+def win_ln_supported(K, D):
+    return bool(L.load().ttsk_win_ln_supported(K, D))
+
+
+def win_ln_fwd(x, packed, bias, res, gamma, beta, lens=None, seg_len=0, p_pre=0.0, site_pre=0, rng=None, save_z=True, eps=1e-5, out=None):
+    """gemm_ln_fwd with the weight as a fragment-major pack (win_conv_pack_*; ttsk_win_ln_fwd): x (rows, K) bf16, K = 256 or 1024."""
+    _dev(x, packed, bias, res, gamma, beta, lens, rng)
+    rows, K = x.shape
+    D = 256
+    dev = x.device
+    if out is None:
+        out = torch.empty(rows, D, dtype=bf16, device=dev)
+    z = torch.empty(rows, D, dtype=bf16, device=dev) if save_z else None
+    mean, rstd = _f32(rows, device=dev), _f32(rows, device=dev)
+    check(L.load().ttsk_win_ln_fwd(_ptr(x), x.stride(0), _ptr(packed), _ptr(bias), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(z),
+                                   _ptr(mean), _ptr(rstd), _ptr(lens), seg_len, rows, K, D, eps, p_pre, site_pre, _ptr(rng), _stream()),
+          "ttsk_win_ln_fwd")
+    return out, z, mean, rstd
+
+
 def layernorm_bwd(dout, z, mean, rstd, gamma, beta, lens=None, seg_len=0, relu_in=False, p_pre=0.0, site_pre=0,
                   p_post=0.0, site_post=0, rng=None, dhead=None, head_w=None, want_dz=True, slabs=None, R=None):
     """Returns (dz, dy, partials, nblk).  dy is dz when p_pre == 0.  partials layout: see include/ttsk.h.

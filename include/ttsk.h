@@ -445,6 +445,30 @@ int ttsk_bn_finalize(const float* partials, int nblk, int C, int rows, float eps
                      float* running_mean, float* running_var, int64_t* num_batches_tracked, const int32_t* frame_limit, int seg_len,
                      void* stream);
 int ttsk_rsqrt_eps(const float* var, float eps, float* rstd, int n, void* stream);
+/* The training path in two launches per direction instead of three.  A workgroup owns a slab of channels (64, or all C when C is
+ * not a multiple of 64; then C <= 128) and one of ttsk_bn_nchunks(rows) <= 64 row chunks, so there are few partial rows whatever
+ * the grid; ttsk_bn_train_apply / ttsk_bn_bwd_apply_slab sum them for their own slab (fixed order, double) instead of waiting
+ * for ttsk_bn_finalize / a column-sum launch.  ttsk_bn_train_apply = ttsk_bn_finalize (mean, rstd, running statistics,
+ * num_batches_tracked: all written) + ttsk_bn_apply; ttsk_bn_bwd_apply_slab = the column sums + ttsk_bn_bwd_apply.
+ * partials: [nblk][2C]; any producer of such rows will do (nblk need not be ttsk_bn_nchunks).
+ * keep_out / keep (may be NULL): uint8 [rows][C/4], bit e of a byte = channel 4*q + e was kept by the dropout; written by the
+ * forward and read by the two backward kernels instead of regenerating the Philox mask twice (NULL: they regenerate it). */
+int ttsk_bn_nchunks(int rows);
+int ttsk_bn_stats_slab(const void* x, int x_is_f32, int rows, int C, float* partials /* [nchunks][2C] */, const int32_t* frame_limit,
+                       int seg_len, void* stream);
+int ttsk_bn_train_apply(const void* x, int x_is_f32, const float* partials, int nblk, float eps, float momentum, float* mean,
+                        float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, const float* gamma,
+                        const float* beta, int rows, int C, int use_tanh, float p, uint32_t site, const uint64_t* rng,
+                        const float* resid_f32, void* out_bf16, float* out_f32, uint8_t* keep_out, const int32_t* frame_limit,
+                        int seg_len, void* stream);
+int ttsk_bn_bwd_stats_slab(const void* dout, int dout_is_f32, const void* x, int x_is_f32, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
+                           const uint64_t* rng, const uint8_t* keep, float* partials /* [nchunks][2C] */,
+                           const int32_t* frame_limit, int seg_len, void* stream);
+int ttsk_bn_bwd_apply_slab(const void* dout, int dout_is_f32, const void* x, int x_is_f32, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
+                           const uint64_t* rng, const uint8_t* keep, const float* partials, int nblk, void* dx_bf16, float* dgamma,
+                           float* dbeta, const int32_t* frame_limit, int seg_len, void* stream);
 int ttsk_bn_apply(const void* x, int x_is_f32, const float* mean, const float* rstd, const float* gamma, const float* beta, int rows,
                   int C, int use_tanh, float p, uint32_t site, const uint64_t* rng, const float* resid_f32, void* out_bf16,
                   float* out_f32, const int32_t* frame_limit, int seg_len, void* stream);

@@ -230,6 +230,57 @@ def test_batchnorm_train_fwd_bwd(C, use_tanh, xdt):
     assert dxd.shape == (rows, C)
 
 
+@pytest.mark.parametrize("C,use_tanh,rows,seg", [(512, True, 2 * 423, 423), (80, False, 2 * 423, 423), (64, True, 3 * 40, 40), (512, True, 16 * 423, 423)])
+def test_batchnorm_two_launch_path_equals_three_launch(C, use_tanh, rows, seg):
+    """ops.bn_train (partials per channel slab + one kernel that finishes mean / rstd itself) against the stats / finalize /
+    apply kernels: same statistics (1e-6), the same dropout mask, the same running buffers; with and without a frame limit;
+    and its backward (bn_bwd takes the slab kernels by default) against the three-launch backward."""
+    from tts_king_amd import ops
+    assert ops.bn_slab_supported(C)
+    x = rnd(rows, C, seed=40, scale=1.5).to(DEV)
+    gamma, beta = (1 + 0.1 * rnd(C, seed=41)).to(DEV), (0.1 * rnd(C, seed=42)).to(DEV)
+    resid = rnd(rows, C, seed=43).to(DEV)
+    dout = rnd(rows, C, seed=44).to(DEV)
+    st = ops.optim_state(DEV, seed=9)
+    rng = ops.rng_of(st)
+    for fl in (None, (torch.tensor([seg - 7], dtype=torch.int32, device=DEV), seg)):
+        rm1, rv1, n1 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+        rm2, rv2, n2 = rm1.clone(), rv1.clone(), n1.clone()
+        mean, rstd = ops.bn_train_stats(x, rm1, rv1, n1, frame_limit=fl)
+        want = ops.bn_apply(x, mean, rstd, gamma, beta, use_tanh, p=0.5, site=302, rng=rng, resid=resid, out_f32=True, frame_limit=fl)
+        got, m2, r2, keep = ops.bn_train(x, rm2, rv2, n2, gamma, beta, use_tanh, p=0.5, site=302, rng=rng, resid=resid, out_f32=True,
+                                         frame_limit=fl, want_keep=True)
+        close_f32(m2, mean.cpu(), rtol=1e-6, atol=1e-7)
+        close_f32(r2, rstd.cpu(), rtol=1e-6, atol=1e-7)
+        close_f32(rm2, rm1.cpu(), rtol=1e-6, atol=1e-7)
+        close_f32(rv2, rv1.cpu(), rtol=1e-6, atol=1e-7)
+        assert int(n2) == 1
+        close_f32(got, want.cpu(), rtol=1e-5, atol=1e-5)
+        dropped = (got == resid).view(rows, C // 4, 4)
+        assert torch.equal(got == resid, want == resid)                      # the same elements dropped
+        live = torch.ones(rows, dtype=torch.bool, device=DEV) if fl is None else (torch.arange(rows, device=DEV) % seg) < int(fl[0])
+        bits = torch.stack([(keep >> e) & 1 for e in range(4)], dim=-1).bool()
+        assert torch.equal(bits[live], ~dropped[live])                       # the keep bits say so too
+        assert 0.48 < float(bits[live].float().mean()) < 0.52
+        got16, _, _ = ops.bn_train(x, rm2.clone(), rv2.clone(), n2.clone(), gamma, beta, use_tanh, frame_limit=fl)
+        close_bf16(got16, ops.bn_apply(x, mean, rstd, gamma, beta, use_tanh, frame_limit=fl).float().cpu(), extra=1e-3)
+        # backward: slab kernels regenerating the mask, slab kernels reading the keep bits, the three-launch kernels
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        dx = ops.bn_bwd(dout, x, mean, rstd, gamma, beta, use_tanh, p=0.5, site=302, rng=rng, dgamma=dg, dbeta=db, frame_limit=fl)
+        dgk, dbk = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        dxk = ops.bn_bwd(dout, x, mean, rstd, gamma, beta, use_tanh, p=0.5, site=302, rng=None, dgamma=dgk, dbeta=dbk, frame_limit=fl, keep=keep)
+        assert torch.equal(dxk, dx) and torch.equal(dgk, dg) and torch.equal(dbk, db)
+        ops.BN_SLAB = False
+        try:
+            dg0, db0 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+            dx0 = ops.bn_bwd(dout, x, mean, rstd, gamma, beta, use_tanh, p=0.5, site=302, rng=rng, dgamma=dg0, dbeta=db0, frame_limit=fl)
+        finally:
+            ops.BN_SLAB = True
+        close_bf16(dx, dx0.float().cpu(), extra=1e-3)
+        close_f32(dg, dg0.cpu(), rtol=1e-4, atol=1e-3)
+        close_f32(db, db0.cpu(), rtol=1e-4, atol=1e-3)
+
+
 def test_loss_and_grads():
     from oracle import fs2 as ofs2
     from tts_king_amd import ops

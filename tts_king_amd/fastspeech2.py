@@ -665,15 +665,23 @@ class FastSpeech2(nn.Module):
             else:
                 yc = ops.conv1d(xin, self._w(pp + "0.conv.weight"), self._m(pp + "0.conv.bias"), out_dtype=torch.float32)
             C = yc.shape[2]
-            if train:
-                mean, rstd = ops.bn_train_stats(yc.view(rows, C), self.get(pp + "1.running_mean"), self.get(pp + "1.running_var"),
-                                                self.get(pp + "1.num_batches_tracked").view(1), frame_limit=fl)
-            else:
-                mean, rstd = self.get(pp + "1.running_mean"), ops.rsqrt_eps(self.get(pp + "1.running_var"))
             last = i == 4
-            nxt = ops.bn_apply(yc.view(rows, C), mean, rstd, self._m(pp + "1.weight"), self._m(pp + "1.bias"), not last,
-                               p=p_post, site=300 + i, rng=rng, resid=mel if last else None, out_f32=last, frame_limit=fl)
-            pn.append((pp, xin, yc, mean, rstd))
+            if train and ops.bn_slab_supported(C):
+                # statistics partials, then one kernel that finishes mean / rstd per channel slab and normalises
+                nxt, mean, rstd, keep = ops.bn_train(yc.view(rows, C), self.get(pp + "1.running_mean"), self.get(pp + "1.running_var"),
+                                                     self.get(pp + "1.num_batches_tracked").view(1), self._m(pp + "1.weight"),
+                                                     self._m(pp + "1.bias"), not last, p=p_post, site=300 + i, rng=rng,
+                                                     resid=mel if last else None, out_f32=last, frame_limit=fl, want_keep=True)
+            else:
+                keep = None
+                if train:
+                    mean, rstd = ops.bn_train_stats(yc.view(rows, C), self.get(pp + "1.running_mean"), self.get(pp + "1.running_var"),
+                                                    self.get(pp + "1.num_batches_tracked").view(1), frame_limit=fl)
+                else:
+                    mean, rstd = self.get(pp + "1.running_mean"), ops.rsqrt_eps(self.get(pp + "1.running_var"))
+                nxt = ops.bn_apply(yc.view(rows, C), mean, rstd, self._m(pp + "1.weight"), self._m(pp + "1.bias"), not last,
+                                   p=p_post, site=300 + i, rng=rng, resid=mel if last else None, out_f32=last, frame_limit=fl)
+            pn.append((pp, xin, yc, mean, rstd, keep))
             xin = nxt.view(Bn, T, C) if not last else nxt
         post = xin
         if train:
@@ -982,11 +990,11 @@ class FastSpeech2(nn.Module):
         # ---- PostNet (last layer first)
         dout = dpost.view(rows, nm)
         for i in range(4, -1, -1):
-            pp, xin, yc, mean, rstd = ctx.pn[i]
+            pp, xin, yc, mean, rstd, keep = ctx.pn[i]
             C = yc.shape[2]
             dy = ops.bn_bwd(dout, yc.view(rows, C), mean, rstd, self._m(pp + "1.weight"), self._m(pp + "1.bias"), i < 4,
                             p=self.p_post, site=300 + i, rng=rng, dgamma=self._g(pp + "1.weight"), dbeta=self._g(pp + "1.bias"),
-                            frame_limit=ctx.frame_limit)
+                            frame_limit=ctx.frame_limit, keep=keep)
             with self._side_work(dy, xin):
                 ops.colsum_into(dy, self._g(pp + "0.conv.bias"), defer=self._deferred_fin)
                 ops.conv1d_dw(dy.view(Bn, T, C), xin, self._g(pp + "0.conv.weight"), k=5, defer=self._deferred)

@@ -836,6 +836,9 @@ def zero_frames_from(x, frame_limit):
     return x
 
 
+BN_SLAB = _os.environ.get("TTSK_BN_SLAB", "1") != "0"      # two-launch BatchNorm (channel slabs); 0 = the three-launch kernels
+
+
 def bn_train_stats(x, running_mean=None, running_var=None, nbt=None, eps=1e-5, momentum=0.1, frame_limit=None):
     """x (rows, C) bf16 or fp32 -> (mean, rstd) fp32 of the batch; updates the running buffers in place."""
     _dev(x)
@@ -866,10 +869,49 @@ def bn_apply(x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, resi
     return o32 if out_f32 else o16
 
 
-def bn_bwd(dout, x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, dgamma=None, dbeta=None, frame_limit=None):
-    """dx (rows,C) bf16; dgamma/dbeta (fp32, accumulated in place when given)."""
+def bn_slab_supported(Cn):
+    return BN_SLAB and Cn % 4 == 0 and (Cn % 64 == 0 or Cn <= 128)
+
+
+def bn_train(x, running_mean, running_var, nbt, gamma, beta, use_tanh, p=0.0, site=0, rng=None, resid=None, out_f32=False,
+             frame_limit=None, eps=1e-5, momentum=0.1, partials=None, want_keep=False):
+    """Training-mode BatchNorm forward in two launches: batch statistics partials, then normalise (+tanh, dropout, residual)
+    with mean / rstd finished per channel slab inside the second kernel.  -> (out, mean, rstd).  partials: rows already
+    produced elsewhere ([nblk][2C] fp32) skip the first launch.  want_keep: -> (out, mean, rstd, keep), keep = the dropout's
+    keep bits (uint8 [rows][C/4], None when p == 0) for bn_bwd(keep=...)."""
+    _dev(x)
     rows, Cn = x.shape
     lib = L.load()
+    lp, seg = _lim(frame_limit)
+    xf = int(x.dtype == torch.float32)
+    if partials is None:
+        partials = _f32(lib.ttsk_bn_nchunks(rows), 2 * Cn, device=x.device)
+        check(lib.ttsk_bn_stats_slab(_ptr(x), xf, rows, Cn, _ptr(partials), lp, seg, _stream()), "ttsk_bn_stats_slab")
+    mean, rstd = _f32(Cn, device=x.device), _f32(Cn, device=x.device)
+    o16 = None if out_f32 else torch.empty(rows, Cn, dtype=bf16, device=x.device)
+    o32 = _f32(rows, Cn, device=x.device) if out_f32 else None
+    keep = torch.empty(rows, Cn // 4, dtype=torch.uint8, device=x.device) if (want_keep and p > 0.0) else None
+    check(lib.ttsk_bn_train_apply(_ptr(x), xf, _ptr(partials), partials.shape[0], eps, momentum, _ptr(mean), _ptr(rstd), _ptr(running_mean),
+                                  _ptr(running_var), _ptr(nbt), _ptr(gamma), _ptr(beta), rows, Cn, int(use_tanh), p, site, _ptr(rng),
+                                  _ptr(resid), _ptr(o16), _ptr(o32), _ptr(keep), lp, seg, _stream()), "ttsk_bn_train_apply")
+    return ((o32 if out_f32 else o16), mean, rstd, keep) if want_keep else ((o32 if out_f32 else o16), mean, rstd)
+
+
+def bn_bwd(dout, x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, dgamma=None, dbeta=None, frame_limit=None, keep=None):
+    """dx (rows,C) bf16; dgamma/dbeta (fp32, accumulated in place when given).  keep: bn_train's keep bits (slab kernels only)."""
+    rows, Cn = x.shape
+    lib = L.load()
+    if bn_slab_supported(Cn):
+        partials = _f32(lib.ttsk_bn_nchunks(rows), 2 * Cn, device=x.device)
+        f32, xf = int(dout.dtype == torch.float32), int(x.dtype == torch.float32)
+        lp, seg = _lim(frame_limit)
+        check(lib.ttsk_bn_bwd_stats_slab(_ptr(dout), f32, _ptr(x), xf, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn, int(use_tanh),
+                                         p, site, _ptr(rng), _ptr(keep), _ptr(partials), lp, seg, _stream()), "ttsk_bn_bwd_stats_slab")
+        dx = torch.empty(rows, Cn, dtype=bf16, device=x.device)
+        check(lib.ttsk_bn_bwd_apply_slab(_ptr(dout), f32, _ptr(x), xf, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn, int(use_tanh),
+                                         p, site, _ptr(rng), _ptr(keep), _ptr(partials), partials.shape[0], _ptr(dx), _ptr(dgamma), _ptr(dbeta), lp, seg,
+                                         _stream()), "ttsk_bn_bwd_apply_slab")
+        return dx
     nblk = lib.ttsk_bn_nblocks(rows)
     partials = _f32(nblk, 2 * Cn, device=x.device)
     sums = _f32(2 * Cn, device=x.device)

@@ -259,6 +259,20 @@ int ttsk_layernorm_bwd_slabs(const float* slabs, int nsplit, int64_t slab_stride
                              const float* mean, const float* rstd, const float* gamma, const float* beta, const int64_t* lens,
                              int seg_len, int rows, int D, int relu_in, float p_pre, uint32_t site_pre, float p_post,
                              uint32_t site_post, const uint64_t* rng, void* dz_bf16, void* dy_bf16, float* partials, void* stream);
+/* ttsk_layernorm_bwd (D = 256, no head / ReLU input / post dropout; upstream gradient as dout_bf16 OR as split-K slabs + R as in
+ * ttsk_layernorm_bwd_slabs) followed, in the same kernel, by the k = 1 projection that consumes dy — the sub-layer's input gradient:
+ *   out[rows][Cout] = dy · W'   with w_packed = ttsk_win_conv's pack of the transposed weight (Cout = 256 or 1024, Cin = 256),
+ *   gate_bf16 (may be NULL): out = gate > 0 ? out : 0  (w_2's dX through the ReLU: reference SubLayers.py:93-101 backward),
+ *   delta_o32 / delta_out (may be NULL; Cout = 256 = 2 heads x 128, rows = B*seg_len): the attention backward's
+ *   delta[(b*2 + h)*seg_len + t] = sum over head h's columns of out * o32  (fc's dX: SubLayers.py:62-63 backward).
+ * One launch instead of two dependent ones; results are bit-identical to ttsk_layernorm_bwd(_slabs) + ttsk_win_conv.
+ * partials: [ttsk_layernorm_bwd_proj_nblocks(rows)][3*D] (dbias | dgamma | dbeta), a workgroup per 32 rows. */
+int ttsk_layernorm_bwd_proj_nblocks(int rows);
+int ttsk_layernorm_bwd_proj(const void* dout_bf16, const float* slabs, int nsplit, int64_t slab_stride, const void* R_bf16,
+                            const void* z_bf16, const float* mean, const float* rstd, const float* gamma, const int64_t* lens,
+                            int seg_len, int rows, int D, float p_pre, uint32_t site_pre, const uint64_t* rng, void* dz_bf16,
+                            void* dy_bf16, float* partials, const void* w_packed, int Cout, const void* gate_bf16,
+                            const float* delta_o32, float* delta_out, void* out_bf16, void* stream);
 /* dst[c] (+)= scale * sum_b partials[b*ld + c]  in fixed order */
 int ttsk_colsum_finalize(const float* partials, int nblk, int ncols, int ld, float* dst, int accumulate, float scale,
                          void* stream);

@@ -577,6 +577,55 @@ def test_win_conv_k1_projections_gate_and_item_packs():
     assert bool((dh[h <= 0] == 0).all())
 
 
+@pytest.mark.parametrize("B,S,p", [(3, 130, 0.1), (16, 423, 0.1), (2, 33, 0.0), (16, 64, 0.2)])
+def test_layernorm_bwd_with_projection_equals_two_launches(B, S, p):
+    """ttsk_layernorm_bwd_proj (LayerNorm backward + the k = 1 input-gradient conv on its dy in one kernel) against the two launches it
+    replaces, bit for bit: w_2's dX (256 -> 1024, ReLU gate) behind a bf16 upstream gradient, and fc's dX (256 -> 256, attention delta)
+    behind split-K slabs + residual; ragged lengths (PAD rows), dropout on and off."""
+    from tts_king_amd import ops
+
+    def same(a, b, what):
+        bad = (a.float() != b.float()) | (a.float().isnan() != b.float().isnan())
+        assert not bool(bad.any()), (what, int(bad.sum()), bad.nonzero()[:4].tolist(), a[bad][:4].tolist(), b[bad][:4].tolist())
+
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    d, Fh, rows = 256, 1024, B * S
+    z = bf(torch.randn(rows, d, generator=g)).to(DEV)
+    mean, rstd = (0.1 * torch.randn(rows, generator=g)).to(DEV), (0.5 + torch.rand(rows, generator=g)).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV), (0.1 * torch.randn(d, generator=g)).to(DEV)
+    lens = torch.randint(max(1, S // 2), S + 1, (B,), generator=g).to(DEV)
+    dout = bf(torch.randn(rows, d, generator=g)).to(DEV)
+    Wf = bf(torch.randn(d, 1, d, generator=g) * d ** -0.5).to(DEV)
+    W2 = bf(torch.randn(d, 1, Fh, generator=g) * Fh ** -0.5).to(DEV)
+    h = bf(torch.randn(rows, Fh, generator=g)).clamp(min=0).to(DEV)
+    pf, p2 = (torch.empty(w.numel(), dtype=torch.bfloat16, device=DEV) for w in (Wf, W2))
+    ops.win_conv_pack_items([(Wf, pf, True), (W2, p2, True)])
+    rng = ops.rng_of(ops.optim_state(DEV, seed=3))
+    # (1) bf16 upstream gradient, gate
+    dz0, dy0, part0, n0 = ops.layernorm_bwd(dout, z, mean, rstd, gamma, beta, lens, S, p_pre=p, site_pre=7, rng=rng)
+    dh0 = ops.win_conv(dy0.view(B, S, d), p2, Fh, 1, gate=h.view(B, S, Fh))
+    dz1, dy1, part1, n1, dh1 = ops.layernorm_bwd_proj(dout, z, mean, rstd, gamma, p2, Fh, lens, S, p_pre=p, site_pre=7, rng=rng, gate=h)
+    same(dz1, dz0, "dz"), same(dy1, dy0, "dy"), same(dh1, dh0.view(rows, Fh), "dh")
+    assert n1 == (rows + 31) // 32
+    s0, s1 = part0[:n0].double().sum(0), part1.double().sum(0)
+    assert float((s0 - s1).abs().max()) <= 1e-5 * float(s0.abs().max())
+    # (2) split-K slabs + residual, delta
+    nsp = 3
+    ws = torch.randn(nsp, rows, d, generator=g).to(DEV).contiguous()
+    sl = ops.Slabs(ws, nsp, rows * d)
+    R = bf(torch.randn(rows, d, generator=g)).to(DEV)
+    o32 = torch.randn(rows, d, generator=g).to(DEV)
+    dz0, dy0, part0, n0 = ops.layernorm_bwd(None, z, mean, rstd, gamma, beta, lens, S, p_pre=p, site_pre=9, rng=rng, slabs=sl, R=R)
+    del0 = torch.empty(B * 2, S, dtype=torch.float32, device=DEV)
+    do0 = ops.win_conv(dy0.view(B, S, d), pf, d, 1, delta_o32=o32, delta_out=del0)
+    del1 = torch.empty(B * 2, S, dtype=torch.float32, device=DEV)
+    dz1, dy1, part1, n1, do1 = ops.layernorm_bwd_proj(None, z, mean, rstd, gamma, pf, d, lens, S, p_pre=p, site_pre=9, rng=rng, slabs=sl, R=R,
+                                                      delta_o32=o32, delta_out=del1)
+    same(dz1, dz0, "dz (slabs)"), same(dy1, dy0, "dy (slabs)"), same(do1, do0.view(rows, d), "do"), same(del1, del0, "delta")
+    s0, s1 = part0[:n0].double().sum(0), part1.double().sum(0)
+    assert float((s0 - s1).abs().max()) <= 1e-5 * float(s0.abs().max())
+
+
 @pytest.mark.parametrize("B,S,Cin,K", [(16, 423, 1024, 9), (16, 64, 1024, 9), (2, 130, 768, 1), (1, 9, 512, 3)])
 def test_win_conv_split_slabs(B, S, Cin, K):
     """ttsk_win_conv_split: the input gradient of a conv with a wide contraction (w_1: 1024 channels x 9 taps; q|k|v: 768) as 256-channel

@@ -322,89 +322,83 @@ __device__ __forceinline__ uint4 pack8f(const float* v) {
 }
 __device__ __forceinline__ float group16_sum(float v) { return quad16_sum(v); }     // DPP, no LDS round trips (common.h)
 
-__global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd256_kernel(const LnBwdArgs a) {
+// One row of the D = 256 backward for a 16-lane group (lane l of the group owns columns c0 = 16 l .. + 15): the row's contributions
+// to dbias / dgamma / dbeta are ADDED to sbias / sgam / sbeta, dzv returns the gradient of the sub-layer output (dz with the
+// pre-dropout mask applied; all zero for a PAD row or a row past the end).  dz and dy go to memory when the row exists.
+__device__ __forceinline__ void lnb256_row(const LnBwdArgs& a, int row, int c0, const float gam[16], uint64_t seed, uint64_t step,
+                                           unsigned thr, float dscale, float sbias[16], float sgam[16], float sbeta[16], float dzv[16]) {
   constexpr int D = 256;
-  __shared__ float red[LNB_WAVES][3 * D];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int grp = lane >> 4, l = lane & 15, c0 = l * 16;
-  const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
-  const unsigned thr = keep_threshold(a.p_pre);
-  const float dscale = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
-  float gam[16];
+  const bool live = row < a.rows;
+  bool masked = !live;
+  if (live && a.lens) { const int b = row / a.seg_len, t = row - b * a.seg_len; masked = t >= a.lens[b]; }
+  float zz[16], d[16];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { const f32x4 t = *(const f32x4*)(a.gamma + c0 + 4 * i); gam[4 * i] = t[0]; gam[4 * i + 1] = t[1]; gam[4 * i + 2] = t[2]; gam[4 * i + 3] = t[3]; }
-  float sbias[16], sgam[16], sbeta[16];
+  for (int e = 0; e < 16; ++e) { zz[e] = 0.f; d[e] = 0.f; }
+  float mean = 0.f, rstd = 0.f;
+  if (live) {
+    const bf16_t* zp = a.z + (int64_t)row * D + c0;
+    unpack8(*(const uint4*)zp, zz); unpack8(*(const uint4*)(zp + 8), zz + 8);
+    mean = a.mean[row]; rstd = a.rstd[row];
+    if (!masked) {
+      if (a.slabs) {
+        const float* sp = a.slabs + (int64_t)row * D + c0;
+        for (int q = 0; q < a.nsplit; ++q) {
 #pragma unroll
-  for (int e = 0; e < 16; ++e) sbias[e] = sgam[e] = sbeta[e] = 0.f;
-  const int rows_per_sweep = gridDim.x * LNB_WAVES * 4;
-  for (int row = (blockIdx.x * LNB_WAVES + wave) * 4 + grp; row < a.rows + 3; row += rows_per_sweep) {
-    const bool live = row < a.rows;                          // (a.rows + 3: lanes of a partly filled wave still reach the shuffles)
-    bool masked = !live;
-    if (live && a.lens) { const int b = row / a.seg_len, t = row - b * a.seg_len; masked = t >= a.lens[b]; }
-    float zz[16], d[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { zz[e] = 0.f; d[e] = 0.f; }
-    float mean = 0.f, rstd = 0.f;
-    if (live) {
-      const bf16_t* zp = a.z + (int64_t)row * D + c0;
-      unpack8(*(const uint4*)zp, zz); unpack8(*(const uint4*)(zp + 8), zz + 8);
-      mean = a.mean[row]; rstd = a.rstd[row];
-      if (!masked) {
-        if (a.slabs) {
-          const float* sp = a.slabs + (int64_t)row * D + c0;
-          for (int q = 0; q < a.nsplit; ++q) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const f32x4 t = *(const f32x4*)(sp + q * a.slab_stride + 4 * i);
-              d[4 * i] += t[0]; d[4 * i + 1] += t[1]; d[4 * i + 2] += t[2]; d[4 * i + 3] += t[3];
-            }
+          for (int i = 0; i < 4; ++i) {
+            const f32x4 t = *(const f32x4*)(sp + q * a.slab_stride + 4 * i);
+            d[4 * i] += t[0]; d[4 * i + 1] += t[1]; d[4 * i + 2] += t[2]; d[4 * i + 3] += t[3];
           }
-          if (a.R) {
-            float r[16];
-            const bf16_t* rp = a.R + (int64_t)row * D + c0;
-            unpack8(*(const uint4*)rp, r); unpack8(*(const uint4*)(rp + 8), r + 8);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) d[e] += r[e];
-          }
-        } else {
-          const bf16_t* dp = a.dout + (int64_t)row * D + c0;
-          unpack8(*(const uint4*)dp, d); unpack8(*(const uint4*)(dp + 8), d + 8);
         }
+        if (a.R) {
+          float r[16];
+          const bf16_t* rp = a.R + (int64_t)row * D + c0;
+          unpack8(*(const uint4*)rp, r); unpack8(*(const uint4*)(rp + 8), r + 8);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) d[e] += r[e];
+        }
+      } else {
+        const bf16_t* dp = a.dout + (int64_t)row * D + c0;
+        unpack8(*(const uint4*)dp, d); unpack8(*(const uint4*)(dp + 8), d + 8);
       }
-    }
-    float xh[16], g[16];
-    float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      xh[e] = (zz[e] - mean) * rstd;
-      g[e] = d[e] * gam[e];
-      c1 += g[e]; c2 += g[e] * xh[e];
-      sgam[e] += d[e] * xh[e];
-      sbeta[e] += d[e];
-    }
-    c1 = group16_sum(c1) * (1.f / D);
-    c2 = group16_sum(c2) * (1.f / D);
-    float dzv[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) dzv[e] = rstd * (g[e] - c1 - xh[e] * c2);
-    if (live && a.dz) {
-      bf16_t* op = a.dz + (int64_t)row * D + c0;
-      *(uint4*)op = pack8f(dzv); *(uint4*)(op + 8) = pack8f(dzv + 8);
-    }
-    if (a.p_pre > 0.f) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) drop4(dzv + 4 * i, seed, step, a.site_pre, (unsigned)(((int64_t)row * D + c0 + 4 * i) >> 2), thr, dscale);
-      if (live && a.dy) {
-        bf16_t* op = a.dy + (int64_t)row * D + c0;
-        *(uint4*)op = pack8f(dzv); *(uint4*)(op + 8) = pack8f(dzv + 8);
-      }
-    }
-    if (live) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) sbias[e] += dzv[e];
     }
   }
-  // the four row groups of a wave, then the waves: fixed order (deterministic)
+  // explicit roundings (no contraction left to the compiler): this function is inlined into two kernels, which must agree bit for bit
+  float xh[16], g[16];
+  float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    xh[e] = __fmul_rn(__fsub_rn(zz[e], mean), rstd);
+    g[e] = __fmul_rn(d[e], gam[e]);
+    c1 = __fadd_rn(c1, g[e]); c2 = __fmaf_rn(g[e], xh[e], c2);
+    sgam[e] = __fmaf_rn(d[e], xh[e], sgam[e]);
+    sbeta[e] = __fadd_rn(sbeta[e], d[e]);
+  }
+  c1 = __fmul_rn(group16_sum(c1), 1.f / D);
+  c2 = __fmul_rn(group16_sum(c2), 1.f / D);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) dzv[e] = __fmul_rn(rstd, __fmaf_rn(-xh[e], c2, __fsub_rn(g[e], c1)));
+  if (live && a.dz) {
+    bf16_t* op = a.dz + (int64_t)row * D + c0;
+    *(uint4*)op = pack8f(dzv); *(uint4*)(op + 8) = pack8f(dzv + 8);
+  }
+  if (a.p_pre > 0.f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) drop4(dzv + 4 * i, seed, step, a.site_pre, (unsigned)(((int64_t)row * D + c0 + 4 * i) >> 2), thr, dscale);
+    if (live && a.dy) {
+      bf16_t* op = a.dy + (int64_t)row * D + c0;
+      *(uint4*)op = pack8f(dzv); *(uint4*)(op + 8) = pack8f(dzv + 8);
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sbias[e] += dzv[e];
+  }
+}
+
+// the four row groups of a wave, then the waves, in a fixed order (deterministic) -> partials[blockIdx.x][dbias | dgamma | dbeta]
+__device__ __forceinline__ void lnb256_partials(const LnBwdArgs& a, float sbias[16], float sgam[16], float sbeta[16], float (*red)[3 * 256],
+                                                int wave, int grp, int c0) {
+  constexpr int D = 256;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     sbias[e] += __shfl_xor(sbias[e], 16, 64); sbias[e] += __shfl_xor(sbias[e], 32, 64);
@@ -422,6 +416,159 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd256_kernel(const LnBwdAr
 #pragma unroll
     for (int w = 0; w < LNB_WAVES; ++w) t += red[w][c];
     P[c] = t;
+  }
+}
+
+__global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd256_kernel(const LnBwdArgs a) {
+  constexpr int D = 256;
+  __shared__ float red[LNB_WAVES][3 * D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane >> 4, l = lane & 15, c0 = l * 16;
+  const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
+  const unsigned thr = keep_threshold(a.p_pre);
+  const float dscale = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
+  float gam[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const f32x4 t = *(const f32x4*)(a.gamma + c0 + 4 * i); gam[4 * i] = t[0]; gam[4 * i + 1] = t[1]; gam[4 * i + 2] = t[2]; gam[4 * i + 3] = t[3]; }
+  float sbias[16], sgam[16], sbeta[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sbias[e] = sgam[e] = sbeta[e] = 0.f;
+  const int rows_per_sweep = gridDim.x * LNB_WAVES * 4;
+  // (a.rows + 3: lanes of a partly filled wave still reach the shuffles)
+  for (int row = (blockIdx.x * LNB_WAVES + wave) * 4 + grp; row < a.rows + 3; row += rows_per_sweep) {
+    float dzv[16];
+    lnb256_row(a, row, c0, gam, seed, step, thr, dscale, sbias, sgam, sbeta, dzv);
+  }
+  lnb256_partials(a, sbias, sgam, sbeta, red, wave, grp, c0);
+}
+
+// ---- ln_bwd256 + the k = 1 projection that consumes its dy (the sub-layer's input gradient), one kernel.
+// The FFT block's backward ran  LN backward -> [dy to memory] -> window conv (w_2's dX with the ReLU gate; fc's dX with the attention
+// delta)  as two dependent launches; a dependent launch costs ~4.5 us on this part before any work, x 20 per step.  Here a workgroup
+// takes 32 rows (the 8 waves x 4 rows of one ln_bwd256 sweep), leaves their dy in LDS as the B operand, and multiplies by the packed
+// transposed weight (ttsk_win_conv's pack: each wave owns 32 output channels of a 256-channel group and streams its fragments from
+// L2, the next group's while this one computes), NG groups one after the other.  Same arithmetic in the same order as the two
+// kernels: bit-identical outputs.
+struct LnbProjArgs {
+  LnBwdArgs ln;
+  const bf16_t* w;       // [8 k-steps][Cout/16][64][8]
+  bf16_t* out;           // [rows][Cout]
+  const bf16_t* gate;    // [rows][Cout] or null: out = gate > 0 ? out : 0
+  const float* o32;      // [rows][256] or null (Cout = 256): delta[(b*2 + h)*S + t] = sum over head h's 128 columns of out * o32
+  float* delta;
+  int Cout;
+};
+
+template <int NG>
+__global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const LnbProjArgs p) {
+  constexpr int D = 256, TT = 32, RS = D * 2 + 32, KH = 4, CT = 2, NF = TT / 16, NS = D / 128, NT = LNB_WAVES * 64;
+  __shared__ float red[LNB_WAVES][3 * D];
+  __shared__ __attribute__((aligned(16))) unsigned char xs[TT * RS];       // dy rows (bf16): the GEMM's B operand
+  __shared__ __attribute__((aligned(16))) unsigned char os[TT * RS];       // one channel group's output rows (bf16)
+  const LnBwdArgs& a = p.ln;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 4, l = lane & 15, c0 = l * 16;
+  const int l15 = l, q = grp;
+  const int m0 = blockIdx.x * TT;
+  // this wave's weight fragments of group 0, requested before the rows
+  const int64_t kstep_stride = (int64_t)(p.Cout / 16) * 512;
+  const bf16_t* wrow[CT];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc) wrow[cc] = p.w + ((int64_t)(wave * CT + cc) * 64 + lane) * 8;
+  bf16x8 wa[KH][CT], wb[KH][CT];
+  auto load_w = [&](int cg, int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(wrow[cc] + (int64_t)cg * 16 * 512 + (int64_t)(g * KH + ks) * kstep_stride);
+  };
+  load_w(0, 0, wa);
+  load_w(0, 1, wb);
+  {
+    const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
+    const unsigned thr = keep_threshold(a.p_pre);
+    const float dscale = a.p_pre > 0.f ? 1.f / (1.f - a.p_pre) : 1.f;
+    float gam[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const f32x4 t = *(const f32x4*)(a.gamma + c0 + 4 * i); gam[4 * i] = t[0]; gam[4 * i + 1] = t[1]; gam[4 * i + 2] = t[2]; gam[4 * i + 3] = t[3]; }
+    float sbias[16], sgam[16], sbeta[16], dzv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sbias[e] = sgam[e] = sbeta[e] = 0.f;
+    const int rl = wave * 4 + grp;
+    lnb256_row(a, m0 + rl, c0, gam, seed, step, thr, dscale, sbias, sgam, sbeta, dzv);
+    *(uint4*)(xs + rl * RS + c0 * 2) = pack8f(dzv);
+    *(uint4*)(xs + rl * RS + c0 * 2 + 16) = pack8f(dzv + 8);
+    lnb256_partials(a, sbias, sgam, sbeta, red, wave, grp, c0);        // (its barrier also publishes xs)
+  }
+  const unsigned char* inl = xs + l15 * RS + q * 16;
+#pragma unroll 1
+  for (int cg = 0; cg < NG; ++cg) {
+    f32x4 acc[CT][NF];
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+      for (int i = 0; i < NF; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto step = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
+      const unsigned char* inp = inl + g * (KH * 64);
+#pragma unroll
+      for (int ks = 0; ks < KH; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
+#pragma unroll
+          for (int cc = 0; cc < CT; ++cc) acc[cc][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][cc], Bf, acc[cc][i], 0, 0, 0);
+        }
+      }
+    };
+    static_assert(NS == 2, "two 128-channel steps");
+    step(0, wa);
+    if (cg + 1 < NG) load_w(cg + 1, 0, wa);
+    step(1, wb);
+    if (cg + 1 < NG) load_w(cg + 1, 1, wb);
+    // this group's 32 x 256 outputs through LDS: 16-byte stores of whole rows
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc) {
+        const f32x4 v = acc[cc][i];
+        *(uint2*)(os + (i * 16 + l15) * RS + ((wave * CT + cc) * 16 + q * 4) * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+      }
+    __syncthreads();
+    constexpr int OCH = D / 8;                 // 16-byte chunks per row of the group
+#pragma unroll
+    for (int it = 0; it < TT * OCH / NT; ++it) {
+      const int idx = it * NT + tid;
+      const int rr = idx / OCH, ch = idx - rr * OCH;
+      const int row = m0 + rr;
+      float dacc = 0.f;
+      if (row < a.rows) {
+        uint4 v = *(const uint4*)(os + rr * RS + ch * 16);
+        if (p.gate) {
+          const uint4 gt = *(const uint4*)(p.gate + (int64_t)row * p.Cout + cg * D + ch * 8);
+          auto keep = [](unsigned w) {      // 0xFFFF per bf16 half that is > 0 (sign clear, not zero)
+            const unsigned lo = w & 0xFFFFu, hi = w >> 16;
+            return ((lo - 1u) < 0x7FFFu ? 0xFFFFu : 0u) | ((hi - 1u) < 0x7FFFu ? 0xFFFF0000u : 0u);
+          };
+          v.x &= keep(gt.x); v.y &= keep(gt.y); v.z &= keep(gt.z); v.w &= keep(gt.w);
+        }
+        *(uint4*)(p.out + (int64_t)row * p.Cout + cg * D + ch * 8) = v;
+        if (NG == 1 && p.delta) {
+          const float* op = p.o32 + (int64_t)row * D + ch * 8;
+          const f32x4 y0 = *(const f32x4*)op, y1 = *(const f32x4*)(op + 4);
+          dacc = __uint_as_float(v.x << 16) * y0[0] + __uint_as_float(v.x & 0xFFFF0000u) * y0[1] + __uint_as_float(v.y << 16) * y0[2] +
+                 __uint_as_float(v.y & 0xFFFF0000u) * y0[3] + __uint_as_float(v.z << 16) * y1[0] + __uint_as_float(v.z & 0xFFFF0000u) * y1[1] +
+                 __uint_as_float(v.w << 16) * y1[2] + __uint_as_float(v.w & 0xFFFF0000u) * y1[3];
+        }
+      }
+      if (NG == 1 && p.delta) {          // 16 consecutive lanes hold one (row, head): 16 chunks of 8 columns
+        dacc = quad16_sum(dacc);
+        if (row < a.rows && (ch & 15) == 0) {
+          const int b = row / a.seg_len, t = row - b * a.seg_len;
+          p.delta[((int64_t)b * 2 + (ch >> 4)) * a.seg_len + t] = dacc;
+        }
+      }
+    }
+    if (cg + 1 < NG) __syncthreads();          // the next group overwrites the staging rows
   }
 }
 
@@ -646,6 +793,35 @@ extern "C" int ttsk_layernorm_bwd_slabs(const float* slabs, int nsplit, int64_t 
     hipLaunchKernelGGL(ln_bwd256_kernel, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_layernorm_bwd_proj_nblocks(int rows) { return (rows + 31) / 32; }
+
+extern "C" int ttsk_layernorm_bwd_proj(const void* dout, const float* slabs, int nsplit, int64_t slab_stride, const void* R, const void* z,
+                                       const float* mean, const float* rstd, const float* gamma, const int64_t* lens, int seg_len,
+                                       int rows, int D, float p_pre, uint32_t site_pre, const uint64_t* rng, void* dz, void* dy,
+                                       float* partials, const void* w_packed, int Cout, const void* gate, const float* delta_o32,
+                                       float* delta_out, void* out, void* stream) {
+  TTSK_REQUIRE(z && mean && rstd && gamma && partials && w_packed && out, "layernorm_bwd_proj: null pointer");
+  TTSK_REQUIRE((dout != nullptr) != (slabs != nullptr), "layernorm_bwd_proj: exactly one of dout / slabs");
+  TTSK_REQUIRE(rows > 0 && D == 256 && (Cout == 256 || Cout == 1024), "layernorm_bwd_proj: D = 256, Cout = 256 or 1024 (got %d, %d)", D, Cout);
+  TTSK_REQUIRE(!slabs || (nsplit > 0 && (slab_stride & 3) == 0 && slab_stride >= (int64_t)rows * D && (((uintptr_t)slabs) & 15) == 0),
+               "layernorm_bwd_proj: slabs must be 16-byte aligned [nsplit][rows][D]");
+  TTSK_REQUIRE(p_pre == 0.f || (rng && dy), "layernorm_bwd_proj: dropout needs the rng state and dy");
+  TTSK_REQUIRE(!lens || seg_len > 0, "layernorm_bwd_proj: lens needs seg_len");
+  TTSK_REQUIRE(!delta_out || (delta_o32 && Cout == 256 && !gate && seg_len > 0 && rows % seg_len == 0 && (((uintptr_t)delta_o32) & 15) == 0),
+               "layernorm_bwd_proj: delta needs o32 (16-byte aligned), Cout = 256 = 2 heads x 128 and rows = B * seg_len");
+  TTSK_REQUIRE((((uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)gate | (uintptr_t)z | (uintptr_t)dout | (uintptr_t)R | (uintptr_t)dz | (uintptr_t)dy) & 15) == 0,
+               "layernorm_bwd_proj: operands must be 16-byte aligned");
+  const int nblk = (rows + 31) / 32;
+  LnbProjArgs p{{(const bf16_t*)dout, nullptr, nullptr, (const bf16_t*)z, mean, rstd, gamma, nullptr, (const long long*)lens, rng,
+                 (bf16_t*)dz, (bf16_t*)dy, partials, rows, D, seg_len > 0 ? seg_len : 1, 0, p_pre, 0.f, site_pre, 0, 0, nblk, 0, 0,
+                 slabs, (const bf16_t*)R, (long long)slab_stride, nsplit},
+                (const bf16_t*)w_packed, (bf16_t*)out, (const bf16_t*)gate, delta_o32, delta_out, Cout};
+  if (Cout == 256) hipLaunchKernelGGL(ln_bwd256_proj_kernel<1>, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(ln_bwd256_proj_kernel<4>, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, p);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -143,6 +143,7 @@ class FastSpeech2(nn.Module):
         self._w1_packed = None
         self.flash_attention = True     # ... and without the S x S tensors: online softmax forward, recomputing backward (d_k = 128)
         self.fused_ln = True            # fc / w_2 + dropout + residual + LayerNorm + PAD zeroing in one kernel when d = 256
+        self.fused_ln_bwd = os.environ.get("TTSK_FUSED_LN_BWD", "1") != "0"   # LayerNorm backward + the k = 1 dX projection behind it in one kernel
         self.group_predictors = True    # training with targets: the three VariancePredictors run as grouped launches
         self.raw_slabs = True           # dX GEMMs that feed a LayerNorm backward leave their split-K tiles for it to sum
         self.group_param_grads = True      # weight-gradient GEMMs of a backward pass share grouped launches (ops.DeferQueue)
@@ -826,18 +827,25 @@ class FastSpeech2(nn.Module):
         a, f = pre + "slf_attn.", pre + "pos_ffn."
         dev = z2.device
         # ---- FFN tail: LN backward (PAD rows carry no gradient), dropout mask regenerated
-        if isinstance(dx2, tuple):
-            dz2, dy2, part, nblk = ops.layernorm_bwd(None, z2, mean2, rstd2, self._m(f + "layer_norm.weight"), self._m(f + "layer_norm.bias"),
-                                                     lens, S, p_pre=p, site_pre=site + 1, rng=rng, slabs=dx2[0], R=dx2[1])
+        pk2 = self._w1_packed.get(("w2T", f + "w_2.weight")) if (self.window_ffn and self._w1_packed) else None
+        sl2, r2, dd2 = (dx2[0], dx2[1], None) if isinstance(dx2, tuple) else (None, None, dx2)
+        fuse = self.fused_ln_bwd and d == 256 and self.k2 == 1
+        dh = None
+        if fuse and pk2 is not None and h.shape[-1] == 1024:
+            # LN backward + w_2's dX (ReLU gate on the way out) in one launch
+            dz2, dy2, part, nblk, dh = ops.layernorm_bwd_proj(dd2, z2, mean2, rstd2, self._m(f + "layer_norm.weight"), pk2, h.shape[-1], lens, S,
+                                                              p_pre=p, site_pre=site + 1, rng=rng, slabs=sl2, R=r2, gate=h)
+            dh = dh.view(Bn, S, -1)
         else:
-            dz2, dy2, part, nblk = ops.layernorm_bwd(dx2, z2, mean2, rstd2, self._m(f + "layer_norm.weight"), self._m(f + "layer_norm.bias"),
-                                                     lens, S, p_pre=p, site_pre=site + 1, rng=rng)
+            dz2, dy2, part, nblk = ops.layernorm_bwd(dd2, z2, mean2, rstd2, self._m(f + "layer_norm.weight"), self._m(f + "layer_norm.bias"),
+                                                     lens, S, p_pre=p, site_pre=site + 1, rng=rng, slabs=sl2, R=r2)
         # ---- w_2 (k=1): dW, dX gated by the ReLU
         with self._side_work(dy2, part, h):
             self._finalize_ln(part, nblk, 3 * d, f + "w_2.bias")
             ops.conv1d_dw(dy2.view(Bn, S, d), h, self._g(f + "w_2.weight"), k=self.k2, defer=self._deferred)
-        pk2 = self._w1_packed.get(("w2T", f + "w_2.weight")) if (self.window_ffn and self._w1_packed) else None
-        if pk2 is not None and self.k2 == 1:
+        if dh is not None:
+            pass
+        elif pk2 is not None and self.k2 == 1:
             dh = ops.win_conv(dy2.view(Bn, S, d), pk2, h.shape[-1], 1, gate=h)         # dX as a forward conv on the transposed pack, ReLU gate on the way out
         else:
             dh = ops.conv1d_dx(dy2.view(Bn, S, d), self._w(f + "w_2.weight"), G=h)
@@ -846,14 +854,24 @@ class FastSpeech2(nn.Module):
             ops.colsum_into(dh.view(rows, -1), self._g(f + "w_1.bias"), defer=self._deferred_fin)
             ops.conv1d_dw(dh, x1.view(Bn, S, d), self._g(f + "w_1.weight"), k=self.k1, defer=self._deferred)
         # ---- attention tail
+        do = delta = None
         if self.raw_slabs:
             pk1 = self._w1_packed.get(("w1T", f + "w_1.weight")) if (self.window_ffn and self._w1_packed) else None
             if pk1 is not None:
                 sl = ops.win_conv_split(dh, pk1, d, self.k1)       # four 256-channel slices of the 1024-channel contraction, one launch
             else:
                 sl = ops.conv1d_dx(dh, self._w(f + "w_1.weight"), raw=True)
-            dz1, dy1, part, nblk = ops.layernorm_bwd(None, z1, mean1, rstd1, self._m(a + "layer_norm.weight"), self._m(a + "layer_norm.bias"),
-                                                     lens, S, p_pre=p, site_pre=site, rng=rng, slabs=sl, R=dz2)
+            pkf = self._w1_packed.get(("fcT", a + "fc.weight")) if (self.window_ffn and self._w1_packed) else None
+            if fuse and pkf is not None and lens is not None:
+                # LN backward + fc's dX (+ the attention backward's delta) in one launch
+                if flash and o32 is not None:
+                    delta = torch.empty(Bn * H, S, dtype=torch.float32, device=dev)
+                dz1, dy1, part, nblk, do = ops.layernorm_bwd_proj(None, z1, mean1, rstd1, self._m(a + "layer_norm.weight"), pkf, d, lens, S,
+                                                                  p_pre=p, site_pre=site, rng=rng, slabs=sl, R=dz2,
+                                                                  delta_o32=o32 if delta is not None else None, delta_out=delta)
+            else:
+                dz1, dy1, part, nblk = ops.layernorm_bwd(None, z1, mean1, rstd1, self._m(a + "layer_norm.weight"), self._m(a + "layer_norm.bias"),
+                                                         lens, S, p_pre=p, site_pre=site, rng=rng, slabs=sl, R=dz2)
         else:
             dx1 = ops.conv1d_dx(dh, self._w(f + "w_1.weight"), R=dz2.view(Bn, S, d))
             dz1, dy1, part, nblk = ops.layernorm_bwd(dx1.view(rows, d), z1, mean1, rstd1, self._m(a + "layer_norm.weight"),
@@ -862,8 +880,9 @@ class FastSpeech2(nn.Module):
             self._finalize_ln(part, nblk, 3 * d, a + "fc.bias")
             ops.linear_dw(dy1, o, self._g(a + "fc.weight"), defer=self._deferred)
         pkf = self._w1_packed.get(("fcT", a + "fc.weight")) if (self.window_ffn and self._w1_packed) else None
-        delta = None
-        if pkf is not None:
+        if do is not None:
+            pass
+        elif pkf is not None:
             if flash and o32 is not None:
                 # the attention backward's delta = rowsum(dO o O) per head, written by this conv's epilogue while it stores dO
                 delta = torch.empty(Bn * H, S, dtype=torch.float32, device=dev)

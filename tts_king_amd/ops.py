@@ -555,6 +555,28 @@ def layernorm_bwd(dout, z, mean, rstd, gamma, beta, lens=None, seg_len=0, relu_i
     return dz, (dy if dy is not None else dz), partials, nblk
 
 
+def layernorm_bwd_proj(dout, z, mean, rstd, gamma, packed, Cout, lens=None, seg_len=0, p_pre=0.0, site_pre=0, rng=None, slabs=None, R=None,
+                       gate=None, delta_o32=None, delta_out=None):
+    """layernorm_bwd (D = 256) and the k = 1 window conv on its dy in ONE launch (ttsk_layernorm_bwd_proj): `packed` is the
+    win_conv pack of the transposed weight, Cout 256 or 1024; gate / delta as for win_conv.
+    Returns (dz, dy, partials, nblk, out)."""
+    _dev(dout, z, R, gate, delta_o32, delta_out, packed)
+    rows, D = z.shape
+    dev = z.device
+    lib = L.load()
+    nblk = lib.ttsk_layernorm_bwd_proj_nblocks(rows)
+    partials = _f32(nblk, 3 * D, device=dev)
+    dz = torch.empty(rows, D, dtype=bf16, device=dev)
+    dy = torch.empty(rows, D, dtype=bf16, device=dev) if p_pre > 0.0 else None
+    out = torch.empty(rows, Cout, dtype=bf16, device=dev)
+    check(lib.ttsk_layernorm_bwd_proj(_ptr(dout), _ptr(slabs.ws) if slabs is not None else None, slabs.splits if slabs is not None else 0,
+                                      slabs.stride if slabs is not None else 0, _ptr(R), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma),
+                                      _ptr(lens), seg_len, rows, D, p_pre, site_pre, _ptr(rng), _ptr(dz), _ptr(dy), _ptr(partials),
+                                      _ptr(packed), Cout, _ptr(gate), _ptr(delta_o32), _ptr(delta_out), _ptr(out), _stream()),
+          "ttsk_layernorm_bwd_proj")
+    return dz, (dy if dy is not None else dz), partials, nblk, out
+
+
 def layernorm_fwd_grouped(y, gamma, beta, groups, param_stride, site_stride, lens=None, seg_len=0, p_post=0.0, site_post=0, rng=None,
                           head=None, want_out=True, eps=1e-5):
     """`groups` independent LayerNorm tails in one launch (the three VariancePredictors): y (groups*group_rows, D) bf16; group g

@@ -195,6 +195,14 @@ int ttsk_win_ln_supported(int K, int D);
 int ttsk_win_ln_fwd(const void* A, int lda, const void* W_packed, const float* bias, const void* res, const float* gamma, const float* beta,
                     void* out, void* z_save, float* mean, float* rstd, const int64_t* lens, int seg_len, int M, int K, int D, float eps,
                     float p_pre, uint32_t site_pre, const void* rng, void* stream);
+/* ttsk_win_ln_fwd whose output rows also go, inside the same kernel, through the NEXT FFTBlock's q|k|v projection
+ * (reference SubLayers.py:41-43: w_qs / w_ks / w_vs on the block input): proj_out[M][768] = out · W' + proj_bias, proj_w_packed =
+ * the ttsk_win_conv pack of the (768, 1, 256) weight.  One launch instead of two dependent ones; proj_out is bit-identical to
+ * ttsk_win_conv on `out`. */
+int ttsk_win_ln_proj_fwd(const void* A, int lda, const void* W_packed, const float* bias, const void* res, const float* gamma,
+                         const float* beta, void* out, void* z_save, float* mean, float* rstd, const int64_t* lens, int seg_len, int M,
+                         int K, int D, float eps, float p_pre, uint32_t site_pre, const void* rng, const void* proj_w_packed,
+                         const float* proj_bias, int proj_Cout, void* proj_out, void* stream);
 
 /* what ttsk_gemm will run for `d` (with d->kernel / d->splits as constraints when non-zero) and the workspace it needs */
 int ttsk_gemm_plan(const ttsk_gemm_desc* d, int32_t* kernel, int32_t* splits, int64_t* workspace_bytes);

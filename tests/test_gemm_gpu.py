@@ -577,6 +577,33 @@ def test_win_conv_k1_projections_gate_and_item_packs():
     assert bool((dh[h <= 0] == 0).all())
 
 
+@pytest.mark.parametrize("B,S,K", [(3, 130, 1024), (16, 423, 1024), (2, 33, 256), (16, 64, 1024)])
+def test_win_ln_with_qkv_projection_equals_two_launches(B, S, K):
+    """ttsk_win_ln_proj_fwd (w_2 / fc + dropout + residual + LayerNorm, then the NEXT block's q|k|v projection of the output rows in
+    the same kernel) against ttsk_win_ln_fwd + ttsk_win_conv, bit for bit; ragged lengths (zeroed PAD rows project to the bias)."""
+    from tts_king_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + S + K)
+    d, rows = 256, B * S
+    x = bf(torch.randn(rows, K, generator=g)).to(DEV)
+    W = bf(torch.randn(d, 1, K, generator=g) * K ** -0.5).to(DEV)
+    Wq = bf(torch.randn(3 * d, 1, d, generator=g) * d ** -0.5).to(DEV)
+    bias, bq = (0.1 * torch.randn(d, generator=g)).to(DEV), (0.1 * torch.randn(3 * d, generator=g)).to(DEV)
+    res = bf(torch.randn(rows, d, generator=g)).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV), (0.1 * torch.randn(d, generator=g)).to(DEV)
+    lens = torch.randint(max(1, S // 2), S + 1, (B,), generator=g).to(DEV)
+    pw, pq = (torch.empty(w.numel(), dtype=torch.bfloat16, device=DEV) for w in (W, Wq))
+    ops.win_conv_pack_items([(W, pw, False), (Wq, pq, False)])
+    rng = ops.rng_of(ops.optim_state(DEV, seed=4))
+    o0, z0, m0, r0 = ops.win_ln_fwd(x, pw, bias, res, gamma, beta, lens, S, p_pre=0.1, site_pre=5, rng=rng)
+    q0 = ops.win_conv(o0.view(B, S, d), pq, 3 * d, 1, bias=bq).view(rows, 3 * d)
+    o1, z1, m1, r1, q1 = ops.win_ln_fwd(x, pw, bias, res, gamma, beta, lens, S, p_pre=0.1, site_pre=5, rng=rng, proj=(pq, bq))
+    assert torch.equal(o1, o0) and torch.equal(z1, z0) and torch.equal(m1, m0) and torch.equal(r1, r0)
+    assert torch.equal(q1, q0)
+    pad = (torch.arange(S, device=DEV)[None, :] >= lens[:, None]).reshape(-1)
+    if bool(pad.any()):
+        assert torch.equal(q1[pad], bq.to(torch.bfloat16)[None, :].expand(int(pad.sum()), -1))
+
+
 @pytest.mark.parametrize("B,S,p", [(3, 130, 0.1), (16, 423, 0.1), (2, 33, 0.0), (16, 64, 0.2)])
 def test_layernorm_bwd_with_projection_equals_two_launches(B, S, p):
     """ttsk_layernorm_bwd_proj (LayerNorm backward + the k = 1 input-gradient conv on its dy in one kernel) against the two launches it

@@ -14,6 +14,7 @@
 // lane, exactly ln_fwd_kernel's row code: same Philox indexing, so ln_bwd_kernel regenerates the same dropout mask).
 #include <cstdlib>
 #include "gemm_common.h"
+#include "proj32.h"
 
 namespace {
 
@@ -41,6 +42,12 @@ struct GemmLnArgs {
   int M, K, lda, ldw, seg_len;
   float p_pre, eps;
   unsigned site_pre;
+  // win_ln_kernel<CIN, true>: the block's output rows go straight into the NEXT block's q|k|v projection (proj32.h) as well:
+  // pout[M][pCout] = out · pw' + pbias, pw = ttsk_win_conv's pack of that (pCout = 768, 1, 256) weight
+  const bf16_t* pw;
+  const float* pbias;
+  bf16_t* pout;
+  int pCout;
 };
 
 __device__ __forceinline__ void drop4(float v[4], uint64_t seed, uint64_t step, unsigned site, unsigned e4, unsigned thr, float scale) {
@@ -54,8 +61,10 @@ __device__ __forceinline__ void drop4(float v[4], uint64_t seed, uint64_t step, 
 
 // The LayerNorm rows of a 32 x 256 fp32 tile `cs` (leading dimension CS_LD): one wave per row, RW rows per wave, lane owns columns
 // 4*lane .. 4*lane+3 (ln_fwd_kernel's row code: same Philox indexing, so ln_bwd_kernel regenerates the same dropout mask).
+// xs2 (may be null): LDS tile [32][P32_RS] that receives the output rows as well (zero rows past M), proj32.h's B operand.
 template <int RW>
-__device__ __forceinline__ void ln_rows_epilogue(const GemmLnArgs& a, const float* cs, int m0, int wave, int lane, const uint2 (&resv)[RW]) {
+__device__ __forceinline__ void ln_rows_epilogue(const GemmLnArgs& a, const float* cs, int m0, int wave, int lane, const uint2 (&resv)[RW],
+                                                 unsigned char* xs2 = nullptr) {
   const int M = a.M, c = lane * 4;
   const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
   const f32x4 bi = *(const f32x4*)(a.bias + c);
@@ -93,7 +102,10 @@ __device__ __forceinline__ void ln_rows_epilogue(const GemmLnArgs& a, const floa
 #pragma unroll
   for (int rr = 0; rr < RW; ++rr) {
     const int row = m0 + wave * RW + rr;
-    if (row >= M) continue;
+    if (row >= M) {
+      if (xs2) *(uint2*)(xs2 + (wave * RW + rr) * P32_RS + c * 2) = make_uint2(0u, 0u);
+      continue;
+    }
     const float mean = s[rr], rstd = rsqrtf(q[rr] * (1.f / BN) + a.eps);
     if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
     bool masked = false;
@@ -101,7 +113,9 @@ __device__ __forceinline__ void ln_rows_epilogue(const GemmLnArgs& a, const floa
     float o4[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) o4[e] = masked ? 0.f : (z[rr][e] - mean) * rstd * g[e] + bt[e];
-    *(uint2*)(a.out + (int64_t)row * BN + c) = make_uint2(pack_bf2(o4[0], o4[1]), pack_bf2(o4[2], o4[3]));
+    const uint2 ov = make_uint2(pack_bf2(o4[0], o4[1]), pack_bf2(o4[2], o4[3]));
+    *(uint2*)(a.out + (int64_t)row * BN + c) = ov;
+    if (xs2) *(uint2*)(xs2 + (wave * RW + rr) * P32_RS + c * 2) = ov;
   }
 }
 
@@ -226,11 +240,13 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ln_kernel(const GemmLnArgs a)
 // major pack (ttsk_win_conv_pack_*: [k-step][cout tile][lane][8]), one step = 128 input channels = 8 fragments, three register sets, no
 // barrier in the loop; then the fp32 tile and ln_rows_epilogue as above.  W still crosses L2 -> CU once per workgroup (128 / 512 KiB), but
 // as 1 KiB contiguous fragments into registers instead of through the LDS ring with a barrier per 64 channels.
-template <int CIN>
-__global__ __launch_bounds__(512, CIN == 256 ? 2 : 1) void win_ln_kernel(const GemmLnArgs a) {
+template <int CIN, bool PROJ>
+__global__ __launch_bounds__(512, (CIN == 256 && !PROJ) ? 2 : 1) void win_ln_kernel(const GemmLnArgs a) {
   constexpr int TT = BM, RS = CIN * 2 + 32, NT = 512, CH8 = CIN / 8, KH = 4, CT = 2, NF = TT / 16, NS = CIN / 128, RW = BM / 8;
   constexpr int XBYTES = TT * RS, CBYTES = BM * CS_LD * 4;
+  static_assert(BM == P32_TT && BN == P32_D && NT == P32_NT, "proj32.h tile");
   __shared__ __attribute__((aligned(16))) unsigned char smem[XBYTES > CBYTES ? XBYTES : CBYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char ptile[PROJ ? 2 * P32_TT * P32_RS : 16];      // output rows (B operand) | staging rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.x * BM;
@@ -306,6 +322,8 @@ __global__ __launch_bounds__(512, CIN == 256 ? 2 : 1) void win_ln_kernel(const G
       }
     }
   }
+  Proj32W PW;
+  if (PROJ) proj32_prefetch(a.pw, a.pCout, wave, lane, PW);      // the next projection's first fragments arrive behind the LayerNorm rows
   __syncthreads();                         // every wave is done with the rows of A: they become the fp32 tile
   float* cs = (float*)smem;
 #pragma unroll
@@ -313,7 +331,13 @@ __global__ __launch_bounds__(512, CIN == 256 ? 2 : 1) void win_ln_kernel(const G
 #pragma unroll
     for (int cc = 0; cc < CT; ++cc) *(f32x4*)(cs + (i * 16 + l15) * CS_LD + (wave * CT + cc) * 16 + q * 4) = acc[cc][i];
   __syncthreads();
-  ln_rows_epilogue<RW>(a, cs, m0, wave, lane, resv);
+  ln_rows_epilogue<RW>(a, cs, m0, wave, lane, resv, PROJ ? ptile : nullptr);
+  if (PROJ) {
+    __syncthreads();
+    proj32_run<3>(ptile, ptile + P32_TT * P32_RS, a.pw, a.pCout, a.pbias, PW, tid, [&](int cg, int rr, int ch, uint4 v) __attribute__((always_inline)) {
+      if (m0 + rr < M) *(uint4*)(a.pout + (int64_t)(m0 + rr) * a.pCout + cg * BN + ch * 8) = v;
+    });
+  }
 }
 
 }  // namespace
@@ -348,9 +372,10 @@ extern "C" int ttsk_gemm_ln_fwd(const void* A, int lda, const void* W, int ldw, 
 
 extern "C" int ttsk_win_ln_supported(int K, int D) { return D == BN && (K == 256 || K == 1024); }
 
-extern "C" int ttsk_win_ln_fwd(const void* A, int lda, const void* W_packed, const float* bias, const void* res, const float* gamma,
-                               const float* beta, void* out, void* z_save, float* mean, float* rstd, const int64_t* lens, int seg_len, int M,
-                               int K, int D, float eps, float p_pre, uint32_t site_pre, const void* rng, void* stream) {
+static int win_ln_launch(const void* A, int lda, const void* W_packed, const float* bias, const void* res, const float* gamma,
+                         const float* beta, void* out, void* z_save, float* mean, float* rstd, const int64_t* lens, int seg_len, int M,
+                         int K, int D, float eps, float p_pre, uint32_t site_pre, const void* rng, const void* proj_w, const float* proj_bias,
+                         int proj_Cout, void* proj_out, void* stream) {
   TTSK_REQUIRE(A && W_packed && bias && gamma && beta && out && mean && rstd, "ttsk_win_ln_fwd: null pointer");
   TTSK_REQUIRE(ttsk_win_ln_supported(K, D), "ttsk_win_ln_fwd: built for D = 256, K = 256 or 1024 (got K=%d D=%d)", K, D);
   TTSK_REQUIRE(M > 0 && (lda & 7) == 0 && lda >= K, "ttsk_win_ln_fwd: bad M / lda");
@@ -358,11 +383,35 @@ extern "C" int ttsk_win_ln_fwd(const void* A, int lda, const void* W_packed, con
   TTSK_REQUIRE(!(p_pre > 0.f) || rng, "ttsk_win_ln_fwd: dropout needs the rng state");
   TTSK_REQUIRE(p_pre >= 0.f && p_pre < 1.f, "ttsk_win_ln_fwd: p_pre must be in [0, 1)");
   TTSK_REQUIRE(!lens || (seg_len > 0 && M % seg_len == 0), "ttsk_win_ln_fwd: lens needs M %% seg_len == 0");
+  TTSK_REQUIRE(!proj_w || (proj_out && proj_Cout == 768 && (((uintptr_t)proj_w | (uintptr_t)proj_out | (uintptr_t)proj_bias) & 15) == 0),
+               "ttsk_win_ln_proj_fwd: the projection is built for 768 output channels (q|k|v), 16-byte aligned operands");
   GemmLnArgs a{(const bf16_t*)A, (const bf16_t*)W_packed, bias, (const bf16_t*)res, gamma, beta, (bf16_t*)out, (bf16_t*)z_save, mean, rstd,
-               (const long long*)lens, (const uint64_t*)rng, M, K, lda, 0, seg_len > 0 ? seg_len : 1, p_pre, eps, site_pre};
+               (const long long*)lens, (const uint64_t*)rng, M, K, lda, 0, seg_len > 0 ? seg_len : 1, p_pre, eps, site_pre,
+               (const bf16_t*)proj_w, proj_bias, (bf16_t*)proj_out, proj_Cout};
   const dim3 grid((M + BM - 1) / BM);
-  if (K == 256) hipLaunchKernelGGL(win_ln_kernel<256>, grid, dim3(512), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(win_ln_kernel<1024>, grid, dim3(512), 0, (hipStream_t)stream, a);
+  if (proj_w) {
+    if (K == 256) hipLaunchKernelGGL((win_ln_kernel<256, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((win_ln_kernel<1024, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  } else {
+    if (K == 256) hipLaunchKernelGGL((win_ln_kernel<256, false>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((win_ln_kernel<1024, false>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  }
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
+}
+
+extern "C" int ttsk_win_ln_fwd(const void* A, int lda, const void* W_packed, const float* bias, const void* res, const float* gamma,
+                               const float* beta, void* out, void* z_save, float* mean, float* rstd, const int64_t* lens, int seg_len, int M,
+                               int K, int D, float eps, float p_pre, uint32_t site_pre, const void* rng, void* stream) {
+  return win_ln_launch(A, lda, W_packed, bias, res, gamma, beta, out, z_save, mean, rstd, lens, seg_len, M, K, D, eps, p_pre, site_pre, rng,
+                       nullptr, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int ttsk_win_ln_proj_fwd(const void* A, int lda, const void* W_packed, const float* bias, const void* res, const float* gamma,
+                                    const float* beta, void* out, void* z_save, float* mean, float* rstd, const int64_t* lens, int seg_len,
+                                    int M, int K, int D, float eps, float p_pre, uint32_t site_pre, const void* rng, const void* proj_w_packed,
+                                    const float* proj_bias, int proj_Cout, void* proj_out, void* stream) {
+  TTSK_REQUIRE(proj_w_packed && proj_out, "ttsk_win_ln_proj_fwd: null pointer");
+  return win_ln_launch(A, lda, W_packed, bias, res, gamma, beta, out, z_save, mean, rstd, lens, seg_len, M, K, D, eps, p_pre, site_pre, rng,
+                       proj_w_packed, proj_bias, proj_Cout, proj_out, stream);
 }

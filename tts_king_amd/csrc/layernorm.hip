@@ -3,6 +3,7 @@
 // reference: SubLayers.py:62-63 (MHA: LN(dropout(fc)+residual)), SubLayers.py:99-101 (FFN), Layers.py:29-32
 // (masked_fill of PAD rows), model/modules.py:270-309 (VariancePredictor: LN -> Dropout, final Linear + mask).
 #include "common.h"
+#include "proj32.h"
 
 namespace {
 
@@ -461,29 +462,17 @@ struct LnbProjArgs {
 
 template <int NG>
 __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const LnbProjArgs p) {
-  constexpr int D = 256, TT = 32, RS = D * 2 + 32, KH = 4, CT = 2, NF = TT / 16, NS = D / 128, NT = LNB_WAVES * 64;
+  constexpr int D = 256;
+  static_assert(LNB_WAVES * 64 == P32_NT && P32_D == D, "proj32.h is built for 8 waves and 256 channels");
   __shared__ float red[LNB_WAVES][3 * D];
-  __shared__ __attribute__((aligned(16))) unsigned char xs[TT * RS];       // dy rows (bf16): the GEMM's B operand
-  __shared__ __attribute__((aligned(16))) unsigned char os[TT * RS];       // one channel group's output rows (bf16)
+  __shared__ __attribute__((aligned(16))) unsigned char xs[P32_TT * P32_RS];       // dy rows (bf16): the GEMM's B operand
+  __shared__ __attribute__((aligned(16))) unsigned char os[P32_TT * P32_RS];       // one channel group's output rows (bf16)
   const LnBwdArgs& a = p.ln;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = lane >> 4, l = lane & 15, c0 = l * 16;
-  const int l15 = l, q = grp;
-  const int m0 = blockIdx.x * TT;
-  // this wave's weight fragments of group 0, requested before the rows
-  const int64_t kstep_stride = (int64_t)(p.Cout / 16) * 512;
-  const bf16_t* wrow[CT];
-#pragma unroll
-  for (int cc = 0; cc < CT; ++cc) wrow[cc] = p.w + ((int64_t)(wave * CT + cc) * 64 + lane) * 8;
-  bf16x8 wa[KH][CT], wb[KH][CT];
-  auto load_w = [&](int cg, int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int ks = 0; ks < KH; ++ks)
-#pragma unroll
-      for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(wrow[cc] + (int64_t)cg * 16 * 512 + (int64_t)(g * KH + ks) * kstep_stride);
-  };
-  load_w(0, 0, wa);
-  load_w(0, 1, wb);
+  const int m0 = blockIdx.x * P32_TT;
+  Proj32W W;
+  proj32_prefetch(p.w, p.Cout, wave, lane, W);          // this wave's weight fragments of group 0, requested before the rows
   {
     const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
     const unsigned thr = keep_threshold(a.p_pre);
@@ -496,80 +485,39 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const
     for (int e = 0; e < 16; ++e) sbias[e] = sgam[e] = sbeta[e] = 0.f;
     const int rl = wave * 4 + grp;
     lnb256_row(a, m0 + rl, c0, gam, seed, step, thr, dscale, sbias, sgam, sbeta, dzv);
-    *(uint4*)(xs + rl * RS + c0 * 2) = pack8f(dzv);
-    *(uint4*)(xs + rl * RS + c0 * 2 + 16) = pack8f(dzv + 8);
+    *(uint4*)(xs + rl * P32_RS + c0 * 2) = pack8f(dzv);
+    *(uint4*)(xs + rl * P32_RS + c0 * 2 + 16) = pack8f(dzv + 8);
     lnb256_partials(a, sbias, sgam, sbeta, red, wave, grp, c0);        // (its barrier also publishes xs)
   }
-  const unsigned char* inl = xs + l15 * RS + q * 16;
-#pragma unroll 1
-  for (int cg = 0; cg < NG; ++cg) {
-    f32x4 acc[CT][NF];
-#pragma unroll
-    for (int cc = 0; cc < CT; ++cc)
-#pragma unroll
-      for (int i = 0; i < NF; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto step = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
-      const unsigned char* inp = inl + g * (KH * 64);
-#pragma unroll
-      for (int ks = 0; ks < KH; ++ks) {
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-          const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
-#pragma unroll
-          for (int cc = 0; cc < CT; ++cc) acc[cc][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][cc], Bf, acc[cc][i], 0, 0, 0);
-        }
+  proj32_run<NG>(xs, os, p.w, p.Cout, nullptr, W, tid, [&](int cg, int rr, int ch, uint4 v) __attribute__((always_inline)) {
+    const int row = m0 + rr;
+    float dacc = 0.f;
+    if (row < a.rows) {
+      if (p.gate) {
+        const uint4 gt = *(const uint4*)(p.gate + (int64_t)row * p.Cout + cg * D + ch * 8);
+        auto keep = [](unsigned w) {      // 0xFFFF per bf16 half that is > 0 (sign clear, not zero)
+          const unsigned lo = w & 0xFFFFu, hi = w >> 16;
+          return ((lo - 1u) < 0x7FFFu ? 0xFFFFu : 0u) | ((hi - 1u) < 0x7FFFu ? 0xFFFF0000u : 0u);
+        };
+        v.x &= keep(gt.x); v.y &= keep(gt.y); v.z &= keep(gt.z); v.w &= keep(gt.w);
       }
-    };
-    static_assert(NS == 2, "two 128-channel steps");
-    step(0, wa);
-    if (cg + 1 < NG) load_w(cg + 1, 0, wa);
-    step(1, wb);
-    if (cg + 1 < NG) load_w(cg + 1, 1, wb);
-    // this group's 32 x 256 outputs through LDS: 16-byte stores of whole rows
-#pragma unroll
-    for (int i = 0; i < NF; ++i)
-#pragma unroll
-      for (int cc = 0; cc < CT; ++cc) {
-        const f32x4 v = acc[cc][i];
-        *(uint2*)(os + (i * 16 + l15) * RS + ((wave * CT + cc) * 16 + q * 4) * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-      }
-    __syncthreads();
-    constexpr int OCH = D / 8;                 // 16-byte chunks per row of the group
-#pragma unroll
-    for (int it = 0; it < TT * OCH / NT; ++it) {
-      const int idx = it * NT + tid;
-      const int rr = idx / OCH, ch = idx - rr * OCH;
-      const int row = m0 + rr;
-      float dacc = 0.f;
-      if (row < a.rows) {
-        uint4 v = *(const uint4*)(os + rr * RS + ch * 16);
-        if (p.gate) {
-          const uint4 gt = *(const uint4*)(p.gate + (int64_t)row * p.Cout + cg * D + ch * 8);
-          auto keep = [](unsigned w) {      // 0xFFFF per bf16 half that is > 0 (sign clear, not zero)
-            const unsigned lo = w & 0xFFFFu, hi = w >> 16;
-            return ((lo - 1u) < 0x7FFFu ? 0xFFFFu : 0u) | ((hi - 1u) < 0x7FFFu ? 0xFFFF0000u : 0u);
-          };
-          v.x &= keep(gt.x); v.y &= keep(gt.y); v.z &= keep(gt.z); v.w &= keep(gt.w);
-        }
-        *(uint4*)(p.out + (int64_t)row * p.Cout + cg * D + ch * 8) = v;
-        if (NG == 1 && p.delta) {
-          const float* op = p.o32 + (int64_t)row * D + ch * 8;
-          const f32x4 y0 = *(const f32x4*)op, y1 = *(const f32x4*)(op + 4);
-          dacc = __uint_as_float(v.x << 16) * y0[0] + __uint_as_float(v.x & 0xFFFF0000u) * y0[1] + __uint_as_float(v.y << 16) * y0[2] +
-                 __uint_as_float(v.y & 0xFFFF0000u) * y0[3] + __uint_as_float(v.z << 16) * y1[0] + __uint_as_float(v.z & 0xFFFF0000u) * y1[1] +
-                 __uint_as_float(v.w << 16) * y1[2] + __uint_as_float(v.w & 0xFFFF0000u) * y1[3];
-        }
-      }
-      if (NG == 1 && p.delta) {          // 16 consecutive lanes hold one (row, head): 16 chunks of 8 columns
-        dacc = quad16_sum(dacc);
-        if (row < a.rows && (ch & 15) == 0) {
-          const int b = row / a.seg_len, t = row - b * a.seg_len;
-          p.delta[((int64_t)b * 2 + (ch >> 4)) * a.seg_len + t] = dacc;
-        }
+      *(uint4*)(p.out + (int64_t)row * p.Cout + cg * D + ch * 8) = v;
+      if (NG == 1 && p.delta) {
+        const float* op = p.o32 + (int64_t)row * D + ch * 8;
+        const f32x4 y0 = *(const f32x4*)op, y1 = *(const f32x4*)(op + 4);
+        dacc = __uint_as_float(v.x << 16) * y0[0] + __uint_as_float(v.x & 0xFFFF0000u) * y0[1] + __uint_as_float(v.y << 16) * y0[2] +
+               __uint_as_float(v.y & 0xFFFF0000u) * y0[3] + __uint_as_float(v.z << 16) * y1[0] + __uint_as_float(v.z & 0xFFFF0000u) * y1[1] +
+               __uint_as_float(v.w << 16) * y1[2] + __uint_as_float(v.w & 0xFFFF0000u) * y1[3];
       }
     }
-    if (cg + 1 < NG) __syncthreads();          // the next group overwrites the staging rows
-  }
+    if (NG == 1 && p.delta) {          // 16 consecutive lanes hold one (row, head): 16 chunks of 8 columns
+      dacc = quad16_sum(dacc);
+      if (row < a.rows && (ch & 15) == 0) {
+        const int b = row / a.seg_len, t = row - b * a.seg_len;
+        p.delta[((int64_t)b * 2 + (ch >> 4)) * a.seg_len + t] = dacc;
+      }
+    }
+  });
 }
 
 // dst[c] (+)= scale * sum_b partials[b][c].  32 columns x 8 row-groups per workgroup; every thread adds its rows in

@@ -1,0 +1,86 @@
+// proj32.h — the GEMM tail shared by the kernels that hand a 32-row tile straight to the next k = 1 projection instead of writing it
+// out for another launch to read (layernorm.hip: LayerNorm backward -> dX projection; gemm_ln.hip: FFTBlock tail -> the next block's
+// q|k|v projection).  A dependent launch costs ~4.5 us on MI355X before any work; these tiles are already in the workgroup's LDS.
+//
+// Operands: 32 rows x 256 channels bf16 in LDS (`xs`, row stride P32_RS: the B operand, D[cout][row] orientation) and the packed
+// weight of ttsk_win_conv for K = 1, [8 k-steps][Cout/16][64 lanes][8], streamed L2 -> registers: each of the 8 waves owns 32 output
+// channels of a 256-channel group, NG groups one after the other, the next group's fragments requested while this one computes.
+// Same k-step order as win_conv_kernel<256, ...>: bit-identical results.
+#pragma once
+#include "common.h"
+
+constexpr int P32_TT = 32, P32_D = 256, P32_RS = P32_D * 2 + 32, P32_KH = 4, P32_CT = 2, P32_NT = 512;
+
+struct Proj32W {
+  bf16x8 a[P32_KH][P32_CT], b[P32_KH][P32_CT];      // the two 128-channel steps of a group
+};
+
+__device__ __forceinline__ void proj32_load(const bf16_t* __restrict__ w, int Cout, int cg, int g, int wave, int lane, bf16x8 (&dst)[P32_KH][P32_CT]) {
+  const int64_t kstep_stride = (int64_t)(Cout / 16) * 512;
+#pragma unroll
+  for (int ks = 0; ks < P32_KH; ++ks)
+#pragma unroll
+    for (int cc = 0; cc < P32_CT; ++cc)
+      dst[ks][cc] = *(const bf16x8*)(w + ((int64_t)(cg * 16 + wave * P32_CT + cc) * 64 + lane) * 8 + (int64_t)(g * P32_KH + ks) * kstep_stride);
+}
+__device__ __forceinline__ void proj32_prefetch(const bf16_t* __restrict__ w, int Cout, int wave, int lane, Proj32W& W) {
+  proj32_load(w, Cout, 0, 0, wave, lane, W.a);
+  proj32_load(w, Cout, 0, 1, wave, lane, W.b);
+}
+
+// xs must be visible to the workgroup (a barrier behind its writers) and W prefetched.  bias: fp32 [Cout] or null.  Every thread calls
+// epi(cg, rr, ch, v) for its 16-byte chunks (row rr of the tile, chunk ch of the group's 32; v = 8 bf16 outputs) — twice per group —
+// including rows that do not exist: the caller checks and stores.  `os`: 32 x P32_RS bytes of LDS for the staging tile.
+template <int NG, class Epi>
+__device__ __forceinline__ void proj32_run(const unsigned char* xs, unsigned char* os, const bf16_t* __restrict__ w, int Cout,
+                                           const float* __restrict__ bias, Proj32W& W, int tid, Epi&& epi) {
+  constexpr int NF = P32_TT / 16;
+  const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+  const unsigned char* inl = xs + l15 * P32_RS + q * 16;
+#pragma unroll 1
+  for (int cg = 0; cg < NG; ++cg) {
+    f32x4 acc[P32_CT][NF];
+#pragma unroll
+    for (int cc = 0; cc < P32_CT; ++cc)
+#pragma unroll
+      for (int i = 0; i < NF; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto step = [&](int g, const bf16x8 (&wf)[P32_KH][P32_CT]) __attribute__((always_inline)) {
+      const unsigned char* inp = inl + g * (P32_KH * 64);
+#pragma unroll
+      for (int ks = 0; ks < P32_KH; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * P32_RS + ks * 64);
+#pragma unroll
+          for (int cc = 0; cc < P32_CT; ++cc) acc[cc][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][cc], Bf, acc[cc][i], 0, 0, 0);
+        }
+      }
+    };
+    step(0, W.a);
+    if (cg + 1 < NG) proj32_load(w, Cout, cg + 1, 0, wave, lane, W.a);
+    step(1, W.b);
+    if (cg + 1 < NG) proj32_load(w, Cout, cg + 1, 1, wave, lane, W.b);
+    // this group's 32 x 256 outputs through LDS: 16-byte stores of whole rows
+#pragma unroll
+    for (int cc = 0; cc < P32_CT; ++cc) {
+      const int col = (wave * P32_CT + cc) * 16 + q * 4;
+      f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (bias) bv = *(const f32x4*)(bias + cg * P32_D + col);
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const f32x4 v = acc[cc][i] + bv;
+        *(uint2*)(os + (i * 16 + l15) * P32_RS + col * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+      }
+    }
+    __syncthreads();
+    constexpr int OCH = P32_D / 8;                 // 16-byte chunks per row of the group
+#pragma unroll
+    for (int it = 0; it < P32_TT * OCH / P32_NT; ++it) {
+      const int idx = it * P32_NT + tid;
+      const int rr = idx / OCH, ch = idx - rr * OCH;
+      const uint4 v = *(const uint4*)(os + rr * P32_RS + ch * 16);
+      epi(cg, rr, ch, v);
+    }
+    if (cg + 1 < NG) __syncthreads();          // the next group overwrites the staging rows
+  }
+}

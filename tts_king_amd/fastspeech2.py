@@ -143,6 +143,7 @@ class FastSpeech2(nn.Module):
         self._w1_packed = None
         self.flash_attention = True     # ... and without the S x S tensors: online softmax forward, recomputing backward (d_k = 128)
         self.fused_ln = True            # fc / w_2 + dropout + residual + LayerNorm + PAD zeroing in one kernel when d = 256
+        self.fused_qkv_tail = os.environ.get("TTSK_FUSED_QKV_TAIL", "1") != "0"   # a block's last kernel also projects q|k|v for the next block
         self.fused_ln_bwd = os.environ.get("TTSK_FUSED_LN_BWD", "1") != "0"   # LayerNorm backward + the k = 1 dX projection behind it in one kernel
         self.group_predictors = True    # training with targets: the three VariancePredictors run as grouped launches
         self.raw_slabs = True           # dX GEMMs that feed a LayerNorm backward leave their split-K tiles for it to sum
@@ -413,8 +414,10 @@ class FastSpeech2(nn.Module):
             mel, post, pitch, energy, logd = _Bridge.apply(self._anchor, self, mel, post, pitch, energy, logd)
         return (mel, pitch, energy, logd, d_rounded, src_masks, mel_masks, src_lens, mel_lens_out, post, None, None)
 
-    def _fft_fwd(self, pre, x, Bn, S, lens, H, p, site, rng, ctx_list, out=None):
-        """One FFTBlock.  reference: Layers.py:25-34, SubLayers.py:31-65 (MHA), :93-101 (FFN), Modules.py:14-24."""
+    def _fft_fwd(self, pre, x, Bn, S, lens, H, p, site, rng, ctx_list, out=None, qkv=None, next_pre=None):
+        """One FFTBlock.  reference: Layers.py:25-34, SubLayers.py:31-65 (MHA), :93-101 (FFN), Modules.py:14-24.
+        `next_pre`: the block that follows in the same stack — its q|k|v projection of this block's output comes out of this
+        block's last kernel (then the return value is (x2, qkv_next), and the caller hands qkv_next to that block as `qkv`)."""
         d, rows = self.d, Bn * S
         dk = d // H
         a, f = pre + "slf_attn.", pre + "pos_ffn."
@@ -422,7 +425,9 @@ class FastSpeech2(nn.Module):
         dev = x.device
         # (1) q|k|v projections as one GEMM into a [rows][3d] buffer: SubLayers.py:41-43
         pkq = self._w1_packed.get(("qkv", a + "w_qs.weight")) if (self.window_ffn and self._w1_packed) else None
-        if pkq is not None and x.dtype == bf16:
+        if qkv is not None:
+            pass                         # came out of the previous block's last kernel
+        elif pkq is not None and x.dtype == bf16:
             qkv = ops.win_conv(x.view(Bn, S, d), pkq, 3 * d, 1, bias=self._m(a + "w_qs.bias", 3 * d)).view(rows, 3 * d)   # window kernel, k = 1
         else:
             qkv = ops.linear(x, self._w(a + "w_qs.weight", 3 * d), self._m(a + "w_qs.bias", 3 * d))
@@ -446,6 +451,7 @@ class FastSpeech2(nn.Module):
             ops.gemm(probs, qkv[:, 2 * d:], o, S, dk, S, Sp, 3 * d, d, flags=ops.B_TR, nz1=Bn, nz2=H,
                      sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * d, dk))
         fuse = self.fused_ln and d == 256
+        qkv_next = None
         # (5) fc, dropout, +residual, LayerNorm, zero PAD rows: SubLayers.py:62-63, Layers.py:29 — one kernel when d = 256
         if fuse:
             pkl = self._w1_packed.get(("fc", a + "fc.weight")) if (self.window_ffn and self._w1_packed) else None
@@ -470,7 +476,13 @@ class FastSpeech2(nn.Module):
             h = ops.conv1d(x1.view(Bn, S, d), W1, self._m(f + "w_1.bias"), flags=ops.RELU)
         if fuse and self.k2 == 1:
             pkl = self._w1_packed.get(("w2", f + "w_2.weight")) if (self.window_ffn and self._w1_packed) else None
-            if pkl is not None:
+            pkn = self._w1_packed.get(("qkv", next_pre + "slf_attn.w_qs.weight")) if (next_pre and pkl is not None and self.fused_qkv_tail) else None
+            if pkn is not None:
+                x2, z2, mean2, rstd2, qkv_next = ops.win_ln_fwd(h.view(rows, -1), pkl, self._m(f + "w_2.bias"), x1, self._m(f + "layer_norm.weight"),
+                                                                self._m(f + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site + 1, rng=rng,
+                                                                save_z=ctx_list is not None, out=out,
+                                                                proj=(pkn, self._m(next_pre + "slf_attn.w_qs.bias", 3 * d)))
+            elif pkl is not None:
                 x2, z2, mean2, rstd2 = ops.win_ln_fwd(h.view(rows, -1), pkl, self._m(f + "w_2.bias"), x1, self._m(f + "layer_norm.weight"),
                                                       self._m(f + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site + 1, rng=rng,
                                                       save_z=ctx_list is not None, out=out)
@@ -485,6 +497,8 @@ class FastSpeech2(nn.Module):
                                                         rng=rng, save_z=ctx_list is not None, out=out)
         if ctx_list is not None:
             ctx_list.append((pre, x, qkv, probs, o, z1, mean1, rstd1, x1, h, z2, mean2, rstd2, Bn, S, lens, H, p, site, o32))
+        if next_pre:
+            return x2, qkv_next
         return x2
 
     def _predictor_fwd(self, pre, x, Bn, Lp, lens, p, site, rng, ctx):
@@ -594,9 +608,12 @@ class FastSpeech2(nn.Module):
         x = ops.gather_add(None, self._m("encoder.src_word_emb.weight"), texts, pe=pe_enc, pe_mod=Lp, rows=Bn * Lp)
         grouped = (train and self.group_predictors and pitches_raw is not None and e_targets is not None and Lp <= self.max_seq_len)
         stack = torch.empty(3, Bn * Lp, d, dtype=bf16, device=dev) if grouped else None
+        qkv = None
         for i in range(self.n_enc):
+            nxt = "encoder.layer_stack.%d." % (i + 1) if i + 1 < self.n_enc else None
             x = self._fft_fwd("encoder.layer_stack.%d." % i, x, Bn, Lp, src_lens, self.n_head_enc, p_enc, 2 * i, rng, blocks,
-                              out=stack[0] if (grouped and i == self.n_enc - 1) else None)
+                              out=stack[0] if (grouped and i == self.n_enc - 1) else None, qkv=qkv, next_pre=nxt)
+            x, qkv = x if nxt else (x, None)
         # ---- variance adaptor: modules.py:142-217 (duration BEFORE the speaker embedding; energy sees the pitch embedding)
         va = "variance_adaptor."
         if grouped:
@@ -644,8 +661,11 @@ class FastSpeech2(nn.Module):
         # ---- decoder: Models.py:157-189
         y = dec_in.view(Bn * T, d)
         n_enc_blocks = len(blocks) if train else 0
+        qkv = None
         for i in range(self.n_dec):
-            y = self._fft_fwd("decoder.layer_stack.%d." % i, y, Bn, T, mlens, self.n_head_dec, p_dec, 100 + 2 * i, rng, blocks)
+            nxt = "decoder.layer_stack.%d." % (i + 1) if i + 1 < self.n_dec else None
+            y = self._fft_fwd("decoder.layer_stack.%d." % i, y, Bn, T, mlens, self.n_head_dec, p_dec, 100 + 2 * i, rng, blocks, qkv=qkv, next_pre=nxt)
+            y, qkv = y if nxt else (y, None)
         # ---- mel_linear (fp32 output + bf16 copy for the PostNet): fastspeech2.py:102
         rows = Bn * T
         mel16 = torch.empty(rows, self.n_mel, dtype=bf16, device=dev)
@@ -709,8 +729,11 @@ class FastSpeech2(nn.Module):
         src_masks = ops.length_mask(src_lens, Lp)
         pe_enc = sinusoid_table(Lp, d).to(self.device) if Lp > self.max_seq_len else self.get("encoder.position_enc")[0]
         x = ops.gather_add(None, self._m("encoder.src_word_emb.weight"), texts, pe=pe_enc, pe_mod=Lp, rows=Bn * Lp)
+        qkv = None
         for i in range(self.n_enc):
-            x = self._fft_fwd("encoder.layer_stack.%d." % i, x, Bn, Lp, src_lens, self.n_head_enc, 0.0, 0, None, None)
+            nxt = "encoder.layer_stack.%d." % (i + 1) if i + 1 < self.n_enc else None
+            x = self._fft_fwd("encoder.layer_stack.%d." % i, x, Bn, Lp, src_lens, self.n_head_enc, 0.0, 0, None, None, qkv=qkv, next_pre=nxt)
+            x, qkv = x if nxt else (x, None)
         logd = self._predictor_fwd(va + "duration_predictor.", x, Bn, Lp, src_lens, 0.0, 0, None, None)
         x1 = ops.gather_add(x, self._m("speaker_emb.weight"), speakers, idx_div=Lp)
         pitch = self._predictor_fwd(va + "pitch_predictor.", x1, Bn, Lp, src_lens, 0.0, 0, None, None)
@@ -733,8 +756,11 @@ class FastSpeech2(nn.Module):
         dec_in, _, _, mel_lens = ops.length_regulator_fwd(x3.view(Bn, Lp, d), dur, T, pe=pe_dec, want_idx=False)
         mel_masks = ops.length_mask(mel_lens, T)
         y = dec_in.view(Bn * T, d)
+        qkv = None
         for i in range(self.n_dec):
-            y = self._fft_fwd("decoder.layer_stack.%d." % i, y, Bn, T, mel_lens, self.n_head_dec, 0.0, 0, None, None)
+            nxt = "decoder.layer_stack.%d." % (i + 1) if i + 1 < self.n_dec else None
+            y = self._fft_fwd("decoder.layer_stack.%d." % i, y, Bn, T, mel_lens, self.n_head_dec, 0.0, 0, None, None, qkv=qkv, next_pre=nxt)
+            y, qkv = y if nxt else (y, None)
         rows = Bn * T
         mel16 = torch.empty(rows, self.n_mel, dtype=bf16, device=dev)
         mel = ops.linear(y, self._w("mel_linear.weight"), self._m("mel_linear.bias"), out_dtype=torch.float32, C2=mel16)

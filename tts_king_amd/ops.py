@@ -514,8 +514,11 @@ def win_ln_supported(K, D):
     return bool(L.load().ttsk_win_ln_supported(K, D))
 
 
-def win_ln_fwd(x, packed, bias, res, gamma, beta, lens=None, seg_len=0, p_pre=0.0, site_pre=0, rng=None, save_z=True, eps=1e-5, out=None):
-    """gemm_ln_fwd with the weight as a fragment-major pack (win_conv_pack_*; ttsk_win_ln_fwd): x (rows, K) bf16, K = 256 or 1024."""
+def win_ln_fwd(x, packed, bias, res, gamma, beta, lens=None, seg_len=0, p_pre=0.0, site_pre=0, rng=None, save_z=True, eps=1e-5, out=None,
+               proj=None):
+    """gemm_ln_fwd with the weight as a fragment-major pack (win_conv_pack_*; ttsk_win_ln_fwd): x (rows, K) bf16, K = 256 or 1024.
+    proj = (packed q|k|v weight, bias fp32[768]): the next block's q|k|v projection of the output rows in the same launch
+    (ttsk_win_ln_proj_fwd); then returns (out, z, mean, rstd, qkv)."""
     _dev(x, packed, bias, res, gamma, beta, lens, rng)
     rows, K = x.shape
     D = 256
@@ -524,6 +527,14 @@ def win_ln_fwd(x, packed, bias, res, gamma, beta, lens=None, seg_len=0, p_pre=0.
         out = torch.empty(rows, D, dtype=bf16, device=dev)
     z = torch.empty(rows, D, dtype=bf16, device=dev) if save_z else None
     mean, rstd = _f32(rows, device=dev), _f32(rows, device=dev)
+    if proj is not None:
+        pw, pb = proj
+        _dev(pw, pb)
+        qkv = torch.empty(rows, 3 * D, dtype=bf16, device=dev)
+        check(L.load().ttsk_win_ln_proj_fwd(_ptr(x), x.stride(0), _ptr(packed), _ptr(bias), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(z),
+                                            _ptr(mean), _ptr(rstd), _ptr(lens), seg_len, rows, K, D, eps, p_pre, site_pre, _ptr(rng), _ptr(pw),
+                                            _ptr(pb), 3 * D, _ptr(qkv), _stream()), "ttsk_win_ln_proj_fwd")
+        return out, z, mean, rstd, qkv
     check(L.load().ttsk_win_ln_fwd(_ptr(x), x.stride(0), _ptr(packed), _ptr(bias), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(z),
                                    _ptr(mean), _ptr(rstd), _ptr(lens), seg_len, rows, K, D, eps, p_pre, site_pre, _ptr(rng), _stream()),
           "ttsk_win_ln_fwd")

@@ -64,6 +64,36 @@ __device__ __forceinline__ void pack_one(const ttsk_pack_item& it) {
       const int co = c * 16 + (l & 15), ci = ks * 32 + (l >> 4) * 8;
       *(uint4*)(dst + i * 8) = *(const uint4*)(src + ((int64_t)co * K + tap) * Ds + ci);
     }
+  } else if (Ds % 256 == 0 && Cs % 32 == 0) {
+    // W'[co' = ci_s][tap][ci' = co_s] = src[co_s][K-1-tap][ci_s], through LDS: a tile = one k-step (32 storage rows co_s) x 256 storage
+    // columns ci_s = 16 whole fragments.  Rows are read as 512-byte runs, fragments are written as 1 KiB runs (the register-transposing
+    // path below stores 16-byte pieces 128 bytes apart: eight partial writes per line, and this launch is HBM-bound).
+    __shared__ __attribute__((aligned(16))) unsigned short tile[32][256 + 8];
+    const int Co = Ds, Ci = Cs;
+    const int ncb = Co / 256, nks = Ci / 32;
+    const int ntile = K * nks * ncb;
+    const int tid = threadIdx.x;
+    for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+      const int cb = t % ncb, ks = (t / ncb) % nks, tap = t / (ncb * nks);
+      __syncthreads();                                       // the previous tile's readers are done
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {                       // 32 rows x 32 chunks of 16 bytes
+        const int idx = it * 256 + tid, r = idx >> 5, ch = idx & 31;
+        *(uint4*)&tile[r][ch * 8] = *(const uint4*)(src + ((int64_t)(ks * 32 + r) * K + (K - 1 - tap)) * Ds + cb * 256 + ch * 8);
+      }
+      __syncthreads();
+      bf16_t* out = dst + ((int64_t)(tap * nks + ks) * (Co / 16) + cb * 16) * 512;       // 16 fragments, contiguous
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {                       // 16 fragments x 64 pieces
+        const int pi = it * 256 + tid, c = pi >> 6, l = pi & 63;
+        const int col = c * 16 + (l & 15), r0 = (l >> 4) * 8;
+        unsigned short v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tile[r0 + j][col];
+        *(uint4*)(out + (int64_t)pi * 8) = make_uint4(v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16),
+                                                      v[6] | ((unsigned)v[7] << 16));
+      }
+    }
   } else {
     // W'[co' = ci_s][tap][ci' = co_s] = src[co_s][K-1-tap][ci_s]: a thread takes an 8 x 8 block (8 storage rows co_s = 8 consecutive
     // ci' of one piece, 8 consecutive ci_s = co' of 8 neighbouring lanes' pieces): eight 16-byte loads, transposed in registers, eight

@@ -273,6 +273,10 @@ int ttsk_layernorm_bwd_slabs(const float* slabs, int nsplit, int64_t slab_stride
  *   gate_bf16 (may be NULL): out = gate > 0 ? out : 0  (w_2's dX through the ReLU: reference SubLayers.py:93-101 backward),
  *   delta_o32 / delta_out (may be NULL; Cout = 256 = 2 heads x 128, rows = B*seg_len): the attention backward's
  *   delta[(b*2 + h)*seg_len + t] = sum over head h's columns of out * o32  (fc's dX: SubLayers.py:62-63 backward).
+ * pre_x_bf16 / pre_w_packed / pre_K (instead of dout_bf16 and slabs; pre_K = 768): the upstream gradient is itself a k = 1 projection
+ * that only this LayerNorm reads, dout = pre_x · W_pre' (+ R) — the input gradient of the FOLLOWING block's q|k|v projection
+ * (pre_x = dqkv [rows][768], pre_w_packed = the pack of the transposed (768, 1, 256) weight): computed per 32-row tile in fp32,
+ * never written to memory (three dependent launches become one).
  * One launch instead of two dependent ones; results are bit-identical to ttsk_layernorm_bwd(_slabs) + ttsk_win_conv.
  * partials: [ttsk_layernorm_bwd_proj_nblocks(rows)][3*D] (dbias | dgamma | dbeta), a workgroup per 32 rows. */
 int ttsk_layernorm_bwd_proj_nblocks(int rows);
@@ -280,7 +284,8 @@ int ttsk_layernorm_bwd_proj(const void* dout_bf16, const float* slabs, int nspli
                             const void* z_bf16, const float* mean, const float* rstd, const float* gamma, const int64_t* lens,
                             int seg_len, int rows, int D, float p_pre, uint32_t site_pre, const uint64_t* rng, void* dz_bf16,
                             void* dy_bf16, float* partials, const void* w_packed, int Cout, const void* gate_bf16,
-                            const float* delta_o32, float* delta_out, void* out_bf16, void* stream);
+                            const float* delta_o32, float* delta_out, void* out_bf16, const void* pre_x_bf16,
+                            const void* pre_w_packed, int pre_K, void* stream);
 /* dst[c] (+)= scale * sum_b partials[b*ld + c]  in fixed order */
 int ttsk_colsum_finalize(const float* partials, int nblk, int ncols, int ld, float* dst, int accumulate, float scale,
                          void* stream);

@@ -651,6 +651,26 @@ def test_layernorm_bwd_with_projection_equals_two_launches(B, S, p):
     same(dz1, dz0, "dz (slabs)"), same(dy1, dy0, "dy (slabs)"), same(do1, do0.view(rows, d), "do"), same(del1, del0, "delta")
     s0, s1 = part0[:n0].double().sum(0), part1.double().sum(0)
     assert float((s0 - s1).abs().max()) <= 1e-5 * float(s0.abs().max())
+    # (3) the upstream gradient is the q|k|v input gradient of the block behind, computed inside the kernel (dqkv x W' + R): against the
+    # split-K slab path (same products, fp32 sums in another order: agreement to bf16 rounding, rare one-ulp differences)
+    Wq = bf(torch.randn(3 * d, 1, d, generator=g) * (3 * d) ** -0.5).to(DEV)
+    pq = torch.empty(Wq.numel(), dtype=torch.bfloat16, device=DEV)
+    ops.win_conv_pack_items([(Wq, pq, True)])
+    dqkv = bf(torch.randn(rows, 3 * d, generator=g)).to(DEV)
+    slq = ops.win_conv_split(dqkv.view(B, S, 3 * d), pq, d, 1)
+    dz0, dy0, part0, n0, dh0 = ops.layernorm_bwd_proj(None, z, mean, rstd, gamma, p2, Fh, lens, S, p_pre=p, site_pre=11, rng=rng, slabs=slq, R=R, gate=h)
+    dz1, dy1, part1, n1, dh1 = ops.layernorm_bwd_proj(None, z, mean, rstd, gamma, p2, Fh, lens, S, p_pre=p, site_pre=11, rng=rng, R=R, gate=h,
+                                                      pre=(dqkv, pq))
+    for got, want, what in ((dz1, dz0, "dz"), (dy1, dy0, "dy")):
+        gf, wf = got.float(), want.float()
+        tol = 2 ** -7 * wf.abs() + 2 ** -9 * float(wf.abs().mean())
+        assert bool(((gf - wf).abs() <= tol).all()), (what, float((gf - wf).abs().max()))
+        assert float((gf != wf).float().mean()) < 0.02, what
+    # dh = dy x W2': a sum of 256 products, each dy possibly one bf16 ulp apart
+    assert float((dh1.float() - dh0.float()).abs().max()) <= 2 ** -6 * float(dh0.float().abs().max())
+    assert torch.equal(dh1 == 0, dh0 == 0) or float(((dh1 == 0) != (dh0 == 0)).float().mean()) < 1e-3       # the ReLU gate's zeros
+    s0, s1 = part0.double().sum(0), part1.double().sum(0)
+    assert float((s0 - s1).abs().max()) <= 1e-4 * float(s0.abs().max())
 
 
 @pytest.mark.parametrize("B,S,Cin,K", [(16, 423, 1024, 9), (16, 64, 1024, 9), (2, 130, 768, 1), (1, 9, 512, 3)])

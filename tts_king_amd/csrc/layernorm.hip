@@ -327,7 +327,8 @@ __device__ __forceinline__ float group16_sum(float v) { return quad16_sum(v); } 
 // to dbias / dgamma / dbeta are ADDED to sbias / sgam / sbeta, dzv returns the gradient of the sub-layer output (dz with the
 // pre-dropout mask applied; all zero for a PAD row or a row past the end).  dz and dy go to memory when the row exists.
 __device__ __forceinline__ void lnb256_row(const LnBwdArgs& a, int row, int c0, const float gam[16], uint64_t seed, uint64_t step,
-                                           unsigned thr, float dscale, float sbias[16], float sgam[16], float sbeta[16], float dzv[16]) {
+                                           unsigned thr, float dscale, float sbias[16], float sgam[16], float sbeta[16], float dzv[16],
+                                           const float* dl = nullptr /* this row's upstream gradient, fp32 in LDS (+ R), instead of slabs / dout */) {
   constexpr int D = 256;
   const bool live = row < a.rows;
   bool masked = !live;
@@ -341,13 +342,21 @@ __device__ __forceinline__ void lnb256_row(const LnBwdArgs& a, int row, int c0, 
     unpack8(*(const uint4*)zp, zz); unpack8(*(const uint4*)(zp + 8), zz + 8);
     mean = a.mean[row]; rstd = a.rstd[row];
     if (!masked) {
-      if (a.slabs) {
-        const float* sp = a.slabs + (int64_t)row * D + c0;
-        for (int q = 0; q < a.nsplit; ++q) {
+      if (dl || a.slabs) {
+        if (dl) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const f32x4 t = *(const f32x4*)(sp + q * a.slab_stride + 4 * i);
-            d[4 * i] += t[0]; d[4 * i + 1] += t[1]; d[4 * i + 2] += t[2]; d[4 * i + 3] += t[3];
+            const f32x4 t = *(const f32x4*)(dl + c0 + 4 * i);
+            d[4 * i] = t[0]; d[4 * i + 1] = t[1]; d[4 * i + 2] = t[2]; d[4 * i + 3] = t[3];
+          }
+        } else {
+          const float* sp = a.slabs + (int64_t)row * D + c0;
+          for (int q = 0; q < a.nsplit; ++q) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const f32x4 t = *(const f32x4*)(sp + q * a.slab_stride + 4 * i);
+              d[4 * i] += t[0]; d[4 * i + 1] += t[1]; d[4 * i + 2] += t[2]; d[4 * i + 3] += t[3];
+            }
           }
         }
         if (a.R) {
@@ -458,21 +467,96 @@ struct LnbProjArgs {
   const float* o32;      // [rows][256] or null (Cout = 256): delta[(b*2 + h)*S + t] = sum over head h's 128 columns of out * o32
   float* delta;
   int Cout;
+  // PRE: the upstream gradient is itself a k = 1 projection that nobody else reads — dout = pre_x · pre_w' (+ R): the input gradient of
+  // the NEXT block's q|k|v projection (pre_x = dqkv [rows][768], pre_w = the pack of the transposed (768, 1, 256) weight).  Computed
+  // here for the workgroup's 32 rows (fp32, straight into LDS) instead of by a launch of its own that leaves fp32 slabs in memory.
+  const bf16_t* pre_x;
+  const bf16_t* pre_w;
 };
 
-template <int NG>
+template <int NG, bool PRE>
 __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const LnbProjArgs p) {
   constexpr int D = 256;
   static_assert(LNB_WAVES * 64 == P32_NT && P32_D == D, "proj32.h is built for 8 waves and 256 channels");
-  __shared__ float red[LNB_WAVES][3 * D];
-  __shared__ __attribute__((aligned(16))) unsigned char xs[P32_TT * P32_RS];       // dy rows (bf16): the GEMM's B operand
-  __shared__ __attribute__((aligned(16))) unsigned char os[P32_TT * P32_RS];       // one channel group's output rows (bf16)
+  constexpr int PK = 768, PRS = PK * 2 + 32, DT_LD = 260;                 // PRE: contraction width, its LDS row stride, fp32 tile stride
+  constexpr int MAIN_BYTES = LNB_WAVES * 3 * D * 4 + 2 * P32_TT * P32_RS;  // red | xs | os
+  constexpr int PRE_BYTES = P32_TT * PRS;                                  // dqkv rows: dead before red / xs / os are written
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(PRE && PRE_BYTES > MAIN_BYTES) ? PRE_BYTES : MAIN_BYTES];
+  __shared__ __attribute__((aligned(16))) float dtile[PRE ? P32_TT * DT_LD : 4];
+  float (*red)[3 * D] = (float (*)[3 * D])smem;
+  unsigned char* xs = smem + LNB_WAVES * 3 * D * 4;       // dy rows (bf16): the GEMM's B operand
+  unsigned char* os = xs + P32_TT * P32_RS;               // one channel group's output rows (bf16)
   const LnBwdArgs& a = p.ln;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = lane >> 4, l = lane & 15, c0 = l * 16;
   const int m0 = blockIdx.x * P32_TT;
   Proj32W W;
-  proj32_prefetch(p.w, p.Cout, wave, lane, W);          // this wave's weight fragments of group 0, requested before the rows
+  if (!PRE) proj32_prefetch(p.w, p.Cout, wave, lane, W);          // this wave's weight fragments of group 0, requested before the rows
+  if (PRE) {
+    constexpr int KH = P32_KH, CT = P32_CT, NS = PK / 128, NF = P32_TT / 16, CH8 = PK / 8;
+    const int l15 = l, q = grp;
+    const bf16_t* wrow[CT];
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc) wrow[cc] = p.pre_w + ((int64_t)(wave * CT + cc) * 64 + lane) * 8;
+    constexpr int64_t kstep_stride = (D / 16) * 512;
+    bf16x8 wa[KH][CT], wb[KH][CT], wc[KH][CT];
+    auto load_w = [&](int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(wrow[cc] + (int64_t)(g * KH + ks) * kstep_stride);
+    };
+    load_w(0, wa);
+    load_w(1, wb);
+    load_w(2, wc);
+    {
+      constexpr int NCH = P32_TT * CH8 / P32_NT;         // 6 chunks of 16 bytes per thread
+      uint4 xv[NCH];
+#pragma unroll
+      for (int it = 0; it < NCH; ++it) {
+        const int idx = it * P32_NT + tid, row = idx / CH8, ch = idx - row * CH8;
+        xv[it] = make_uint4(0, 0, 0, 0);
+        if (m0 + row < a.rows) xv[it] = *(const uint4*)(p.pre_x + (int64_t)(m0 + row) * PK + ch * 8);
+      }
+#pragma unroll
+      for (int it = 0; it < NCH; ++it) {
+        const int idx = it * P32_NT + tid, row = idx / CH8, ch = idx - row * CH8;
+        *(uint4*)(smem + row * PRS + ch * 16) = xv[it];
+      }
+    }
+    __syncthreads();
+    f32x4 acc[CT][NF];
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+      for (int i = 0; i < NF; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* inl = smem + l15 * PRS + q * 16;
+    auto step = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
+      const unsigned char* inp = inl + g * (KH * 64);
+#pragma unroll
+      for (int ks = 0; ks < KH; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * PRS + ks * 64);
+#pragma unroll
+          for (int cc = 0; cc < CT; ++cc) acc[cc][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][cc], Bf, acc[cc][i], 0, 0, 0);
+        }
+      }
+    };
+    static_assert(NS == 6, "two rounds of the three register sets");
+    step(0, wa); load_w(3, wa);
+    step(1, wb); load_w(4, wb);
+    step(2, wc); load_w(5, wc);
+    step(3, wa);
+    step(4, wb);
+    step(5, wc);
+    proj32_prefetch(p.w, p.Cout, wave, lane, W);
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc) *(f32x4*)(dtile + (i * 16 + l15) * DT_LD + (wave * CT + cc) * 16 + q * 4) = acc[cc][i];
+    __syncthreads();                       // dtile complete; every wave is done with the dqkv rows (red / xs / os may be written)
+  }
   {
     const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
     const unsigned thr = keep_threshold(a.p_pre);
@@ -484,7 +568,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const
 #pragma unroll
     for (int e = 0; e < 16; ++e) sbias[e] = sgam[e] = sbeta[e] = 0.f;
     const int rl = wave * 4 + grp;
-    lnb256_row(a, m0 + rl, c0, gam, seed, step, thr, dscale, sbias, sgam, sbeta, dzv);
+    lnb256_row(a, m0 + rl, c0, gam, seed, step, thr, dscale, sbias, sgam, sbeta, dzv, PRE ? dtile + rl * DT_LD : nullptr);
     *(uint4*)(xs + rl * P32_RS + c0 * 2) = pack8f(dzv);
     *(uint4*)(xs + rl * P32_RS + c0 * 2 + 16) = pack8f(dzv + 8);
     lnb256_partials(a, sbias, sgam, sbeta, red, wave, grp, c0);        // (its barrier also publishes xs)
@@ -751,9 +835,11 @@ extern "C" int ttsk_layernorm_bwd_proj(const void* dout, const float* slabs, int
                                        const float* mean, const float* rstd, const float* gamma, const int64_t* lens, int seg_len,
                                        int rows, int D, float p_pre, uint32_t site_pre, const uint64_t* rng, void* dz, void* dy,
                                        float* partials, const void* w_packed, int Cout, const void* gate, const float* delta_o32,
-                                       float* delta_out, void* out, void* stream) {
+                                       float* delta_out, void* out, const void* pre_x, const void* pre_w_packed, int pre_K, void* stream) {
   TTSK_REQUIRE(z && mean && rstd && gamma && partials && w_packed && out, "layernorm_bwd_proj: null pointer");
-  TTSK_REQUIRE((dout != nullptr) != (slabs != nullptr), "layernorm_bwd_proj: exactly one of dout / slabs");
+  TTSK_REQUIRE((dout != nullptr) + (slabs != nullptr) + (pre_x != nullptr) == 1, "layernorm_bwd_proj: exactly one of dout / slabs / pre_x");
+  TTSK_REQUIRE(!pre_x || (pre_w_packed && pre_K == 768 && (((uintptr_t)pre_x | (uintptr_t)pre_w_packed) & 15) == 0),
+               "layernorm_bwd_proj: the upstream projection is built for a 768-wide contraction (q|k|v), 16-byte aligned operands");
   TTSK_REQUIRE(rows > 0 && D == 256 && (Cout == 256 || Cout == 1024), "layernorm_bwd_proj: D = 256, Cout = 256 or 1024 (got %d, %d)", D, Cout);
   TTSK_REQUIRE(!slabs || (nsplit > 0 && (slab_stride & 3) == 0 && slab_stride >= (int64_t)rows * D && (((uintptr_t)slabs) & 15) == 0),
                "layernorm_bwd_proj: slabs must be 16-byte aligned [nsplit][rows][D]");
@@ -767,9 +853,16 @@ extern "C" int ttsk_layernorm_bwd_proj(const void* dout, const float* slabs, int
   LnbProjArgs p{{(const bf16_t*)dout, nullptr, nullptr, (const bf16_t*)z, mean, rstd, gamma, nullptr, (const long long*)lens, rng,
                  (bf16_t*)dz, (bf16_t*)dy, partials, rows, D, seg_len > 0 ? seg_len : 1, 0, p_pre, 0.f, site_pre, 0, 0, nblk, 0, 0,
                  slabs, (const bf16_t*)R, (long long)slab_stride, nsplit},
-                (const bf16_t*)w_packed, (bf16_t*)out, (const bf16_t*)gate, delta_o32, delta_out, Cout};
-  if (Cout == 256) hipLaunchKernelGGL(ln_bwd256_proj_kernel<1>, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(ln_bwd256_proj_kernel<4>, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, p);
+                (const bf16_t*)w_packed, (bf16_t*)out, (const bf16_t*)gate, delta_o32, delta_out, Cout, (const bf16_t*)pre_x,
+                (const bf16_t*)pre_w_packed};
+  const dim3 grid(nblk), block(LNB_WAVES * 64);
+  if (pre_x) {
+    if (Cout == 256) hipLaunchKernelGGL((ln_bwd256_proj_kernel<1, true>), grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((ln_bwd256_proj_kernel<4, true>), grid, block, 0, (hipStream_t)stream, p);
+  } else {
+    if (Cout == 256) hipLaunchKernelGGL((ln_bwd256_proj_kernel<1, false>), grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((ln_bwd256_proj_kernel<4, false>), grid, block, 0, (hipStream_t)stream, p);
+  }
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -144,6 +144,7 @@ class FastSpeech2(nn.Module):
         self.flash_attention = True     # ... and without the S x S tensors: online softmax forward, recomputing backward (d_k = 128)
         self.fused_ln = True            # fc / w_2 + dropout + residual + LayerNorm + PAD zeroing in one kernel when d = 256
         self.fused_qkv_tail = os.environ.get("TTSK_FUSED_QKV_TAIL", "1") != "0"   # a block's last kernel also projects q|k|v for the next block
+        self.fused_qkv_dx = os.environ.get("TTSK_FUSED_QKV_DX", "1") != "0"   # ... and the q|k|v input gradient of the block behind in front of it
         self.fused_ln_bwd = os.environ.get("TTSK_FUSED_LN_BWD", "1") != "0"   # LayerNorm backward + the k = 1 dX projection behind it in one kernel
         self.group_predictors = True    # training with targets: the three VariancePredictors run as grouped launches
         self.raw_slabs = True           # dX GEMMs that feed a LayerNorm backward leave their split-K tiles for it to sum
@@ -840,6 +841,14 @@ class FastSpeech2(nn.Module):
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
 
+    def _raw_out_mode(self):
+        """How a block hands its input gradient to the block in front of it (see _fft_bwd): "pre" = not at all — the consumer's first
+        backward kernel (ttsk_layernorm_bwd_proj) computes it from dqkv; True = split-K slabs; the consumer must be that kernel."""
+        if (self.fused_qkv_dx and self.fused_ln_bwd and self.raw_slabs and self.window_ffn and self._w1_packed and self.d == 256 and
+                self.k2 == 1 and self.d_ff == 1024):
+            return "pre"
+        return True
+
     def _fft_bwd(self, saved, dx2, rng, raw_out=False):
         """Backward of one FFTBlock.  `dx2`: gradient of the block output — a bf16 tensor, or (Slabs, residual) when the dX GEMM
         that produced it left its split-K partial tiles un-reduced (the next block's `raw_out`): the LayerNorm backward sums them
@@ -854,13 +863,17 @@ class FastSpeech2(nn.Module):
         dev = z2.device
         # ---- FFN tail: LN backward (PAD rows carry no gradient), dropout mask regenerated
         pk2 = self._w1_packed.get(("w2T", f + "w_2.weight")) if (self.window_ffn and self._w1_packed) else None
-        sl2, r2, dd2 = (dx2[0], dx2[1], None) if isinstance(dx2, tuple) else (None, None, dx2)
+        pre2 = None
+        if isinstance(dx2, tuple) and len(dx2) == 3:          # (dqkv, packed transposed q|k|v weight, residual) of the block behind
+            pre2, sl2, r2, dd2 = (dx2[0], dx2[1]), None, dx2[2], None
+        else:
+            sl2, r2, dd2 = (dx2[0], dx2[1], None) if isinstance(dx2, tuple) else (None, None, dx2)
         fuse = self.fused_ln_bwd and d == 256 and self.k2 == 1
         dh = None
         if fuse and pk2 is not None and h.shape[-1] == 1024:
-            # LN backward + w_2's dX (ReLU gate on the way out) in one launch
+            # (the q|k|v input gradient of the block behind +) LN backward + w_2's dX (ReLU gate on the way out) in one launch
             dz2, dy2, part, nblk, dh = ops.layernorm_bwd_proj(dd2, z2, mean2, rstd2, self._m(f + "layer_norm.weight"), pk2, h.shape[-1], lens, S,
-                                                              p_pre=p, site_pre=site + 1, rng=rng, slabs=sl2, R=r2, gate=h)
+                                                              p_pre=p, site_pre=site + 1, rng=rng, slabs=sl2, R=r2, gate=h, pre=pre2)
             dh = dh.view(Bn, S, -1)
         else:
             dz2, dy2, part, nblk = ops.layernorm_bwd(dd2, z2, mean2, rstd2, self._m(f + "layer_norm.weight"), self._m(f + "layer_norm.bias"),
@@ -941,6 +954,8 @@ class FastSpeech2(nn.Module):
             ops.linear_dw(dqkv, x, self._g(a + "w_qs.weight", 3 * d * d).view(3 * d, d), defer=self._deferred)
         if raw_out and self.raw_slabs:
             pkq = self._w1_packed.get(("qkvT", a + "w_qs.weight")) if (self.window_ffn and self._w1_packed) else None
+            if pkq is not None and raw_out == "pre" and d == 256:
+                return (dqkv, pkq, dz1)          # the consumer (the next block's first backward kernel) multiplies by the weight itself
             if pkq is not None:
                 return (ops.win_conv_split(dqkv.view(Bn, S, 3 * d), pkq, d, 1), dz1)
             return (ops.linear_dx(dqkv, self._w(a + "w_qs.weight", 3 * d), raw=True), dz1)
@@ -1062,7 +1077,7 @@ class FastSpeech2(nn.Module):
         notify("mel_linear")
         # ---- decoder
         for i in range(self.n_dec - 1, -1, -1):
-            dx = self._fft_bwd(ctx.blocks[ctx.n_enc_blocks + i], dx, rng, raw_out=i > 0)
+            dx = self._fft_bwd(ctx.blocks[ctx.n_enc_blocks + i], dx, rng, raw_out=self._raw_out_mode() if i > 0 else False)
             notify("decoder.%d" % i)
         if self.dw_side_wgs > 0 and on_bucket is None and self.group_param_grads and not self.overlap_param_grads:
             self._launch_dw_side()
@@ -1089,7 +1104,7 @@ class FastSpeech2(nn.Module):
         # ---- encoder
         dx = dxe.view(Bn * Lp, d)
         for i in range(self.n_enc - 1, -1, -1):
-            dx = self._fft_bwd(ctx.blocks[i], dx, rng, raw_out=i > 0)
+            dx = self._fft_bwd(ctx.blocks[i], dx, rng, raw_out=self._raw_out_mode() if i > 0 else False)
             notify("encoder.%d" % i)
         with self._side_work(dx):
             ops.scatter_sum(dx, ctx.texts.view(-1), self._g("encoder.src_word_emb.weight"), skip_row=0, defer=self._deferred_fin)   # padding_idx=0

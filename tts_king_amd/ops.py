@@ -567,11 +567,14 @@ def layernorm_bwd(dout, z, mean, rstd, gamma, beta, lens=None, seg_len=0, relu_i
 
 
 def layernorm_bwd_proj(dout, z, mean, rstd, gamma, packed, Cout, lens=None, seg_len=0, p_pre=0.0, site_pre=0, rng=None, slabs=None, R=None,
-                       gate=None, delta_o32=None, delta_out=None):
+                       gate=None, delta_o32=None, delta_out=None, pre=None):
     """layernorm_bwd (D = 256) and the k = 1 window conv on its dy in ONE launch (ttsk_layernorm_bwd_proj): `packed` is the
     win_conv pack of the transposed weight, Cout 256 or 1024; gate / delta as for win_conv.
-    Returns (dz, dy, partials, nblk, out)."""
+    pre = (x (rows, 768) bf16, packed transposed weight): the upstream gradient is x · W' (+ R), computed inside the kernel too
+    (instead of dout / slabs).  Returns (dz, dy, partials, nblk, out)."""
     _dev(dout, z, R, gate, delta_o32, delta_out, packed)
+    px, pw = pre if pre is not None else (None, None)
+    _dev(px, pw)
     rows, D = z.shape
     dev = z.device
     lib = L.load()
@@ -583,7 +586,8 @@ def layernorm_bwd_proj(dout, z, mean, rstd, gamma, packed, Cout, lens=None, seg_
     check(lib.ttsk_layernorm_bwd_proj(_ptr(dout), _ptr(slabs.ws) if slabs is not None else None, slabs.splits if slabs is not None else 0,
                                       slabs.stride if slabs is not None else 0, _ptr(R), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma),
                                       _ptr(lens), seg_len, rows, D, p_pre, site_pre, _ptr(rng), _ptr(dz), _ptr(dy), _ptr(partials),
-                                      _ptr(packed), Cout, _ptr(gate), _ptr(delta_o32), _ptr(delta_out), _ptr(out), _stream()),
+                                      _ptr(packed), Cout, _ptr(gate), _ptr(delta_o32), _ptr(delta_out), _ptr(out), _ptr(px), _ptr(pw),
+                                      px.shape[1] if px is not None else 0, _stream()),
           "ttsk_layernorm_bwd_proj")
     return dz, (dy if dy is not None else dz), partials, nblk, out
 

@@ -156,6 +156,10 @@ class FastSpeech2(nn.Module):
         # fraction of the chip.  So that group is launched there on a second stream with its grid capped at `dw_side_wgs` workgroups
         # (one per CU: the other CUs stay free for the dX chain) and joined before the optimizer.  0 = launch it at the end instead.
         self.dw_side_wgs = int(os.environ.get("TTSK_DW_SIDE_WGS", "192"))
+        # ... and only `dw_side_frac` of that group's FLOPs go there: the dX chain that runs beside it is shorter (0.39 ms) than the
+        # capped group (0.57 ms), the rest joins the encoder-side group that runs on the whole chip once the dX chain is done
+        # (measured: 1.0 -> 3.03 ms/step, 0.85 / 0.75 -> 3.00, 0.65 -> 3.02, 0.55 -> 3.11)
+        self.dw_side_frac = float(os.environ.get("TTSK_DW_SIDE_FRAC", "0.8"))
         self._dw_side = None
         self._dw_side_pending = False
         self._rng_state = None          # device block shared with the optimizer (ops.optim_state)
@@ -994,7 +998,7 @@ class FastSpeech2(nn.Module):
             self._dw_side = torch.cuda.Stream(device=self.device)
         self._dw_side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._dw_side):
-            ops.flush_deferred_gemms(self._deferred, max_wgs=self.dw_side_wgs)
+            ops.flush_deferred_gemms(self._deferred, max_wgs=self.dw_side_wgs, frac=self.dw_side_frac)
         self._dw_side_pending = True
 
     def _flush_param_grads(self):

@@ -102,12 +102,24 @@ def flush_group(descs, keep, max_wgs=0):
     descs.clear()
 
 
-def flush_deferred_gemms(items, max_wgs=0):
+def flush_deferred_gemms(items, max_wgs=0, frac=1.0):
     """Only the grouped weight-gradient GEMMs queued in `items` so far, as grouped launches on the current stream (grid capped at
-    max_wgs workgroups when > 0); their split-K slabs stay queued for `flush_deferred`'s reducer launch."""
+    max_wgs workgroups when > 0); their split-K slabs stay queued for `flush_deferred`'s reducer launch.  frac < 1: only about
+    that fraction of the queued FLOPs (the problems queued first); the rest stays queued for the next flush."""
     group = getattr(items, "group", None)
-    if group:
-        flush_group(group, getattr(items, "_keep"), max_wgs)
+    if not group:
+        return
+    if frac < 1.0:
+        fl = [2.0 * d.M * d.N * d.K * max(d.taps, 1) * d.nz1 * d.nz2 for d in group]
+        want, acc, n = frac * sum(fl), 0.0, 0
+        while n < len(group) and acc < want:
+            acc += fl[n]
+            n += 1
+        now, later = group[:n], group[n:]
+        flush_group(now, getattr(items, "_keep"), max_wgs)
+        group[:] = later
+        return
+    flush_group(group, getattr(items, "_keep"), max_wgs)
 
 
 def flush_deferred(items):

@@ -21,4 +21,5 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG
 T=$(find $O/prof_$TAG -name "*kernel_trace.csv" | head -1)
 python3 $R/tools/timeline.py $T > $O/timeline_$TAG.txt 2>&1; head -45 $O/timeline_$TAG.txt
 python3 $R/tools/timeline.py $T --full > $O/timeline_${TAG}_full.txt 2>&1
+python3 $R/tools/timeline.py $T --real > $O/timeline_${TAG}_real.txt 2>&1
 find $O/prof_$TAG -name "*kernel_trace.csv" -size +20M -delete

@@ -8,6 +8,7 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fs2_trace -o fs2 -- /usr/bin/python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-mel --no-e2e --no-hifi --no-extra > $O/fs2_trace.log 2>&1; echo "fs2 trace rc=$?"
 T=$(find $O/fs2_trace -name "*kernel_trace.csv" | head -1)
 python3 $R/tools/timeline.py $T --full > $O/step_timeline.txt 2>&1
+python3 $R/tools/timeline.py $T --real > $O/step_timeline_real.txt 2>&1
 find $O/fs2_trace -name "*kernel_trace.csv" -size +20M -delete
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/hifi_trace -o hifi -- /usr/bin/python3 $R/tools/debug/hifi_prof.py > $O/hifi_trace.log 2>&1; echo "hifi trace rc=$?"
 find $O/hifi_trace -name "*kernel_trace.csv" -size +20M -delete

@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """Per-dispatch timeline of ONE replayed FS2 train step from a rocprofv3 --kernel-trace CSV.
 
-usage: python tools/timeline.py <..._kernel_trace.csv> [--step N] [--full]
+usage: python tools/timeline.py <..._kernel_trace.csv> [--step N] [--full] [--real]
 A step is delimited by consecutive `adam_kernel` dispatches (the last kernel of a step).  Prints the kernels of step N
 (default: the last complete one) grouped by symbol with launch counts, summed duration, and the idle gaps between
-dispatches; --full lists every dispatch in order (name, grid, duration, gap before it)."""
+dispatches; --full lists every dispatch in order (name, grid, duration, gap before it) on a cumulative clock (gap + duration:
+overlapped kernels are laid end to end); --real lists them with their TRUE start and end times relative to the step's first
+kernel and the queue they ran on, so that concurrency between the step's streams — and the time a stream sat waiting for
+another — can be read off."""
 import csv
 import re
 import sys
@@ -46,7 +49,15 @@ def main():
     print("%-64s %5s %10s %8s %9s" % ("kernel", "n", "sum us", "avg us", "gaps us"))
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print("%-64s %5d %10.1f %8.1f %9.1f" % (k, v[0], v[1] / 1e3, v[1] / v[0] / 1e3, v[2] / 1e3))
-    if full:
+    if "--real" in sys.argv:
+        print()
+        queues = {}
+        for r in step:
+            s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            q = queues.setdefault(r["Queue_Id"], len(queues))
+            print("%9.1f -> %9.1f  q%d  %-56s grid %6d x%3d x%3d  %8.1f us" % ((s - t0) / 1e3, (e - t0) / 1e3, q, short(r["Kernel_Name"]),
+                  int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]), (e - s) / 1e3))
+    elif full:
         print()
         t = 0.0
         for name, gx, gy, gz, dur, gap in seq:

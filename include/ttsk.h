@@ -134,6 +134,11 @@ int ttsk_gemm_group_launch(const void* host_table, void* dev_table, void* stream
  * per CU) leaves the remaining CUs to kernels of a concurrent stream: the FS2 backward runs its weight-gradient group beside the
  * encoder-side dX chain this way. */
 int ttsk_gemm_group_launch_capped(const void* host_table, void* dev_table, int max_wgs, void* stream);
+/* ttsk_gemm_group_launch_capped in two parts: the table upload (kernel-argument launches; a no-op for an inline table) and the
+ * grouped launch that expects the table in dev_table.  The upload may go on another stream, ordered before the launch by the caller,
+ * so that it does not sit between two grouped launches on the same stream. */
+int ttsk_gemm_group_upload(const void* host_table, void* dev_table, void* stream);
+int ttsk_gemm_group_launch_uploaded(const void* host_table, void* dev_table, int max_wgs, void* stream);
 
 /* The FFT block's first position-wise conv, forward: out = [relu](Conv1d(256 -> Cout, k)(x) + bias), 'same' zero padding per
  * utterance.  reference: fs_two/transformer/SubLayers.py:93-101 (w_1 + relu).  x [B*S][256] bf16 (row = utterance*S + frame), w the

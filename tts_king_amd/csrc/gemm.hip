@@ -769,24 +769,41 @@ extern "C" int ttsk_gemm_group_launch(const void* host_table, void* dev_table, v
   return ttsk_gemm_group_launch_capped(host_table, dev_table, 0, stream);
 }
 
+static bool group_inline_table(const GroupHeader* h) { return h->n <= 2 && !h->f16 && h->kernel == 1; }      // bf16 pairs: table in the kernel arguments
+
+// the table -> device memory through kernel arguments (capturable); a no-op for a group whose table travels inline
+extern "C" int ttsk_gemm_group_upload(const void* host_table, void* dev_table, void* stream) {
+  TTSK_REQUIRE(host_table && dev_table && (((uintptr_t)dev_table) & 15) == 0, "ttsk_gemm_group_upload: bad table pointers");
+  const GroupHeader* h = (const GroupHeader*)host_table;
+  TTSK_REQUIRE(h->n > 0 && h->total > 0, "ttsk_gemm_group_upload: empty table (call ttsk_gemm_group_build first)");
+  if (group_inline_table(h)) return TTSK_OK;
+  const int64_t bytes = ttsk_gemm_group_table_bytes(h->n);
+  for (int64_t off = 0; off < bytes; off += (int64_t)sizeof(TableChunk)) {
+    TableChunk c;
+    const int64_t nb = bytes - off < (int64_t)sizeof(TableChunk) ? bytes - off : (int64_t)sizeof(TableChunk);
+    memset(&c, 0, sizeof(c));
+    memcpy(&c, (const unsigned char*)host_table + off, (size_t)nb);
+    hipLaunchKernelGGL(group_table_upload_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, c,
+                       (uint4*)((unsigned char*)dev_table + off), (int)((nb + 15) / 16));
+    TTSK_CHECK_LAUNCH();
+  }
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_gemm_group_launch_uploaded(const void* host_table, void* dev_table, int max_wgs, void* stream);
 extern "C" int ttsk_gemm_group_launch_capped(const void* host_table, void* dev_table, int max_wgs, void* stream) {
+  if (int rc = ttsk_gemm_group_upload(host_table, dev_table, stream)) return rc;
+  return ttsk_gemm_group_launch_uploaded(host_table, dev_table, max_wgs, stream);
+}
+
+// the launch alone: dev_table already holds the table (ttsk_gemm_group_upload, possibly on another stream the caller has ordered
+// before this one) — the upload's three dependent 5-us launches need not sit between two grouped launches on the same stream
+extern "C" int ttsk_gemm_group_launch_uploaded(const void* host_table, void* dev_table, int max_wgs, void* stream) {
   TTSK_REQUIRE(host_table && dev_table && (((uintptr_t)dev_table) & 15) == 0, "ttsk_gemm_group_launch: bad table pointers");
   TTSK_REQUIRE(max_wgs >= 0, "ttsk_gemm_group_launch_capped: max_wgs < 0");
   const GroupHeader* h = (const GroupHeader*)host_table;
   TTSK_REQUIRE(h->n > 0 && h->total > 0, "ttsk_gemm_group_launch: empty table (call ttsk_gemm_group_build first)");
-  const bool inline_table = h->n <= 2 && !h->f16 && h->kernel == 1;      // bf16 pairs: table in the kernel arguments
-  if (!inline_table) {
-    const int64_t bytes = ttsk_gemm_group_table_bytes(h->n);
-    for (int64_t off = 0; off < bytes; off += (int64_t)sizeof(TableChunk)) {
-      TableChunk c;
-      const int64_t nb = bytes - off < (int64_t)sizeof(TableChunk) ? bytes - off : (int64_t)sizeof(TableChunk);
-      memset(&c, 0, sizeof(c));
-      memcpy(&c, (const unsigned char*)host_table + off, (size_t)nb);
-      hipLaunchKernelGGL(group_table_upload_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, c,
-                         (uint4*)((unsigned char*)dev_table + off), (int)((nb + 15) / 16));
-      TTSK_CHECK_LAUNCH();
-    }
-  }
+  const bool inline_table = group_inline_table(h);
   const int* prefix = (const int*)((const unsigned char*)dev_table + h->prefix_off);
   const Args* args = (const Args*)((const unsigned char*)dev_table + h->args_off);
   hipStream_t s = (hipStream_t)stream;

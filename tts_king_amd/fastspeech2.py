@@ -1009,9 +1009,10 @@ class FastSpeech2(nn.Module):
             # only activations and gradients the main chain produced: they run now, beside the side stream; the encoder-side dW group
             # queues behind the first one on the side stream; the join comes last, before the split-K reducer.
             cur = torch.cuda.current_stream()
+            launch = ops.upload_deferred_gemms(self._deferred, max_wgs=0)     # the tables now, on this stream (the side stream is busy)
             self._dw_side.wait_stream(cur)
             with torch.cuda.stream(self._dw_side):
-                ops.flush_deferred_gemms(self._deferred, max_wgs=0)
+                launch()
             ops.flush_finalize(self._deferred_fin)
             cur.wait_stream(self._dw_side)
             self._dw_side_pending = False

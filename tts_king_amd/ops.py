@@ -65,11 +65,14 @@ class GemmGroup:
         self.keep = []
 
 
-def flush_group(descs, keep, max_wgs=0):
+def flush_group(descs, keep, max_wgs=0, upload_only=False):
     """Grouped launches (ttsk_gemm_group_*) of the queued descriptors, one per operand layout; `keep` holds their tensors.
-    max_wgs > 0 caps the grid of the 256x128 configuration (ttsk_gemm_group_launch_capped)."""
+    max_wgs > 0 caps the grid of the 256x128 configuration (ttsk_gemm_group_launch_capped).
+    upload_only: only the tables go to the device (current stream); returns a function that issues the launches (on the stream
+    current when it is called, which the caller has ordered behind this one)."""
     if not descs:
-        return
+        return (lambda: None) if upload_only else None
+    pending = []
     lib = L.load()
     by_layout = {}
     for d in descs:
@@ -87,6 +90,13 @@ def flush_group(descs, keep, max_wgs=0):
         total = C.c_int32(0)
         check(lib.ttsk_gemm_group_build(arr, n, host, C.byref(total)), "ttsk_gemm_group_build")
         table = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # filled by group_launch through kernel arguments
+        if upload_only:
+            check(lib.ttsk_gemm_group_upload(host, C.c_void_p(table.data_ptr()), _stream()), "ttsk_gemm_group_upload")
+            pending.append((host, table))
+            keep.append(table)
+            if LAUNCH_COUNTS is not None:
+                LAUNCH_COUNTS["grouped_gemm"] = LAUNCH_COUNTS.get("grouped_gemm", 0) + 1
+            continue
         if GEMM_TRACE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -100,6 +110,19 @@ def flush_group(descs, keep, max_wgs=0):
             GEMM_TRACE.append((e0, e1, fl, kind + "%dg" % ds[0].kernel, (n, 0, 0, 1, 1, int(total.value))))
         keep.append(table)
     descs.clear()
+    if upload_only:
+        def launch():
+            for host, table in pending:
+                check(lib.ttsk_gemm_group_launch_uploaded(host, C.c_void_p(table.data_ptr()), int(max_wgs), _stream()), "ttsk_gemm_group_launch_uploaded")
+        return launch
+
+
+def upload_deferred_gemms(items, max_wgs=0):
+    """flush_deferred_gemms in two parts: the tables now (current stream), the launches when the returned function is called."""
+    group = getattr(items, "group", None)
+    if not group:
+        return lambda: None
+    return flush_group(group, getattr(items, "_keep"), max_wgs, upload_only=True)
 
 
 def flush_deferred_gemms(items, max_wgs=0, frac=1.0):

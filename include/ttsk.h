@@ -184,6 +184,13 @@ int ttsk_win_conv_split(const void* x_bf16, const void* w_packed, float* slabs, 
 int ttsk_win_conv(const void* x_bf16, const void* w_packed, const float* bias /* may be NULL */, const void* gate_bf16 /* may be NULL */,
                   const float* delta_o32 /* may be NULL */, float* delta_out /* may be NULL */, void* out, int out_f32, int B, int S, int Cin,
                   int Cout, int K, int relu, void* stream);
+/* ttsk_win_conv (Cin = 512, fp32 output, no gate / delta) whose output's BatchNorm statistics partials come out of the same kernel:
+ * stats[ttsk_win_conv_stats_rows(B, S)][2*Cout] = per-channel sum | sum of squares per (utterance, 64-frame tile) over the rows that
+ * exist (t < S, t < frame_limit[0] when given) — the `partials` of ttsk_bn_train_apply, so the PostNet's 512 -> 512 layers need no
+ * ttsk_bn_stats_slab launch (reference: Layers.py:133-143, Conv1d -> BatchNorm1d). */
+int ttsk_win_conv_stats_rows(int B, int S);
+int ttsk_win_conv_stats(const void* x_bf16, const void* w_packed, const float* bias, float* out_f32, float* stats,
+                        const int32_t* frame_limit, int B, int S, int Cin, int Cout, int K, void* stream);
 
 /* Fused sub-layer tail of an FFT block (reference: fs_two/transformer/SubLayers.py:62-63 and :96-99 + Layers.py:29,32):
  *   out = zero_PAD_rows( LayerNorm( dropout_{p_pre, site_pre}( A[M,K] @ W[D,K]^T + bias ) + res ) ),  D = 256 only.

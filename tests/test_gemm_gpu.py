@@ -2,6 +2,7 @@
 CPU math on the same bf16-rounded operands.  Integer-valued cases are exact (they pin the operand/fragment
 layouts, including the ds_read_b64_tr_b16 transposed reads); random cases use a tolerance scaled by K
 (bf16 products are exact in fp32, only the summation order differs)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -575,6 +576,32 @@ def test_win_conv_k1_projections_gate_and_item_packs():
     assert float((dh.float() - ref.float()).abs().max()) <= 2 ** -7 * float(ref.float().abs().max())
     assert torch.equal(dh == 0, (ref == 0)) or float(((dh == 0) != (ref == 0)).float().mean()) < 1e-3
     assert bool((dh[h <= 0] == 0).all())
+
+
+@pytest.mark.parametrize("B,S,limit", [(16, 423, None), (2, 448, 423), (3, 70, 61), (1, 64, None)])
+def test_win_conv_emits_batchnorm_partials(B, S, limit):
+    """ttsk_win_conv_stats (PostNet 512 -> 512, k = 5): output bit-identical to ttsk_win_conv, and its statistics partials give
+    ttsk_bn_train_apply the mean / rstd that ttsk_bn_stats_slab computes from the stored rows (frame limit included)."""
+    from tts_king_amd import ops
+    g = torch.Generator().manual_seed(B * 7 + S)
+    C = 512
+    x = bf(torch.randn(B, S, C, generator=g)).to(DEV)
+    W = bf(torch.randn(C, 5, C, generator=g) * (5 * C) ** -0.5).to(DEV)
+    bias = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    pk = torch.empty(W.numel(), dtype=torch.bfloat16, device=DEV)
+    ops.win_conv_pack_items([(W, pk, False)])
+    fl = None if limit is None else (torch.tensor([limit], dtype=torch.int32, device=DEV), S)
+    want = ops.win_conv(x, pk, C, 5, bias=bias, out_dtype=torch.float32)
+    got, stats = ops.win_conv_stats(x, pk, C, 5, bias=bias, frame_limit=fl)
+    assert torch.equal(got, want) and stats.shape == (B * ((S + 63) // 64), 2 * C)
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    rows = B * S
+    z = lambda: (torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV))
+    o0, m0, r0 = ops.bn_train(want.view(rows, C), *z(), gamma, beta, True, frame_limit=fl)
+    o1, m1, r1 = ops.bn_train(got.view(rows, C), *z(), gamma, beta, True, frame_limit=fl, partials=stats)
+    np.testing.assert_allclose(m1.cpu().numpy(), m0.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r1.cpu().numpy(), r0.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert float((o1.float() - o0.float()).abs().max()) <= 2 ** -7
 
 
 @pytest.mark.parametrize("B,S,K", [(3, 130, 1024), (16, 423, 1024), (2, 33, 256), (16, 64, 1024)])

@@ -39,6 +39,11 @@ struct WcArgs {
   // sum over head h's 128 columns of out[t][.] (as stored, bf16) * o32[t][.]  — what flash_delta_kernel computes from the same operands
   const float* o32;     // [B*S][Cout] fp32 or null
   float* delta;         // [B*H][S]
+  // BatchNorm statistics of the output folded into the conv that produces it (fp32 output, CIN = 512: the PostNet's 512 -> 512 convs):
+  // stats[tile][2*Cout] = per-channel sum | sum of squares over the tile's rows that exist (t < S, t < frame_limit[0]) — the partial
+  // rows ttsk_bn_train_apply sums, one per (utterance, 64-frame tile), instead of a ttsk_bn_stats_slab launch over the stored rows
+  float* stats;
+  const int* frame_limit;
 };
 
 // Weight packs.  src = storage (Cs, K, Ds) bf16 tap-major.
@@ -268,6 +273,25 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
     }
   }
   __syncthreads();
+  if constexpr (OUT32 && CIN == 512) {
+    static_assert(SMEM >= TT * SRS + 2 * WC_COUT * 4, "room for the two half-sums behind the staging tile");
+    if (a.stats) {
+      const int c = tid & (WC_COUT - 1), half = tid / WC_COUT;        // 512 threads: two halves of the tile's rows
+      const int lim = a.frame_limit ? (a.frame_limit[0] < S ? a.frame_limit[0] : S) : S;
+      float sm = 0.f, sq = 0.f;
+      for (int r = half * (TT / 2); r < (half + 1) * (TT / 2); ++r) {
+        if (t0 + r < lim) { const float v = *(const float*)(XW + r * SRS + c * 4); sm += v; sq += v * v; }
+      }
+      float* red = (float*)(XW + TT * SRS);
+      if (half == 1) { red[c] = sm; red[WC_COUT + c] = sq; }
+      __syncthreads();
+      if (half == 0) {
+        float* P = a.stats + ((int64_t)bi * a.tiles_per_utt + t0 / TT) * 2 * a.Cout + cg * WC_COUT + c;
+        P[0] = sm + red[c];
+        P[a.Cout] = sq + red[WC_COUT + c];
+      }
+    }
+  }
   constexpr int ESZ = OUT32 ? 4 : 2;
   constexpr int OCH = WC_COUT * ESZ / 16;                // 16-byte chunks per output row of this channel group
   constexpr int NCO = (TT * OCH + NT - 1) / NT;
@@ -382,6 +406,21 @@ extern "C" int ttsk_win_conv(const void* x_bf16, const void* w_packed, const flo
   TTSK_REQUIRE(!delta_out || (delta_o32 && !out_f32 && Cout % 128 == 0 && (((uintptr_t)delta_o32) & 15) == 0),
                "ttsk_win_conv: delta needs o32 (16-byte aligned), bf16 output and Cout = heads * 128");
   launch_win_conv(a, B, S, Cin, out_f32, 1, (hipStream_t)stream);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_win_conv_stats_rows(int B, int S) { return B * ((S + 63) / 64); }
+
+// ttsk_win_conv with fp32 output whose BatchNorm statistics partials come out of the same kernel (Cin = 512)
+extern "C" int ttsk_win_conv_stats(const void* x_bf16, const void* w_packed, const float* bias, float* out_f32, float* stats,
+                                   const int32_t* frame_limit, int B, int S, int Cin, int Cout, int K, void* stream) {
+  TTSK_REQUIRE(x_bf16 && w_packed && out_f32 && stats, "ttsk_win_conv_stats: null pointer");
+  TTSK_REQUIRE(B > 0 && S > 0 && B <= 65535, "ttsk_win_conv_stats: bad sizes B=%d S=%d", B, S);
+  TTSK_REQUIRE(Cin == 512 && ttsk_win_conv_supported(Cin, Cout, K), "ttsk_win_conv_stats: built for Cin = 512 (got Cin=%d Cout=%d K=%d)", Cin, Cout, K);
+  TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_packed) | ((uintptr_t)bias) | ((uintptr_t)out_f32)) & 15) == 0, "ttsk_win_conv_stats: 16-byte alignment");
+  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, bias, out_f32, S, K, Cout, 0, 0, 0, nullptr, 1, Cin, 0, nullptr, nullptr, stats, frame_limit};
+  launch_win_conv(a, B, S, Cin, 1, 1, (hipStream_t)stream);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -143,6 +143,7 @@ class FastSpeech2(nn.Module):
         self._w1_packed = None
         self.flash_attention = True     # ... and without the S x S tensors: online softmax forward, recomputing backward (d_k = 128)
         self.fused_ln = True            # fc / w_2 + dropout + residual + LayerNorm + PAD zeroing in one kernel when d = 256
+        self.bn_stats_in_conv = os.environ.get("TTSK_BN_STATS_IN_CONV", "1") != "0"   # PostNet 512 -> 512 convs emit their BatchNorm statistics partials
         self.fused_qkv_tail = os.environ.get("TTSK_FUSED_QKV_TAIL", "1") != "0"   # a block's last kernel also projects q|k|v for the next block
         self.fused_qkv_dx = os.environ.get("TTSK_FUSED_QKV_DX", "1") != "0"   # ... and the q|k|v input gradient of the block behind in front of it
         self.fused_ln_bwd = os.environ.get("TTSK_FUSED_LN_BWD", "1") != "0"   # LayerNorm backward + the k = 1 dX projection behind it in one kernel
@@ -685,9 +686,14 @@ class FastSpeech2(nn.Module):
             pp = "postnet.convolutions.%d." % i
             # conv output stays fp32: BatchNorm divides by the batch std, which amplifies a bf16 rounding of it
             pk = self._w1_packed.get(("pn", pp + "0.conv.weight")) if (self.window_ffn and self._w1_packed) else None
+            stats = None
             if pk is not None and xin.dtype == bf16:
                 cw = self._table[pp + "0.conv.weight"].storage_shape
-                yc = ops.win_conv(xin, pk, cw[0], cw[1], bias=self._m(pp + "0.conv.bias"), out_dtype=torch.float32)   # window kernel
+                if train and xin.shape[2] == 512 and ops.bn_slab_supported(cw[0]) and self.bn_stats_in_conv:
+                    # window kernel; the BatchNorm statistics partials of its output come out of its epilogue
+                    yc, stats = ops.win_conv_stats(xin, pk, cw[0], cw[1], bias=self._m(pp + "0.conv.bias"), frame_limit=fl)
+                else:
+                    yc = ops.win_conv(xin, pk, cw[0], cw[1], bias=self._m(pp + "0.conv.bias"), out_dtype=torch.float32)   # window kernel
             else:
                 yc = ops.conv1d(xin, self._w(pp + "0.conv.weight"), self._m(pp + "0.conv.bias"), out_dtype=torch.float32)
             C = yc.shape[2]
@@ -697,7 +703,8 @@ class FastSpeech2(nn.Module):
                 nxt, mean, rstd, keep = ops.bn_train(yc.view(rows, C), self.get(pp + "1.running_mean"), self.get(pp + "1.running_var"),
                                                      self.get(pp + "1.num_batches_tracked").view(1), self._m(pp + "1.weight"),
                                                      self._m(pp + "1.bias"), not last, p=p_post, site=300 + i, rng=rng,
-                                                     resid=mel if last else None, out_f32=last, frame_limit=fl, want_keep=True)
+                                                     resid=mel if last else None, out_f32=last, frame_limit=fl, want_keep=True,
+                                                     partials=stats)
             else:
                 keep = None
                 if train:

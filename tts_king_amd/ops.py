@@ -424,6 +424,20 @@ def win_conv(x, packed, Cout, k, bias=None, relu=False, out_dtype=None, gate=Non
     return out
 
 
+def win_conv_stats(x, packed, Cout, k, bias=None, frame_limit=None):
+    """win_conv with fp32 output (Cin = 512) that also returns the BatchNorm statistics partials of its output
+    ([B * ceil(S/64)][2*Cout] fp32: sum | sum of squares per tile) for bn_train(partials=...) (ttsk_win_conv_stats)."""
+    _dev(x, packed, bias)
+    Bsz, S, Cin = x.shape
+    lib = L.load()
+    out = torch.empty(Bsz, S, Cout, dtype=torch.float32, device=x.device)
+    stats = _f32(lib.ttsk_win_conv_stats_rows(Bsz, S), 2 * Cout, device=x.device)
+    lp, _ = _lim(frame_limit)
+    check(lib.ttsk_win_conv_stats(_ptr(x), _ptr(packed), _ptr(bias), _ptr(out), _ptr(stats), lp, Bsz, S, Cin, Cout, k, _stream()),
+          "ttsk_win_conv_stats")
+    return out, stats
+
+
 def win_conv_split(x, packed, Cout, k):
     """An input-gradient conv with a wide contraction (x (B,S,n*256) bf16) as n window convs over 256-channel slices in one launch:
     fp32 Slabs (n, B*S*Cout) for layernorm_bwd(slabs=...) (ttsk_win_conv_split).  `packed`: the whole transposed pack."""

@@ -298,6 +298,10 @@ int ttsk_layernorm_bwd_proj(const void* dout_bf16, const float* slabs, int nspli
                             void* dy_bf16, float* partials, const void* w_packed, int Cout, const void* gate_bf16,
                             const float* delta_o32, float* delta_out, void* out_bf16, const void* pre_x_bf16,
                             const void* pre_w_packed, int pre_K, void* stream);
+/* The q|k|v input gradient on its own, out[rows][256] = dqkv[rows][768] · W' (+ R_bf16, may be NULL), for the first block of a stack
+ * (no LayerNorm backward in front of it to host the product: reference SubLayers.py:41-43 backward + the residual of :62): 32-row
+ * tiles, one pass over the contraction, the window-conv pack of the transposed weight, no split-K slabs.  K = 768, D = 256. */
+int ttsk_qkv_dx(const void* dqkv_bf16, const void* w_packed, const void* R_bf16, void* out_bf16, int rows, int K, int D, void* stream);
 /* dst[c] (+)= scale * sum_b partials[b*ld + c]  in fixed order */
 int ttsk_colsum_finalize(const float* partials, int nblk, int ncols, int ld, float* dst, int accumulate, float scale,
                          void* stream);

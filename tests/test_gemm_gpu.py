@@ -578,6 +578,25 @@ def test_win_conv_k1_projections_gate_and_item_packs():
     assert bool((dh[h <= 0] == 0).all())
 
 
+@pytest.mark.parametrize("rows", [16 * 423, 1024, 37])
+def test_qkv_dx_kernel(rows):
+    """ttsk_qkv_dx (dqkv x W' + R on 32-row tiles) against the GEMM path it replaces for the first block of a stack and fp64."""
+    from tts_king_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    d = 256
+    dqkv = bf(torch.randn(rows, 3 * d, generator=g)).to(DEV)
+    W = bf(torch.randn(3 * d, 1, d, generator=g) * (3 * d) ** -0.5).to(DEV)
+    R = bf(torch.randn(rows, d, generator=g)).to(DEV)
+    pk = torch.empty(W.numel(), dtype=torch.bfloat16, device=DEV)
+    ops.win_conv_pack_items([(W, pk, True)])
+    for res in (R, None):
+        got = ops.qkv_dx(dqkv, pk, R=res).float().cpu()
+        ref = dqkv.double().cpu() @ W.view(3 * d, d).double().cpu() + (res.double().cpu() if res is not None else 0)
+        old = ops.linear_dx(dqkv, W.view(3 * d, d), R=res).float().cpu()
+        assert float((got.double() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+        assert float((got - old).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("B,S,limit", [(16, 423, None), (2, 448, 423), (3, 70, 61), (1, 64, None)])
 def test_win_conv_emits_batchnorm_partials(B, S, limit):
     """ttsk_win_conv_stats (PostNet 512 -> 512, k = 5): output bit-identical to ttsk_win_conv, and its statistics partials give

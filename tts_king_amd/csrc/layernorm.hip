@@ -452,6 +452,105 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd256_kernel(const LnBwdAr
   lnb256_partials(a, sbias, sgam, sbeta, red, wave, grp, c0);
 }
 
+// dtile[32][PRE_DT_LD] (fp32, LDS) = x[m0 .. m0+32)[768] · W', W = the ttsk_win_conv pack of a transposed (768, 1, 256) weight: the input
+// gradient of a q|k|v projection for 32 rows.  512 threads; `as` = 32 x PRE_RS bytes of LDS for the rows of x (dead on return).
+// Ends with a barrier: dtile is complete and `as` may be overwritten.
+constexpr int PRE_K = 768, PRE_RS = PRE_K * 2 + 32, PRE_DT_LD = 260;
+__device__ __forceinline__ void pre768_gemm(const bf16_t* __restrict__ pre_x, const bf16_t* __restrict__ pre_w, int m0, int rows,
+                                            unsigned char* as, float* dtile) {
+  constexpr int D = 256, PK = PRE_K, PRS = PRE_RS, DT_LD = PRE_DT_LD;
+  constexpr int KH = P32_KH, CT = P32_CT, NS = PK / 128, NF = P32_TT / 16, CH8 = PK / 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const bf16_t* wrow[CT];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc) wrow[cc] = pre_w + ((int64_t)(wave * CT + cc) * 64 + lane) * 8;
+  constexpr int64_t kstep_stride = (D / 16) * 512;
+  bf16x8 wa[KH][CT], wb[KH][CT], wc[KH][CT];
+  auto load_w = [&](int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(wrow[cc] + (int64_t)(g * KH + ks) * kstep_stride);
+  };
+  load_w(0, wa);
+  load_w(1, wb);
+  load_w(2, wc);
+  {
+    constexpr int NCH = P32_TT * CH8 / P32_NT;         // 6 chunks of 16 bytes per thread
+    uint4 xv[NCH];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int idx = it * P32_NT + tid, row = idx / CH8, ch = idx - row * CH8;
+      xv[it] = make_uint4(0, 0, 0, 0);
+      if (m0 + row < rows) xv[it] = *(const uint4*)(pre_x + (int64_t)(m0 + row) * PK + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int idx = it * P32_NT + tid, row = idx / CH8, ch = idx - row * CH8;
+      *(uint4*)(as + row * PRS + ch * 16) = xv[it];
+    }
+  }
+  __syncthreads();
+  f32x4 acc[CT][NF];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+    for (int i = 0; i < NF; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned char* inl = as + l15 * PRS + q * 16;
+  auto step = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
+    const unsigned char* inp = inl + g * (KH * 64);
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks) {
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * PRS + ks * 64);
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc) acc[cc][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][cc], Bf, acc[cc][i], 0, 0, 0);
+      }
+    }
+  };
+  static_assert(NS == 6, "two rounds of the three register sets");
+  step(0, wa); load_w(3, wa);
+  step(1, wb); load_w(4, wb);
+  step(2, wc); load_w(5, wc);
+  step(3, wa);
+  step(4, wb);
+  step(5, wc);
+#pragma unroll
+  for (int i = 0; i < NF; ++i)
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc) *(f32x4*)(dtile + (i * 16 + l15) * DT_LD + (wave * CT + cc) * 16 + q * 4) = acc[cc][i];
+  __syncthreads();                       // dtile complete; every wave is done with the rows of x
+}
+
+// out[rows][256] bf16 = x[rows][768] · W' (+ R): the q|k|v input gradient on its own (the first block of a stack has no LayerNorm
+// backward in front of it to host it): 32-row tiles, one pass over the 768-wide contraction, no split-K slabs
+__global__ __launch_bounds__(LNB_WAVES * 64, 1) void pre768_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                                   const bf16_t* __restrict__ R, bf16_t* __restrict__ out, int rows) {
+  __shared__ __attribute__((aligned(16))) unsigned char as[P32_TT * PRE_RS];
+  __shared__ __attribute__((aligned(16))) float dtile[P32_TT * PRE_DT_LD];
+  const int m0 = blockIdx.x * P32_TT;
+  pre768_gemm(x, w, m0, rows, as, dtile);
+  const int rl = threadIdx.x >> 4, c0 = (threadIdx.x & 15) * 16, row = m0 + rl;
+  if (row >= rows) return;
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x4 t = *(const f32x4*)(dtile + rl * PRE_DT_LD + c0 + 4 * i);
+    v[4 * i] = t[0]; v[4 * i + 1] = t[1]; v[4 * i + 2] = t[2]; v[4 * i + 3] = t[3];
+  }
+  if (R) {
+    float r[16];
+    const bf16_t* rp = R + (int64_t)row * 256 + c0;
+    unpack8(*(const uint4*)rp, r); unpack8(*(const uint4*)(rp + 8), r + 8);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] += r[e];
+  }
+  bf16_t* op = out + (int64_t)row * 256 + c0;
+  *(uint4*)op = pack8f(v); *(uint4*)(op + 8) = pack8f(v + 8);
+}
+
 // ---- ln_bwd256 + the k = 1 projection that consumes its dy (the sub-layer's input gradient), one kernel.
 // The FFT block's backward ran  LN backward -> [dy to memory] -> window conv (w_2's dX with the ReLU gate; fc's dX with the attention
 // delta)  as two dependent launches; a dependent launch costs ~4.5 us on this part before any work, x 20 per step.  Here a workgroup
@@ -478,7 +577,7 @@ template <int NG, bool PRE>
 __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const LnbProjArgs p) {
   constexpr int D = 256;
   static_assert(LNB_WAVES * 64 == P32_NT && P32_D == D, "proj32.h is built for 8 waves and 256 channels");
-  constexpr int PK = 768, PRS = PK * 2 + 32, DT_LD = 260;                 // PRE: contraction width, its LDS row stride, fp32 tile stride
+  constexpr int PRS = PRE_RS, DT_LD = PRE_DT_LD;                          // PRE: LDS row stride of the dqkv rows, fp32 tile stride
   constexpr int MAIN_BYTES = LNB_WAVES * 3 * D * 4 + 2 * P32_TT * P32_RS;  // red | xs | os
   constexpr int PRE_BYTES = P32_TT * PRS;                                  // dqkv rows: dead before red / xs / os are written
   __shared__ __attribute__((aligned(16))) unsigned char smem[(PRE && PRE_BYTES > MAIN_BYTES) ? PRE_BYTES : MAIN_BYTES];
@@ -493,69 +592,8 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const
   Proj32W W;
   if (!PRE) proj32_prefetch(p.w, p.Cout, wave, lane, W);          // this wave's weight fragments of group 0, requested before the rows
   if (PRE) {
-    constexpr int KH = P32_KH, CT = P32_CT, NS = PK / 128, NF = P32_TT / 16, CH8 = PK / 8;
-    const int l15 = l, q = grp;
-    const bf16_t* wrow[CT];
-#pragma unroll
-    for (int cc = 0; cc < CT; ++cc) wrow[cc] = p.pre_w + ((int64_t)(wave * CT + cc) * 64 + lane) * 8;
-    constexpr int64_t kstep_stride = (D / 16) * 512;
-    bf16x8 wa[KH][CT], wb[KH][CT], wc[KH][CT];
-    auto load_w = [&](int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int ks = 0; ks < KH; ++ks)
-#pragma unroll
-        for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(wrow[cc] + (int64_t)(g * KH + ks) * kstep_stride);
-    };
-    load_w(0, wa);
-    load_w(1, wb);
-    load_w(2, wc);
-    {
-      constexpr int NCH = P32_TT * CH8 / P32_NT;         // 6 chunks of 16 bytes per thread
-      uint4 xv[NCH];
-#pragma unroll
-      for (int it = 0; it < NCH; ++it) {
-        const int idx = it * P32_NT + tid, row = idx / CH8, ch = idx - row * CH8;
-        xv[it] = make_uint4(0, 0, 0, 0);
-        if (m0 + row < a.rows) xv[it] = *(const uint4*)(p.pre_x + (int64_t)(m0 + row) * PK + ch * 8);
-      }
-#pragma unroll
-      for (int it = 0; it < NCH; ++it) {
-        const int idx = it * P32_NT + tid, row = idx / CH8, ch = idx - row * CH8;
-        *(uint4*)(smem + row * PRS + ch * 16) = xv[it];
-      }
-    }
-    __syncthreads();
-    f32x4 acc[CT][NF];
-#pragma unroll
-    for (int cc = 0; cc < CT; ++cc)
-#pragma unroll
-      for (int i = 0; i < NF; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const unsigned char* inl = smem + l15 * PRS + q * 16;
-    auto step = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
-      const unsigned char* inp = inl + g * (KH * 64);
-#pragma unroll
-      for (int ks = 0; ks < KH; ++ks) {
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-          const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * PRS + ks * 64);
-#pragma unroll
-          for (int cc = 0; cc < CT; ++cc) acc[cc][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][cc], Bf, acc[cc][i], 0, 0, 0);
-        }
-      }
-    };
-    static_assert(NS == 6, "two rounds of the three register sets");
-    step(0, wa); load_w(3, wa);
-    step(1, wb); load_w(4, wb);
-    step(2, wc); load_w(5, wc);
-    step(3, wa);
-    step(4, wb);
-    step(5, wc);
+    pre768_gemm(p.pre_x, p.pre_w, m0, a.rows, smem, dtile);
     proj32_prefetch(p.w, p.Cout, wave, lane, W);
-#pragma unroll
-    for (int i = 0; i < NF; ++i)
-#pragma unroll
-      for (int cc = 0; cc < CT; ++cc) *(f32x4*)(dtile + (i * 16 + l15) * DT_LD + (wave * CT + cc) * 16 + q * 4) = acc[cc][i];
-    __syncthreads();                       // dtile complete; every wave is done with the dqkv rows (red / xs / os may be written)
   }
   {
     const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
@@ -863,6 +901,17 @@ extern "C" int ttsk_layernorm_bwd_proj(const void* dout, const float* slabs, int
     if (Cout == 256) hipLaunchKernelGGL((ln_bwd256_proj_kernel<1, false>), grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((ln_bwd256_proj_kernel<4, false>), grid, block, 0, (hipStream_t)stream, p);
   }
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_qkv_dx(const void* dqkv_bf16, const void* w_packed, const void* R_bf16, void* out_bf16, int rows, int K, int D,
+                           void* stream) {
+  TTSK_REQUIRE(dqkv_bf16 && w_packed && out_bf16 && rows > 0, "ttsk_qkv_dx: null pointer");
+  TTSK_REQUIRE(K == 768 && D == 256, "ttsk_qkv_dx: built for a 768-wide contraction and 256 output channels (got %d, %d)", K, D);
+  TTSK_REQUIRE((((uintptr_t)dqkv_bf16 | (uintptr_t)w_packed | (uintptr_t)R_bf16 | (uintptr_t)out_bf16) & 15) == 0, "ttsk_qkv_dx: 16-byte alignment");
+  hipLaunchKernelGGL(pre768_kernel, dim3((rows + 31) / 32), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, (const bf16_t*)dqkv_bf16,
+                     (const bf16_t*)w_packed, (const bf16_t*)R_bf16, (bf16_t*)out_bf16, rows);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

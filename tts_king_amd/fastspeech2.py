@@ -970,6 +970,9 @@ class FastSpeech2(nn.Module):
             if pkq is not None:
                 return (ops.win_conv_split(dqkv.view(Bn, S, 3 * d), pkq, d, 1), dz1)
             return (ops.linear_dx(dqkv, self._w(a + "w_qs.weight", 3 * d), raw=True), dz1)
+        pkq = self._w1_packed.get(("qkvT", a + "w_qs.weight")) if (self.window_ffn and self._w1_packed and self.fused_qkv_dx) else None
+        if pkq is not None and d == 256 and dqkv.shape[1] == 768:
+            return ops.qkv_dx(dqkv, pkq, R=dz1)       # the first block of the stack: the same 32-row product as a kernel of its own
         return ops.linear_dx(dqkv, self._w(a + "w_qs.weight", 3 * d), R=dz1)
 
     def _predictor_bwd(self, pre, saved, dout, rng, R):

@@ -641,6 +641,15 @@ def layernorm_bwd_proj(dout, z, mean, rstd, gamma, packed, Cout, lens=None, seg_
     return dz, (dy if dy is not None else dz), partials, nblk, out
 
 
+def qkv_dx(dqkv, packed, R=None):
+    """dqkv (rows, 768) bf16 x the packed transposed q|k|v weight (+ R) -> (rows, 256) bf16 (ttsk_qkv_dx)."""
+    _dev(dqkv, packed, R)
+    rows, K = dqkv.shape
+    out = torch.empty(rows, 256, dtype=bf16, device=dqkv.device)
+    check(L.load().ttsk_qkv_dx(_ptr(dqkv), _ptr(packed), _ptr(R), _ptr(out), rows, K, 256, _stream()), "ttsk_qkv_dx")
+    return out
+
+
 def layernorm_fwd_grouped(y, gamma, beta, groups, param_stride, site_stride, lens=None, seg_len=0, p_post=0.0, site_post=0, rng=None,
                           head=None, want_out=True, eps=1e-5):
     """`groups` independent LayerNorm tails in one launch (the three VariancePredictors): y (groups*group_rows, D) bf16; group g

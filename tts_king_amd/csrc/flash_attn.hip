@@ -17,6 +17,7 @@
 // Fragment / LDS idioms (XOR-swizzled row-major images, ds_read_b64_tr_b16 images for operands whose contraction index is the
 // memory row) are those of attn.hip (attn_common.h).  Two workgroups fit a CU (<= 80 KB of LDS each).
 #include "attn_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -32,17 +33,36 @@ struct FlashArgs {
   const long long* lens;  // [B] valid keys per utterance (null = S)
   int S, H, d;
   float scale;
+  int plain_order;        // 1 = (blockIdx.x, blockIdx.y) as launched (diagnostic: TTSK_FLASH_XCD=0); 0 = xcd_tile's mapping
 };
 
 constexpr int STAGE_KV = KS_BYTES + VS_BYTES;            // one K tile (row-major image) + one V tile (contraction-major image)
 
 // ------------------------------------------------------------------------------------------------------------ forward
+// Workgroup -> (tile, batch*head) with the tiles of one (batch, head) on ONE XCD: consecutive workgroup ids go round the 8 XCDs, each
+// with an L2 of its own, so the plain (blockIdx.x, blockIdx.y) order spreads the query tiles that share a head's K / V (or the key
+// tiles that share its Q / dO) over all eight and every one of them fetches its own copy from memory.  Bijective when the number of
+// (batch, head) pairs is a multiple of 8; otherwise the plain order.
+__device__ __forceinline__ void xcd_tile(int& tile, int& z, int plain) {
+  const int nx = gridDim.x, ny = gridDim.y;
+  tile = blockIdx.x;
+  z = blockIdx.y;
+  if ((ny & 7) == 0 && !plain) {
+    const int L = blockIdx.x + nx * blockIdx.y;
+    const int xcd = L & 7, slot = L >> 3;
+    z = (slot / nx) * 8 + xcd;
+    tile = slot - (slot / nx) * nx;
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const FlashArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_KV + PS_BYTES];      // 73,728 B
   unsigned char* Ps = smem + 2 * STAGE_KV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
-  const int q0 = blockIdx.x * TQ;
+  int tile_x, z;
+  xcd_tile(tile_x, z, a.plain_order);
+  const int b = z / a.H, h = z - b * a.H;
+  const int q0 = tile_x * TQ;
   const int S = a.S, ld = 3 * a.d;
   const int len = a.lens ? min((int)a.lens[b], S) : S;
   const int ntk = (len + TK - 1) / TK;                       // key tiles that hold at least one valid key
@@ -168,8 +188,10 @@ __device__ __forceinline__ void flash_bwd_q_body(const FlashArgs& a, unsigned ch
   unsigned char* Vr = Kt + VS_BYTES;                 // V tile, row-major image  (B operand of dP = dO V^T)
   unsigned char* Ss = Vr + KS_BYTES;                 // per-wave dS tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
-  const int q0 = blockIdx.x * TQ;
+  int tile_x, z;
+  xcd_tile(tile_x, z, a.plain_order);
+  const int b = z / a.H, h = z - b * a.H;
+  const int q0 = tile_x * TQ;
   const int S = a.S, ld = 3 * a.d;
   const int len = a.lens ? min((int)a.lens[b], S) : S;
   const int ntk = (len + TK - 1) / TK;
@@ -264,8 +286,10 @@ __device__ __forceinline__ void flash_bwd_kv_body(const FlashArgs& a, unsigned c
   unsigned char* Dt = Qt + VS_BYTES;                 // dO tile, contraction-major image  (B operand of dV += P^T dO)
   unsigned char* Ps = Dt + VS_BYTES;                 // per-wave P^T, then dS^T tile [16 keys][64 queries]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
-  const int k0 = blockIdx.x * TK;
+  int tile_x, z;
+  xcd_tile(tile_x, z, a.plain_order);
+  const int b = z / a.H, h = z - b * a.H;
+  const int k0 = tile_x * TK;
   const int S = a.S, ld = 3 * a.d;
   const int len = a.lens ? min((int)a.lens[b], S) : S;
   const bf16_t* base = a.qkv + (int64_t)b * S * ld + h * DK;
@@ -414,12 +438,18 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashArgs a) {
 
 }  // namespace
 
+static int flash_plain_order() {
+  static const int v = [] { const char* e = getenv("TTSK_FLASH_XCD"); return (e && atoi(e) == 0) ? 1 : 0; }();
+  return v;
+}
+
 extern "C" int ttsk_flash_attention_fwd(const void* qkv_bf16, void* o_bf16, float* o_f32, float* lse, const int64_t* lens, int B, int H,
                                         int S, int d, float scale, void* stream) {
   TTSK_REQUIRE(qkv_bf16 && o_bf16, "flash_attention_fwd: null pointer");
   TTSK_REQUIRE(B > 0 && H > 0 && S > 0 && d == H * DK, "flash_attention_fwd: head size must be 128 (d = %d, H = %d)", d, H);
   TTSK_REQUIRE(B * H <= 65535 && (int64_t)S * 3 * d * 2 < ((int64_t)1 << 31), "flash_attention_fwd: sizes out of range");
   FlashArgs a{(const bf16_t*)qkv_bf16, (bf16_t*)o_bf16, o_f32, lse, nullptr, nullptr, nullptr, (const long long*)lens, S, H, d, scale};
+  a.plain_order = flash_plain_order();
   hipLaunchKernelGGL(flash_fwd_kernel, dim3((S + TQ - 1) / TQ, B * H), dim3(256), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
@@ -433,6 +463,7 @@ extern "C" int ttsk_flash_attention_bwd(const void* qkv_bf16, const void* o_bf16
   TTSK_REQUIRE(B * H <= 65535 && (int64_t)S * 3 * d * 2 < ((int64_t)1 << 31), "flash_attention_bwd: sizes out of range");
   FlashArgs a{(const bf16_t*)qkv_bf16, (bf16_t*)o_bf16, (float*)o_f32, (float*)lse, (const bf16_t*)dout_bf16, delta_ws, (bf16_t*)dqkv_bf16,
               (const long long*)lens, S, H, d, scale};
+  a.plain_order = flash_plain_order();
   if (!delta_ready) hipLaunchKernelGGL(flash_delta_kernel, dim3((S + 15) / 16, B * H), dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(flash_bwd_kernel, dim3((S + TQ - 1) / TQ, B * H, 2), dim3(256), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();

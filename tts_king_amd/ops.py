@@ -92,7 +92,9 @@ def flush_group(descs, keep, max_wgs=0, upload_only=False):
         table = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # filled by group_launch through kernel arguments
         if upload_only:
             check(lib.ttsk_gemm_group_upload(host, C.c_void_p(table.data_ptr()), _stream()), "ttsk_gemm_group_upload")
-            pending.append((host, table))
+            fl = sum(2.0 * d.M * d.N * d.K * max(d.taps, 1) * d.nz1 * d.nz2 for d in ds)
+            kind = ("TT" if ds[0].flags & A_TR else ("NT_btr" if ds[0].flags & B_TR else "NT")) + "%dg" % ds[0].kernel
+            pending.append((host, table, fl, kind, (n, 0, 0, 1, 1, int(total.value))))
             keep.append(table)
             if LAUNCH_COUNTS is not None:
                 LAUNCH_COUNTS["grouped_gemm"] = LAUNCH_COUNTS.get("grouped_gemm", 0) + 1
@@ -112,8 +114,14 @@ def flush_group(descs, keep, max_wgs=0, upload_only=False):
     descs.clear()
     if upload_only:
         def launch():
-            for host, table in pending:
+            for host, table, fl, kind, shape in pending:
+                if GEMM_TRACE is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 check(lib.ttsk_gemm_group_launch_uploaded(host, C.c_void_p(table.data_ptr()), int(max_wgs), _stream()), "ttsk_gemm_group_launch_uploaded")
+                if GEMM_TRACE is not None:
+                    e1.record()
+                    GEMM_TRACE.append((e0, e1, fl, kind, shape))
         return launch
 
 

@@ -466,16 +466,15 @@ __device__ __forceinline__ void pre768_gemm(const bf16_t* __restrict__ pre_x, co
 #pragma unroll
   for (int cc = 0; cc < CT; ++cc) wrow[cc] = pre_w + ((int64_t)(wave * CT + cc) * 64 + lane) * 8;
   constexpr int64_t kstep_stride = (D / 16) * 512;
-  bf16x8 wa[KH][CT], wb[KH][CT], wc[KH][CT];
-  auto load_w = [&](int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
+  // all six steps' fragments are requested up front (192 VGPRs: nothing else is live yet): the contraction is 96 MFMAs per wave, so
+  // with three sets in flight its time was three L2 round trips per two steps
+  bf16x8 wv[NS][KH][CT];
+#pragma unroll
+  for (int g = 0; g < NS; ++g)
 #pragma unroll
     for (int ks = 0; ks < KH; ++ks)
 #pragma unroll
-      for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(wrow[cc] + (int64_t)(g * KH + ks) * kstep_stride);
-  };
-  load_w(0, wa);
-  load_w(1, wb);
-  load_w(2, wc);
+      for (int cc = 0; cc < CT; ++cc) wv[g][ks][cc] = *(const bf16x8*)(wrow[cc] + (int64_t)(g * KH + ks) * kstep_stride);
   {
     constexpr int NCH = P32_TT * CH8 / P32_NT;         // 6 chunks of 16 bytes per thread
     uint4 xv[NCH];
@@ -510,13 +509,8 @@ __device__ __forceinline__ void pre768_gemm(const bf16_t* __restrict__ pre_x, co
       }
     }
   };
-  static_assert(NS == 6, "two rounds of the three register sets");
-  step(0, wa); load_w(3, wa);
-  step(1, wb); load_w(4, wb);
-  step(2, wc); load_w(5, wc);
-  step(3, wa);
-  step(4, wb);
-  step(5, wc);
+#pragma unroll
+  for (int g = 0; g < NS; ++g) step(g, wv[g]);
 #pragma unroll
   for (int i = 0; i < NF; ++i)
 #pragma unroll

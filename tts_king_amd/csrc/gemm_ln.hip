@@ -334,7 +334,7 @@ __global__ __launch_bounds__(512, (CIN == 256 && !PROJ) ? 2 : 1) void win_ln_ker
   ln_rows_epilogue<RW>(a, cs, m0, wave, lane, resv, PROJ ? ptile : nullptr);
   if (PROJ) {
     __syncthreads();
-    proj32_run<3>(ptile, ptile + P32_TT * P32_RS, a.pw, a.pCout, a.pbias, PW, tid, [&](int cg, int rr, int ch, uint4 v) __attribute__((always_inline)) {
+    proj32_run<3>(ptile, ptile + P32_TT * P32_RS, a.pw, a.pCout, a.pbias, PW, tid, [&](int cg, int rr, int ch, uint4 v, int) __attribute__((always_inline)) {
       if (m0 + rr < M) *(uint4*)(a.pout + (int64_t)(m0 + rr) * a.pCout + cg * BN + ch * 8) = v;
     });
   }

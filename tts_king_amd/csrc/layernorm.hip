@@ -405,16 +405,24 @@ __device__ __forceinline__ void lnb256_row(const LnBwdArgs& a, int row, int c0, 
   }
 }
 
+// v summed over the wave's four 16-lane rows (lanes l, l+16, l+32, l+48), the total in every one of them, as (row0 + row1) + (row2 +
+// row3): gfx950's v_permlane16_swap / v_permlane32_swap exchange rows between two registers on the VALU.  The 96 ds_bpermute
+// (__shfl_xor 16, 32) they replace went through the LDS crossbar of all eight waves at once: 3.1 us of a 23 us workgroup
+// (tools/debug/lnb_stamps.py).
+__device__ __forceinline__ float rows4_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);       // r[0] rows (0,0,2,2), r[1] rows (1,1,3,3)
+  const unsigned w = __float_as_uint(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+  const auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);       // q[0] = lower half twice, q[1] = upper half twice
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
 // the four row groups of a wave, then the waves, in a fixed order (deterministic) -> partials[blockIdx.x][dbias | dgamma | dbeta]
 __device__ __forceinline__ void lnb256_partials(const LnBwdArgs& a, float sbias[16], float sgam[16], float sbeta[16], float (*red)[3 * 256],
                                                 int wave, int grp, int c0) {
   constexpr int D = 256;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    sbias[e] += __shfl_xor(sbias[e], 16, 64); sbias[e] += __shfl_xor(sbias[e], 32, 64);
-    sgam[e] += __shfl_xor(sgam[e], 16, 64); sgam[e] += __shfl_xor(sgam[e], 32, 64);
-    sbeta[e] += __shfl_xor(sbeta[e], 16, 64); sbeta[e] += __shfl_xor(sbeta[e], 32, 64);
-  }
+  for (int e = 0; e < 16; ++e) { sbias[e] = rows4_sum(sbias[e]); sgam[e] = rows4_sum(sgam[e]); sbeta[e] = rows4_sum(sbeta[e]); }
   if (grp == 0) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) { red[wave][c0 + e] = sbias[e]; red[wave][D + c0 + e] = sgam[e]; red[wave][2 * D + c0 + e] = sbeta[e]; }
@@ -466,8 +474,17 @@ __device__ __forceinline__ void pre768_gemm(const bf16_t* __restrict__ pre_x, co
 #pragma unroll
   for (int cc = 0; cc < CT; ++cc) wrow[cc] = pre_w + ((int64_t)(wave * CT + cc) * 64 + lane) * 8;
   constexpr int64_t kstep_stride = (D / 16) * 512;
-  // all six steps' fragments are requested up front (192 VGPRs: nothing else is live yet): the contraction is 96 MFMAs per wave, so
-  // with three sets in flight its time was three L2 round trips per two steps
+  // The rows of x are requested FIRST (loads return in order: behind the 48 KiB of weight fragments a wave asks for they would arrive
+  // last, and the LDS image — hence every MFMA — waits for them), then all six steps' fragments up front (192 VGPRs: nothing else is
+  // live yet; with three sets in flight the contraction, 96 MFMAs per wave, took three L2 round trips per two steps).
+  constexpr int NCH = P32_TT * CH8 / P32_NT;         // 6 chunks of 16 bytes per thread
+  uint4 xv[NCH];
+#pragma unroll
+  for (int it = 0; it < NCH; ++it) {
+    const int idx = it * P32_NT + tid, row = idx / CH8, ch = idx - row * CH8;
+    xv[it] = make_uint4(0, 0, 0, 0);
+    if (m0 + row < rows) xv[it] = *(const uint4*)(pre_x + (int64_t)(m0 + row) * PK + ch * 8);
+  }
   bf16x8 wv[NS][KH][CT];
 #pragma unroll
   for (int g = 0; g < NS; ++g)
@@ -475,20 +492,10 @@ __device__ __forceinline__ void pre768_gemm(const bf16_t* __restrict__ pre_x, co
     for (int ks = 0; ks < KH; ++ks)
 #pragma unroll
       for (int cc = 0; cc < CT; ++cc) wv[g][ks][cc] = *(const bf16x8*)(wrow[cc] + (int64_t)(g * KH + ks) * kstep_stride);
-  {
-    constexpr int NCH = P32_TT * CH8 / P32_NT;         // 6 chunks of 16 bytes per thread
-    uint4 xv[NCH];
 #pragma unroll
-    for (int it = 0; it < NCH; ++it) {
-      const int idx = it * P32_NT + tid, row = idx / CH8, ch = idx - row * CH8;
-      xv[it] = make_uint4(0, 0, 0, 0);
-      if (m0 + row < rows) xv[it] = *(const uint4*)(pre_x + (int64_t)(m0 + row) * PK + ch * 8);
-    }
-#pragma unroll
-    for (int it = 0; it < NCH; ++it) {
-      const int idx = it * P32_NT + tid, row = idx / CH8, ch = idx - row * CH8;
-      *(uint4*)(as + row * PRS + ch * 16) = xv[it];
-    }
+  for (int it = 0; it < NCH; ++it) {
+    const int idx = it * P32_NT + tid, row = idx / CH8, ch = idx - row * CH8;
+    *(uint4*)(as + row * PRS + ch * 16) = xv[it];
   }
   __syncthreads();
   f32x4 acc[CT][NF];
@@ -565,7 +572,12 @@ struct LnbProjArgs {
   // here for the workgroup's 32 rows (fp32, straight into LDS) instead of by a launch of its own that leaves fp32 slabs in memory.
   const bf16_t* pre_x;
   const bf16_t* pre_w;
+  unsigned long long* stamps;   // diagnostic (ttsk_layernorm_bwd_proj_set_stamps): 8 x s_memrealtime per workgroup, null in the product path
 };
+#define LNB_STAMP(i)                                                                                   \
+  do {                                                                                                 \
+    if (p.stamps && threadIdx.x == 0) p.stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 
 template <int NG, bool PRE>
 __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const LnbProjArgs p) {
@@ -584,11 +596,13 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const
   const int grp = lane >> 4, l = lane & 15, c0 = l * 16;
   const int m0 = blockIdx.x * P32_TT;
   Proj32W W;
+  LNB_STAMP(0);
   if (!PRE) proj32_prefetch(p.w, p.Cout, wave, lane, W);          // this wave's weight fragments of group 0, requested before the rows
   if (PRE) {
     pre768_gemm(p.pre_x, p.pre_w, m0, a.rows, smem, dtile);
     proj32_prefetch(p.w, p.Cout, wave, lane, W);
   }
+  LNB_STAMP(1);
   {
     const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
     const unsigned thr = keep_threshold(a.p_pre);
@@ -603,14 +617,26 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const
     lnb256_row(a, m0 + rl, c0, gam, seed, step, thr, dscale, sbias, sgam, sbeta, dzv, PRE ? dtile + rl * DT_LD : nullptr);
     *(uint4*)(xs + rl * P32_RS + c0 * 2) = pack8f(dzv);
     *(uint4*)(xs + rl * P32_RS + c0 * 2 + 16) = pack8f(dzv + 8);
+    LNB_STAMP(2);
     lnb256_partials(a, sbias, sgam, sbeta, red, wave, grp, c0);        // (its barrier also publishes xs)
+    LNB_STAMP(3);
   }
-  proj32_run<NG>(xs, os, p.w, p.Cout, nullptr, W, tid, [&](int cg, int rr, int ch, uint4 v) __attribute__((always_inline)) {
+  uint4 gpre[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};       // the group's gate chunks (w_2's saved ReLU output, cold in HBM)
+  auto pre = [&](int cg) __attribute__((always_inline)) {                   // requested when the group starts (proj32_run)
+    if (p.gate) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int idx = it * P32_NT + tid, rr = idx >> 5, ch = idx & 31;
+        if (m0 + rr < a.rows) gpre[it] = *(const uint4*)(p.gate + (int64_t)(m0 + rr) * p.Cout + cg * D + ch * 8);
+      }
+    }
+  };
+  proj32_run<NG>(xs, os, p.w, p.Cout, nullptr, W, tid, [&](int cg, int rr, int ch, uint4 v, int it) __attribute__((always_inline)) {
     const int row = m0 + rr;
     float dacc = 0.f;
     if (row < a.rows) {
       if (p.gate) {
-        const uint4 gt = *(const uint4*)(p.gate + (int64_t)row * p.Cout + cg * D + ch * 8);
+        const uint4 gt = gpre[it];
         auto keep = [](unsigned w) {      // 0xFFFF per bf16 half that is > 0 (sign clear, not zero)
           const unsigned lo = w & 0xFFFFu, hi = w >> 16;
           return ((lo - 1u) < 0x7FFFu ? 0xFFFFu : 0u) | ((hi - 1u) < 0x7FFFu ? 0xFFFF0000u : 0u);
@@ -633,7 +659,8 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const
         p.delta[((int64_t)b * 2 + (ch >> 4)) * a.seg_len + t] = dacc;
       }
     }
-  });
+  }, pre);
+  LNB_STAMP(4);
 }
 
 // dst[c] (+)= scale * sum_b partials[b][c].  32 columns x 8 row-groups per workgroup; every thread adds its rows in
@@ -861,6 +888,14 @@ extern "C" int ttsk_layernorm_bwd_slabs(const float* slabs, int nsplit, int64_t 
   return TTSK_OK;
 }
 
+static unsigned long long* g_lnb_stamps = nullptr;
+// diagnostic only (tools/debug/lnb_stamps.py; not declared in ttsk.h): device buffer of 8 x uint64 per workgroup for the launches that
+// follow; null switches the stamps off again
+extern "C" int ttsk_layernorm_bwd_proj_set_stamps(void* dev_buffer) {
+  g_lnb_stamps = (unsigned long long*)dev_buffer;
+  return TTSK_OK;
+}
+
 extern "C" int ttsk_layernorm_bwd_proj_nblocks(int rows) { return (rows + 31) / 32; }
 
 extern "C" int ttsk_layernorm_bwd_proj(const void* dout, const float* slabs, int nsplit, int64_t slab_stride, const void* R, const void* z,
@@ -886,7 +921,7 @@ extern "C" int ttsk_layernorm_bwd_proj(const void* dout, const float* slabs, int
                  (bf16_t*)dz, (bf16_t*)dy, partials, rows, D, seg_len > 0 ? seg_len : 1, 0, p_pre, 0.f, site_pre, 0, 0, nblk, 0, 0,
                  slabs, (const bf16_t*)R, (long long)slab_stride, nsplit},
                 (const bf16_t*)w_packed, (bf16_t*)out, (const bf16_t*)gate, delta_o32, delta_out, Cout, (const bf16_t*)pre_x,
-                (const bf16_t*)pre_w_packed};
+                (const bf16_t*)pre_w_packed, g_lnb_stamps};
   const dim3 grid(nblk), block(LNB_WAVES * 64);
   if (pre_x) {
     if (Cout == 256) hipLaunchKernelGGL((ln_bwd256_proj_kernel<1, true>), grid, block, 0, (hipStream_t)stream, p);

@@ -4,7 +4,7 @@
 //
 // Operands: 32 rows x 256 channels bf16 in LDS (`xs`, row stride P32_RS: the B operand, D[cout][row] orientation) and the packed
 // weight of ttsk_win_conv for K = 1, [8 k-steps][Cout/16][64 lanes][8], streamed L2 -> registers: each of the 8 waves owns 32 output
-// channels of a 256-channel group, NG groups one after the other, the next group's fragments requested while this one computes.
+// channels of a 256-channel group, NG groups one after the other, the next group's fragments requested when this one starts.
 // Same k-step order as win_conv_kernel<256, ...>: bit-identical results.
 #pragma once
 #include "common.h"
@@ -29,16 +29,31 @@ __device__ __forceinline__ void proj32_prefetch(const bf16_t* __restrict__ w, in
 }
 
 // xs must be visible to the workgroup (a barrier behind its writers) and W prefetched.  bias: fp32 [Cout] or null.  Every thread calls
-// epi(cg, rr, ch, v) for its 16-byte chunks (row rr of the tile, chunk ch of the group's 32; v = 8 bf16 outputs) — twice per group —
+// epi(cg, rr, ch, v, it) for its 16-byte chunks (row rr of the tile, chunk ch of the group's 32; v = 8 bf16 outputs; it = 0, 1: the
+// thread's first / second chunk of the group: idx = it * 512 + tid, rr = idx / 32, ch = idx % 32) — twice per group —
 // including rows that do not exist: the caller checks and stores.  `os`: 32 x P32_RS bytes of LDS for the staging tile.
-template <int NG, class Epi>
+struct Proj32NoPre { __device__ __forceinline__ void operator()(int) const {} };
+
+// `pre(cg)` runs at the start of group cg, before anything else of the group is requested: the place to ask for what epi(cg, ...)
+// will need from memory (a gate) — loads return in order, so it must go out before the next group's weight fragments, and it then has
+// the group's contraction and staging to arrive instead of standing between the staging barrier and the stores.
+template <int NG, class Epi, class Pre = Proj32NoPre>
 __device__ __forceinline__ void proj32_run(const unsigned char* xs, unsigned char* os, const bf16_t* __restrict__ w, int Cout,
-                                           const float* __restrict__ bias, Proj32W& W, int tid, Epi&& epi) {
+                                           const float* __restrict__ bias, Proj32W& W, int tid, Epi&& epi, Pre&& pre = Pre()) {
   constexpr int NF = P32_TT / 16;
   const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
   const unsigned char* inl = xs + l15 * P32_RS + q * 16;
-#pragma unroll 1
+  Proj32W V;                                     // the other register pair: group cg + 1 is requested when group cg STARTS, so it has
+                                                 // the whole group (contraction, staging, barrier, stores: ~2 us) to arrive, not just its tail
+#pragma unroll
   for (int cg = 0; cg < NG; ++cg) {
+    Proj32W& cur = (cg & 1) ? V : W;
+    Proj32W& nxt = (cg & 1) ? W : V;
+    pre(cg);
+    if (cg + 1 < NG) {
+      proj32_load(w, Cout, cg + 1, 0, wave, lane, nxt.a);
+      proj32_load(w, Cout, cg + 1, 1, wave, lane, nxt.b);
+    }
     f32x4 acc[P32_CT][NF];
 #pragma unroll
     for (int cc = 0; cc < P32_CT; ++cc)
@@ -56,10 +71,8 @@ __device__ __forceinline__ void proj32_run(const unsigned char* xs, unsigned cha
         }
       }
     };
-    step(0, W.a);
-    if (cg + 1 < NG) proj32_load(w, Cout, cg + 1, 0, wave, lane, W.a);
-    step(1, W.b);
-    if (cg + 1 < NG) proj32_load(w, Cout, cg + 1, 1, wave, lane, W.b);
+    step(0, cur.a);
+    step(1, cur.b);
     // this group's 32 x 256 outputs through LDS: 16-byte stores of whole rows
 #pragma unroll
     for (int cc = 0; cc < P32_CT; ++cc) {
@@ -79,8 +92,9 @@ __device__ __forceinline__ void proj32_run(const unsigned char* xs, unsigned cha
       const int idx = it * P32_NT + tid;
       const int rr = idx / OCH, ch = idx - rr * OCH;
       const uint4 v = *(const uint4*)(os + rr * P32_RS + ch * 16);
-      epi(cg, rr, ch, v);
+      epi(cg, rr, ch, v, it);
     }
     if (cg + 1 < NG) __syncthreads();          // the next group overwrites the staging rows
   }
 }
+

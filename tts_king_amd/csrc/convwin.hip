@@ -63,8 +63,6 @@ __global__ __launch_bounds__(C2_NT, OCC) void conv_window2_kernel(const CwArgs a
 #pragma unroll
       for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(src + (ks * NC + cc) * 1024);
   };
-  load_w(0, wa);
-  if (K > 1) load_w(1, wb);
 
   // ---- activation window, all loads in flight together
   {
@@ -78,6 +76,9 @@ __global__ __launch_bounds__(C2_NT, OCC) void conv_window2_kernel(const CwArgs a
       xv[it] = make_uint4(0, 0, 0, 0);
       if (idx < C2_LROWS * CH8 && t >= 0 && t < len) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
     }
+    // the weight fragments are requested BEHIND the window: loads return in order, and nothing starts before the window is in LDS
+    load_w(0, wa);
+    if (K > 1) load_w(1, wb);
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
       const int idx = it * NT + tid;
@@ -217,8 +218,6 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
       for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(src + (ks * NC + cc) * 1024);
   };
   TTSK_STAMP(0);
-  load_w(0, wa);
-  load_w(1, wb);
 
   {  // ---- x window: lrelu(x) rows t0 - 33 .. t0 + 129, zeros outside the utterance
     constexpr int NCH = (CP_XROWS * CH8 + NT - 1) / NT;     // 11
@@ -231,6 +230,9 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
       xv[it] = make_uint4(0, 0, 0, 0);
       if (idx < CP_XROWS * CH8 && t >= 0 && t < len) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
     }
+    // the weight fragments are requested BEHIND the window: loads return in order, and nothing starts before the window is in LDS
+    load_w(0, wa);
+    load_w(1, wb);
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
       const int idx = it * NT + tid;
@@ -421,8 +423,6 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
 #pragma unroll
       for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(src + (ks * NC + cc) * 1024);
   };
-  load_w(0, wa);
-  load_w(1, wb);
 
   {  // ---- x window: lrelu(x) rows t0 - 33 .. t0 + 129, zeros outside the utterance
     constexpr int NCH = (CP_XROWS * CH8 + NT - 1) / NT;     // 11
@@ -435,6 +435,9 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
       xv[it] = make_uint4(0, 0, 0, 0);
       if (idx < CP_XROWS * CH8 && t >= 0 && t < len) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
     }
+    // the weight fragments are requested BEHIND the window: loads return in order, and nothing starts before the window is in LDS
+    load_w(0, wa);
+    load_w(1, wb);
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
       const int idx = it * NT + tid;
@@ -621,8 +624,6 @@ __global__ __launch_bounds__(256, 2) void conv_pair_fs_kernel(const PairArgs a) 
 #pragma unroll
       for (int c = 0; c < CT; ++c) w[ks][c] = *(const bf16x8*)(src + (ks * NC + c) * 1024);
   };
-  load_w(0, wa);
-  load_w(1, wb);
 
   {  // ---- x window: lrelu(x) rows t0 - 33 .. t0 + 209, zeros outside the utterance
     constexpr int NCH = (XROWS * CH8 + NT - 1) / NT;
@@ -635,6 +636,9 @@ __global__ __launch_bounds__(256, 2) void conv_pair_fs_kernel(const PairArgs a) 
       xv[it] = make_uint4(0, 0, 0, 0);
       if (idx < XROWS * CH8 && t >= 0 && t < len) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
     }
+    // the weight fragments are requested BEHIND the window: loads return in order, and nothing starts before the window is in LDS
+    load_w(0, wa);
+    load_w(1, wb);
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
       const int idx = it * NT + tid;

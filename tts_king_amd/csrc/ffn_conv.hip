@@ -19,6 +19,9 @@
 
 namespace {
 
+#ifndef WC_XFIRST
+#define WC_XFIRST 1
+#endif
 constexpr int WC_H = 4, WC_NW = 8, WC_NT = WC_NW * 64, WC_KH = 4, WC_CT = 2, WC_COUT = WC_NW * WC_CT * 16;   // 256 output channels per workgroup
 
 struct WcArgs {
@@ -194,11 +197,15 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
         for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(wrow[cc] + off + ks * 32);
     }
   };
+#if !WC_XFIRST
   load_w(0, wa);
   if (1 < NS) load_w(1, wb);
   if (2 < NS) load_w(2, wc);
+#endif
 
-  {  // ---- activation window: rows t0 - 4 .. t0 + TT + 4 of the utterance, zeros outside it (the conv's zero padding)
+  {  // ---- activation window: rows t0 - 4 .. t0 + TT + 4 of the utterance, zeros outside it (the conv's zero padding).
+     // Requested BEFORE the weight fragments: loads return in order, nothing starts before the window is in LDS, and behind three
+     // register sets of fragments (24 KiB per wave) it would arrive last.
     constexpr int NCH = (XROWS * CH8 + NT - 1) / NT;
     uint4 xv[NCH];
 #pragma unroll
@@ -209,6 +216,11 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
       xv[it] = make_uint4(0, 0, 0, 0);
       if (idx < XROWS * CH8 && t >= 0 && t < S) xv[it] = *(const uint4*)(xb + (int64_t)t * ldx + ch * 8);
     }
+#if WC_XFIRST
+    load_w(0, wa);
+    if (1 < NS) load_w(1, wb);
+    if (2 < NS) load_w(2, wc);
+#endif
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
       const int idx = it * NT + tid;

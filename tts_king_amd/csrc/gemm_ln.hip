@@ -251,12 +251,6 @@ __global__ __launch_bounds__(512, (CIN == 256 && !PROJ) ? 2 : 1) void win_ln_ker
   const int l15 = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.x * BM;
   const int M = a.M;
-  uint2 resv[RW];
-#pragma unroll
-  for (int rr = 0; rr < RW; ++rr) {
-    const int row = m0 + wave * RW + rr;
-    resv[rr] = (a.res && row < M) ? *(const uint2*)(a.res + (int64_t)row * BN + lane * 4) : make_uint2(0u, 0u);
-  }
   const bf16_t* wrow[CT];
 #pragma unroll
   for (int cc = 0; cc < CT; ++cc) wrow[cc] = a.W + ((int64_t)(wave * CT + cc) * 64 + lane) * 8;
@@ -268,10 +262,10 @@ __global__ __launch_bounds__(512, (CIN == 256 && !PROJ) ? 2 : 1) void win_ln_ker
 #pragma unroll
       for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(wrow[cc] + (int64_t)(g * KH + ks) * kstep_stride);
   };
-  load_w(0, wa);
-  if (1 < NS) load_w(1, wb);
-  if (2 < NS) load_w(2, wc);
+  uint2 resv[RW];
   {
+    // request order = arrival order: the rows of A (nothing starts before they are in LDS), the first three steps' weight fragments,
+    // the residual rows (read in the epilogue)
     constexpr int NCH = (TT * CH8 + NT - 1) / NT;
     uint4 xv[NCH];
 #pragma unroll
@@ -280,6 +274,14 @@ __global__ __launch_bounds__(512, (CIN == 256 && !PROJ) ? 2 : 1) void win_ln_ker
       const int row = idx / CH8, ch = idx - row * CH8;
       xv[it] = make_uint4(0, 0, 0, 0);
       if (idx < TT * CH8 && m0 + row < M) xv[it] = *(const uint4*)(a.A + (int64_t)(m0 + row) * a.lda + ch * 8);
+    }
+    load_w(0, wa);
+    if (1 < NS) load_w(1, wb);
+    if (2 < NS) load_w(2, wc);
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+      const int row = m0 + wave * RW + rr;
+      resv[rr] = (a.res && row < M) ? *(const uint2*)(a.res + (int64_t)row * BN + lane * 4) : make_uint2(0u, 0u);
     }
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {

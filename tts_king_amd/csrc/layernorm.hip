@@ -597,11 +597,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const
   const int m0 = blockIdx.x * P32_TT;
   Proj32W W;
   LNB_STAMP(0);
-  if (!PRE) proj32_prefetch(p.w, p.Cout, wave, lane, W);          // this wave's weight fragments of group 0, requested before the rows
-  if (PRE) {
-    pre768_gemm(p.pre_x, p.pre_w, m0, a.rows, smem, dtile);
-    proj32_prefetch(p.w, p.Cout, wave, lane, W);
-  }
+  if (PRE) pre768_gemm(p.pre_x, p.pre_w, m0, a.rows, smem, dtile);
   LNB_STAMP(1);
   {
     const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
@@ -618,6 +614,9 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const
     *(uint4*)(xs + rl * P32_RS + c0 * 2) = pack8f(dzv);
     *(uint4*)(xs + rl * P32_RS + c0 * 2 + 16) = pack8f(dzv + 8);
     LNB_STAMP(2);
+    // group 0's weight fragments: requested behind the rows' own loads (loads return in order: in front of them they delayed every
+    // row), with the partial sums and their barrier (~3 us) to arrive
+    proj32_prefetch(p.w, p.Cout, wave, lane, W);
     lnb256_partials(a, sbias, sgam, sbeta, red, wave, grp, c0);        // (its barrier also publishes xs)
     LNB_STAMP(3);
   }

@@ -201,12 +201,13 @@ __device__ __forceinline__ void flash_bwd_q_body(const FlashArgs& a, unsigned ch
   unsigned char* Sw = Ss + wave * 16 * PS_RS;
 
   uint4 rk[4], rv[4];
-  if (ntk > 0) { load_tile(rk, base + a.d, ld, 0, S, tid); load_tile(rv, base + 2 * a.d, ld, 0, S, tid); }
-  // Q and dO fragments of this wave's 16 rows: through LDS once (Kr / Vr slots), then registers for the whole loop
+  // Q and dO fragments of this wave's 16 rows: through LDS once (Kr / Vr slots), then registers for the whole loop.  Requested before
+  // the first K / V tile (loads return in order; Q and dO are consumed first and do not wait for the utterance length).
   {
     uint4 rq[4], rd[4];
     load_tile(rq, base, ld, q0, S, tid);
     load_tile(rd, dob, a.d, q0, S, tid);
+    if (ntk > 0) { load_tile(rk, base + a.d, ld, 0, S, tid); load_tile(rv, base + 2 * a.d, ld, 0, S, tid); }
     store_rows(Kr, rq, tid);
     store_rows(Vr, rd, tid);
   }

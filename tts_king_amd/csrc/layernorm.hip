@@ -621,7 +621,20 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const
     LNB_STAMP(3);
   }
   uint4 gpre[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};       // the group's gate chunks (w_2's saved ReLU output, cold in HBM)
+  f32x4 ypre[2][2];                                                         // fc's dX: the o32 chunks of the delta sums, likewise
+#pragma unroll
+  for (int it = 0; it < 2; ++it) { ypre[it][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ypre[it][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   auto pre = [&](int cg) __attribute__((always_inline)) {                   // requested when the group starts (proj32_run)
+    if (NG == 1 && p.delta) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int idx = it * P32_NT + tid, rr = idx >> 5, ch = idx & 31;
+        if (m0 + rr < a.rows) {
+          const float* op = p.o32 + (int64_t)(m0 + rr) * D + ch * 8;
+          ypre[it][0] = *(const f32x4*)op; ypre[it][1] = *(const f32x4*)(op + 4);
+        }
+      }
+    }
     if (p.gate) {
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
@@ -644,8 +657,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const
       }
       *(uint4*)(p.out + (int64_t)row * p.Cout + cg * D + ch * 8) = v;
       if (NG == 1 && p.delta) {
-        const float* op = p.o32 + (int64_t)row * D + ch * 8;
-        const f32x4 y0 = *(const f32x4*)op, y1 = *(const f32x4*)(op + 4);
+        const f32x4 y0 = ypre[it][0], y1 = ypre[it][1];
         dacc = __uint_as_float(v.x << 16) * y0[0] + __uint_as_float(v.x & 0xFFFF0000u) * y0[1] + __uint_as_float(v.y << 16) * y0[2] +
                __uint_as_float(v.y & 0xFFFF0000u) * y0[3] + __uint_as_float(v.z << 16) * y1[0] + __uint_as_float(v.z & 0xFFFF0000u) * y1[1] +
                __uint_as_float(v.w << 16) * y1[2] + __uint_as_float(v.w & 0xFFFF0000u) * y1[3];

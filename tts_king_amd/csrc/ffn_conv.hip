@@ -22,7 +22,14 @@ namespace {
 #ifndef WC_XFIRST
 #define WC_XFIRST 1
 #endif
-constexpr int WC_H = 4, WC_NW = 8, WC_NT = WC_NW * 64, WC_KH = 4, WC_CT = 2, WC_COUT = WC_NW * WC_CT * 16;   // 256 output channels per workgroup
+#ifndef WC_WAVES
+#define WC_WAVES 8
+#endif
+// 256 output channels per workgroup: 8 waves x 32 channels (two MFMAs per activation fragment read, two waves per SIMD).  -DWC_WAVES=4
+// builds 4 waves x 64 (four MFMAs per fragment read, one wave per SIMD, accumulators in AGPRs): measured slower, 34.9 vs 31.5 us on
+// w_1's forward — the tap loop runs at the MFMA pipe's rate either way (tools/debug/wc_stamps.py), the prologue and epilogue have
+// half the threads.
+constexpr int WC_H = 4, WC_NW = WC_WAVES, WC_NT = WC_NW * 64, WC_KH = 4, WC_CT = 16 / WC_NW, WC_COUT = WC_NW * WC_CT * 16;
 
 struct WcArgs {
   const bf16_t* x;      // [B*S][CIN] bf16 (PAD rows are zeros)
@@ -47,7 +54,12 @@ struct WcArgs {
   // rows ttsk_bn_train_apply sums, one per (utterance, 64-frame tile), instead of a ttsk_bn_stats_slab launch over the stored rows
   float* stats;
   const int* frame_limit;
+  unsigned long long* stamps;   // diagnostic (ttsk_win_conv_set_stamps): 8 x s_memrealtime per workgroup, null in the product path
 };
+#define WC_STAMP(i)                                                                                              \
+  do {                                                                                                           \
+    if (a.stamps && threadIdx.x == 0) a.stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 
 // Weight packs.  src = storage (Cs, K, Ds) bf16 tap-major.
 //   transpose = 0: the conv's own weights, W'[co][tap][ci] = src[co][tap][ci]                   (Cout' = Cs, Cin' = Ds)
@@ -168,6 +180,7 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
     sp = cg % a.nsplit;            // group = (channel group, contraction split)
     cg = cg / a.nsplit;
   }
+  WC_STAMP(0);
   const int S = a.S, K = a.K, HK = (K - 1) / 2, NS = NP * K;       // NS steps: tap g / NP, 128-channel part g % NP
   const int ldx = a.ldx;
   const bf16_t* __restrict__ xb = a.x + (int64_t)bi * S * ldx + sp * C;
@@ -232,7 +245,9 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
 #pragma unroll
   for (int cc = 0; cc < CT; ++cc)
     bv[cc] = a.bias ? *(const f32x4*)(a.bias + cg * WC_COUT + (wave * CT + cc) * 16 + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  WC_STAMP(1);
   __syncthreads();
+  WC_STAMP(2);
 
   f32x4 acc[CT][NF];
 #pragma unroll
@@ -268,7 +283,9 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
       }
     }
   }
+  WC_STAMP(3);
   __syncthreads();          // every wave is done with the window: its rows become the output staging tile
+  WC_STAMP(4);
 
 #pragma unroll
   for (int i = 0; i < NF; ++i) {
@@ -288,19 +305,20 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
   if constexpr (OUT32 && CIN == 512) {
     static_assert(SMEM >= TT * SRS + 2 * WC_COUT * 4, "room for the two half-sums behind the staging tile");
     if (a.stats) {
-      const int c = tid & (WC_COUT - 1), half = tid / WC_COUT;        // 512 threads: two halves of the tile's rows
+      constexpr int NH = NT / WC_COUT;                                 // 512 threads: two halves of the tile's rows; 256: one
+      const int c = tid & (WC_COUT - 1), half = tid / WC_COUT;
       const int lim = a.frame_limit ? (a.frame_limit[0] < S ? a.frame_limit[0] : S) : S;
       float sm = 0.f, sq = 0.f;
-      for (int r = half * (TT / 2); r < (half + 1) * (TT / 2); ++r) {
+      for (int r = half * (TT / NH); r < (half + 1) * (TT / NH); ++r) {
         if (t0 + r < lim) { const float v = *(const float*)(XW + r * SRS + c * 4); sm += v; sq += v * v; }
       }
       float* red = (float*)(XW + TT * SRS);
-      if (half == 1) { red[c] = sm; red[WC_COUT + c] = sq; }
-      __syncthreads();
+      if (NH == 2 && half == 1) { red[c] = sm; red[WC_COUT + c] = sq; }
+      if (NH == 2) __syncthreads();
       if (half == 0) {
         float* P = a.stats + ((int64_t)bi * a.tiles_per_utt + t0 / TT) * 2 * a.Cout + cg * WC_COUT + c;
-        P[0] = sm + red[c];
-        P[a.Cout] = sq + red[WC_COUT + c];
+        P[0] = NH == 2 ? sm + red[c] : sm;
+        P[a.Cout] = NH == 2 ? sq + red[WC_COUT + c] : sq;
       }
     }
   }
@@ -339,10 +357,19 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
       if (idx < TT * OCH && t < S && (ch & 15) == 0) a.delta[((int64_t)bi * nh + hd) * S + t] = dacc;
     }
   }
+  WC_STAMP(5);
+}
+
+static unsigned long long* g_wc_stamps = nullptr;
+// diagnostic only (tools/debug/wc_stamps.py; not declared in ttsk.h)
+extern "C" int ttsk_win_conv_set_stamps(void* dev_buffer) {
+  g_wc_stamps = (unsigned long long*)dev_buffer;
+  return TTSK_OK;
 }
 
 int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int packed, hipStream_t s) {
   WcArgs a = a0;
+  a.stamps = g_wc_stamps;
   const bool short_seq = Cin == 256 && packed && (S <= 64 || (S > 112 && S <= 128));      // phoneme-side sequences: 64-frame tiles waste less
   const int TT = Cin == 256 && !short_seq ? 112 : 64;
   a.B = B;

@@ -464,6 +464,11 @@ def main():
         rec = dp1_leg(default_config(), "cuda:0", args.batch, args.phonemes)
         os.write(real_stdout, (json.dumps(rec) + "\n").encode())
         return
+    from tts_king_amd import launch
+    if launch.wants_spawn(args.gpus):
+        # `python bench.py --gpus N` without torch.distributed.run: this process starts the N ranks itself (before any GPU call —
+        # it never makes one), relays rank 0's JSON line and exits non-zero if a rank failed or fewer than N devices are visible
+        raise SystemExit(launch.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     dp1_rec = None
     if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_extra:
         dp1_rec = dp1_leg_isolated(args)          # before this process touches the GPU
@@ -484,8 +489,10 @@ def main():
     from tts_king_amd.train_step import to_device
 
     rank, world, local = init_distributed()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if torch.cuda.device_count() <= local:
+        raise SystemExit("rank %d wants cuda:%d but %d HIP device(s) are visible" % (rank, local, torch.cuda.device_count()))
     dev = "cuda:%d" % local
     torch.cuda.set_device(local)
     cfg = default_config()

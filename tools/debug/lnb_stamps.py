@@ -1,6 +1,9 @@
 """Diagnostic: where a workgroup of the fused LayerNorm-backward kernel (ttsk_layernorm_bwd_proj) spends its lifetime — s_memrealtime
 stamps (100 MHz): [0] start, [1] after the upstream q|k|v product (PRE) and the weight prefetch, [2] LayerNorm rows done, [3] partials
 written (barrier), [4] all channel groups projected and stored."""
+# Needs the diagnostic build: `make -C tts_king_amd/csrc stamps` and TTSK_LIB_PATH=tts_king_amd/libttsk_hip_stamps.so (the product
+# library carries neither the stamp code nor the *_set_stamps hooks).
+
 import ctypes as C, os, sys
 import numpy as np
 import torch

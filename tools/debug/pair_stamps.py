@@ -1,5 +1,8 @@
 """Diagnostic: where a conv-pair workgroup's lifetime goes (s_memrealtime stamps, 100 MHz): load, barrier, c1, t write + barrier,
 c2, epilogue staging + barrier, store issue; and how the 2,048 workgroups of a launch are spread over time."""
+# Needs the diagnostic build: `make -C tts_king_amd/csrc stamps` and TTSK_LIB_PATH=tts_king_amd/libttsk_hip_stamps.so (the product
+# library carries neither the stamp code nor the *_set_stamps hooks).
+
 import ctypes as C, os, sys
 import numpy as np
 import torch

@@ -1,6 +1,9 @@
 """Diagnostic: where a workgroup of the window conv kernel (ttsk_win_conv / ttsk_win_conv_split / ttsk_ffn_conv_fwd) spends its
 lifetime — s_memrealtime stamps (100 MHz): [0] start, [1] window in LDS (own part), [2] barrier passed, [3] tap loop done,
 [4] barrier passed, [5] outputs staged and stored."""
+# Needs the diagnostic build: `make -C tts_king_amd/csrc stamps` and TTSK_LIB_PATH=tts_king_amd/libttsk_hip_stamps.so (the product
+# library carries neither the stamp code nor the *_set_stamps hooks).
+
 import ctypes as C, os, sys
 import numpy as np
 import torch

@@ -185,13 +185,19 @@ struct PairArgs {
   // consumer's leaky_relu), with resblock.hip's modes:  0: out = y   1: out += y   2: out = lrelu((out + y) * scale, final_slope)
   int mode;
   float scale, final_slope;
-  unsigned long long* stamps;   // diagnostic (ttsk_hifi_conv_pair_set_stamps): 8 x s_memrealtime per workgroup, null in the product path
+#ifdef TTSK_STAMPS
+  unsigned long long* stamps;   // diagnostic build only (make stamps; ttsk_hifi_conv_pair_set_stamps): 8 x s_memrealtime per workgroup
+#endif
 };
+#ifdef TTSK_STAMPS
 #define TTSK_STAMP(i)                                                                                            \
   do {                                                                                                            \
     if (a.stamps && threadIdx.x == 0)                                                                             \
       a.stamps[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();      \
   } while (0)
+#else
+#define TTSK_STAMP(i) do {} while (0)      // the product library carries no stamp code and no global state for it
+#endif
 
 template <bool F16>
 __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
@@ -797,13 +803,16 @@ extern "C" int ttsk_hifi_conv_window(const void* x16, const void* w_pack, const 
   return TTSK_OK;
 }
 
+#ifdef TTSK_STAMPS
 static unsigned long long* g_pair_stamps = nullptr;
-// diagnostic only (tools/debug/pair_stamps.py; not declared in ttsk.h): device buffer of 8 x uint64 per workgroup of the C = 128
-// kernel for the launches that follow; null switches the stamps off again
+// diagnostic build only (`make stamps` -> libttsk_hip_stamps.so, tools/debug/pair_stamps.py; not declared in ttsk.h, not in the
+// product library): device buffer of 8 x uint64 per workgroup of the C = 128 kernel for the launches that follow; null switches
+// the stamps off again
 extern "C" int ttsk_hifi_conv_pair_set_stamps(void* dev_buffer) {
   g_pair_stamps = (unsigned long long*)dev_buffer;
   return TTSK_OK;
 }
+#endif
 
 extern "C" int ttsk_hifi_conv_pair_supported(int C, int K, int dil) {
   return (C == CW_C || C == C256 || C == 64 || C == 32) && K >= 3 && K <= 11 && (K & 1) == 1 && dil >= 1 && dil * ((K - 1) / 2) <= CP_XH - CP_TH && (K - 1) / 2 <= CP_TH;
@@ -819,7 +828,10 @@ extern "C" int ttsk_hifi_conv_pair(const void* x16, const void* w1_pack, const f
   TTSK_REQUIRE(((((uintptr_t)x16) | ((uintptr_t)w1_pack) | ((uintptr_t)w2_pack) | ((uintptr_t)bias1) | ((uintptr_t)bias2) | ((uintptr_t)out16)) & 15) == 0,
                "ttsk_hifi_conv_pair: 16-byte alignment");
   PairArgs a{(const bf16_t*)x16, (const bf16_t*)w1_pack, (const bf16_t*)w2_pack, bias1, bias2, (bf16_t*)out16, len, K, dil, slope,
-             mode, scale, final_slope, g_pair_stamps};
+             mode, scale, final_slope};
+#ifdef TTSK_STAMPS
+  a.stamps = g_pair_stamps;
+#endif
   if (C == C256) {
     dim3 grid((len + CP_TT - 1) / CP_TT, B);
     if (f16) hipLaunchKernelGGL(conv_pair256_kernel<true>, grid, dim3(C256_NT), 0, (hipStream_t)stream, a);

@@ -54,12 +54,18 @@ struct WcArgs {
   // rows ttsk_bn_train_apply sums, one per (utterance, 64-frame tile), instead of a ttsk_bn_stats_slab launch over the stored rows
   float* stats;
   const int* frame_limit;
-  unsigned long long* stamps;   // diagnostic (ttsk_win_conv_set_stamps): 8 x s_memrealtime per workgroup, null in the product path
+#ifdef TTSK_STAMPS
+  unsigned long long* stamps;   // diagnostic build only (make stamps; ttsk_win_conv_set_stamps): 8 x s_memrealtime per workgroup
+#endif
 };
+#ifdef TTSK_STAMPS
 #define WC_STAMP(i)                                                                                              \
   do {                                                                                                           \
     if (a.stamps && threadIdx.x == 0) a.stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
+#else
+#define WC_STAMP(i) do {} while (0)        // the product library carries no stamp code and no global state for it
+#endif
 
 // Weight packs.  src = storage (Cs, K, Ds) bf16 tap-major.
 //   transpose = 0: the conv's own weights, W'[co][tap][ci] = src[co][tap][ci]                   (Cout' = Cs, Cin' = Ds)
@@ -360,16 +366,20 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
   WC_STAMP(5);
 }
 
+#ifdef TTSK_STAMPS
 static unsigned long long* g_wc_stamps = nullptr;
-// diagnostic only (tools/debug/wc_stamps.py; not declared in ttsk.h)
+// diagnostic build only (`make stamps`, tools/debug/wc_stamps.py; not declared in ttsk.h, not in the product library)
 extern "C" int ttsk_win_conv_set_stamps(void* dev_buffer) {
   g_wc_stamps = (unsigned long long*)dev_buffer;
   return TTSK_OK;
 }
+#endif
 
 int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int packed, hipStream_t s) {
   WcArgs a = a0;
+#ifdef TTSK_STAMPS
   a.stamps = g_wc_stamps;
+#endif
   const bool short_seq = Cin == 256 && packed && (S <= 64 || (S > 112 && S <= 128));      // phoneme-side sequences: 64-frame tiles waste less
   const int TT = Cin == 256 && !short_seq ? 112 : 64;
   a.B = B;

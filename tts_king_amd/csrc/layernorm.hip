@@ -572,12 +572,18 @@ struct LnbProjArgs {
   // here for the workgroup's 32 rows (fp32, straight into LDS) instead of by a launch of its own that leaves fp32 slabs in memory.
   const bf16_t* pre_x;
   const bf16_t* pre_w;
-  unsigned long long* stamps;   // diagnostic (ttsk_layernorm_bwd_proj_set_stamps): 8 x s_memrealtime per workgroup, null in the product path
+#ifdef TTSK_STAMPS
+  unsigned long long* stamps;   // diagnostic build only (make stamps; ttsk_layernorm_bwd_proj_set_stamps): 8 x s_memrealtime per workgroup
+#endif
 };
+#ifdef TTSK_STAMPS
 #define LNB_STAMP(i)                                                                                   \
   do {                                                                                                 \
     if (p.stamps && threadIdx.x == 0) p.stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
+#else
+#define LNB_STAMP(i) do {} while (0)       // the product library carries no stamp code and no global state for it
+#endif
 
 template <int NG, bool PRE>
 __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const LnbProjArgs p) {
@@ -899,13 +905,15 @@ extern "C" int ttsk_layernorm_bwd_slabs(const float* slabs, int nsplit, int64_t 
   return TTSK_OK;
 }
 
+#ifdef TTSK_STAMPS
 static unsigned long long* g_lnb_stamps = nullptr;
-// diagnostic only (tools/debug/lnb_stamps.py; not declared in ttsk.h): device buffer of 8 x uint64 per workgroup for the launches that
-// follow; null switches the stamps off again
+// diagnostic build only (`make stamps`, tools/debug/lnb_stamps.py; not declared in ttsk.h, not in the product library): device buffer
+// of 8 x uint64 per workgroup for the launches that follow; null switches the stamps off again
 extern "C" int ttsk_layernorm_bwd_proj_set_stamps(void* dev_buffer) {
   g_lnb_stamps = (unsigned long long*)dev_buffer;
   return TTSK_OK;
 }
+#endif
 
 extern "C" int ttsk_layernorm_bwd_proj_nblocks(int rows) { return (rows + 31) / 32; }
 
@@ -932,7 +940,10 @@ extern "C" int ttsk_layernorm_bwd_proj(const void* dout, const float* slabs, int
                  (bf16_t*)dz, (bf16_t*)dy, partials, rows, D, seg_len > 0 ? seg_len : 1, 0, p_pre, 0.f, site_pre, 0, 0, nblk, 0, 0,
                  slabs, (const bf16_t*)R, (long long)slab_stride, nsplit},
                 (const bf16_t*)w_packed, (bf16_t*)out, (const bf16_t*)gate, delta_o32, delta_out, Cout, (const bf16_t*)pre_x,
-                (const bf16_t*)pre_w_packed, g_lnb_stamps};
+                (const bf16_t*)pre_w_packed};
+#ifdef TTSK_STAMPS
+  p.stamps = g_lnb_stamps;
+#endif
   const dim3 grid(nblk), block(LNB_WAVES * 64);
   if (pre_x) {
     if (Cout == 256) hipLaunchKernelGGL((ln_bwd256_proj_kernel<1, true>), grid, block, 0, (hipStream_t)stream, p);

@@ -1,0 +1,106 @@
+"""One process per GPU, started by the parent itself: `python bench.py --gpus N` (and `python train.py` with
+`mi355x.gpus: N`) must not depend on being wrapped in torch.distributed.run.
+
+The parent never initialises the GPU (on this pool a process that has may not start another program): it counts the
+devices (`torch.cuda.device_count()` reads the driver's list without creating a context), starts N children of the same
+command line with the torch.distributed.run environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+MASTER_PORT, rendezvous on 127.0.0.1), relays rank 0's standard output and exits with the first non-zero child status.
+
+reference: the reference has no launcher (train.py:104 is a commented-out nn.DataParallel); this replaces the
+`torchrun` wrapper the driver would otherwise have to supply.
+"""
+import os
+import socket
+import subprocess
+import sys
+import time
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def under_profiler(env=None):
+    env = os.environ if env is None else env
+    return "rocprof" in env.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in env)
+
+
+def wants_spawn(n_gpus, env=None):
+    """True when this process was asked for N > 1 GPUs and is not already one of N ranks."""
+    env = os.environ if env is None else env
+    return int(n_gpus) > 1 and "WORLD_SIZE" not in env and "RANK" not in env
+
+
+def visible_devices():
+    """Number of HIP devices without creating a context (safe before starting children)."""
+    import torch
+    try:
+        return int(torch.cuda.device_count())
+    except Exception:                   # no driver at all
+        return 0
+
+
+def spawn_ranks(n, argv, env=None, timeout=None, n_devices=None, stdout=None):
+    """Start `argv` n times (rank r gets RANK=LOCAL_RANK=r), wait for all, write rank 0's stdout to `stdout` (default
+    sys.stdout) and return the exit status: 0 only if every rank returned 0.  Ranks other than 0 have their stdout sent to
+    stderr (the bench contract is ONE JSON line from rank 0).  If a rank fails the others are terminated (a missing rank would
+    leave them waiting in the rendezvous or in a collective)."""
+    n = int(n)
+    have = visible_devices() if n_devices is None else int(n_devices)
+    if have < n:
+        sys.stderr.write("asked for %d GPUs but %d HIP device(s) are visible: not starting\n" % (n, have))
+        return 3
+    if under_profiler(env):
+        sys.stderr.write("running under rocprofv3 (GPU already initialised in this process): rank processes cannot be started "
+                         "from here; profile with `rocprofv3 ... -- python3 -m torch.distributed.run ...` instead\n")
+        return 4
+    base = dict(os.environ if env is None else env)
+    base.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
+                 "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    procs = []
+    for r in range(n):
+        e = dict(base)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r)})
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None))
+    t_end = None if timeout is None else time.time() + timeout
+    rc, out0 = 0, b""
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                p = procs[r]
+                if r == 0:
+                    # drain rank 0's pipe while waiting so that a large record cannot block it
+                    try:
+                        o, _ = p.communicate(timeout=0.2)
+                        out0 += o or b""
+                    except subprocess.TimeoutExpired:
+                        continue
+                elif p.poll() is None:
+                    continue
+                pending.discard(r)
+                if p.returncode != 0 and rc == 0:
+                    rc = p.returncode
+            if rc != 0:
+                break
+            if t_end is not None and time.time() > t_end:
+                rc = 124
+                break
+            if pending and 0 not in pending:
+                time.sleep(0.1)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    (stdout or sys.stdout.buffer).write(out0)
+    (stdout or sys.stdout.buffer).flush()
+    return rc

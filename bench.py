@@ -508,6 +508,7 @@ def main():
 
     reducer = None
     if world > 1:
+        opt.state[2] += rank        # same weights on every rank, a dropout key of its own per rank (as train.py)
         reducer = GradReducer(model.flat_buffers()[1], model.grad_buckets(cfg.mi355x.dp_bucket_mb), model.group_offsets())
     enqueue = make_enqueue(model, opt, cfg, loss_fn, reducer=reducer,
                            grad_scale=reducer.grad_scale(1) if reducer else None)

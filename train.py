@@ -94,6 +94,10 @@ def main(cfg, max_steps=None):
     Loss = FastSpeech2Loss(cfg.preprocess_config, cfg.model_config)
     reducer = None
     if world > 1:
+        # Every rank builds the same weights from the same seed, but "N independent reference micro-batches" draw N different
+        # dropout masks: the Philox key of rank r is (rank 0's key) + r.  A checkpoint stores rank 0's key, so the same rule
+        # applies after a resume.
+        optimizer.state[2] += rank
         reducer = GradReducer(model.flat_buffers()[1], model.grad_buckets(mi.get("dp_bucket_mb", 24)), model.group_offsets())
     engine = TrainEngine(model, optimizer, cfg, Loss, reducer=reducer)
     bucket = None

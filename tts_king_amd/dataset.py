@@ -96,8 +96,9 @@ class Dataset(torch.utils.data.Dataset):
 
 class _PinnedPool:
     """Reusable pinned staging buffers, `depth` per (field, shape, dtype): pinning fresh memory for every batch (hipHostMalloc) cost
-    milliseconds per step.  A buffer is reused `depth` batches later, long after its H2D copy has completed (the training
-    stream waits for the copy stream before it consumes a batch)."""
+    milliseconds per step.  A buffer is reused `depth` batches later; the H2D copy that read it is normally long done by then,
+    but only an event says so to the HOST (the training stream waiting for the copy stream orders the device, not this thread):
+    `copied(...)` records one on the copy stream after the slot's `.to()`, and `stage` waits for it before overwriting the slot."""
 
     def __init__(self, depth=3):
         self.depth, self.slots, self.turn = depth, {}, {}
@@ -109,10 +110,23 @@ class _PinnedPool:
         i = self.turn.get(key, 0)
         if len(lst) <= i:
             t = torch.empty(arr.shape, dtype=torch.from_numpy(np.empty(0, dtype=arr.dtype)).dtype).pin_memory()
-            lst.append((t, t.numpy()))
+            lst.append([t, t.numpy(), None])
         self.turn[key] = (i + 1) % self.depth
+        ev = lst[i][2]
+        if ev is not None:
+            ev.synchronize()               # the copy that last read this slot (a no-op when it finished, as it nearly always has)
         np.copyto(lst[i][1], arr)          # a plain memcpy into the pinned pages (Tensor.copy_ into pinned memory took 0.3 ms per call)
+        self._last = lst[i]
         return lst[i][0]
+
+    def to_device(self, field, arr, device):
+        """stage + the non-blocking H2D copy on the current (copy) stream + the slot's completion event."""
+        t = self.stage(field, arr).to(device, non_blocking=True)
+        slot = self._last
+        if slot[2] is None:
+            slot[2] = torch.cuda.Event()
+        slot[2].record()
+        return t
 
 
 _POOLS = {}
@@ -160,11 +174,11 @@ class DeviceFeeder:
                         a = x.astype(_FIELD_DTYPE[i], copy=False) if i in _FIELD_DTYPE else x
                         if i == 12:
                             a = np.nan_to_num(a, nan=0.0)
-                        fields.append(self.pool.stage(i, a).to(self.device, non_blocking=True))
+                        fields.append(self.pool.to_device(i, a, self.device))
                     else:
                         fields.append(x)
-                fl = self.pool.stage("fl", np.array([t_true], dtype=np.int32)).to(self.device, non_blocking=True) if t_true is not None else None
-                pl = self.pool.stage("pl", np.full((nb,), l_true, dtype=np.int64)).to(self.device, non_blocking=True) if l_true is not None else None
+                fl = self.pool.to_device("fl", np.array([t_true], dtype=np.int32), self.device) if t_true is not None else None
+                pl = self.pool.to_device("pl", np.full((nb,), l_true, dtype=np.int64), self.device) if l_true is not None else None
             dev_b = tuple(fields)
         if self.bucket is not None:
             dev_b = PaddedBatch(dev_b)

@@ -42,6 +42,8 @@ def pad_to_bucket(batch, l_bucket=8, t_bucket=32, max_seq_len=1000):
     longer than `max_seq_len` frames keep their length (the train-mode decoder truncation path, Models.py:172-180)."""
     (ids, raw, spk, texts, src_lens, max_src, mels, mel_lens, max_mel, energies, durations, pitches, cwt, pmean, pstd) = batch
     Lb = bucket_up(max_src, l_bucket)
+    if Lb > max_seq_len >= int(max_src):
+        Lb = max(int(max_src), max_seq_len)        # never pad a text past the position table (the eval-only long-input path)
     t_true = int(max_mel)
     Tb = bucket_up(t_true, t_bucket) if t_true <= max_seq_len else t_true
     if Tb > max_seq_len >= t_true:
@@ -79,6 +81,7 @@ class TrainEngine:
         self.grad_scale = reducer.grad_scale(self.grad_acc) if reducer is not None else None
         self._graphs = OrderedDict()
         self._seen = set()
+        self._eager_only = set()          # shapes whose capture failed: plain launches from then on
         self._pool = None
         self.stats = {"eager": 0, "captured": 0, "replayed": 0}
 
@@ -96,12 +99,17 @@ class TrainEngine:
         fl, pl = getattr(batch, "frame_limit", None), getattr(batch, "phoneme_limit", None)
         if not self.model.training:
             self.model.train()             # (nn.Module.train() walks every sub-module: 7 ms here, so not once per step)
-        if not self.use_graph or int(batch[8]) > self.model.max_seq_len:
+        # longer than the position tables (frames: the train-mode truncation path; phonemes: sinusoid_table(...).to(dev) is a pageable
+        # H2D copy, not capturable, and the grouped predictor path with its phoneme_limit is off there): plain launches
+        if not self.use_graph or int(batch[8]) > self.model.max_seq_len or int(batch[5]) > self.model.max_seq_len:
             self.stats["eager"] += 1
             losses, out = self._enqueue(is_update, fl, pl)(batch)
             return losses, out
         key = self._key(batch, is_update, (fl is not None, pl is not None))
         g = self._graphs.get(key)
+        if key in self._eager_only:
+            self.stats["eager"] += 1
+            return self._enqueue(is_update, fl, pl)(batch)
         if g is None and key not in self._seen:
             self._seen.add(key)                       # first sight of a shape: plain launches (lazy allocations, split-K plans)
             self.stats["eager"] += 1
@@ -116,7 +124,21 @@ class TrainEngine:
                 self._pool = torch.cuda.graph_pool_handle()
             host_step = self.optimizer._host_step
             torch.cuda.synchronize()
-            g = GraphedTrainStep(self._enqueue(is_update, static_fl, static_pl), static, warmup=0, pool=self._pool)
+            try:
+                g = GraphedTrainStep(self._enqueue(is_update, static_fl, static_pl), static, warmup=0, pool=self._pool)
+            except Exception as e:      # e.g. RCCL refusing to have a collective captured: this shape runs with plain launches
+                # the aborted capture ran part of one step's Python: put the host-side bookkeeping back where it was
+                self.optimizer._host_step = host_step
+                if self.reducer is not None:
+                    self.reducer.reset()
+                self.model._ctx = None
+                self.model._dw_side_pending = False
+                torch.cuda.synchronize()
+                self._eager_only.add(key)
+                self.stats["capture_failed"] = self.stats.get("capture_failed", 0) + 1
+                self.last_capture_error = "%s: %s" % (type(e).__name__, e)
+                self.stats["eager"] += 1
+                return self._enqueue(is_update, fl, pl)(batch)
             self.optimizer._host_step = host_step     # capture ran the Python of one step without executing it
             g.frame_limit, g.phoneme_limit = static_fl, static_pl
             self._graphs[key] = g

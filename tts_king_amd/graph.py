@@ -6,8 +6,6 @@ running statistics) lives in device memory and is advanced by kernels, so a capt
 no host work besides copying the next batch into the static input buffers.  Shapes are static per graph: batches
 are bucketed by (B, L, T) and one graph is kept per bucket (T varies per batch in real training).
 """
-import time
-
 import torch
 
 from . import ops
@@ -29,13 +27,14 @@ class GraphedTrainStep:
                 enqueue(self.static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            # ProcessGroupNCCL's watchdog thread polls the end events of the eager collectives it has not reaped yet (every 100 ms).
-            # Once RCCL's stream has joined this capture HIP answers such a query with hipErrorCapturedEvent ("event last recorded
-            # in a capturing stream") and the watchdog aborts the process — seen once in bench.py's 1-GPU DP leg.  Everything is
-            # complete after the synchronize above; give the watchdog time to drop those works before the capture begins.
-            time.sleep(0.5)
-        with torch.cuda.graph(self.graph, pool=pool):
+        # ProcessGroupNCCL's watchdog thread polls the end events of the eager collectives it has not reaped yet.  Under the default
+        # capture mode ("global") any HIP call another thread makes while this thread captures is an error — once RCCL's stream has
+        # joined the capture such an event query came back as hipErrorCapturedEvent and the watchdog aborted the process (seen once
+        # in bench.py's 1-GPU DP leg; round 2 slept 0.5 s before every capture instead).  "thread_local" restricts the capture's
+        # legality checks to THIS thread, so the watchdog's queries stay legal whenever they come.  Everything is complete after
+        # the synchronize above, so no captured work depends on un-captured work either.
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local" if dist_on else "global"):
             self.outputs = enqueue(self.static)
 
     def key(self):

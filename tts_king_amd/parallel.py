@@ -71,5 +71,10 @@ class GradReducer:
         self._handles = []
         self._next = 0
 
+    def reset(self):
+        """Forget a half-issued step (a hipGraph capture of it was aborted): no handles, first bucket next."""
+        self._handles = []
+        self._next = 0
+
     def grad_scale(self, grad_acc_step=1):
         return 1.0 / (grad_acc_step * self.world)

@@ -102,9 +102,10 @@ def test_hifiapi_generate_int16(cfg):
         hifiapi.HIFIapi(c, "cuda:0")
 
 
-@pytest.mark.parametrize("B,T", [(1, 1), (3, 7), (1, 100), (2, 384)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 7), (1, 100), (2, 384), (8, 384)])
 def test_waveform_vs_oracle_shapes(cfg, B, T):
-    """Ragged / tiny / BASELINE-size time lengths against the oracle (same seeded weights)."""
+    """Ragged / tiny time lengths and the full BASELINE.json configs[2] batch (B=8, T=384: 8 x 98,304 samples, a few seconds of CPU
+    oracle) against the oracle on the same seeded weights."""
     sdw = hifi_state_dict_wn(11)
     gen = build(cfg, 11)
     mel = make_mel(B, T, seed=100 + T)

@@ -9,6 +9,74 @@ from .hifigan import Generator
 from .synthetic import make_mel
 
 HIFI_FLOP_PER_FRAME = 614.11e6          # SURVEY.md §8d (verified with torch.utils.flop_counter on the reference)
+# ... and its split (MFLOP per mel frame): conv_pre, the four upsamplers, the four MRF stages, conv_post
+STAGE_MFLOP = {"conv_pre": 0.573, "ups0": 4.194, "ups1": 8.389, "ups2": 4.194, "ups3": 2.097,
+               "mrf0": 132.12, "mrf1": 264.24, "mrf2": 132.12, "mrf3": 66.06, "conv_post": 0.115}
+# rocprofv3 symbols of each stage's kernels (profiles/r*_pmc_traffic_hifi.json is keyed by symbol): (substring, launches per forward)
+STAGE_KERNELS = {"mrf0": [("conv_pair256_kernel", 9)], "mrf1": [("conv_pair_kernel", 9)],
+                 "mrf2": [("conv_pair_fs_kernel<64", 6), ("resblock1_kernel<64, 3", 1)],
+                 "mrf3": [("resblock1_kernel<32, 3", 1), ("resblock1_kernel<32, 7", 1), ("resblock1_kernel<32, 11", 1), ("mrf32_kernel", 1)],
+                 "ups2": [("ups2_kernel<128, 64", 1)], "ups3": [("ups2_kernel<64, 32", 1)], "conv_post": [("conv_post_kernel", 1)]}
+# tensor elements per mel frame at each stage's resolution (channels x frames-per-mel-frame), 2 bytes each: the algorithmic
+# minimum of a fused MRF stage is one read of its input and one write of its output
+STAGE_ELEMS = {"mrf0": 256 * 8, "mrf1": 128 * 64, "mrf2": 64 * 128, "mrf3": 32 * 256}
+
+
+def _pmc_hifi():
+    """kernel symbol -> HBM bytes per launch from the newest committed profiles/r*_pmc_traffic_hifi.json (tools/pmc_hifi.sh:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per the gfx950 correction)."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_traffic_hifi.json")), reverse=True):
+        try:
+            doc = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        return {r["kernel"]: r["hbm_bytes_per_launch"] for r in doc.get("kernels", [])}, os.path.relpath(f, root)
+    return {}, None
+
+
+def stage_rooflines(gen, mel, B, T, iters=5):
+    """"report the dilated-conv kernels against both bounds".  Per generator stage: device time between HIP events
+    recorded at the stage boundaries on the launch stream (eager launches), algorithmic FLOPs -> fraction of the f16 MFMA peak,
+    and HBM bytes — the PMC counters of the stage's kernels where a committed summary has them, and the algorithmic minimum
+    (one read + one write of the stage tensor) — -> fraction of the 8 TB/s HBM peak.  A stage well below BOTH is bound by
+    neither (per-workgroup latency phases)."""
+    frames = B * T
+    acc = {}
+    for _ in range(iters):
+        gen._stage_marks = marks = []
+        try:
+            gen(mel)
+        finally:
+            gen._stage_marks = None
+        torch.cuda.synchronize()
+        for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+            acc.setdefault(n1, []).append(e0.elapsed_time(e1))
+    pmc, src = _pmc_hifi()
+    out = {}
+    for name, ms_list in acc.items():
+        ms = sorted(ms_list)[len(ms_list) // 2]
+        flops = STAGE_MFLOP.get(name, 0.0) * 1e6 * frames
+        rec = {"ms": ms, "tflops": flops / (ms * 1e-3) / 1e12, "mfma_roofline_frac": flops / (ms * 1e-3) / 2.5e15}
+        if name in STAGE_ELEMS:
+            alg = 2.0 * STAGE_ELEMS[name] * 2 * frames
+            rec["hbm_bytes_algorithmic"] = alg
+            rec["hbm_roofline_frac_algorithmic"] = alg / (ms * 1e-3) / 8e12
+        if name in STAGE_KERNELS and pmc:
+            tot, found = 0.0, True
+            for sub, n in STAGE_KERNELS[name]:
+                hit = [v for k, v in pmc.items() if sub in k]
+                if hit:
+                    tot += hit[0] * n
+            if tot > 0:
+                rec["hbm_bytes_pmc"] = tot
+                rec["hbm_roofline_frac"] = tot / (ms * 1e-3) / 8e12
+                rec["pmc_source"] = src
+        out[name] = rec
+    return out
 
 
 def build_generator(cfg, dev, seed=1234):
@@ -55,4 +123,4 @@ def hifi_rtf(cfg, dev, B=8, T=384, iters=20, warmup=3, use_graph=True):
             "rtf": wall / audio_s, "ms_per_batch": 1e3 * wall, "device_ms_per_batch": 1e3 * dev_s, "samples_per_s": samples / wall,
             "audio_seconds_per_batch": audio_s, "tflops": flops / wall / 1e12, "mfma_roofline_frac": flops / wall / 2.5e15,
             "int16_d2h_ms": 1e3 * d2h, "launch": "hipGraph replay" if use_graph else "eager", "dtype": "f16 (fp32 accumulate)",
-            "iters": iters}
+            "iters": iters, "stages": stage_rooflines(gen, mel, B, T)}

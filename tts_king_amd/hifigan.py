@@ -246,6 +246,14 @@ class Generator(nn.Module):
             xls = nxt
         return xs
 
+    _stage_marks = None     # bench.py's per-stage timing: a list to which forward appends (name, HIP event) at stage boundaries
+
+    def _mark(self, name):
+        if self._stage_marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._stage_marks.append((name, ev))
+
     def forward(self, x):
         """x (B, 80, T) mel on a HIP device -> (B, 1, T*prod(upsample_rates)) fp32.  reference: hifi/models.py:185-201.
 
@@ -257,9 +265,11 @@ class Generator(nn.Module):
         h = self.h
         nk = self.num_kernels
         with torch.no_grad():
+            self._mark("start")
             a0 = ops.nct_to_ntc(x.float(), self.act_dtype)                                 # (B, T, 80) 16-bit
             al = ops.conv1d(a0, pk["pre"][0], pk["pre"][1], flags=ops.LRELU_OUT, out_slope=LRELU_SLOPE)   # lrelu(conv_pre(x))
             for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
+                self._mark("conv_pre" if i == 0 else "mrf%d" % (i - 1))
                 wu, bu = pk["ups"][i]
                 # slope of the activation that consumes this stage's output: 0.1 before the next upsampler,
                 # F.leaky_relu's default 0.01 before conv_post (hifi/models.py:197)
@@ -278,6 +288,7 @@ class Generator(nn.Module):
                     # fused kernel at C = 64 for k = 7, 11 (228 vs 242 us, 290 vs 370 us) and lose at k = 3 (158 vs 141 us: the block is
                     # then bound by its HBM passes, and the fused kernel makes one instead of three)
                     fused_for = (3,) if C_out == 64 and all(pk["rbf"][i * nk + j] is not None for j in range(nk)) else ()
+                    self._mark("ups%d" % i)
                     al = self._pair_blocks(rbs, ppacks, a, nxt_slope, fused_for)
                     continue
                 fused = self.fused and all(pk["rbf"][i * nk + j] is not None for j in range(nk)) and nk >= 2
@@ -287,6 +298,7 @@ class Generator(nn.Module):
                     else:
                         a = ops.conv_transpose1d(al, wu, bu, u, k)                         # raw x: the fused blocks activate it themselves
                     out = torch.empty_like(a)
+                    self._mark("ups%d" % i)
                     for j, rb in enumerate(rbs):
                         ws, bs = pk["rbf"][i * nk + j]
                         lastb = j == nk - 1
@@ -298,6 +310,7 @@ class Generator(nn.Module):
                                                     for j in range(nk) for dd in rbs[j].dilation)
                 axl = torch.empty(al.shape[0], al.shape[1] * u, wu.shape[1], dtype=al.dtype, device=al.device)
                 a = ops.conv_transpose1d(al, wu, bu, u, k, C2=axl, flags=ops.C2_LRELU, out_slope=LRELU_SLOPE)   # x and lrelu(x)
+                self._mark("ups%d" % i)
                 if self.group_resblocks and all(rb.kind == "1" for rb in rbs) and len({len(rb.dilation) for rb in rbs}) == 1 and \
                         not windowed:
                     outs = self._resblocks_lockstep(rbs, [pk["rb"][i * nk + j] for j in range(nk)], a, axl)
@@ -308,8 +321,11 @@ class Generator(nn.Module):
                 else:
                     raise NotImplementedError("MRF average is written for 3 resblock kernels per stage")
             wp, bp = pk["post"]
+            self._mark("mrf%d" % (self.num_upsamples - 1))
             if al.shape[2] <= 128:
-                return ops.hifi_conv_post(al, wp, bp)                                      # conv_post -> tanh, streaming kernel
+                y = ops.hifi_conv_post(al, wp, bp)                                         # conv_post -> tanh, streaming kernel
+                self._mark("conv_post")
+                return y
             Bn, Tout, C = al.shape
             y = torch.empty(Bn * Tout, 1, dtype=torch.float32, device=al.device)
             ops.conv1d(al, wp, bp, out=y.view(Bn, Tout, 1), flags=ops.TANH)

@@ -133,33 +133,34 @@ def test_train_mode_losses_and_gradients(cfg):
     print("losses", got, "golden", g["losses"])
     np.testing.assert_allclose(got[:5], g["losses"][:5], rtol=0.01)
     check_mel(o[0], g["mel"], "train mel")
-    # train-mode PostNet normalises by BATCH statistics (Layers.py:133-143): post - mel = gamma * (y - mu) / sigma + beta per channel, so
-    # the bf16-level noise of the conv output y (relative to y's own magnitude sqrt(mu^2 + sigma^2)) reaches the output multiplied by
-    # a = sqrt(mu^2 + sigma^2) / sigma — large for the low-variance channels this synthetic case has.  The bound is per channel:
-    #     rms_ch(err) <= c * 2^-8 * |gamma_ch| * a_ch + 1 % of rms_ch(mel)          (c = 12: five conv + BatchNorm layers deep)
-    # with mu, sigma of the LAST BatchNorm recovered from the reference's own running statistics after this one step (golden bn/*).
-    sd0 = fs2_state_dict(cfg, int(g["weight_seed"]))
-    pk = "postnet.convolutions.4.1."
-    mu = (torch.from_numpy(g["bn/" + pk + "running_mean"]) - 0.9 * sd0[pk + "running_mean"]) / 0.1
-    var_unb = (torch.from_numpy(g["bn/" + pk + "running_var"]) - 0.9 * sd0[pk + "running_var"]) / 0.1
-    n_rows = float(g["post"].shape[0] * g["post"].shape[1])
-    sigma = (var_unb * (n_rows - 1.0) / n_rows + 1e-5).sqrt()
-    amp = (mu * mu + sigma * sigma).sqrt() / sigma
-    gamma = sd0[pk + "weight"].abs()
+    # train-mode PostNet (Layers.py:133-143) divides every conv output by its BATCH std.  On this synthetic case that makes the
+    # PostNet itself an amplifier of whatever error its INPUT carries: the reference PostNet (the oracle, fp32) turns a random
+    # perturbation of the mel of the size of the bf16 path's mel error (0.78 % rel-RMS) into 5 % after its first layer (batch std down
+    # to 0.06 there) and 15 % at its output (measured on the CPU, fp32 throughout).  So the comparison with the golden output cannot
+    # be tight, and a loose bar says nothing about the HIP PostNet.  The sharp statement is two-part:
+    #   (1) INPUT error, explained exactly: the oracle PostNet fed with the HIP path's own mel reproduces the HIP PostNet's output up
+    #       to the PostNet's own 16-bit storage (five layers of bf16 activations and weights model out at 3.6 % on the CPU): <= 5 %
+    #       overall, and per mel channel <= 8 % of that channel's PostNet-output rms;
+    #   (2) the end-to-end difference from the reference's recorded output stays under the 12 % the amplification allows.
+    keep_drop = ofs2._drop
+    ofs2._drop = lambda x, p, train: x                      # the oracle's PostNet dropout is hard-coded (0.5): off, as on the HIP side
+    try:
+        sd_ref = fs2_state_dict(cfg, int(g["weight_seed"]))
+        mel_h = o[0].detach().float().cpu()
+        with torch.no_grad():
+            pn_pred = ofs2.postnet(sd_ref, mel_h, True, None)
+    finally:
+        ofs2._drop = keep_drop
     post_h, post_r = o[9].detach().float().cpu(), torch.from_numpy(g["post"])
-    err_ch = (post_h - post_r).pow(2).mean(dim=(0, 1)).sqrt()
-    mel_ch = torch.from_numpy(g["mel"]).pow(2).mean(dim=(0, 1)).sqrt()
-    C_BN = 12.0
-    bound = C_BN * 2.0 ** -8 * gamma * amp + 0.01 * mel_ch
-    ratio = err_ch / bound
-    wc = int(ratio.argmax())
-    implied = (err_ch / (2.0 ** -8 * gamma * amp)).max()
+    pn_h = post_h - mel_h
+    r_own = rel_rms(pn_h, pn_pred)
+    ch_err = (pn_h - pn_pred).pow(2).mean(dim=(0, 1)).sqrt() / pn_pred.pow(2).mean(dim=(0, 1)).sqrt()
+    wc = int(ch_err.argmax())
     r = rel_rms(post_h, post_r)
-    print("train postnet mel: rel-RMS %.3f%%; per-channel bound c=%.0f: worst channel %d at %.2f of its bound (err %.4f, sigma %.4f, mu %.4f, "
-          "amplification %.1f, gamma %.3f); largest implied c %.2f; amplification range %.1f-%.1f"
-          % (100 * r, C_BN, wc, float(ratio[wc]), float(err_ch[wc]), float(sigma[wc]), float(mu[wc]), float(amp[wc]), float(gamma[wc]),
-             float(implied), float(amp.min()), float(amp.max())))
-    assert float(ratio.max()) <= 1.0, "channel %d: err %.4f > bound %.4f" % (wc, float(err_ch[wc]), float(bound[wc]))
+    print("train postnet mel: vs the oracle PostNet on the HIP mel rel-RMS %.3f%% (worst channel %d: %.3f%%); vs the golden %.3f%%"
+          % (100 * r_own, wc, 100 * float(ch_err[wc]), 100 * r))
+    assert r_own <= 0.05, r_own
+    assert float(ch_err.max()) <= 0.08, (wc, float(ch_err[wc]))
     assert r <= 0.12
     named = dict(m.named_parameters())
     gn = {str(k): float(v) for k, v in zip(g["grad_keys"], g["grad_norms"])}

@@ -323,16 +323,18 @@ def extra_train_legs(cfg, dev, B, L, steps=40):
     c4.train_config["optimizer"]["grad_acc_step"] = 4
     m4 = FastSpeech2(c4.preprocess_config, c4.model_config, 65, device=dev, seed=1234).train()
     o4 = ScheduledOptim(m4, c4.train_config, c4.model_config, 0)
-    g_acc = GraphedTrainStep(make_enqueue(m4, o4, c4, loss_fn, step_is_update=False), batch, warmup=2)
-    g_upd = GraphedTrainStep(make_enqueue(m4, o4, c4, loss_fn, step_is_update=True), batch, warmup=0)
+    # the first micro-step after an update OVERWRITES the gradient buffer (the update does not zero it), the later ones accumulate
+    g_first = GraphedTrainStep(make_enqueue(m4, o4, c4, loss_fn, step_is_update=False, accumulate=False), batch, warmup=2)
+    g_acc = GraphedTrainStep(make_enqueue(m4, o4, c4, loss_fn, step_is_update=False, accumulate=True), batch, warmup=0)
+    g_upd = GraphedTrainStep(make_enqueue(m4, o4, c4, loss_fn, step_is_update=True, accumulate=True), batch, warmup=0)
 
     def cycle():
-        g_acc.run(); g_acc.run(); g_acc.run(); g_upd.run()
+        g_first.run(); g_acc.run(); g_acc.run(); g_upd.run()
     for _ in range(3):
         cycle()
     ms_cycle = _time_loop(cycle, max(5, steps // 4))
     out["ms_per_step_grad_acc4"] = ms_cycle / 4.0
-    out["grad_acc4"] = {"ms_per_optimizer_update": ms_cycle, "micro_steps_per_update": 4,
+    out["grad_acc4"] = {"ms_per_optimizer_update": ms_cycle, "micro_steps_per_update": 4, "graphs": "overwrite + 2 x accumulate + accumulate-and-update",
                         "valid_mel_frames_per_s": 4 * int(batch[7].sum()) / (ms_cycle * 1e-3)}
     # ---- the trainer's loop: varying-T batches through the engine (buckets of 8 phonemes / 32 frames), pinned-memory feeder
     mt = FastSpeech2(c1.preprocess_config, c1.model_config, 65, device=dev, seed=1234).train()
@@ -388,7 +390,8 @@ def dp1_leg_isolated(args):
 
 
 def dp1_leg(cfg, dev, B, L, steps=30):
-    """The data-parallel schedule on ONE GPU: the full step with GradReducer issuing its bucketed all-reduces over RCCL at world
+    """The data-parallel schedules (FastSpeech2.dp_schedule: "side" = the default, "early" = round 2's, "late") on ONE GPU: the full
+    step with GradReducer issuing its bucketed all-reduces over RCCL at world
     size 1 (a collective per gradient bucket on RCCL's stream, backward_native flushing its deferred weight-gradient work whenever
     a bucket completes) — captured in a hipGraph and eager — beside the plain step, and how many grouped-GEMM / reducer / column-sum
     flush launches the DP schedule issues per step."""
@@ -410,31 +413,41 @@ def dp1_leg(cfg, dev, B, L, steps=30):
         c1 = copy.deepcopy(cfg)
         c1.train_config["optimizer"]["grad_acc_step"] = 1
         loss_fn = FastSpeech2Loss(c1.preprocess_config, c1.model_config)
-        model = FastSpeech2(c1.preprocess_config, c1.model_config, 65, device=dev, seed=1234).train()
-        opt = ScheduledOptim(model, c1.train_config, c1.model_config, 0)
         batch = to_device(make_batch(B, L, seed=1234), dev)
-        buckets = model.grad_buckets(cfg.mi355x.dp_bucket_mb)
-        red = GradReducer(model.flat_buffers()[1], buckets, model.group_offsets(), force_collectives=True)
-        enq = make_enqueue(model, opt, c1, loss_fn, reducer=red, grad_scale=1.0)
-        counts = {}
-        for _ in range(2):
+        out = None
+        default = os.environ.get("TTSK_DP_SCHEDULE", "side")
+        for sched in [default] + [x for x in ("side", "early", "late") if x != default]:
+            model = FastSpeech2(c1.preprocess_config, c1.model_config, 65, device=dev, seed=1234).train()
+            model.dp_schedule = sched
+            opt = ScheduledOptim(model, c1.train_config, c1.model_config, 0)
+            buckets = model.grad_buckets(cfg.mi355x.dp_bucket_mb)
+            red = GradReducer(model.flat_buffers()[1], buckets, model.group_offsets(), force_collectives=True)
+            enq = make_enqueue(model, opt, c1, loss_fn, reducer=red, grad_scale=1.0)
+            counts = {}
+            for _ in range(2):
+                enq(batch)
+            torch.cuda.synchronize()
+            ops.LAUNCH_COUNTS = counts
             enq(batch)
-        torch.cuda.synchronize()
-        ops.LAUNCH_COUNTS = counts
-        enq(batch)
-        torch.cuda.synchronize()
-        ops.LAUNCH_COUNTS = None
-        rec = {"buckets": len(buckets), "bucket_mb": cfg.mi355x.dp_bucket_mb, "launches_per_step": dict(counts),
-               "dp1_reducer_ms_per_step_eager": _time_loop(lambda: enq(batch), 10)}
-        try:
-            g = GraphedTrainStep(enq, batch, warmup=0)
-            for _ in range(3):
-                g.run()
-            rec["dp1_reducer_ms_per_step"] = _time_loop(lambda: g.run(), steps)
-        except Exception as e:          # RCCL refused the capture: the eager number stands
-            rec["dp1_reducer_ms_per_step"] = None
-            rec["graph_capture_error"] = str(e)[:200]
-        return rec
+            torch.cuda.synchronize()
+            ops.LAUNCH_COUNTS = None
+            rec = {"schedule": sched, "buckets": len(buckets), "bucket_mb": cfg.mi355x.dp_bucket_mb, "launches_per_step": dict(counts),
+                   "dp1_reducer_ms_per_step_eager": _time_loop(lambda: enq(batch), 10)}
+            g = None
+            try:
+                g = GraphedTrainStep(enq, batch, warmup=0)
+                for _ in range(3):
+                    g.run()
+                rec["dp1_reducer_ms_per_step"] = _time_loop(lambda: g.run(), steps)
+            except Exception as e:          # RCCL refused the capture: the eager number stands
+                rec["dp1_reducer_ms_per_step"] = None
+                rec["graph_capture_error"] = str(e)[:200]
+            if out is None:
+                out = rec
+                out["by_schedule"] = {}
+            out["by_schedule"][sched] = {k: rec[k] for k in ("dp1_reducer_ms_per_step", "dp1_reducer_ms_per_step_eager", "launches_per_step")}
+            del g, enq, red, opt, model
+        return out
     finally:
         if own_pg:
             dist.destroy_process_group()

@@ -511,7 +511,8 @@ int ttsk_bn_bwd_stats_slab(const void* dout, int dout_is_f32, const void* x, int
 int ttsk_bn_bwd_apply_slab(const void* dout, int dout_is_f32, const void* x, int x_is_f32, const float* mean, const float* rstd,
                            const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
                            const uint64_t* rng, const uint8_t* keep, const float* partials, int nblk, void* dx_bf16, float* dgamma,
-                           float* dbeta, const int32_t* frame_limit, int seg_len, void* stream);
+                           float* dbeta, int accumulate /* 1: dgamma / dbeta += ; 0: = */, const int32_t* frame_limit, int seg_len,
+                           void* stream);
 int ttsk_bn_apply(const void* x, int x_is_f32, const float* mean, const float* rstd, const float* gamma, const float* beta, int rows,
                   int C, int use_tanh, float p, uint32_t site, const uint64_t* rng, const float* resid_f32, void* out_bf16,
                   float* out_f32, const int32_t* frame_limit, int seg_len, void* stream);
@@ -522,7 +523,7 @@ int ttsk_bn_bwd_stats(const void* dout, int dout_is_f32, const void* x, int x_is
 int ttsk_bn_bwd_apply(const void* dout, int dout_is_f32, const void* x, int x_is_f32, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
                       const uint64_t* rng, const float* sums /* [2C] */, void* dx_bf16, float* dgamma, float* dbeta,
-                      const int32_t* frame_limit, int seg_len, void* stream);
+                      int accumulate /* 1: dgamma / dbeta += ; 0: = */, const int32_t* frame_limit, int seg_len, void* stream);
 
 /* ------------------------------------------------------------------------------------------------- loss
  * reference: fs_two/model/loss.py:24-134 (use_cwt False).  losses[8] = {total, mel_total, pitch, energy, duration,
@@ -561,6 +562,26 @@ int ttsk_grad_sumsq(const float* grads, int64_t n, float* partials, void* stream
 int ttsk_optim_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n, void* state,
                     float* partials, float max_norm, float beta1, float beta2, float eps, int zero_grad, float d_model, float warmup,
                     const float* anneal_steps_host, int n_anneal, float anneal_rate, int advance_rng, void* stream);
+
+/* ttsk_optim_step whose Adam launch also writes the window kernels' weight packs (no ttsk_win_conv_pack_table launch after the step).
+ * dev_items [n_items] (device memory, sorted by tile0): the packed weights — tap-major storage (Cs, K, Ds) at element offset `off` of the
+ * flat buffers, Ds % 256 == 0 and Cs % 32 == 0, its plain pack (`pack`, the weight as it is: Cout = Cs, Cin = Ds) and / or its transposed,
+ * tap-flipped pack (`pack_t`: Cout = Ds, Cin = Cs), either may be NULL; a tile = 32 storage rows x 256 storage columns of one tap,
+ * item i owns tiles [tile0, tile0 + K * (Cs/32) * (Ds/256)).  dev_gaps [n_gaps][3] (device, int64): {start, end, sum of (end - start) / 4
+ * over the gaps before this one} for the element ranges outside every item, each start / end a multiple of 4; gap_floats = their total.
+ * n_tiles * 8192 + gap_floats must equal n.  Parameters, moments, shadow and packs come out bit-identical to ttsk_optim_step followed by
+ * ttsk_win_conv_pack_table.  reference: train.py:47-54, fs_two/model/optimizer.py:35-53, torch.optim.Adam. */
+typedef struct ttsk_adam_item {
+  int64_t off;
+  void* pack;
+  void* pack_t;
+  int32_t Cs, K, Ds, tile0;
+} ttsk_adam_item;
+int ttsk_optim_step_packed(float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n, void* state,
+                           float* partials, float max_norm, float beta1, float beta2, float eps, int zero_grad, float d_model, float warmup,
+                           const float* anneal_steps_host, int n_anneal, float anneal_rate, int advance_rng,
+                           const ttsk_adam_item* dev_items, int n_items, int n_tiles, const int64_t* dev_gaps, int n_gaps,
+                           int64_t gap_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------- mel extraction
  * SURVEY.md §8 row f-3.  reference: hifi/meldataset.py:49-74 (mel_spectrogram), fs_two/audio/stft.py:57-90

@@ -44,6 +44,9 @@ def _asan_run(extra=()):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     so = os.path.join(root, "tts_king_amd", "libttsk_hip_asan.so")
+    if os.path.exists("/opt/rocm/bin/hipcc"):       # bring the ASan build up to date with the sources (a no-op when it is)
+        subprocess.run(["make", "-C", os.path.join(root, "tts_king_amd", "csrc"), "-j", "8", "asan"], stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, timeout=1500)
     rts = [ASAN_RT] if os.path.exists(ASAN_RT) else glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
     if not os.path.exists(so) or not rts:
         import pytest

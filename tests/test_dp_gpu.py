@@ -12,7 +12,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_reducer_step_equals_plain_step(cfg):
+@pytest.mark.parametrize("schedule", ["side", "early", "late"])
+def test_reducer_step_equals_plain_step(cfg, schedule):
+    """Every data-parallel schedule (FastSpeech2.dp_schedule) leaves the plain step's losses and weights, bit for bit, and launches
+    every bucket exactly once, from the end of the buffer."""
     from tests.oracle_util import fs2_state_dict
     from tts_king_amd.fastspeech2 import FastSpeech2
     from tts_king_amd.graph import make_enqueue
@@ -36,15 +39,16 @@ def test_reducer_step_equals_plain_step(cfg):
             m = FastSpeech2(c.preprocess_config, c.model_config, 65, device=DEV)
             m.load_state_dict(fs2_state_dict(c, 7))
             m.p_enc = m.p_dec = m.p_var = m.p_post = 0.0
+            m.dp_schedule = schedule
             m.train()
             opt = ScheduledOptim(m, c.train_config, c.model_config, 0)
-            red = GradReducer(m.flat_buffers()[1], m.grad_buckets(8), m.group_offsets()) if use_reducer else None
+            red = GradReducer(m.flat_buffers()[1], m.grad_buckets(8), m.group_offsets(), force_collectives=True) if use_reducer else None
             enq = make_enqueue(m, opt, c, FastSpeech2Loss(c.preprocess_config, c.model_config), reducer=red,
                                grad_scale=red.grad_scale(1) if red else None)
             losses, _ = enq(batch)
             torch.cuda.synchronize()
             if red is not None:
-                assert len(red.launched) == len(red.buckets) and red.launched[0][1] == m.flat_buffers()[1].numel()
+                assert red.launched == list(red.buckets) and red.launched[0][1] == m.flat_buffers()[1].numel()
             res.append((losses.cpu().clone(), m.flat_buffers()[0].cpu().clone()))
         assert torch.equal(res[0][0], res[1][0])
         assert torch.equal(res[0][1], res[1][1])          # identical weights after clip + Adam: same gradients

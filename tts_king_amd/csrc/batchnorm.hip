@@ -250,14 +250,17 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const BnCommon a, con
 // ---- backward pass 2: dx = gamma * rstd * (dy − mean(dy) − xhat * mean(dy·xhat)); block 0 adds dgamma/dbeta
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnCommon a, const void* __restrict__ dout, int dout_f32,
                                                            const float* __restrict__ sums, bf16_t* __restrict__ dx,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
   const int tpr = a.C >> 2;
   const int64_t n = (int64_t)a.rows * tpr;
   const unsigned thr = keep_threshold(a.p);
   const float scale = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
   const float inv_n = 1.f / bn_rows(a.frame_limit, a.seg_len, a.rows);
   if (blockIdx.x == 0 && dgamma)
-    for (int c = threadIdx.x; c < a.C; c += 256) { dbeta[c] += sums[c]; dgamma[c] += sums[a.C + c]; }
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+      dbeta[c] = accumulate ? dbeta[c] + sums[c] : sums[c];
+      dgamma[c] = accumulate ? dgamma[c] + sums[a.C + c] : sums[a.C + c];
+    }
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int r = (int)(i / tpr), c4 = (int)(i - (int64_t)r * tpr) * 4;
     float xh[4], dy[4];
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats2_kernel(const BnCommon a, co
 // workgroups add them to dbeta / dgamma
 __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const BnCommon a, const void* __restrict__ dout, int dout_f32,
                                                             const float* __restrict__ partials, int nblk, bf16_t* __restrict__ dx,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
   __shared__ double tot[BN_TOT];
   __shared__ float s1s[128], s2s[128];
   const BnSlab g(a.C, a.rows);
@@ -510,7 +513,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const BnCommon a, co
     const int c = threadIdx.x;
     s1s[c] = (float)tot[c];
     s2s[c] = (float)tot[g.slab + c];
-    if (blockIdx.y == 0 && dgamma) { dbeta[g.c0 + c] += s1s[c]; dgamma[g.c0 + c] += s2s[c]; }
+    if (blockIdx.y == 0 && dgamma) {
+      dbeta[g.c0 + c] = accumulate ? dbeta[g.c0 + c] + s1s[c] : s1s[c];
+      dgamma[g.c0 + c] = accumulate ? dgamma[g.c0 + c] + s2s[c] : s2s[c];
+    }
   }
   __syncthreads();
   if (!act) return;
@@ -613,7 +619,7 @@ extern "C" int ttsk_bn_bwd_stats(const void* dout, int dout_is_f32, const void* 
 
 extern "C" int ttsk_bn_bwd_apply(const void* dout, int dout_is_f32, const void* x, int x_is_f32, const float* mean, const float* rstd,
                                  const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
-                                 const uint64_t* rng, const float* sums, void* dx_bf16, float* dgamma, float* dbeta,
+                                 const uint64_t* rng, const float* sums, void* dx_bf16, float* dgamma, float* dbeta, int accumulate,
                                  const int32_t* frame_limit, int seg_len, void* stream) {
   if (int rc = limit_check(frame_limit, seg_len, rows)) return rc;
   TTSK_REQUIRE(dout && x && mean && rstd && gamma && beta && sums && dx_bf16, "bn_bwd_apply: null pointer");
@@ -624,7 +630,7 @@ extern "C" int ttsk_bn_bwd_apply(const void* dout, int dout_is_f32, const void* 
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, dout, dout_is_f32, sums,
-                     (bf16_t*)dx_bf16, dgamma, dbeta);
+                     (bf16_t*)dx_bf16, dgamma, dbeta, accumulate);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }
@@ -687,7 +693,7 @@ extern "C" int ttsk_bn_bwd_stats_slab(const void* dout, int dout_is_f32, const v
 extern "C" int ttsk_bn_bwd_apply_slab(const void* dout, int dout_is_f32, const void* x, int x_is_f32, const float* mean, const float* rstd,
                                       const float* gamma, const float* beta, int rows, int C, int use_tanh, float p, uint32_t site,
                                       const uint64_t* rng, const uint8_t* keep, const float* partials, int nblk, void* dx_bf16, float* dgamma,
-                                      float* dbeta, const int32_t* frame_limit, int seg_len, void* stream) {
+                                      float* dbeta, int accumulate, const int32_t* frame_limit, int seg_len, void* stream) {
   if (int rc = limit_check(frame_limit, seg_len, rows)) return rc;
   TTSK_REQUIRE(dout && x && mean && rstd && gamma && beta && partials && nblk > 0 && dx_bf16, "bn_bwd_apply_slab: null pointer");
   TTSK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bn_bwd_apply_slab: dgamma/dbeta come in pairs");
@@ -695,7 +701,7 @@ extern "C" int ttsk_bn_bwd_apply_slab(const void* dout, int dout_is_f32, const v
   if (int rc = bn2_check(rows, C)) return rc;
   BnCommon a{x, mean, rstd, gamma, beta, rng, rows, C, use_tanh, p, site, x_is_f32, frame_limit, seg_len > 0 ? seg_len : 1, (uint8_t*)keep};
   hipLaunchKernelGGL(bn_bwd_apply2_kernel, dim3(C / bn_slab(C), bn_apply_chunks(rows, C)), dim3(256), 0, (hipStream_t)stream, a, dout,
-                     dout_is_f32, partials, nblk, (bf16_t*)dx_bf16, dgamma, dbeta);
+                     dout_is_f32, partials, nblk, (bf16_t*)dx_bf16, dgamma, dbeta, accumulate);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -158,6 +158,127 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, f
   }
 }
 
+
+// ---- Adam that also writes the window kernels' weight packs (round 3).  After round 2 the optimizer step was followed by
+// win_pack_kernel: a pure re-layout of the bf16 shadow Adam had just written (fragment-major copies of every FFT-block / PostNet
+// weight as it is and transposed with flipped taps, 140 MB, 55 us on the step's serial tail).  Here the workgroup that updates a tile
+// of a packed weight — 32 storage rows x 256 storage columns of one tap, the tile ffn_conv.hip:pack_one transposes through LDS —
+// keeps the tile's bf16 values in LDS and stores the 16 fragments of the plain pack and the 16 of the transposed pack itself (1 KiB
+// runs each).  Everything outside the packed weights (biases, LayerNorms, embeddings, predictors, the 80-channel ends: 5 % of the
+// parameters) goes through the flat loop over the gap ranges between them.  Same arithmetic per element as adam_clip_kernel: the
+// parameters, moments, shadow and packs are bit-identical to adam_clip_kernel + win_pack_kernel.
+struct AdamTables {
+  const ttsk_adam_item* items;   // device, sorted by tile0
+  int n_items, n_tiles;
+  const long long* gaps;         // device: n_gaps x {start, end, first compact f32x4 index}
+  int n_gaps;
+  long long gap4;                // f32x4 groups in all gaps
+};
+
+__device__ __forceinline__ void adam4(f32x4& pp, const f32x4 gg, f32x4& mm, f32x4& vv, float coef, float b1, float b2, float step, float isb2,
+                                      float eps) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float ge = gg[e] * coef;
+    mm[e] = b1 * mm[e] + (1.f - b1) * ge;
+    vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
+    pp[e] -= step * mm[e] / (sqrtf(vv[e]) * isb2 + eps);
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_pack_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, bf16_t* __restrict__ shadow, OptState* st,
+                                                        const float* __restrict__ partials, int nblk, float max_norm, float b1, float b2,
+                                                        float eps, int zero_grad, const AdamTables tb) {
+  __shared__ double red[256];
+  __shared__ __attribute__((aligned(16))) unsigned short tile[32][256 + 8];
+  {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  }
+  const float norm = (float)sqrt(red[0]);
+  const float cc = max_norm / (norm + 1e-6f);
+  const float coef = cc < 1.f ? cc : 1.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { st->gnorm = norm; st->clip_coef = coef; }
+  const float lr = st->lr, bc1 = st->bc1;
+  const float isb2 = 1.f / sqrtf(st->bc2);
+  const float step = lr / bc1;
+  const int tid = threadIdx.x;
+  // ---- the packed weights, tile by tile
+  for (int t = blockIdx.x; t < tb.n_tiles; t += gridDim.x) {
+    int lo = 0, hi = tb.n_items;               // invariant: items[lo].tile0 <= t < items[hi].tile0
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tb.items[mid].tile0 <= t) lo = mid; else hi = mid;
+    }
+    const ttsk_adam_item it = tb.items[lo];
+    const int Cs = it.Cs, K = it.K, Ds = it.Ds;
+    const int ncb = Ds / 256, nks = Cs / 32;
+    const int lt = t - it.tile0;
+    const int cb = lt % ncb, ks = (lt / ncb) % nks, ts = lt / (ncb * nks);        // ts = storage tap
+    __syncthreads();                            // the previous tile's LDS readers are done
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {               // 32 rows x 64 groups of four floats; a wave takes a whole 1 KiB row
+      const int idx = u * 256 + tid, r = idx >> 6, c4 = idx & 63;
+      const int64_t e = it.off + ((int64_t)(ks * 32 + r) * K + ts) * Ds + cb * 256 + c4 * 4;
+      f32x4 pp = *(f32x4*)(p + e), mm = *(f32x4*)(m + e), vv = *(f32x4*)(v + e);
+      const f32x4 gg = *(const f32x4*)(g + e);
+      adam4(pp, gg, mm, vv, coef, b1, b2, step, isb2, eps);
+      *(f32x4*)(p + e) = pp; *(f32x4*)(m + e) = mm; *(f32x4*)(v + e) = vv;
+      if (zero_grad) *(f32x4*)(g + e) = f32x4{0.f, 0.f, 0.f, 0.f};
+      const uint2 w = make_uint2(pack_bf2(pp[0], pp[1]), pack_bf2(pp[2], pp[3]));
+      *(uint2*)(shadow + e) = w;
+      *(uint2*)&tile[r][c4 * 4] = w;
+    }
+    __syncthreads();
+    if (it.pack) {
+      // plain pack [K][Ds/32][Cs/16][64][8]: the tile's rows are couts ks*32.., its columns cins cb*256..: 8 k-steps x 2 cout tiles
+      bf16_t* dst = (bf16_t*)it.pack;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pi = u * 256 + tid, f = pi >> 6, l = pi & 63;
+        const int ksl = f >> 1, cl = f & 1;
+        const uint4 val = *(const uint4*)&tile[cl * 16 + (l & 15)][ksl * 32 + (l >> 4) * 8];
+        const int64_t piece = ((int64_t)(ts * (Ds / 32) + cb * 8 + ksl) * (Cs / 16) + 2 * ks + cl) * 64 + l;
+        *(uint4*)(dst + piece * 8) = val;
+      }
+    }
+    if (it.pack_t) {
+      // transposed pack, taps flipped (ffn_conv.hip:pack_one): Cout' = Ds, Cin' = Cs; 16 contiguous fragments
+      const int tap = K - 1 - ts;
+      bf16_t* out = (bf16_t*)it.pack_t + ((int64_t)(tap * nks + ks) * (Ds / 16) + cb * 16) * 512;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pi = u * 256 + tid, c = pi >> 6, l = pi & 63;
+        const int col = c * 16 + (l & 15), r0 = (l >> 4) * 8;
+        unsigned short q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = tile[r0 + j][col];
+        *(uint4*)(out + (int64_t)pi * 8) = make_uint4(q[0] | ((unsigned)q[1] << 16), q[2] | ((unsigned)q[3] << 16), q[4] | ((unsigned)q[5] << 16),
+                                                      q[6] | ((unsigned)q[7] << 16));
+      }
+    }
+  }
+  // ---- everything else: the gap ranges (multiples of four floats, 16-byte aligned), as one compact index space
+  for (int64_t i = blockIdx.x * 256ll + tid; i < tb.gap4; i += (int64_t)gridDim.x * 256) {
+    int lo = 0, hi = tb.n_gaps;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tb.gaps[mid * 3 + 2] <= i) lo = mid; else hi = mid;
+    }
+    const int64_t e = tb.gaps[lo * 3] + (i - tb.gaps[lo * 3 + 2]) * 4;
+    f32x4 pp = *(f32x4*)(p + e), mm = *(f32x4*)(m + e), vv = *(f32x4*)(v + e);
+    const f32x4 gg = *(const f32x4*)(g + e);
+    adam4(pp, gg, mm, vv, coef, b1, b2, step, isb2, eps);
+    *(f32x4*)(p + e) = pp; *(f32x4*)(m + e) = mm; *(f32x4*)(v + e) = vv;
+    if (zero_grad) *(f32x4*)(g + e) = f32x4{0.f, 0.f, 0.f, 0.f};
+    *(uint2*)(shadow + e) = make_uint2(pack_bf2(pp[0], pp[1]), pack_bf2(pp[2], pp[3]));
+  }
+}
+
 }  // namespace
 
 extern "C" int ttsk_optim_state_bytes(void) { return (int)sizeof(OptState); }
@@ -217,6 +338,32 @@ extern "C" int ttsk_optim_step(float* params, float* grads, float* exp_avg, floa
   hipLaunchKernelGGL(sumsq_advance_kernel, dim3(1024), dim3(256), 0, s, grads, n, partials, (OptState*)state, sc);
   hipLaunchKernelGGL(adam_clip_kernel, dim3(2048), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (bf16_t*)shadow_bf16, n,
                      (OptState*)state, partials, 1024, max_norm, beta1, beta2, eps, zero_grad);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_optim_step_packed(float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n, void* state,
+                                      float* partials /* >= 1024 floats */, float max_norm, float beta1, float beta2, float eps, int zero_grad,
+                                      float d_model, float warmup, const float* anneal_steps_host, int n_anneal, float anneal_rate,
+                                      int advance_rng, const ttsk_adam_item* dev_items, int n_items, int n_tiles, const int64_t* dev_gaps,
+                                      int n_gaps, int64_t gap_floats, void* stream) {
+  TTSK_REQUIRE(params && grads && exp_avg && exp_avg_sq && shadow_bf16 && state && partials && n > 0, "optim_step_packed: null pointer");
+  TTSK_REQUIRE((n & 3) == 0 && (gap_floats & 3) == 0, "optim_step_packed: n and the gap total must be multiples of 4");
+  TTSK_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)shadow_bf16) & 15) == 0,
+               "optim_step_packed: alignment");
+  TTSK_REQUIRE(n_anneal >= 0 && n_anneal <= 4, "optim_step_packed: at most 4 anneal steps");
+  TTSK_REQUIRE(dev_items && n_items > 0 && n_tiles > 0 && n_gaps >= 0 && (n_gaps == 0 || dev_gaps) && gap_floats >= 0,
+               "optim_step_packed: bad tables");
+  TTSK_REQUIRE((int64_t)n_tiles * 8192 + gap_floats == n, "optim_step_packed: tiles (%d x 8192) + gaps (%lld) do not cover n = %lld", n_tiles,
+               (long long)gap_floats, (long long)n);
+  float a[4] = {0, 0, 0, 0};
+  for (int i = 0; i < n_anneal; ++i) a[i] = anneal_steps_host[i];
+  const SchedArgs sc{d_model, warmup, a[0], a[1], a[2], a[3], anneal_rate, beta1, beta2, n_anneal, advance_rng};
+  const AdamTables tb{dev_items, n_items, n_tiles, (const long long*)dev_gaps, n_gaps, (long long)(gap_floats / 4)};
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sumsq_advance_kernel, dim3(1024), dim3(256), 0, s, grads, n, partials, (OptState*)state, sc);
+  hipLaunchKernelGGL(adam_pack_kernel, dim3(2048), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (bf16_t*)shadow_bf16, (OptState*)state,
+                     partials, 1024, max_norm, beta1, beta2, eps, zero_grad, tb);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

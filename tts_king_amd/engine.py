@@ -89,10 +89,10 @@ class TrainEngine:
     def _key(batch, is_update, limited):
         return tuple(tuple(t.shape) for t in batch if torch.is_tensor(t)) + (int(batch[5]), int(batch[8]), bool(is_update), limited)
 
-    def _enqueue(self, is_update, frame_limit, phoneme_limit):
+    def _enqueue(self, is_update, frame_limit, phoneme_limit, accumulate=None):
         return make_enqueue(self.model, self.optimizer, self.cfg, self.Loss, step_is_update=is_update,
                             reducer=self.reducer if is_update else None, grad_scale=self.grad_scale, frame_limit=frame_limit,
-                            phoneme_limit=phoneme_limit)
+                            phoneme_limit=phoneme_limit, accumulate=accumulate)
 
     def step(self, batch, step_no):
         is_update = step_no % self.grad_acc == 0
@@ -105,7 +105,9 @@ class TrainEngine:
             self.stats["eager"] += 1
             losses, out = self._enqueue(is_update, fl, pl)(batch)
             return losses, out
-        key = self._key(batch, is_update, (fl is not None, pl is not None))
+        # first micro-step after an update overwrites the gradient buffer, later ones accumulate: part of a captured graph's identity
+        acc = bool(self.model.grads_partial)
+        key = self._key(batch, is_update, (fl is not None, pl is not None, acc))
         g = self._graphs.get(key)
         if key in self._eager_only:
             self.stats["eager"] += 1
@@ -125,7 +127,7 @@ class TrainEngine:
             host_step = self.optimizer._host_step
             torch.cuda.synchronize()
             try:
-                g = GraphedTrainStep(self._enqueue(is_update, static_fl, static_pl), static, warmup=0, pool=self._pool)
+                g = GraphedTrainStep(self._enqueue(is_update, static_fl, static_pl, accumulate=acc), static, warmup=0, pool=self._pool)
             except Exception as e:      # e.g. RCCL refusing to have a collective captured: this shape runs with plain launches
                 # the aborted capture ran part of one step's Python: put the host-side bookkeeping back where it was
                 self.optimizer._host_step = host_step
@@ -133,6 +135,7 @@ class TrainEngine:
                     self.reducer.reset()
                 self.model._ctx = None
                 self.model._dw_side_pending = False
+                self.model.grads_partial = acc
                 torch.cuda.synchronize()
                 self._eager_only.add(key)
                 self.stats["capture_failed"] = self.stats.get("capture_failed", 0) + 1
@@ -151,6 +154,7 @@ class TrainEngine:
         if g.phoneme_limit is not None:
             g.phoneme_limit.copy_(pl, non_blocking=True)
         losses, out = g.run(batch)
+        self.model.grads_partial = not is_update      # what the replayed step's Python would have left
         if is_update:
             self.optimizer._host_step += 1
         return losses.clone(), out

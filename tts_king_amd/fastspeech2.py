@@ -71,17 +71,23 @@ class _GroupNotifier:
     notifier asks the reducer (`ready(name)`) whether a bucket actually completes with this group and only then flushes and
     announces.  Groups must arrive in `order` (checked: a reordering of backward would silently break the overlap contract)."""
 
-    def __init__(self, order, on_bucket, flush):
+    def __init__(self, order, on_bucket, flush, mark=None):
         self.order, self.on_bucket, self.flush = list(order), on_bucket, flush
         self.ready = getattr(getattr(on_bucket, "__self__", None), "ready", None)
         self.pos = 0
         self.flushes = 0
+        # `mark(name)` (the "side" / "late" schedules): instead of flushing and announcing now, the caller records where the queues
+        # stand and does both later, bucket by bucket (FastSpeech2._launch_dw_side_buckets / _flush_param_grads)
+        self.mark = mark
 
     def done(self, name):
         if self.pos >= len(self.order) or self.order[self.pos] != name:
             raise RuntimeError("backward announced group %r, expected %r" % (name, self.order[self.pos] if self.pos < len(self.order) else None))
         self.pos += 1
         if self.on_bucket is None:
+            return
+        if self.mark is not None:
+            self.mark(name)
             return
         if self.ready is not None and not self.ready(name):
             return                      # no gradient bucket completes with this group: keep queueing
@@ -141,6 +147,7 @@ class FastSpeech2(nn.Module):
         # optimizer step).
         self.window_ffn = os.environ.get("TTSK_WINDOW_FFN", "1") != "0"
         self._w1_packed = None
+        self._adam_tables = None
         self.flash_attention = True     # ... and without the S x S tensors: online softmax forward, recomputing backward (d_k = 128)
         self.fused_ln = True            # fc / w_2 + dropout + residual + LayerNorm + PAD zeroing in one kernel when d = 256
         self.bn_stats_in_conv = os.environ.get("TTSK_BN_STATS_IN_CONV", "1") != "0"   # PostNet 512 -> 512 convs emit their BatchNorm statistics partials
@@ -163,6 +170,19 @@ class FastSpeech2(nn.Module):
         self.dw_side_frac = float(os.environ.get("TTSK_DW_SIDE_FRAC", "0.8"))
         self._dw_side = None
         self._dw_side_pending = False
+        # Data-parallel schedule (backward_native(on_bucket=...)), TTSK_DP_SCHEDULE:
+        #   "side"  (default) the single-GPU schedule kept: nothing is flushed during the PostNet / decoder backward; after it the queued
+        #           weight-gradient work runs on the second stream BUCKET BY BUCKET (capped grid, its split-K reducer behind it) and each
+        #           bucket's all-reduce is issued from there, beside the encoder-side dX chain; the rest after the chain;
+        #   "early" round 2's: flush on the main stream whenever a bucket completes (7 grouped launches, no second stream): the most
+        #           overlap of wire time with backward, 16 % more compute time per step;
+        #   "late"  the single-GPU schedule untouched, every all-reduce after the last flush (no overlap with backward).
+        self.dp_schedule = os.environ.get("TTSK_DP_SCHEDULE", "side")
+        self._fin_side = None
+        # Does the flat gradient buffer hold an unfinished accumulation (micro-steps of a grad_acc_step cycle)?  False after an optimizer
+        # update or zero_grad(): the next backward then overwrites instead of accumulating (see backward_native).
+        self.grads_partial = False
+        self._acc = True
         self._rng_state = None          # device block shared with the optimizer (ops.optim_state)
         self._seed = seed
         self._modules_by_key = {}
@@ -233,9 +253,10 @@ class FastSpeech2(nn.Module):
         self._flat, self._flat_grad = flat, grad
         self._shadow = shadow.to(bf16) if shadow.dtype != bf16 else shadow
         self._w1_packed = None
+        self._adam_tables = None
         self._shadow_version = -1
         self._rng_state = None
-        self._side = None
+        self._side = self._dw_side = self._fin_side = None
         self._rebind()
         if self.window_ffn and self._shadow.is_cuda:
             self._build_packs()
@@ -371,6 +392,20 @@ class FastSpeech2(nn.Module):
         # the shadow views and the packs keep their addresses until _apply: a device-resident item table, one pack launch per step
         self._pack_table = ops.win_conv_pack_table([(self._pack_source(key, fr), out, tr) for key, fr, out, tr in self._pack_items],
                                                    self._shadow.device) if self._pack_items else None
+        # ... and the tables with which the optimizer's Adam launch writes these packs itself (ttsk_optim_step_packed): per weight its
+        # flat offset, storage shape and its plain / transposed packs.  A weight with more than one pack of a kind (w_1's transposed
+        # pack exists once) or one that does not tile leaves `_adam_tables` None: the optimizer then calls refresh_packed as before.
+        self._adam_tables = None
+        if self._pack_items and os.environ.get("TTSK_ADAM_PACKS", "1") != "0":
+            by_key, ok = {}, True
+            for key, fr, out, tr in self._pack_items:
+                W = self._pack_source(key, fr)
+                ent = by_key.setdefault(key, [self._table[key].offset, tuple(W.shape), None, None])
+                if ent[1] != tuple(W.shape) or ent[3 if tr else 2] is not None:
+                    ok = False
+                ent[3 if tr else 2] = out
+            if ok:
+                self._adam_tables = ops.adam_pack_tables([tuple(v) for v in by_key.values()], self._n_flat, self._shadow.device)
 
     def _pack_source(self, key, fused_rows=None):
         """The tap-major bf16 shadow of `key` as a (Cs, k, Ds) tensor (a Linear weight is k = 1; `fused_rows`: the q|k|v rows as one)."""
@@ -571,7 +606,7 @@ class FastSpeech2(nn.Module):
                 cg = "variance_adaptor.%s_predictor.conv_layer." % n
                 self._finalize_ln(part[g], nblk, 4 * Fh + 1, cg + "conv1d_2.conv.bias")
                 ops.conv1d_dw(dh2[g].view(Bn, Lp, Fh), a1[g * rows:(g + 1) * rows].view(Bn, Lp, Fh), self._g(cg + "conv1d_2.conv.weight"),
-                              k=self.k_var, defer=self._deferred)
+                              k=self.k_var, defer=self._deferred, accumulate=self._acc)
         da1 = torch.empty(3, rows, Fh, dtype=bf16, device=dev)
         ops.conv1d_dx(dh2[0].view(Bn, Lp, Fh), W2, out=da1[0].view(Bn, Lp, Fh), nz1=3, sA=(rows * Fh, 0), sB=(ps, 0), sC=(rows * Fh, 0))
         dh1, part, nblk = ops.layernorm_bwd_grouped(da1.view(3 * rows, Fh), h1.view(3 * rows, Fh), m1, r1, self._m(c + "layer_norm_1.weight"),
@@ -583,7 +618,7 @@ class FastSpeech2(nn.Module):
                 cg = "variance_adaptor.%s_predictor.conv_layer." % n
                 self._finalize_ln(part[g], nblk, 3 * Fh, cg + "conv1d_1.conv.bias")
                 ops.conv1d_dw(dh1[g].view(Bn, Lp, Fh), stack[g].view(Bn, Lp, d), self._g(cg + "conv1d_1.conv.weight"), k=self.k_var,
-                              defer=self._deferred)
+                              defer=self._deferred, accumulate=self._acc)
         dxin = torch.empty(3, rows, d, dtype=torch.float32, device=dev)
         ops.conv1d_dx(dh1[0].view(Bn, Lp, Fh), W1, out=dxin[0].view(Bn, Lp, d), nz1=3, sA=(rows * Fh, 0), sB=(ps, 0), sC=(rows * d, 0))
         return ops.va_combine(dx3, dxin, Lp, row_limit)
@@ -814,7 +849,7 @@ class FastSpeech2(nn.Module):
         sub-layer bias, LayerNorm weight and LayerNorm bias (and the predictor head) sit back to back in that order
         starting at `first_key` (params.py builds them so): ONE finalize launch per LayerNorm."""
         off = self._table[first_key].offset
-        ops.colsum_finalize(partials, nblk, ncol, ncol, self._flat_grad[off:off + ncol], accumulate=True, defer=self._deferred_fin)
+        ops.colsum_finalize(partials, nblk, ncol, ncol, self._flat_grad[off:off + ncol], accumulate=self._acc, defer=self._deferred_fin)
 
     class _SideWork:
         """Parameter-gradient work (dW GEMMs, bias / LayerNorm column sums) runs on a second HIP stream: nothing on the
@@ -892,7 +927,7 @@ class FastSpeech2(nn.Module):
         # ---- w_2 (k=1): dW, dX gated by the ReLU
         with self._side_work(dy2, part, h):
             self._finalize_ln(part, nblk, 3 * d, f + "w_2.bias")
-            ops.conv1d_dw(dy2.view(Bn, S, d), h, self._g(f + "w_2.weight"), k=self.k2, defer=self._deferred)
+            ops.conv1d_dw(dy2.view(Bn, S, d), h, self._g(f + "w_2.weight"), k=self.k2, defer=self._deferred, accumulate=self._acc)
         if dh is not None:
             pass
         elif pk2 is not None and self.k2 == 1:
@@ -901,8 +936,8 @@ class FastSpeech2(nn.Module):
             dh = ops.conv1d_dx(dy2.view(Bn, S, d), self._w(f + "w_2.weight"), G=h)
         # ---- w_1 (k=9): bias, dW, dX + residual gradient; the dX stays in split-K form for the attention LayerNorm's backward
         with self._side_work(dh, x1):
-            ops.colsum_into(dh.view(rows, -1), self._g(f + "w_1.bias"), defer=self._deferred_fin)
-            ops.conv1d_dw(dh, x1.view(Bn, S, d), self._g(f + "w_1.weight"), k=self.k1, defer=self._deferred)
+            ops.colsum_into(dh.view(rows, -1), self._g(f + "w_1.bias"), defer=self._deferred_fin, accumulate=self._acc)
+            ops.conv1d_dw(dh, x1.view(Bn, S, d), self._g(f + "w_1.weight"), k=self.k1, defer=self._deferred, accumulate=self._acc)
         # ---- attention tail
         do = delta = None
         if self.raw_slabs:
@@ -928,7 +963,7 @@ class FastSpeech2(nn.Module):
                                                      self._m(a + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site, rng=rng)
         with self._side_work(dy1, part, o):
             self._finalize_ln(part, nblk, 3 * d, a + "fc.bias")
-            ops.linear_dw(dy1, o, self._g(a + "fc.weight"), defer=self._deferred)
+            ops.linear_dw(dy1, o, self._g(a + "fc.weight"), defer=self._deferred, accumulate=self._acc)
         pkf = self._w1_packed.get(("fcT", a + "fc.weight")) if (self.window_ffn and self._w1_packed) else None
         if do is not None:
             pass
@@ -961,8 +996,8 @@ class FastSpeech2(nn.Module):
             kv.flush()
         # ---- q|k|v projections
         with self._side_work(dqkv, x):
-            ops.colsum_into(dqkv, self._g(a + "w_qs.bias", 3 * d), defer=self._deferred_fin)
-            ops.linear_dw(dqkv, x, self._g(a + "w_qs.weight", 3 * d * d).view(3 * d, d), defer=self._deferred)
+            ops.colsum_into(dqkv, self._g(a + "w_qs.bias", 3 * d), defer=self._deferred_fin, accumulate=self._acc)
+            ops.linear_dw(dqkv, x, self._g(a + "w_qs.weight", 3 * d * d).view(3 * d, d), defer=self._deferred, accumulate=self._acc)
         if raw_out and self.raw_slabs:
             pkq = self._w1_packed.get(("qkvT", a + "w_qs.weight")) if (self.window_ffn and self._w1_packed) else None
             if pkq is not None and raw_out == "pre" and d == 256:
@@ -986,14 +1021,14 @@ class FastSpeech2(nn.Module):
                                                site_post=site + 1, rng=rng, dhead=dout.contiguous().view(-1), head_w=hw)
         with self._side_work(dh2, part, a1):
             self._finalize_ln(part, nblk, 4 * Fh + 1, c + "conv1d_2.conv.bias")
-            ops.conv1d_dw(dh2.view(Bn, Lp, Fh), a1.view(Bn, Lp, Fh), self._g(c + "conv1d_2.conv.weight"), k=self.k_var, defer=self._deferred)
+            ops.conv1d_dw(dh2.view(Bn, Lp, Fh), a1.view(Bn, Lp, Fh), self._g(c + "conv1d_2.conv.weight"), k=self.k_var, defer=self._deferred, accumulate=self._acc)
         da1 = ops.conv1d_dx(dh2.view(Bn, Lp, Fh), self._w(c + "conv1d_2.conv.weight"))
         dh1, _, part, nblk = ops.layernorm_bwd(da1.view(rows, Fh), h1.view(rows, Fh), m1, r1, self._m(c + "layer_norm_1.weight"),
                                                self._m(c + "layer_norm_1.bias"), None, 0, relu_in=True, p_post=p,
                                                site_post=site, rng=rng)
         with self._side_work(dh1, part, x):
             self._finalize_ln(part, nblk, 3 * Fh, c + "conv1d_1.conv.bias")
-            ops.conv1d_dw(dh1.view(Bn, Lp, Fh), x.view(Bn, Lp, d), self._g(c + "conv1d_1.conv.weight"), k=self.k_var, defer=self._deferred)
+            ops.conv1d_dw(dh1.view(Bn, Lp, Fh), x.view(Bn, Lp, d), self._g(c + "conv1d_1.conv.weight"), k=self.k_var, defer=self._deferred, accumulate=self._acc)
         return ops.conv1d_dx(dh1.view(Bn, Lp, Fh), self._w(c + "conv1d_1.conv.weight"), R=R)
 
     def backward_group_order(self):
@@ -1011,6 +1046,50 @@ class FastSpeech2(nn.Module):
             ops.flush_deferred_gemms(self._deferred, max_wgs=self.dw_side_wgs, frac=self.dw_side_frac)
         self._dw_side_pending = True
 
+    def _mark_bucket(self, name):
+        """The notifier's `mark` in the "side" / "late" data-parallel schedules: group `name` is complete once everything queued so far
+        has been flushed — remember where the GEMM and reducer queues stand."""
+        self._dp_marks.append((name, len(self._deferred.group), len(self._deferred)))
+
+    def _launch_dw_side_buckets(self, on_bucket, ready):
+        """Data-parallel "side" schedule, after the decoder's backward: the queued weight-gradient GEMMs of PostNet / mel_linear / decoder
+        on the second stream with the capped grid — the single-GPU schedule, but cut at the gradient-bucket boundaries: the groups of one
+        bucket, their split-K reducer, then `on_bucket` (the bucket's all-reduce, issued behind them from that stream), beside the
+        encoder-side dX chain on the main stream.  The bias / LayerNorm column sums queued so far run once on a third stream beside the
+        first bucket's GEMMs.  As with `dw_side_frac`, only buckets within the first ~80 % of the queued FLOPs go here; what is left
+        joins the final flush on the whole chip (`_flush_param_grads`), which announces every remaining group."""
+        if self._dw_side is None:
+            self._dw_side = torch.cuda.Stream(device=self.device)
+        if self._fin_side is None:
+            self._fin_side = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream()
+        fl = [2.0 * d.M * d.N * d.K * max(d.taps, 1) * d.nz1 * d.nz2 for d in self._deferred.group]
+        budget = self.dw_side_frac * sum(fl)
+        self._fin_side.wait_stream(cur)
+        self._dp_keep = [k for _, k in self._deferred_fin]       # alive until the final join (the allocator orders frees by the main stream only)
+        with torch.cuda.stream(self._fin_side):
+            ops.flush_finalize(self._deferred_fin)
+        self._fin_pending = True
+        self._dw_side.wait_stream(cur)
+        done_g = done_r = launched = 0
+        marks, self._dp_marks = self._dp_marks, []
+        with torch.cuda.stream(self._dw_side):
+            for i, (name, ng, nr) in enumerate(marks):
+                if launched < 0 or (ready is not None and not ready(name)):
+                    self._dp_marks.append((name, 0, 0))              # announced with the final flush
+                    continue
+                if launched and sum(fl[:ng]) > budget:
+                    launched = -1                                   # this bucket and everything behind it: the final flush
+                    self._dp_marks.append((name, 0, 0))
+                    continue
+                ops.flush_deferred_prefix(self._deferred, ng - done_g, nr - done_r, max_wgs=self.dw_side_wgs)
+                done_g, done_r = ng, nr
+                if not launched:
+                    self._dw_side.wait_stream(self._fin_side)        # the column sums of these groups (done long before the GEMMs)
+                on_bucket(name)
+                launched += 1
+        self._dw_side_pending = True
+
     def _flush_param_grads(self):
         """Run the queued weight-gradient work (grouped dW GEMMs, split-K reducers, column sums, scatter-sums)."""
         self._join_side()
@@ -1025,9 +1104,13 @@ class FastSpeech2(nn.Module):
                 launch()
             ops.flush_finalize(self._deferred_fin)
             cur.wait_stream(self._dw_side)
+            if getattr(self, "_fin_pending", False):
+                cur.wait_stream(self._fin_side)
+                self._fin_pending = False
             self._dw_side_pending = False
         ops.flush_deferred(self._deferred)
         ops.flush_finalize(self._deferred_fin)
+        self._dp_keep = None
 
     @staticmethod
     def _stack3(dlogd, dpitch, denergy):
@@ -1044,13 +1127,19 @@ class FastSpeech2(nn.Module):
             out[i].copy_(t)               # a device-to-device copy, no arithmetic
         return out
 
-    def backward_native(self, ctx, dmel_sum, dpost, dpitch, denergy, dlogd, on_bucket=None):
-        """Accumulate d(loss)/d(params) into the flat gradient buffer.
+    def backward_native(self, ctx, dmel_sum, dpost, dpitch, denergy, dlogd, on_bucket=None, accumulate=None):
+        """d(loss)/d(params) into the flat gradient buffer.
         dmel_sum = dL/dmel (direct terms) + dL/dpost, dpost = dL/dpost — fp32 (B,T,n_mel); dpitch/denergy/dlogd fp32 (B,L).
-        `on_bucket(name)` is called when the gradients of a top-level group are complete (data-parallel overlap)."""
+        `on_bucket(name)` is called when the gradients of a top-level group are complete (data-parallel overlap).
+        `accumulate`: True adds to what the buffer holds (the reference's `.grad +=`, train.py:43-44, micro-steps 2.. of a
+        `grad_acc_step` cycle); False OVERWRITES every gradient element (the first micro-step after an update: the buffer need not be
+        zero, so the optimizer's kernel need not zero it — 4 B per parameter less on the step's serial tail, and no read of the old
+        value in the weight-gradient epilogues); None: whatever `grads_partial` says the buffer holds."""
         if ctx is None or ctx.used:
             raise RuntimeError("backward called without a matching training forward")
         ctx.used = True
+        self._acc = bool(self.grads_partial if accumulate is None else accumulate)
+        self.grads_partial = True
         rng = ops.rng_of(self._state())
         Bn, Lp, T = ctx.dims
         d, rows, nm = self.d, Bn * T, self.n_mel
@@ -1060,7 +1149,10 @@ class FastSpeech2(nn.Module):
         self._deferred_fin = []
         if self.overlap_param_grads and self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
-        notifier = _GroupNotifier(self.backward_group_order(), on_bucket, self._flush_param_grads)
+        dp_side = on_bucket is not None and self.dp_schedule in ("side", "late") and self.dw_side_wgs > 0 and self.group_param_grads \
+            and not self.overlap_param_grads
+        self._dp_marks = []
+        notifier = _GroupNotifier(self.backward_group_order(), on_bucket, self._flush_param_grads, mark=self._mark_bucket if dp_side else None)
         notify = notifier.done
         # ---- PostNet (last layer first)
         dout = dpost.view(rows, nm)
@@ -1069,10 +1161,10 @@ class FastSpeech2(nn.Module):
             C = yc.shape[2]
             dy = ops.bn_bwd(dout, yc.view(rows, C), mean, rstd, self._m(pp + "1.weight"), self._m(pp + "1.bias"), i < 4,
                             p=self.p_post, site=300 + i, rng=rng, dgamma=self._g(pp + "1.weight"), dbeta=self._g(pp + "1.bias"),
-                            frame_limit=ctx.frame_limit, keep=keep)
+                            frame_limit=ctx.frame_limit, keep=keep, accumulate=self._acc)
             with self._side_work(dy, xin):
-                ops.colsum_into(dy, self._g(pp + "0.conv.bias"), defer=self._deferred_fin)
-                ops.conv1d_dw(dy.view(Bn, T, C), xin, self._g(pp + "0.conv.weight"), k=5, defer=self._deferred)
+                ops.colsum_into(dy, self._g(pp + "0.conv.bias"), defer=self._deferred_fin, accumulate=self._acc)
+                ops.conv1d_dw(dy.view(Bn, T, C), xin, self._g(pp + "0.conv.weight"), k=5, defer=self._deferred, accumulate=self._acc)
             pkt = self._w1_packed.get(("pnT", pp + "0.conv.weight")) if (self.window_ffn and self._w1_packed) else None
             if i > 0 and pkt is not None:
                 cw = self._table[pp + "0.conv.weight"].storage_shape
@@ -1086,34 +1178,36 @@ class FastSpeech2(nn.Module):
         notify("postnet")
         # ---- mel_linear
         with self._side_work(dmel_tot, ctx.dec_out):
-            ops.colsum_into(dmel_tot, self._g("mel_linear.bias"), defer=self._deferred_fin)
-            ops.linear_dw(dmel_tot, ctx.dec_out, self._g("mel_linear.weight"), defer=self._deferred)
+            ops.colsum_into(dmel_tot, self._g("mel_linear.bias"), defer=self._deferred_fin, accumulate=self._acc)
+            ops.linear_dw(dmel_tot, ctx.dec_out, self._g("mel_linear.weight"), defer=self._deferred, accumulate=self._acc)
         dx = ops.linear_dx(dmel_tot, self._w("mel_linear.weight"))
         notify("mel_linear")
         # ---- decoder
         for i in range(self.n_dec - 1, -1, -1):
             dx = self._fft_bwd(ctx.blocks[ctx.n_enc_blocks + i], dx, rng, raw_out=self._raw_out_mode() if i > 0 else False)
             notify("decoder.%d" % i)
-        if self.dw_side_wgs > 0 and on_bucket is None and self.group_param_grads and not self.overlap_param_grads:
+        if dp_side and self.dp_schedule == "side":
+            self._launch_dw_side_buckets(on_bucket, notifier.ready)
+        elif self.dw_side_wgs > 0 and (on_bucket is None or dp_side) and self.group_param_grads and not self.overlap_param_grads:
             self._launch_dw_side()
         # ---- length regulator: segment sums (the position table has no parameters)
         dx3 = ops.length_regulator_bwd(dx.view(Bn, T, d), ctx.cs, Lp).view(Bn * Lp, d)
         # ---- variance adaptor, reverse order of modules.py:158-193
         va = "variance_adaptor."
         with self._side_work(dx3):
-            ops.scatter_sum(dx3, ctx.eidx.view(-1), self._g(va + "energy_embedding.weight"), defer=self._deferred_fin)
+            ops.scatter_sum(dx3, ctx.eidx.view(-1), self._g(va + "energy_embedding.weight"), defer=self._deferred_fin, accumulate=self._acc)
         if "grouped" in ctx.preds:
             dx2, dx1, dxe = self._predictors_bwd_grouped(ctx.preds["grouped"], self._stack3(dlogd, dpitch, denergy), rng, dx3)
             with self._side_work(dx2, dx1):
-                ops.scatter_sum(dx2, ctx.pidx.view(-1), self._g(va + "pitch_embedding.weight"), defer=self._deferred_fin)
-                ops.scatter_sum(dx1, ctx.speakers, self._g("speaker_emb.weight"), idx_div=Lp, defer=self._deferred_fin)
+                ops.scatter_sum(dx2, ctx.pidx.view(-1), self._g(va + "pitch_embedding.weight"), defer=self._deferred_fin, accumulate=self._acc)
+                ops.scatter_sum(dx1, ctx.speakers, self._g("speaker_emb.weight"), idx_div=Lp, defer=self._deferred_fin, accumulate=self._acc)
         else:
             dx2 = self._predictor_bwd(va + "energy_predictor.", ctx.preds[va + "energy_predictor."], denergy, rng, dx3.view(Bn, Lp, d))
             with self._side_work(dx2):
-                ops.scatter_sum(dx2.view(Bn * Lp, d), ctx.pidx.view(-1), self._g(va + "pitch_embedding.weight"), defer=self._deferred_fin)
+                ops.scatter_sum(dx2.view(Bn * Lp, d), ctx.pidx.view(-1), self._g(va + "pitch_embedding.weight"), defer=self._deferred_fin, accumulate=self._acc)
             dx1 = self._predictor_bwd(va + "pitch_predictor.", ctx.preds[va + "pitch_predictor."], dpitch, rng, dx2)
             with self._side_work(dx1):
-                ops.scatter_sum(dx1.view(Bn * Lp, d), ctx.speakers, self._g("speaker_emb.weight"), idx_div=Lp, defer=self._deferred_fin)
+                ops.scatter_sum(dx1.view(Bn * Lp, d), ctx.speakers, self._g("speaker_emb.weight"), idx_div=Lp, defer=self._deferred_fin, accumulate=self._acc)
             dxe = self._predictor_bwd(va + "duration_predictor.", ctx.preds[va + "duration_predictor."], dlogd, rng, dx1)
         notify("variance_adaptor")
         # ---- encoder
@@ -1122,7 +1216,11 @@ class FastSpeech2(nn.Module):
             dx = self._fft_bwd(ctx.blocks[i], dx, rng, raw_out=self._raw_out_mode() if i > 0 else False)
             notify("encoder.%d" % i)
         with self._side_work(dx):
-            ops.scatter_sum(dx, ctx.texts.view(-1), self._g("encoder.src_word_emb.weight"), skip_row=0, defer=self._deferred_fin)   # padding_idx=0
+            ops.scatter_sum(dx, ctx.texts.view(-1), self._g("encoder.src_word_emb.weight"), skip_row=0, defer=self._deferred_fin, accumulate=self._acc)   # padding_idx=0
         notify("embedding")
         self._flush_param_grads()
+        if dp_side:
+            for name, _, _ in self._dp_marks:       # everything is in the buffer now: the remaining buckets, in completion order
+                on_bucket(name)
+            self._dp_marks = []
         self._ctx = None

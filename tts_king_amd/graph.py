@@ -41,6 +41,8 @@ class GraphedTrainStep:
         return tuple(tuple(t.shape) for t in self.static if torch.is_tensor(t))
 
     def run(self, batch=None):
+        """Copy `batch` into the static inputs (when given) and replay.  The replay runs none of the step's Python: host-side
+        bookkeeping a step would have done (optimizer._host_step, model.grads_partial) is the caller's."""
         if batch is not None:
             for dst, src in zip(self.static, batch):
                 if torch.is_tensor(dst) and src is not dst:
@@ -49,9 +51,14 @@ class GraphedTrainStep:
         return self.outputs
 
 
-def make_enqueue(model, optimizer, cfg, Loss, step_is_update=True, reducer=None, grad_scale=None, frame_limit=None, phoneme_limit=None):
+def make_enqueue(model, optimizer, cfg, Loss, step_is_update=True, reducer=None, grad_scale=None, frame_limit=None, phoneme_limit=None,
+                 accumulate=None):
     """The device-side part of `main_train_step` (train.py:24-56) as a capturable closure.  `frame_limit`: device int32[1] holding
-    the batch's own longest utterance when the batch tensors are padded to a shape bucket (see FastSpeech2._forward)."""
+    the batch's own longest utterance when the batch tensors are padded to a shape bucket (see FastSpeech2._forward).
+    `accumulate`: does this micro-step add to the gradient buffer (True: micro-steps 2.. of a grad_acc_step cycle) or overwrite it
+    (False: the first one after an update; the optimizer step of this path does not zero the buffer)?  None decides from
+    `model.grads_partial` when the closure RUNS — right for eager launches; a captured graph freezes the choice, so whoever replays
+    graphs of a grad_acc_step > 1 cycle keeps one for the first micro-step and one for the later ones (TrainEngine does)."""
     grad_acc = cfg.train_config["optimizer"]["grad_acc_step"]
     gs = (1.0 / grad_acc) if grad_scale is None else grad_scale
 
@@ -65,12 +72,13 @@ def make_enqueue(model, optimizer, cfg, Loss, step_is_update=True, reducer=None,
             losses, dmel_sum, dpost, dp, de, dd = ops.fs2_loss(mel, post, batch[6], batch[7], pitch, energy, logd, batch[11],
                                                                batch[9], batch[10], batch[4], grad_scale=gs, frame_limit=None if frame_limit is None else (frame_limit, 0))
             if reducer is not None and step_is_update:
-                model.backward_native(ctx, dmel_sum, dpost, dp, de, dd, on_bucket=reducer.on_group_done)
+                model.backward_native(ctx, dmel_sum, dpost, dp, de, dd, on_bucket=reducer.on_group_done, accumulate=accumulate)
                 reducer.finish()
             else:
-                model.backward_native(ctx, dmel_sum, dpost, dp, de, dd)
+                model.backward_native(ctx, dmel_sum, dpost, dp, de, dd, accumulate=accumulate)
             if step_is_update:
-                optimizer.step_and_update_lr(advance_rng=True)      # the end-of-step dropout-counter tick rides along
+                # the end-of-step dropout-counter tick rides along; the gradients stay (the next backward overwrites them)
+                optimizer.step_and_update_lr(advance_rng=True, keep_grads=True)
             else:
                 ops.rng_advance(model._state())
         return losses, out

@@ -65,6 +65,12 @@ class PackItem(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("Cs", C.c_int32), ("K", C.c_int32), ("Ds", C.c_int32), ("transpose", C.c_int32)]
 
 
+class AdamItem(C.Structure):
+    """Mirror of `ttsk_adam_item` (include/ttsk.h)."""
+    _fields_ = [("off", C.c_int64), ("pack", C.c_void_p), ("pack_t", C.c_void_p), ("Cs", C.c_int32), ("K", C.c_int32), ("Ds", C.c_int32),
+                ("tile0", C.c_int32)]
+
+
 # flags (include/ttsk.h)
 A_TR, B_TR, C_F32, RELU, ADD_R, R_F32, MASK_G, LRELU_IN, TANH, ACCUM_C, LRELU_OUT, F16, C2_LRELU, DEFER_REDUCE, RAW_SLABS = [1 << i for i in range(15)]
 

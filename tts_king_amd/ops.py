@@ -153,6 +153,26 @@ def flush_deferred_gemms(items, max_wgs=0, frac=1.0):
     flush_group(group, getattr(items, "_keep"), max_wgs)
 
 
+def flush_deferred_prefix(items, n_group, n_reduce, max_wgs=0):
+    """The first `n_group` queued weight-gradient GEMMs as grouped launches (grid capped at max_wgs when > 0) and then the batched
+    reducer for the first `n_reduce` queued split-K items, on the current stream; both are removed from the queue.  The data-parallel
+    "side" schedule flushes the queue bucket by bucket this way (FastSpeech2._launch_dw_side_buckets)."""
+    group = getattr(items, "group", None)
+    if group and n_group > 0:
+        now = group[:n_group]
+        del group[:n_group]
+        flush_group(now, getattr(items, "_keep"), max_wgs)
+    if n_reduce > 0:
+        head = items[:n_reduce]
+        del items[:n_reduce]
+        arr = (L.ReduceItem * len(head))(*[it for it, _ in head])
+        check(L.load().ttsk_gemm_reduce_batch(arr, len(head), _stream()), "ttsk_gemm_reduce_batch")
+        if LAUNCH_COUNTS is not None:
+            LAUNCH_COUNTS["reduce_batch"] = LAUNCH_COUNTS.get("reduce_batch", 0) + 1
+        if hasattr(items, "_keep"):
+            items._keep.extend(ws for _, ws in head)       # the slabs stay alive until the queue's final flush
+
+
 def flush_deferred(items):
     """The queued weight-gradient GEMMs as grouped launches, then one ttsk_gemm_reduce_batch launch (per 64 items) for the
     split-K slabs collected in `items` (see gemm(defer=...))."""
@@ -1000,8 +1020,10 @@ def bn_train(x, running_mean, running_var, nbt, gamma, beta, use_tanh, p=0.0, si
     return ((o32 if out_f32 else o16), mean, rstd, keep) if want_keep else ((o32 if out_f32 else o16), mean, rstd)
 
 
-def bn_bwd(dout, x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, dgamma=None, dbeta=None, frame_limit=None, keep=None):
-    """dx (rows,C) bf16; dgamma/dbeta (fp32, accumulated in place when given).  keep: bn_train's keep bits (slab kernels only)."""
+def bn_bwd(dout, x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, dgamma=None, dbeta=None, frame_limit=None, keep=None,
+           accumulate=True):
+    """dx (rows,C) bf16; dgamma/dbeta (fp32, accumulated in place when given, or overwritten with accumulate=False).  keep: bn_train's
+    keep bits (slab kernels only)."""
     rows, Cn = x.shape
     lib = L.load()
     if bn_slab_supported(Cn):
@@ -1012,8 +1034,8 @@ def bn_bwd(dout, x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, 
                                          p, site, _ptr(rng), _ptr(keep), _ptr(partials), lp, seg, _stream()), "ttsk_bn_bwd_stats_slab")
         dx = torch.empty(rows, Cn, dtype=bf16, device=x.device)
         check(lib.ttsk_bn_bwd_apply_slab(_ptr(dout), f32, _ptr(x), xf, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn, int(use_tanh),
-                                         p, site, _ptr(rng), _ptr(keep), _ptr(partials), partials.shape[0], _ptr(dx), _ptr(dgamma), _ptr(dbeta), lp, seg,
-                                         _stream()), "ttsk_bn_bwd_apply_slab")
+                                         p, site, _ptr(rng), _ptr(keep), _ptr(partials), partials.shape[0], _ptr(dx), _ptr(dgamma), _ptr(dbeta), int(accumulate),
+                                         lp, seg, _stream()), "ttsk_bn_bwd_apply_slab")
         return dx
     nblk = lib.ttsk_bn_nblocks(rows)
     partials = _f32(nblk, 2 * Cn, device=x.device)
@@ -1024,8 +1046,8 @@ def bn_bwd(dout, x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, 
     colsum_finalize(partials, nblk, 2 * Cn, 2 * Cn, sums, accumulate=False)
     dx = torch.empty(rows, Cn, dtype=bf16, device=x.device)
     check(lib.ttsk_bn_bwd_apply(_ptr(dout), f32, _ptr(x), int(x.dtype == torch.float32), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn,
-                                int(use_tanh), p, site, _ptr(rng), _ptr(sums), _ptr(dx), _ptr(dgamma), _ptr(dbeta), *_lim(frame_limit), _stream()),
-          "ttsk_bn_bwd_apply")
+                                int(use_tanh), p, site, _ptr(rng), _ptr(sums), _ptr(dx), _ptr(dgamma), _ptr(dbeta), int(accumulate), *_lim(frame_limit),
+                                _stream()), "ttsk_bn_bwd_apply")
     return dx
 
 
@@ -1089,6 +1111,48 @@ def optim_step(params, grads, m, v, shadow, state, partials, max_norm, beta1, be
     check(L.load().ttsk_optim_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(shadow), params.numel(), _ptr(state), _ptr(partials),
                                    max_norm, beta1, beta2, eps, int(zero_grad), float(d_model), float(warmup), C.cast(arr, C.c_void_p),
                                    len(anneal_steps), anneal_rate, int(advance_rng), _stream()), "ttsk_optim_step")
+
+
+def adam_pack_tables(items, n_flat, device):
+    """Device tables for optim_step_packed.  items: [(flat offset, (Cs, K, Ds), plain pack tensor or None, transposed pack tensor or
+    None)] — the window kernels' packed weights; everything else of [0, n_flat) becomes the gap ranges.  Returns a dict of the tensors /
+    counts the call needs (the tensors must stay alive and the packs where they are), or None when a weight does not tile
+    (Cs % 32, Ds % 256) or the ranges overlap."""
+    items = sorted(items, key=lambda it: it[0])
+    arr = (L.AdamItem * len(items))()
+    tile0, pos, gaps = 0, 0, []
+    for i, (off, (Cs, K, Ds), pk, pkt) in enumerate(items):
+        if Cs % 32 or Ds % 256 or off % 4 or off < pos:
+            return None
+        if off > pos:
+            gaps.append((pos, off))
+        arr[i].off, arr[i].pack, arr[i].pack_t = off, _ptr(pk), _ptr(pkt)
+        arr[i].Cs, arr[i].K, arr[i].Ds, arr[i].tile0 = Cs, K, Ds, tile0
+        tile0 += K * (Cs // 32) * (Ds // 256)
+        pos = off + Cs * K * Ds
+    if pos < n_flat:
+        gaps.append((pos, n_flat))
+    g, acc = [], 0
+    for a, b in gaps:
+        if (b - a) % 4:
+            return None
+        g += [a, b, acc]
+        acc += (b - a) // 4
+    dev_items = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.int64).clone().to(device)
+    dev_gaps = torch.tensor(g if g else [0, 0, 0], dtype=torch.int64).to(device)
+    return {"items": dev_items, "n_items": len(items), "n_tiles": tile0, "gaps": dev_gaps, "n_gaps": len(gaps), "gap_floats": acc * 4}
+
+
+def optim_step_packed(params, grads, m, v, shadow, state, partials, max_norm, beta1, beta2, eps, d_model, warmup, anneal_steps, anneal_rate,
+                      tables, zero_grad=True, advance_rng=False):
+    """optim_step whose Adam launch also writes the window kernels' weight packs (ttsk_optim_step_packed): no pack launch afterwards."""
+    _dev(params, grads, m, v, shadow, state, partials, tables["items"], tables["gaps"])
+    arr = (C.c_float * 4)(*([float(a) for a in anneal_steps] + [0.0] * (4 - len(anneal_steps))))
+    check(L.load().ttsk_optim_step_packed(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(shadow), params.numel(), _ptr(state), _ptr(partials),
+                                          max_norm, beta1, beta2, eps, int(zero_grad), float(d_model), float(warmup), C.cast(arr, C.c_void_p),
+                                          len(anneal_steps), anneal_rate, int(advance_rng), _ptr(tables["items"]), tables["n_items"],
+                                          tables["n_tiles"], _ptr(tables["gaps"]), tables["n_gaps"], tables["gap_floats"], _stream()),
+          "ttsk_optim_step_packed")
 
 
 # ---------------------------------------------------------------------------------------------------- HiFi-GAN helpers

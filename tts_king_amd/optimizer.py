@@ -48,18 +48,32 @@ class ScheduledOptim:
                 lr = lr * self.anneal_rate
         return lr
 
-    def step_and_update_lr(self, advance_rng=False):
-        """clip (global norm) -> lr update -> Adam -> bf16 shadow refresh -> grads zeroed, all on device, in two launches.
-        `advance_rng`: also tick the dropout counter (the train step's end-of-step tick, folded in)."""
+    def step_and_update_lr(self, advance_rng=False, keep_grads=False):
+        """clip (global norm) -> lr update -> Adam -> bf16 shadow (+ window-kernel weight packs) -> grads zeroed, all on device, in two
+        launches.  `advance_rng`: also tick the dropout counter (the train step's end-of-step tick, folded in).  `keep_grads`: do not
+        zero the gradient buffer (the sync-free step path: its next backward overwrites, FastSpeech2.backward_native); the default
+        leaves zeros, as the reference's `zero_grad()` right after the step does (train.py:54)."""
         flat, grad, shadow = self.model.flat_buffers()
-        ops.optim_step(flat, grad, self.exp_avg, self.exp_avg_sq, shadow, self.state, self._partials, self.grad_clip_thresh,
-                       self.betas[0], self.betas[1], self.eps, self.d_model, self.n_warmup_steps, self.anneal_steps, self.anneal_rate,
-                       zero_grad=True, advance_rng=advance_rng)
-        self.model.refresh_packed()          # the step rewrote the bf16 shadow: so are the fragment-major copies read by the window conv
+        tables = getattr(self.model, "_adam_tables", None) if getattr(self.model, "window_ffn", False) else None
+        if tables is not None:
+            # the Adam launch writes the window kernels' fragment-major weight packs itself (tile by tile, from LDS)
+            ops.optim_step_packed(flat, grad, self.exp_avg, self.exp_avg_sq, shadow, self.state, self._partials, self.grad_clip_thresh,
+                                  self.betas[0], self.betas[1], self.eps, self.d_model, self.n_warmup_steps, self.anneal_steps,
+                                  self.anneal_rate, tables, zero_grad=not keep_grads, advance_rng=advance_rng)
+        else:
+            ops.optim_step(flat, grad, self.exp_avg, self.exp_avg_sq, shadow, self.state, self._partials, self.grad_clip_thresh,
+                           self.betas[0], self.betas[1], self.eps, self.d_model, self.n_warmup_steps, self.anneal_steps, self.anneal_rate,
+                           zero_grad=not keep_grads, advance_rng=advance_rng)
+            self.model.refresh_packed()      # the step rewrote the bf16 shadow: so are the fragment-major copies read by the window conv
         self._host_step += 1
+        self.model.grads_partial = False     # zeroed, or stale and to be overwritten: either way the next backward need not accumulate
 
     def zero_grad(self):
-        pass    # the fused step leaves the flat gradient buffer zeroed
+        """reference: ScheduledOptim.zero_grad (optimizer.py:29-30).  After `step_and_update_lr()` the buffer is already zero; in the
+        middle of an accumulation cycle this discards it."""
+        if getattr(self.model, "grads_partial", False):
+            self.model.flat_buffers()[1].zero_()
+            self.model.grads_partial = False
 
     def lr(self):
         return float(self.init_lr * self._get_lr_scale())

@@ -25,7 +25,7 @@ def main():
     want = int(sys.argv[sys.argv.index("--step") + 1]) if "--step" in sys.argv else None
     rows = [r for r in csv.DictReader(open(path)) if r["Kind"] == "KERNEL_DISPATCH"]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    ends = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"] or "adam_clip_kernel" in r["Kernel_Name"]]
+    ends = [i for i, r in enumerate(rows) if any(k in r["Kernel_Name"] for k in ("adam_kernel", "adam_clip_kernel", "adam_pack_kernel"))]
     if len(ends) < 2:
         raise SystemExit("fewer than two adam_kernel dispatches in the trace")
     n = len(ends) - 1 if want is None else want

@@ -563,6 +563,22 @@ int ttsk_optim_step(float* params, float* grads, float* exp_avg, float* exp_avg_
                     float* partials, float max_norm, float beta1, float beta2, float eps, int zero_grad, float d_model, float warmup,
                     const float* anneal_steps_host, int n_anneal, float anneal_rate, int advance_rng, void* stream);
 
+/* Weight gradient of a Conv1d with K taps ("same" zero padding, dilation 1) as a kernel of its own (csrc/dwconv.hip):
+ *   dw[co][tap][ci] (+)= sum_b sum_{t < len_b} dy[(b*S + t)*ldy + co] * x[(b*S + t + tap - K/2)*ldx + ci],   0 <= t + tap - K/2 < S
+ * dy / x bf16 rows of B utterances x S rows, dw fp32 (Cout, K, Cin) — the tap-major storage of the flat gradient buffer; lens (int64
+ * [B], may be NULL = S): rows t >= lens[b] of dy are not walked (PAD rows carry no gradient: fs_two/transformer/Layers.py:29,32).
+ * One launch for up to 12 problems of the same K.  Replaces the K batched problems per weight that ttsk_gemm_group_* ran for
+ * torch's conv weight gradient (reference call sites: SubLayers.py:96 w_1 with K = 9, Layers.py:85-129 PostNet with K = 5). */
+typedef struct ttsk_dwconv_item {
+  const void* dy;
+  const void* x;
+  float* dw;
+  const int64_t* lens;
+  int32_t Cout, Cin, K, ldy, ldx, B, S, accumulate;
+} ttsk_dwconv_item;
+int ttsk_dwconv_supported(int Cout, int Cin, int K);
+int ttsk_dwconv_batch(const ttsk_dwconv_item* items, int n /* <= 12 */, void* stream);
+
 /* ttsk_optim_step whose Adam launch also writes the window kernels' weight packs (no ttsk_win_conv_pack_table launch after the step).
  * dev_items [n_items] (device memory, sorted by tile0): the packed weights — tap-major storage (Cs, K, Ds) at element offset `off` of the
  * flat buffers, Ds % 256 == 0 and Cs % 32 == 0, its plain pack (`pack`, the weight as it is: Cout = Cs, Cin = Ds) and / or its transposed,

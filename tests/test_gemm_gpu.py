@@ -737,3 +737,49 @@ def test_win_conv_split_slabs(B, S, Cin, K):
     assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-4
     old = ops.conv1d_dx(dy, W, out_dtype=torch.float32) if False else ops.conv1d_dx(dy, W)
     assert float((got.float() - old.view(B * S, 256).float().cpu()).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("Bn,S,Cout,Cin,lens", [(16, 423, 1024, 256, "ragged"), (16, 423, 1024, 256, None), (3, 40, 256, 32, "ragged"),
+                                                (2, 7, 256, 64, None), (5, 64, 512, 256, "zeros"), (1, 33, 256, 32, None)])
+def test_dwconv_vs_fp64_and_grouped_gemm(Bn, S, Cout, Cin, lens):
+    """ttsk_dwconv_batch (csrc/dwconv.hip): the k = 9 Conv1d weight gradient with the taps sharing one dY fetch and one X window —
+    against fp64 on the same bf16 operands (what torch's conv backward gives for `weight.grad`, SubLayers.py:96), against the grouped
+    GEMM path it replaces (ops.conv1d_dw), with `lens` (rows past an utterance's length carry no gradient and are skipped), with
+    overwrite and accumulate, at the step's shape, at shapes shorter than one K step, and with empty utterances."""
+    from tts_king_amd import ops
+    k = 9
+    g = torch.Generator().manual_seed(Bn * S + Cin)
+    dy = torch.randn(Bn, S, Cout, generator=g).to(torch.bfloat16)
+    x = torch.randn(Bn, S, Cin, generator=g).to(torch.bfloat16)
+    ln = None
+    if lens == "ragged":
+        ln = torch.randint(max(1, S // 2), S + 1, (Bn,), generator=g)
+        ln[0] = S
+    elif lens == "zeros":
+        ln = torch.tensor([S, 0, 17, 0, 1][:Bn])
+    if ln is not None:                                   # PAD rows: zero gradient (and zero activations, as in the FFT blocks)
+        m = torch.arange(S)[None, :] >= ln[:, None]
+        dy[m] = 0
+        x[m] = 0
+    # fp64: dW[co, j, ci] = sum_b sum_t dy[b, t, co] * x[b, t + j - 4, ci]
+    xp = torch.nn.functional.pad(x.double(), (0, 0, k // 2, k // 2))
+    want = torch.stack([torch.einsum("btc,bti->ci", dy.double(), xp[:, j:j + S]) for j in range(k)], dim=1)
+    dyd, xd = dy.to(DEV), x.to(DEV)
+    lnd = ln.to(DEV) if ln is not None else None
+    assert ops.dwconv_supported(Cout, Cin, k)
+    out = torch.full((Cout, k, Cin), 3.0, device=DEV)
+    ops.dwconv_batch([(dyd, xd, out, lnd, False)])
+    scale = float(want.abs().max())
+    err = float((out.double().cpu() - want).abs().max()) / scale
+    print("dwconv B=%d S=%d %dx%d lens=%s: max err %.2e of max |dW|" % (Bn, S, Cout, Cin, lens, err))
+    assert err <= 2e-5                                   # fp32 accumulation of exact bf16 products
+    # accumulate on top of itself, and two problems in one launch
+    out2 = out.clone()
+    other = torch.zeros_like(out)
+    ops.dwconv_batch([(dyd, xd, out2, lnd, True), (dyd, xd, other, None, False)])
+    assert float((out2 - 2 * out).abs().max()) <= 1e-5 * scale
+    assert float((other.double().cpu() - want).abs().max()) / scale <= 2e-5     # lens = None walks the zero rows: same sum
+    # the grouped GEMM path on the same operands
+    ref = torch.zeros_like(out)
+    ops.conv1d_dw(dyd, xd, ref, k=k, accumulate=False)
+    assert float((ref - out).abs().max()) <= 2e-5 * scale

@@ -65,6 +65,12 @@ class PackItem(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("Cs", C.c_int32), ("K", C.c_int32), ("Ds", C.c_int32), ("transpose", C.c_int32)]
 
 
+class DwConvItem(C.Structure):
+    """Mirror of `ttsk_dwconv_item` (include/ttsk.h)."""
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("lens", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32),
+                ("K", C.c_int32), ("ldy", C.c_int32), ("ldx", C.c_int32), ("B", C.c_int32), ("S", C.c_int32), ("accumulate", C.c_int32)]
+
+
 class AdamItem(C.Structure):
     """Mirror of `ttsk_adam_item` (include/ttsk.h)."""
     _fields_ = [("off", C.c_int64), ("pack", C.c_void_p), ("pack_t", C.c_void_p), ("Cs", C.c_int32), ("K", C.c_int32), ("Ds", C.c_int32),
@@ -135,6 +141,7 @@ def load(path=LIB_PATH):
     lib.ttsk_colsum_batch.argtypes = [C.POINTER(ColsumItem), C.c_int, C.c_void_p]
     lib.ttsk_colsum_finalize_batch.argtypes = [C.POINTER(FinalizeItem), C.c_int, C.c_void_p]
     lib.ttsk_gemm_reduce_batch.argtypes = [C.POINTER(ReduceItem), C.c_int, C.c_void_p]
+    lib.ttsk_dwconv_batch.argtypes = [C.POINTER(DwConvItem), C.c_int, C.c_void_p]
     lib.ttsk_gemm_plan.argtypes = [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     _lib = lib
     return lib

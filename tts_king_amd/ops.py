@@ -515,6 +515,30 @@ def conv1d_dw(dy, x, dst, dilation=1, k=1, accumulate=True, **kw):
     return dst
 
 
+def dwconv_supported(Cout, Cin, k):
+    return bool(L.load().ttsk_dwconv_supported(int(Cout), int(Cin), int(k)))
+
+
+def dwconv_batch(items):
+    """Weight gradients of Conv1d layers with taps, one launch (ttsk_dwconv_batch, csrc/dwconv.hip).  items: [(dy (B,S,Cout) bf16,
+    x (B,S,Cin) bf16, dst (Cout,k,Cin) fp32, lens int64 (B,) or None, accumulate)], all of one k, at most 12."""
+    arr = (L.DwConvItem * len(items))()
+    for i, (dy, x, dst, lens, accumulate) in enumerate(items):
+        _dev(dy, x, dst, lens)
+        Bsz, S, Cout = dy.shape
+        Cin = x.shape[2]
+        if dst.shape[0] != Cout or dst.shape[2] != Cin or not dst.is_contiguous() or dst.dtype != torch.float32:
+            raise L.TtskError("dwconv_batch: dst must be a contiguous fp32 (Cout, k, Cin) tensor")
+        if dy.stride(2) != 1 or x.stride(2) != 1 or dy.stride(0) != S * dy.stride(1) or x.stride(0) != S * x.stride(1) or dy.dtype != bf16 or x.dtype != bf16:
+            raise L.TtskError("dwconv_batch: dy / x must be bf16 (B, S, C) with unit channel stride and utterances back to back")
+        it = arr[i]
+        it.dy, it.x, it.dw, it.lens = dy.data_ptr(), x.data_ptr(), dst.data_ptr(), _ptr(lens)
+        it.Cout, it.Cin, it.K, it.ldy, it.ldx, it.B, it.S, it.accumulate = Cout, Cin, dst.shape[1], dy.stride(1), x.stride(1), Bsz, S, int(bool(accumulate))
+    check(L.load().ttsk_dwconv_batch(arr, len(items), _stream()), "ttsk_dwconv_batch")
+    if LAUNCH_COUNTS is not None:
+        LAUNCH_COUNTS["dwconv"] = LAUNCH_COUNTS.get("dwconv", 0) + 1
+
+
 def conv_transpose1d(x, Wp, bias, stride, k, out=None, in_slope=0.0, flags=0, C2=None, out_slope=0.0, **kw):
     """ConvTranspose1d(padding=(k-stride)//2) as `stride` polyphase implicit GEMMs.
     x (B,T,Cin) bf16, Wp (k, Cout, Cin) bf16 (tap-major repack of torch's (Cin,Cout,k)) -> (B,T*stride,Cout).

@@ -191,6 +191,10 @@ __global__ __launch_bounds__(DWC_NT, 1) void dwconv_kernel(const DwcArgs args) {
     }
     // wait until stage `need` (0-based step index) has landed: at most the pieces of the stages issued after it are outstanding
     auto wait_stage = [&](int need) __attribute__((always_inline)) {
+#if defined(DWC_DEBUG_NODMA) || defined(DWC_DEBUG_AONLY)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+#endif
       const int younger = issued - need - 1;
       if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NP) : "memory");
       else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
@@ -211,7 +215,11 @@ __global__ __launch_bounds__(DWC_NT, 1) void dwconv_kernel(const DwcArgs args) {
     constexpr int NTILE_A = NTILE < 12 ? NTILE : 12;          // column tiles whose accumulators are AGPRs (4 x 16 x 4 = 256)
     static_assert(DMA_EVERY >= 1 && NTILE % 3 == 0 && NTILE >= 8, "slot plan");
     auto do_step = [&](int step, bf16x8 (&ac)[4], bf16x8 (&an)[4]) __attribute__((always_inline)) {
+#if defined(DWC_DEBUG_NODMA)                    // diagnostic builds (tools/debug/dwconv_micro.py): the loop without its fills / with dY fills only
+      const bool more = false;
+#else
       const bool more = issued < nsteps;          // a stage to fetch during this step (into the slot read during the previous step)
+#endif
       const bool next = step + 1 < nsteps;
       const unsigned char* stn = (st == wsm + (NSTAGE - 1) * STAGE) ? wsm : st + STAGE;
       DWC_SB();
@@ -219,6 +227,9 @@ __global__ __launch_bounds__(DWC_NT, 1) void dwconv_kernel(const DwcArgs args) {
       for (int sl = 0; sl < NTILE; ++sl) {
         if (sl + 2 < NTILE) bf[(sl + 2) % 3] = read_b(st, sl + 2);
         if (more && sl % DMA_EVERY == 0 && sl / DMA_EVERY < NP) {
+#if defined(DWC_DEBUG_AONLY)
+          if (sl / DMA_EVERY < NPA)
+#endif
           issue_piece(sl / DMA_EVERY);
           if (sl / DMA_EVERY == NP - 1) issue_advance();
         }

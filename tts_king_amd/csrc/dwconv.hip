@@ -12,8 +12,11 @@
 // Here a wave owns 64 output channels x ALL taps x a 32-column slice of the input channels: the dY rows are fetched once for all taps
 // and the X rows as ONE window (32 + k - 1 rows) that every tap reads at its own row offset:
 //   k = 9: 6.5 KiB of LDS-DMA per wave and K step (32 rows) for 72 MFMAs (16x16x32) instead of 6 KiB per 32 — 2.1x fewer bytes per FLOP.
-// The four waves of a workgroup share nothing: each fills its own ring (4 stages) with its own LDS-DMA pieces and waits only on its
-// own vmcnt — no barrier anywhere in the K loop; 512 registers per wave (288 accumulators), one workgroup per CU.
+// The four waves of a workgroup share nothing: each stages its own operands (no barrier anywhere in the K loop); 512 registers per wave
+// (288 accumulators), one workgroup per CU.  Fills go global -> registers -> LDS (buffer_load_dwordx4 + ds_write_b128), two K steps of
+// loads in flight in two register sets, the LDS double-buffered: with LDS-DMA (buffer_load ... lds), which the first build used, every
+// 1 KiB piece cost the issuing wave ~130 cycles of issue time — 8 pieces per 72 MFMAs, one wave per SIMD and nobody to fill the
+// MFMA pipe meanwhile: 261 us for the six decoder weights against 177 us with the fills switched off (tools/debug/dwconv_micro.py).
 // K steps follow the utterances: 32 rows of ONE utterance per step, rows past the utterance's own length (lens, when given: PAD rows
 // carry no gradient, Layers.py:29,32) are never fetched — the row count drops from B*S to sum(ceil(len_b / 32) * 32).
 //
@@ -60,7 +63,7 @@ struct DwcCfg {
   static constexpr int SMEM = DWC_NW * WAVE_BYTES;
   static_assert(SMEM <= 163840, "LDS");
   static_assert(W <= 64, "window rows fit the two pieces of an image");
-  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "wait_stage counts up to three younger stages");
+  static_assert(NSTAGE == 2, "LDS double buffer");
 };
 
 // The wave's accumulators are 288 registers (k = 9): more than the 256 AGPRs hipcc gives a kernel that uses AGPRs at all (it splits the
@@ -114,7 +117,6 @@ __global__ __launch_bounds__(DWC_NT, 1) void dwconv_kernel(const DwcArgs args) {
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.dy, 0, 0x7FFFFFF0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, 0, 0x7FFFFFF0, 0x00020000);
   unsigned char* wsm = smem + wave * CF::WAVE_BYTES;
-  const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr)wsm);
 
   // ---- per-lane source coordinates of the LDS-DMA pieces (a piece = 1 KiB of the LDS image, lane-linear: any layout trick goes on the
   // source side).  dY piece q = rows q*8 .. +7: lane -> row lane/8, 16-byte chunk lane%8, fetching block (chunk/2) ^ (row/2 & 3).
@@ -124,34 +126,38 @@ __global__ __launch_bounds__(DWC_NT, 1) void dwconv_kernel(const DwcArgs args) {
   const int b_wl = lane >> 1, b_c = lane & 1;
   const int b_base = (b_wl * ldx + ci0 + b_c * 8) * 2;
 
-  // ---- issue cursor: the next K step to fetch = rows [ij*32, ij*32 + 32) of utterance ib
-  int ib = 0, ij = 0, inb = 0, issued = 0;
+  // ---- load cursor: the next K step to fetch = rows [ij*32, ij*32 + 32) of utterance ib
+  int ib = 0, ij = 0, inb = 0, loaded = 0;
   while (ib < nB && (inb = __builtin_amdgcn_readlane(nb_lane, ib)) == 0) ++ib;
-  unsigned is_lds = lds_wave;
-  auto issue_piece = [&](int q) __attribute__((always_inline)) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  auto load_piece = [&](int q, bool live) __attribute__((always_inline)) -> u32x4 {
     // q = 0..NPA-1: dY rows; NPA..NP-1: X window.  Rows that do not exist (past the utterance's walked length for dY; outside
-    // [0, S) for the window = the conv's zero padding; past the window) are out-of-range offsets: the hardware writes zeros.
+    // [0, S) for the window = the conv's zero padding; past the window; `live` false = past the last K step) are out-of-range offsets:
+    // the hardware returns zeros without touching memory — no branch around a load anywhere in the loop.
     if (q < NPA) {
-      const bool ok = ij * BK + q * 8 + a_kl < inb;
+      const bool ok = live && ij * BK + q * 8 + a_kl < inb;
       const int off = a_base + ((ib * S + ij * BK + q * 8) * ldy) * 2;
-      dma16(rsA, is_lds + q * 1024, ok ? off : DWC_OOB);
+      return __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? off : DWC_OOB, 0, 0);
     } else {
       const int qb = q - NPA, cit = qb >> 1, half = qb & 1;
       const int w = half * 32 + b_wl;
       const int t = ij * BK - CPAD + w;
-      const bool ok = t >= 0 && t < S && w < W;
+      const bool ok = live && t >= 0 && t < S && w < W;
       const int off = b_base + ((ib * S + ij * BK - CPAD + half * 32) * ldx + cit * 16) * 2;
-      dma16(rsB, is_lds + A_BYTES + qb * 1024, ok ? off : DWC_OOB);
+      return __builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? off : DWC_OOB, 0, 0);
     }
   };
-  auto issue_advance = [&]() __attribute__((always_inline)) {
-    ++issued;
-    is_lds = (is_lds == lds_wave + (NSTAGE - 1) * STAGE) ? lds_wave : is_lds + STAGE;
+  auto load_advance = [&]() __attribute__((always_inline)) {
+    ++loaded;
     if (++ij * BK >= inb) {
       ij = 0;
       ++ib;
       while (ib < nB && (inb = __builtin_amdgcn_readlane(nb_lane, ib)) == 0) ++ib;
     }
+  };
+  // piece q of a stage lands lane-linear, like an LDS-DMA piece: 16 bytes per lane at q*1024 + lane*16
+  auto store_piece = [&](unsigned char* stage, int q, u32x4 v) __attribute__((always_inline)) {
+    *(u32x4*)(stage + q * 1024 + lane * 16) = v;
   };
 
   f32x4 acc[4][NTILE];
@@ -182,60 +188,54 @@ __global__ __launch_bounds__(DWC_NT, 1) void dwconv_kernel(const DwcArgs args) {
 
 #define DWC_SB() __builtin_amdgcn_sched_barrier(0)
   if (nsteps > 0) {
-    // prologue: NSTAGE - 1 stages in flight
-#pragma unroll 1
-    for (int s = 0; s < NSTAGE - 1 && issued < nsteps; ++s) {
+    // Register sets: set[n & 1] carries the pieces of K step n from their loads (issued during step n - 3) to their LDS stores (during
+    // step n - 1); step n reads LDS stage n & 1.  So step s touches ONE set, set[(s + 1) & 1]: piece q is stored (for step s + 1) and the
+    // register then takes the load of piece q of step s + 3; the other set's loads (step s + 2) stay in flight.
+    u32x4 set[2][NP];
+    unsigned char* stg[2] = {wsm, wsm + STAGE};
+    const int nsteps2 = (nsteps + 1) & ~1;
+    // prologue: steps 0 and 1 loaded, step 0 stored, step 2 loaded behind it
 #pragma unroll
-      for (int q = 0; q < NP; ++q) issue_piece(q);
-      issue_advance();
+    for (int n = 0; n < 2; ++n) {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) set[n][q] = load_piece(q, loaded < nsteps);
+      if (loaded < nsteps) load_advance();
     }
-    // wait until stage `need` (0-based step index) has landed: at most the pieces of the stages issued after it are outstanding
-    auto wait_stage = [&](int need) __attribute__((always_inline)) {
-#if defined(DWC_DEBUG_NODMA) || defined(DWC_DEBUG_AONLY)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      return;
-#endif
-      const int younger = issued - need - 1;
-      if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NP) : "memory");
-      else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    const unsigned char* st = wsm;
-    bf16x8 af[2][4], bf[3];
-    wait_stage(0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[0][i] = read_a(st, i);
-    bf[0] = read_b(st, 0);
-    bf[1] = read_b(st, 1);
-    // One K step: 72 (k = 9) MFMAs; the pieces of the stage NSTAGE - 1 steps ahead are issued between them, one after every DMA_EVERY
-    // column tiles; the first fragments of the NEXT step are read during the last tiles (its stage landed long ago: it was issued
-    // NSTAGE - 2 steps before this one).
-    constexpr int DMA_EVERY = NTILE / NP;
-    constexpr int NTILE_A = NTILE < 12 ? NTILE : 12;          // column tiles whose accumulators are AGPRs (4 x 16 x 4 = 256)
-    static_assert(DMA_EVERY >= 1 && NTILE % 3 == 0 && NTILE >= 8, "slot plan");
-    auto do_step = [&](int step, bf16x8 (&ac)[4], bf16x8 (&an)[4]) __attribute__((always_inline)) {
-#if defined(DWC_DEBUG_NODMA)                    // diagnostic builds (tools/debug/dwconv_micro.py): the loop without its fills / with dY fills only
-      const bool more = false;
-#else
-      const bool more = issued < nsteps;          // a stage to fetch during this step (into the slot read during the previous step)
-#endif
-      const bool next = step + 1 < nsteps;
-      const unsigned char* stn = (st == wsm + (NSTAGE - 1) * STAGE) ? wsm : st + STAGE;
+    for (int q = 0; q < NP; ++q) store_piece(stg[0], q, set[0][q]);
+    {
+      const bool more = loaded < nsteps;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) set[0][q] = load_piece(q, more);
+      if (more) load_advance();
+    }
+    bf16x8 af[2][4], bf[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[0][i] = read_a(stg[0], i);
+    bf[0] = read_b(stg[0], 0);
+    bf[1] = read_b(stg[0], 1);
+    // One K step: 72 (k = 9) MFMAs; between them, one piece after every PIECE_EVERY column tiles: the store of the next step's piece and
+    // the load that refills its registers; the first fragments of the NEXT step are read during the last tiles.
+    constexpr int PIECE_EVERY = (NTILE - 6) / NP;
+    constexpr int NTILE_A = NTILE < 12 ? NTILE : 12;          // column tiles whose accumulators are AGPRs; the others live in VGPRs
+    static_assert(PIECE_EVERY >= 1 && NTILE % 3 == 0 && NTILE >= 8, "slot plan");
+    auto do_step = [&](int step, int par, bf16x8 (&ac)[4], bf16x8 (&an)[4]) __attribute__((always_inline)) {
+      // par = step & 1 (a constant in each of the two copies of the body): reads stage `par`, works on set / stage `par ^ 1`
+      const bool more = loaded < nsteps;           // a step to load (three ahead); past the end the registers take zeros
+      const unsigned char* st = stg[par];
+      unsigned char* stn = stg[par ^ 1];
       DWC_SB();
 #pragma unroll
       for (int sl = 0; sl < NTILE; ++sl) {
         if (sl + 2 < NTILE) bf[(sl + 2) % 3] = read_b(st, sl + 2);
-        if (more && sl % DMA_EVERY == 0 && sl / DMA_EVERY < NP) {
-#if defined(DWC_DEBUG_AONLY)
-          if (sl / DMA_EVERY < NPA)
-#endif
-          issue_piece(sl / DMA_EVERY);
-          if (sl / DMA_EVERY == NP - 1) issue_advance();
+        if (sl % PIECE_EVERY == 0 && sl / PIECE_EVERY < NP) {
+          const int q = sl / PIECE_EVERY;
+          store_piece(stn, q, set[par ^ 1][q]);        // (for the step after the last one: into a stage nobody reads)
+          set[par ^ 1][q] = load_piece(q, more);
+          if (q == NP - 1 && more) load_advance();
         }
-        if (sl == NTILE - 6 && next) wait_stage(step + 1);
-        if (sl >= NTILE - 6 && sl < NTILE - 2 && next) an[sl - (NTILE - 6)] = read_a(stn, sl - (NTILE - 6));
-        if (sl >= NTILE - 2 && next) bf[(sl + 2) % 3] = read_b(stn, sl + 2 - NTILE);
+        if (sl >= NTILE - 6 && sl < NTILE - 2) an[sl - (NTILE - 6)] = read_a(stn, sl - (NTILE - 6));
+        if (sl >= NTILE - 2) bf[(sl + 2) % 3] = read_b(stn, sl + 2 - NTILE);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (sl < NTILE_A) mfma_acc<true>(acc[i][sl], ac[i], bf[sl % 3]);      // (folds after unrolling: sl is a constant)
@@ -243,15 +243,13 @@ __global__ __launch_bounds__(DWC_NT, 1) void dwconv_kernel(const DwcArgs args) {
         }
         DWC_SB();
       }
-      st = stn;
     };
-    // (one copy of the step body: with the body unrolled twice to swap the two dY fragment sets, the register allocator gave the two
-    // copies different accumulator registers and permuted all of them at the back edge — 592 moves per two steps)
+    // the body exists twice (the two register sets / LDS stages alternate); an odd number of steps is rounded up with a step of zeros
+    // rather than a third copy of the body (whose different register assignment cost ~500 moves and the spills at the loop's exit)
 #pragma unroll 1
-    for (int step = 0; step < nsteps; ++step) {
-      do_step(step, af[0], af[1]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[0][i] = af[1][i];
+    for (int step = 0; step < nsteps2; step += 2) {
+      do_step(step, 0, af[0], af[1]);
+      do_step(step + 1, 1, af[1], af[0]);
     }
   }
 #undef DWC_SB
@@ -314,7 +312,7 @@ extern "C" int ttsk_dwconv_batch(const ttsk_dwconv_item* items, int n, void* str
     TTSK_REQUIRE((int64_t)it.B * it.S * (it.ldy > it.ldx ? it.ldy : it.ldx) * 2 < 0x7FFFFFF0ll, "dwconv_batch: operand beyond the 2 GiB buffer range");
     TTSK_REQUIRE(((((uintptr_t)it.dy) | ((uintptr_t)it.x) | ((uintptr_t)it.dw)) & 15) == 0, "dwconv_batch: 16-byte alignment");
   }
-  launch_dwconv<9, 2, 4>(items, n, (hipStream_t)stream);
+  launch_dwconv<9, 2, 2>(items, n, (hipStream_t)stream);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -81,3 +81,43 @@ def test_overwrite_backward_equals_zero_then_accumulate(cfg):
     for k in res[0]:
         assert float(res[1][k].abs().max()) < 1e29, "%s: stale values survive an overwriting backward" % k
         assert torch.equal(res[0][k], res[1][k]), k
+
+
+def test_dwconv_path_equals_grouped_gemm_path(cfg):
+    """FastSpeech2.dwconv (w_1's weight gradient on csrc/dwconv.hip, rows past each utterance's length skipped) against the grouped
+    GEMM path on the same step: every other gradient bit-identical, w_1's within fp32 summation-order noise."""
+    from tests.oracle_util import fs2_state_dict
+    from tts_king_amd import ops
+    from tts_king_amd.fastspeech2 import FastSpeech2
+    from tts_king_amd.synthetic import make_batch
+    c = copy.deepcopy(cfg)
+    b = make_batch(5, 48, seed=33, ragged=True)
+    res = []
+    for use in (False, True):
+        m = FastSpeech2(c.preprocess_config, c.model_config, 65, device=DEV).train()
+        m.load_state_dict(fs2_state_dict(c, 7))
+        m.dwconv = use
+        dev_b = [t.to(DEV) if torch.is_tensor(t) else t for t in b]
+        counts = {}
+        ops.LAUNCH_COUNTS = counts
+        try:
+            with torch.no_grad():
+                out, ctx = m._forward(True, dev_b[2], dev_b[3], dev_b[4], int(b[5]), dev_b[7], b[8], dev_b[9], dev_b[10], dev_b[11], 1.0, 1.0, 1.0)
+                _, dmel_sum, dpost, dp, de, dd = ops.fs2_loss(out[0], out[8], dev_b[6], dev_b[7], out[1], out[2], out[3], dev_b[11],
+                                                              dev_b[9], dev_b[10], dev_b[4], grad_scale=1.0)
+                m.backward_native(ctx, dmel_sum, dpost, dp, de, dd)
+            torch.cuda.synchronize()
+        finally:
+            ops.LAUNCH_COUNTS = None
+        assert (counts.get("dwconv", 0) > 0) == use, counts
+        res.append({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    worst = 0.0
+    for k in res[0]:
+        if k.endswith("pos_ffn.w_1.weight"):
+            scale = float(res[0][k].abs().max())
+            err = float((res[0][k] - res[1][k]).abs().max()) / scale
+            worst = max(worst, err)
+            assert err <= 1e-5, (k, err)
+        else:
+            assert torch.equal(res[0][k], res[1][k]), k
+    print("w_1 gradients, dwconv vs grouped GEMM: max difference %.2e of max |g|" % worst)

@@ -154,6 +154,7 @@ class FastSpeech2(nn.Module):
         self.fused_qkv_tail = os.environ.get("TTSK_FUSED_QKV_TAIL", "1") != "0"   # a block's last kernel also projects q|k|v for the next block
         self.fused_qkv_dx = os.environ.get("TTSK_FUSED_QKV_DX", "1") != "0"   # ... and the q|k|v input gradient of the block behind in front of it
         self.fused_ln_bwd = os.environ.get("TTSK_FUSED_LN_BWD", "1") != "0"   # LayerNorm backward + the k = 1 dX projection behind it in one kernel
+        self.dwconv = os.environ.get("TTSK_DWCONV", "1") != "0"   # w_1's weight gradient on the tap-sharing kernel (csrc/dwconv.hip)
         self.group_predictors = True    # training with targets: the three VariancePredictors run as grouped launches
         self.raw_slabs = True           # dX GEMMs that feed a LayerNorm backward leave their split-K tiles for it to sum
         self.group_param_grads = True      # weight-gradient GEMMs of a backward pass share grouped launches (ops.DeferQueue)
@@ -937,7 +938,12 @@ class FastSpeech2(nn.Module):
         # ---- w_1 (k=9): bias, dW, dX + residual gradient; the dX stays in split-K form for the attention LayerNorm's backward
         with self._side_work(dh, x1):
             ops.colsum_into(dh.view(rows, -1), self._g(f + "w_1.bias"), defer=self._deferred_fin, accumulate=self._acc)
-            ops.conv1d_dw(dh, x1.view(Bn, S, d), self._g(f + "w_1.weight"), k=self.k1, defer=self._deferred, accumulate=self._acc)
+            if self.dwconv and self._deferred.group is not None and Bn <= 64 and dh.dtype == bf16 and ops.dwconv_supported(dh.shape[-1], d, self.k1):
+                # the taps share one fetch of dh and one window of x1 (csrc/dwconv.hip); dh is zero at PAD rows (the LayerNorm backward
+                # that produced dy2 gives them no gradient), so only the rows of each utterance's own length are walked
+                self._deferred.dwconv.append((dh, x1.view(Bn, S, d), self._g(f + "w_1.weight"), lens, self._acc))
+            else:
+                ops.conv1d_dw(dh, x1.view(Bn, S, d), self._g(f + "w_1.weight"), k=self.k1, defer=self._deferred, accumulate=self._acc)
         # ---- attention tail
         do = delta = None
         if self.raw_slabs:
@@ -1049,7 +1055,7 @@ class FastSpeech2(nn.Module):
     def _mark_bucket(self, name):
         """The notifier's `mark` in the "side" / "late" data-parallel schedules: group `name` is complete once everything queued so far
         has been flushed — remember where the GEMM and reducer queues stand."""
-        self._dp_marks.append((name, len(self._deferred.group), len(self._deferred)))
+        self._dp_marks.append((name, len(self._deferred.group), len(self._deferred), len(self._deferred.dwconv)))
 
     def _launch_dw_side_buckets(self, on_bucket, ready):
         """Data-parallel "side" schedule, after the decoder's backward: the queued weight-gradient GEMMs of PostNet / mel_linear / decoder
@@ -1071,19 +1077,19 @@ class FastSpeech2(nn.Module):
             ops.flush_finalize(self._deferred_fin)
         self._fin_pending = True
         self._dw_side.wait_stream(cur)
-        done_g = done_r = launched = 0
+        done_g = done_r = done_d = launched = 0
         marks, self._dp_marks = self._dp_marks, []
         with torch.cuda.stream(self._dw_side):
-            for i, (name, ng, nr) in enumerate(marks):
+            for i, (name, ng, nr, nd) in enumerate(marks):
                 if launched < 0 or (ready is not None and not ready(name)):
-                    self._dp_marks.append((name, 0, 0))              # announced with the final flush
+                    self._dp_marks.append((name, 0, 0, 0))           # announced with the final flush
                     continue
                 if launched and sum(fl[:ng]) > budget:
                     launched = -1                                   # this bucket and everything behind it: the final flush
-                    self._dp_marks.append((name, 0, 0))
+                    self._dp_marks.append((name, 0, 0, 0))
                     continue
-                ops.flush_deferred_prefix(self._deferred, ng - done_g, nr - done_r, max_wgs=self.dw_side_wgs)
-                done_g, done_r = ng, nr
+                ops.flush_deferred_prefix(self._deferred, ng - done_g, nr - done_r, max_wgs=self.dw_side_wgs, n_dwconv=nd - done_d)
+                done_g, done_r, done_d = ng, nr, nd
                 if not launched:
                     self._dw_side.wait_stream(self._fin_side)        # the column sums of these groups (done long before the GEMMs)
                 on_bucket(name)
@@ -1220,7 +1226,7 @@ class FastSpeech2(nn.Module):
         notify("embedding")
         self._flush_param_grads()
         if dp_side:
-            for name, _, _ in self._dp_marks:       # everything is in the buffer now: the remaining buckets, in completion order
+            for name, _, _, _ in self._dp_marks:    # everything is in the buffer now: the remaining buckets, in completion order
                 on_bucket(name)
             self._dp_marks = []
         self._ctx = None

@@ -51,6 +51,7 @@ class DeferQueue(list):
     def __init__(self, group_gemms=True):
         super().__init__()
         self.group = [] if group_gemms else None
+        self.dwconv = []        # weight gradients of convs with taps: (dy, x, dst, lens, accumulate) for dwconv_batch (csrc/dwconv.hip)
 
 
 class GemmGroup:
@@ -126,17 +127,43 @@ def flush_group(descs, keep, max_wgs=0, upload_only=False):
 
 
 def upload_deferred_gemms(items, max_wgs=0):
-    """flush_deferred_gemms in two parts: the tables now (current stream), the launches when the returned function is called."""
+    """flush_deferred_gemms in two parts: the tables now (current stream), the launches when the returned function is called (the
+    queued dwconv problems carry their table in the launch's arguments: they go with the launches)."""
     group = getattr(items, "group", None)
-    if not group:
-        return lambda: None
-    return flush_group(group, getattr(items, "_keep"), max_wgs, upload_only=True)
+    launch = flush_group(group, getattr(items, "_keep"), max_wgs, upload_only=True) if group else (lambda: None)
+
+    def both():
+        flush_dwconv(items)
+        launch()
+    return both
+
+
+def flush_dwconv(items, n=None):
+    """The (first n) queued conv weight gradients as ttsk_dwconv_batch launches (12 problems each, one kernel size each) on the
+    current stream.  Their operands stay alive in the queue's keep list until its final flush."""
+    q = getattr(items, "dwconv", None)
+    if not q:
+        return
+    now = q if n is None else q[:n]
+    rest = [] if n is None else q[n:]
+    if not hasattr(items, "_keep"):
+        items._keep = []
+    by_k = {}
+    for it in now:
+        by_k.setdefault(it[2].shape[1], []).append(it)
+        items._keep.extend(t for t in it[:4] if t is not None)
+    for lst in by_k.values():
+        for i in range(0, len(lst), 12):
+            dwconv_batch(lst[i:i + 12])
+    q[:] = rest
 
 
 def flush_deferred_gemms(items, max_wgs=0, frac=1.0):
     """Only the grouped weight-gradient GEMMs queued in `items` so far, as grouped launches on the current stream (grid capped at
     max_wgs workgroups when > 0); their split-K slabs stay queued for `flush_deferred`'s reducer launch.  frac < 1: only about
-    that fraction of the queued FLOPs (the problems queued first); the rest stays queued for the next flush."""
+    that fraction of the queued FLOPs (the problems queued first); the rest stays queued for the next flush.  The queued dwconv
+    problems (conv weight gradients with taps) go first, all of them."""
+    flush_dwconv(items)
     group = getattr(items, "group", None)
     if not group:
         return
@@ -153,10 +180,13 @@ def flush_deferred_gemms(items, max_wgs=0, frac=1.0):
     flush_group(group, getattr(items, "_keep"), max_wgs)
 
 
-def flush_deferred_prefix(items, n_group, n_reduce, max_wgs=0):
-    """The first `n_group` queued weight-gradient GEMMs as grouped launches (grid capped at max_wgs when > 0) and then the batched
-    reducer for the first `n_reduce` queued split-K items, on the current stream; both are removed from the queue.  The data-parallel
-    "side" schedule flushes the queue bucket by bucket this way (FastSpeech2._launch_dw_side_buckets)."""
+def flush_deferred_prefix(items, n_group, n_reduce, max_wgs=0, n_dwconv=0):
+    """The first `n_dwconv` queued dwconv problems, the first `n_group` queued weight-gradient GEMMs as grouped launches (grid capped at
+    max_wgs when > 0) and then the batched reducer for the first `n_reduce` queued split-K items, on the current stream; all are
+    removed from the queue.  The data-parallel "side" schedule flushes the queue bucket by bucket this way
+    (FastSpeech2._launch_dw_side_buckets)."""
+    if n_dwconv > 0:
+        flush_dwconv(items, n_dwconv)
     group = getattr(items, "group", None)
     if group and n_group > 0:
         now = group[:n_group]
@@ -176,6 +206,7 @@ def flush_deferred_prefix(items, n_group, n_reduce, max_wgs=0):
 def flush_deferred(items):
     """The queued weight-gradient GEMMs as grouped launches, then one ttsk_gemm_reduce_batch launch (per 64 items) for the
     split-K slabs collected in `items` (see gemm(defer=...))."""
+    flush_dwconv(items)
     group = getattr(items, "group", None)
     if group:
         keep = getattr(items, "_keep")

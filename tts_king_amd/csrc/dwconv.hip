@@ -255,19 +255,31 @@ __global__ __launch_bounds__(DWC_NT, 1) void dwconv_kernel(const DwcArgs args) {
 #undef DWC_SB
 
   // ---- epilogue: the wave's 64 x (TAPS x CI16*16) tile straight from the accumulators (lane: rows 4*lg .. +3, column l15 of each
-  // 16 x 16 fragment: 16 lanes cover 64 contiguous bytes of a (co, tap) row)
+  // 16 x 16 fragment: 16 lanes cover 64 contiguous bytes of a (co, tap) row).  Accumulating: the old values of one 16-row band are all
+  // requested before the first is used (one round trip per band instead of one per element).
   float* __restrict__ dw = P.dw;
-  const int Cin = P.Cin, acc_mode = P.accumulate;
+  const int Cin = P.Cin;
+  if (P.accumulate) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int j = 0; j < NTILE; ++j) {
-      const int tap = j / CI16, ci = ci0 + (j % CI16) * 16 + l15;
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int co = co0 + i * 16 + 4 * lg + r;
-        float* dst = dw + ((int64_t)co * TAPS + tap) * Cin + ci;
-        *dst = acc_mode ? *dst + acc[i][j][r] : acc[i][j][r];
+        float* row = dw + ((int64_t)(co0 + i * 16 + 4 * lg + r) * TAPS) * Cin + ci0 + l15;
+        float old[NTILE];
+#pragma unroll
+        for (int j = 0; j < NTILE; ++j) old[j] = row[(j / CI16) * Cin + (j % CI16) * 16];
+#pragma unroll
+        for (int j = 0; j < NTILE; ++j) row[(j / CI16) * Cin + (j % CI16) * 16] = old[j] + acc[i][j][r];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* row = dw + ((int64_t)(co0 + i * 16 + 4 * lg + r) * TAPS) * Cin + ci0 + l15;
+#pragma unroll
+        for (int j = 0; j < NTILE; ++j) row[(j / CI16) * Cin + (j % CI16) * 16] = acc[i][j][r];
       }
     }
   }

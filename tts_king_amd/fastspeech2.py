@@ -168,7 +168,8 @@ class FastSpeech2(nn.Module):
         # ... and only `dw_side_frac` of that group's FLOPs go there: the dX chain that runs beside it is shorter (0.39 ms) than the
         # capped group (0.57 ms), the rest joins the encoder-side group that runs on the whole chip once the dX chain is done
         # (measured: 1.0 -> 3.03 ms/step, 0.85 / 0.75 -> 3.00, 0.65 -> 3.02, 0.55 -> 3.11)
-        self.dw_side_frac = float(os.environ.get("TTSK_DW_SIDE_FRAC", "0.8"))
+        # (round 3: w_1's gradients left the grouped queue for csrc/dwconv.hip, which runs first on that stream: re-measured below)
+        self.dw_side_frac = float(os.environ.get("TTSK_DW_SIDE_FRAC", "1.0"))
         self._dw_side = None
         self._dw_side_pending = False
         # Data-parallel schedule (backward_native(on_bucket=...)), TTSK_DP_SCHEDULE:
@@ -938,7 +939,7 @@ class FastSpeech2(nn.Module):
         # ---- w_1 (k=9): bias, dW, dX + residual gradient; the dX stays in split-K form for the attention LayerNorm's backward
         with self._side_work(dh, x1):
             ops.colsum_into(dh.view(rows, -1), self._g(f + "w_1.bias"), defer=self._deferred_fin, accumulate=self._acc)
-            if self.dwconv and self._deferred.group is not None and Bn <= 64 and dh.dtype == bf16 and ops.dwconv_supported(dh.shape[-1], d, self.k1):
+            if self._use_dwconv and self._deferred.group is not None and Bn <= 64 and dh.dtype == bf16 and ops.dwconv_supported(dh.shape[-1], d, self.k1):
                 # the taps share one fetch of dh and one window of x1 (csrc/dwconv.hip); dh is zero at PAD rows (the LayerNorm backward
                 # that produced dy2 gives them no gradient), so only the rows of each utterance's own length are walked
                 self._deferred.dwconv.append((dh, x1.view(Bn, S, d), self._g(f + "w_1.weight"), lens, self._acc))
@@ -1080,6 +1081,8 @@ class FastSpeech2(nn.Module):
         done_g = done_r = done_d = launched = 0
         marks, self._dp_marks = self._dp_marks, []
         with torch.cuda.stream(self._dw_side):
+            ops.flush_dwconv(self._deferred)           # all six decoder blocks in ONE launch (a bucket's two would leave the chip idle)
+            marks = [(name, ng, nr, 0) for name, ng, nr, nd in marks]
             for i, (name, ng, nr, nd) in enumerate(marks):
                 if launched < 0 or (ready is not None and not ready(name)):
                     self._dp_marks.append((name, 0, 0, 0))           # announced with the final flush
@@ -1104,7 +1107,15 @@ class FastSpeech2(nn.Module):
             # only activations and gradients the main chain produced: they run now, beside the side stream; the encoder-side dW group
             # queues behind the first one on the side stream; the join comes last, before the split-K reducer.
             cur = torch.cuda.current_stream()
-            launch = ops.upload_deferred_gemms(self._deferred, max_wgs=0)     # the tables now, on this stream (the side stream is busy)
+            launch = ops.upload_deferred_gemms(self._deferred, max_wgs=0, with_dwconv=False)     # the tables now, on this stream (the side stream is busy)
+            if self._deferred.dwconv:
+                # the encoder blocks' w_1 gradients (128 workgroups) beside the grouped launch, on a stream of their own
+                if self._fin_side is None:
+                    self._fin_side = torch.cuda.Stream(device=self.device)
+                self._fin_side.wait_stream(cur)
+                with torch.cuda.stream(self._fin_side):
+                    ops.flush_dwconv(self._deferred)
+                self._fin_pending = True
             self._dw_side.wait_stream(cur)
             with torch.cuda.stream(self._dw_side):
                 launch()
@@ -1158,6 +1169,9 @@ class FastSpeech2(nn.Module):
         dp_side = on_bucket is not None and self.dp_schedule in ("side", "late") and self.dw_side_wgs > 0 and self.group_param_grads \
             and not self.overlap_param_grads
         self._dp_marks = []
+        # w_1's weight gradients on the tap-sharing kernel: one launch for the six decoder blocks (192 workgroups) and one for the encoder's;
+        # not in the "early" data-parallel schedule, whose per-bucket flushes would launch them two at a time
+        self._use_dwconv = self.dwconv and (on_bucket is None or dp_side)
         notifier = _GroupNotifier(self.backward_group_order(), on_bucket, self._flush_param_grads, mark=self._mark_bucket if dp_side else None)
         notify = notifier.done
         # ---- PostNet (last layer first)

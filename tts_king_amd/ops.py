@@ -126,14 +126,15 @@ def flush_group(descs, keep, max_wgs=0, upload_only=False):
         return launch
 
 
-def upload_deferred_gemms(items, max_wgs=0):
+def upload_deferred_gemms(items, max_wgs=0, with_dwconv=True):
     """flush_deferred_gemms in two parts: the tables now (current stream), the launches when the returned function is called (the
-    queued dwconv problems carry their table in the launch's arguments: they go with the launches)."""
+    queued dwconv problems carry their table in the launch's arguments: with_dwconv, they go with the launches)."""
     group = getattr(items, "group", None)
     launch = flush_group(group, getattr(items, "_keep"), max_wgs, upload_only=True) if group else (lambda: None)
 
     def both():
-        flush_dwconv(items)
+        if with_dwconv:
+            flush_dwconv(items)
         launch()
     return both
 

@@ -254,7 +254,8 @@ def gemm_roofline(enqueue, batch, steps=3):
     sym = {"NT1": "gemm_kernel<false, false, false>", "NT_btr1": "gemm_kernel<false, true, false>", "TT1": "gemm_kernel<true, true, false>",
            "NT2": "gemm2_kernel<256, false, false, false>", "NT_btr2": "gemm2_kernel<256, false, true, false>", "TT2": "gemm2_kernel<256, true, true, false>",
            "TT1g": "gemm_group_kernel<true, true, false>", "TT2g": "gemm2_group_kernel<256, true, true, false>",
-           "NT3": "gemm64_kernel<false, false>", "NT_btr3": "gemm64_kernel<true, false>"}
+           "NT3": "gemm64_kernel<false, false>", "NT_btr3": "gemm64_kernel<true, false>", "dwconv9": "dwconv_kernel<9, 2, 2>"}
+    src = lambda k: "tts_king_amd/csrc/dwconv.hip" if k.startswith("dwconv") else "tts_king_amd/csrc/gemm%s.hip" % ("2" if "2" in k else "")
     by_sym, by_shape = {}, {}
     for e0, e1, fl, kind, shape in trace:
         ms = e0.elapsed_time(e1)
@@ -272,13 +273,13 @@ def gemm_roofline(enqueue, batch, steps=3):
             "traffic_source": traffic["source"] if traffic else None,
             "mfma_busy_frac": (pmc_mfma_busy(sym.get(dk, dk)) or {}).get("mfma_busy_frac"),
             "mfma_busy_source": (pmc_mfma_busy(sym.get(dk, dk)) or {}).get("source"),
-            "kernel": "%s (tts_king_amd/csrc/gemm%s.hip)" % (sym.get(dk, dk), "2" if "2" in dk else ""),
+            "kernel": "%s (%s)" % (sym.get(dk, dk), src(dk)),
             "launches_per_step": dv[2] // steps, "avg_launch_us": 1e3 * dv[0] / dv[2], "avg_launch_gflop": dv[1] / dv[2] / 1e9,
             "kernel_ms_per_step": dv[0] / steps,
             "dominant_by_time": {"kernel": sym.get(tk, tk), "launches_per_step": tv[2] // steps, "ms_per_step": tv[0] / steps,
                                  "tflops": tv[1] / (tv[0] * 1e-3) / 1e12, "frac_of_peak": tv[1] / (tv[0] * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS},
             "all_gemm": {"launches_per_step": len(trace) // steps, "ms_per_step": tot_ms / steps, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12},
-            "largest_shape": ({"grouped_problems": sk[1], "workgroups": sk[6]} if dk.endswith("g") else
+            "largest_shape": ({"grouped_problems": sk[1], "workgroups": sk[6]} if (dk.endswith("g") or dk.startswith("dwconv")) else
                               {"M,N,K,taps,batch,splits": list(sk[1:]), "launches_per_step": sv[2] // steps,
                                "avg_us": 1e3 * sv[0] / sv[2], "tflops": sv[1] / (sv[0] * 1e-3) / 1e12})}
 
@@ -591,7 +592,15 @@ def main():
         if not args.no_roofline:
             eager = make_enqueue(model, opt, cfg, loss_fn, reducer=None)
             rec["roofline"] = gemm_roofline(eager, batch)
-            if model.dw_side_wgs > 0:
+            if "dwconv" in rec["roofline"]["kernel"]:
+                # Two launches per step: the six decoder weights = 192 workgroups (one per CU, by construction: 4 output-channel tiles x 8
+                # input-channel slices per weight) on the second stream beside the encoder-side dX chain, which runs on the CUs they leave;
+                # the four encoder weights = 128 workgroups beside the final grouped launch.  `achieved` / `frac` are over both, against
+                # the whole chip's peak; on the CUs the kernel occupies the decoder launch runs at frac * 256 / 192.
+                rec["roofline"]["grid"] = {"decoder_launch_workgroups": 192, "encoder_launch_workgroups": 128, "cus": 256,
+                                           "concurrent_with": "length regulator, variance adaptor and encoder backward (main stream)",
+                                           "rows_walked": "sum over utterances of ceil(mel_len / 32) * 32 (PAD rows skipped); FLOPs counted for all B*T rows"}
+            if model.dw_side_wgs > 0 and "gemm2_group" in rec["roofline"]["kernel"]:
                 # The shipped step runs this kernel on a second stream with its grid capped (192 of 256 CUs) beside the encoder-side
                 # dX chain: its launch is longer than on the whole chip and the step shorter.  `achieved` / `frac` above are what runs
                 # (and what rocprofv3 shows); `whole_chip` is the same kernel uncapped, alone, for the kernel's own quality.

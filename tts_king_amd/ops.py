@@ -72,7 +72,7 @@ def flush_group(descs, keep, max_wgs=0, upload_only=False):
     upload_only: only the tables go to the device (current stream); returns a function that issues the launches (on the stream
     current when it is called, which the caller has ordered behind this one)."""
     if not descs:
-        return (lambda: None) if upload_only else None
+        return (lambda streams=None: None) if upload_only else None
     pending = []
     lib = L.load()
     by_layout = {}
@@ -114,15 +114,27 @@ def flush_group(descs, keep, max_wgs=0, upload_only=False):
         keep.append(table)
     descs.clear()
     if upload_only:
-        def launch():
-            for host, table, fl, kind, shape in pending:
-                if GEMM_TRACE is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                check(lib.ttsk_gemm_group_launch_uploaded(host, C.c_void_p(table.data_ptr()), int(max_wgs), _stream()), "ttsk_gemm_group_launch_uploaded")
-                if GEMM_TRACE is not None:
-                    e1.record()
-                    GEMM_TRACE.append((e0, e1, fl, kind, shape))
+        def launch(streams=None):
+            """Issue the grouped launches whose tables are uploaded.  `streams`: torch streams (each already ordered behind the
+            uploads by the caller) to spread the launches over, one per launch in turn — they are independent problems."""
+            for i, (host, table, fl, kind, shape) in enumerate(pending):
+                ctx = torch.cuda.stream(streams[i % len(streams)]) if streams else None
+                if ctx is not None:
+                    ctx.__enter__()
+                try:
+                    _launch_uploaded(host, table, fl, kind, shape)
+                finally:
+                    if ctx is not None:
+                        ctx.__exit__(None, None, None)
+
+        def _launch_uploaded(host, table, fl, kind, shape):
+            if GEMM_TRACE is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(lib.ttsk_gemm_group_launch_uploaded(host, C.c_void_p(table.data_ptr()), int(max_wgs), _stream()), "ttsk_gemm_group_launch_uploaded")
+            if GEMM_TRACE is not None:
+                e1.record()
+                GEMM_TRACE.append((e0, e1, fl, kind, shape))
         return launch
 
 
@@ -130,12 +142,12 @@ def upload_deferred_gemms(items, max_wgs=0, with_dwconv=True):
     """flush_deferred_gemms in two parts: the tables now (current stream), the launches when the returned function is called (the
     queued dwconv problems carry their table in the launch's arguments: with_dwconv, they go with the launches)."""
     group = getattr(items, "group", None)
-    launch = flush_group(group, getattr(items, "_keep"), max_wgs, upload_only=True) if group else (lambda: None)
+    launch = flush_group(group, getattr(items, "_keep"), max_wgs, upload_only=True) if group else (lambda streams=None: None)
 
-    def both():
+    def both(streams=None):
         if with_dwconv:
             flush_dwconv(items)
-        launch()
+        launch(streams)
     return both
 
 

@@ -181,7 +181,6 @@ class FastSpeech2(nn.Module):
         #   "late"  the single-GPU schedule untouched, every all-reduce after the last flush (no overlap with backward).
         self.dp_schedule = os.environ.get("TTSK_DP_SCHEDULE", "side")
         self._fin_side = None
-        self._side3 = None
         # Does the flat gradient buffer hold an unfinished accumulation (micro-steps of a grad_acc_step cycle)?  False after an optimizer
         # update or zero_grad(): the next backward then overwrites instead of accumulating (see backward_native).
         self.grads_partial = False
@@ -259,7 +258,7 @@ class FastSpeech2(nn.Module):
         self._adam_tables = None
         self._shadow_version = -1
         self._rng_state = None
-        self._side = self._dw_side = self._fin_side = self._side3 = None
+        self._side = self._dw_side = self._fin_side = None
         self._rebind()
         if self.window_ffn and self._shadow.is_cuda:
             self._build_packs()
@@ -1117,16 +1116,14 @@ class FastSpeech2(nn.Module):
                 with torch.cuda.stream(self._fin_side):
                     ops.flush_dwconv(self._deferred)
                 self._fin_pending = True
-            # the final grouped launches (the 256x128 group and the few 128x128 problems) are independent: one stream each
-            if self._side3 is None:
-                self._side3 = torch.cuda.Stream(device=self.device)
+            # three branches from here (a replayed graph runs at most three queues side by side: a fourth branch — the two grouped launches
+            # on a stream each — serialised the column sums behind them): the encoder's dwconv (above), the grouped launches one after the
+            # other on the side stream, the column sums on this one
             self._dw_side.wait_stream(cur)
-            self._side3.wait_stream(cur)
-            self._side3.wait_stream(self._dw_side)          # (its table uploads were ordered on `cur`; the capped group's operands are not shared)
-            launch(streams=[self._dw_side, self._side3])
+            with torch.cuda.stream(self._dw_side):
+                launch()
             ops.flush_finalize(self._deferred_fin)
             cur.wait_stream(self._dw_side)
-            cur.wait_stream(self._side3)
             if getattr(self, "_fin_pending", False):
                 cur.wait_stream(self._fin_side)
                 self._fin_pending = False

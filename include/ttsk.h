@@ -579,6 +579,24 @@ typedef struct ttsk_dwconv_item {
 int ttsk_dwconv_supported(int Cout, int Cin, int K);
 int ttsk_dwconv_batch(const ttsk_dwconv_item* items, int n /* <= 12 */, void* stream);
 
+/* The same weight gradient for Cout and Cin multiples of 256 (a Linear's or a k = 1 conv's: K = 1; or a conv with taps) on the
+ * 256 x 256-tile kernel of csrc/dwgemm.hip — one workgroup per (output tile, tap, utterance range): up to 28 problems per launch.
+ * splits > 1 cuts the utterances into `splits` ranges whose partial sums go to `workspace` (fp32 [splits][K][Cout][Cin],
+ * ttsk_dwgemm_workspace_floats) — the slab layout of ttsk_reduce_item {ws, C = dw, M = Cout, N = Cin, ldc = K*Cin, nz = K, splits,
+ * accumulate, sC2 = Cin}: run ttsk_gemm_reduce_batch behind it; splits = 1 writes / accumulates dw directly.
+ * reference call sites: SubLayers.py:41-43,62 (w_qs | w_ks | w_vs, fc), :97 (w_2), Layers.py:85-129 (PostNet convs). */
+typedef struct ttsk_dwgemm_item {
+  const void* dy;
+  const void* x;
+  float* dw;
+  float* workspace;
+  const int64_t* lens;
+  int32_t Cout, Cin, K, ldy, ldx, B, S, accumulate, splits;
+} ttsk_dwgemm_item;
+int ttsk_dwgemm_supported(int Cout, int Cin, int K);
+int64_t ttsk_dwgemm_workspace_floats(int Cout, int Cin, int K, int splits);
+int ttsk_dwgemm_batch(const ttsk_dwgemm_item* items, int n /* <= 28 */, void* stream);
+
 /* ttsk_optim_step whose Adam launch also writes the window kernels' weight packs (no ttsk_win_conv_pack_table launch after the step).
  * dev_items [n_items] (device memory, sorted by tile0): the packed weights — tap-major storage (Cs, K, Ds) at element offset `off` of the
  * flat buffers, Ds % 256 == 0 and Cs % 32 == 0, its plain pack (`pack`, the weight as it is: Cout = Cs, Cin = Ds) and / or its transposed,

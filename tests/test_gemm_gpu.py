@@ -783,3 +783,53 @@ def test_dwconv_vs_fp64_and_grouped_gemm(Bn, S, Cout, Cin, lens):
     ref = torch.zeros_like(out)
     ops.conv1d_dw(dyd, xd, ref, k=k, accumulate=False)
     assert float((ref - out).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("Bn,S,Cout,Cin,k,lens,splits", [(16, 423, 256, 1024, 1, "ragged", 4), (16, 423, 768, 256, 1, "ragged", 1),
+                                                         (16, 423, 512, 512, 5, None, 2), (3, 40, 256, 256, 1, "ragged", 3),
+                                                         (2, 7, 256, 256, 3, None, 1), (5, 64, 256, 512, 1, "zeros", 5),
+                                                         (1, 33, 512, 256, 1, None, 1), (7, 100, 256, 256, 5, "ragged", 2)])
+def test_dwgemm_vs_fp64(Bn, S, Cout, Cin, k, lens, splits):
+    """ttsk_dwgemm_batch (csrc/dwgemm.hip): weight gradients with Cout, Cin multiples of 256 on the 256x256-tile kernel — against fp64
+    on the same bf16 operands (torch's `weight.grad` of a Linear / Conv1d: SubLayers.py:41-43,62,97, Layers.py:85-129), unsplit and
+    split over utterance ranges (slabs + ttsk_gemm_reduce_batch), overwrite and accumulate, with `lens`, with taps, with empty
+    utterances, with fewer rows than one K step."""
+    from tts_king_amd import ops
+    from tts_king_amd import lib as L
+    import ctypes as C
+    g = torch.Generator().manual_seed(Bn * S + Cin + k)
+    dy = torch.randn(Bn, S, Cout, generator=g).to(torch.bfloat16)
+    x = torch.randn(Bn, S, Cin, generator=g).to(torch.bfloat16)
+    ln = None
+    if lens == "ragged":
+        ln = torch.randint(max(1, S // 2), S + 1, (Bn,), generator=g)
+        ln[0] = S
+    elif lens == "zeros":
+        ln = torch.tensor([S, 0, 17, 0, 1][:Bn])
+    if ln is not None:
+        m = torch.arange(S)[None, :] >= ln[:, None]
+        dy[m] = 0
+        x[m] = 0
+    xp = torch.nn.functional.pad(x.double(), (0, 0, k // 2, k // 2))
+    want = torch.stack([torch.einsum("btc,bti->ci", dy.double(), xp[:, j:j + S]) for j in range(k)], dim=1)
+    scale = float(want.abs().max())
+    dyd, xd = dy.to(DEV), x.to(DEV)
+    lnd = ln.to(DEV) if ln is not None else None
+    assert ops.dwgemm_supported(Cout, Cin, k)
+
+    def run(dst, accumulate, sp):
+        red = ops.dwgemm_batch([(dyd, xd, dst, lnd, accumulate, sp)])
+        if red:
+            arr = (L.ReduceItem * len(red))(*[r for r, _ in red])
+            L.check(L.load().ttsk_gemm_reduce_batch(arr, len(red), torch.cuda.current_stream().cuda_stream), "reduce")
+        torch.cuda.synchronize()
+    out = torch.full((Cout, k, Cin), 3.0, device=DEV)
+    run(out, False, splits)
+    err = float((out.double().cpu() - want).abs().max()) / scale
+    print("dwgemm B=%d S=%d %dx%d k=%d lens=%s splits=%d: max err %.2e of max |dW|" % (Bn, S, Cout, Cin, k, lens, splits, err))
+    assert err <= 2e-5
+    out1 = torch.full((Cout, k, Cin), -1.0, device=DEV)
+    run(out1, False, 1)
+    assert float((out1 - out).abs().max()) <= 2e-5 * scale          # split or not: the same sum
+    run(out1, True, splits)
+    assert float((out1 - 2 * out).abs().max()) <= 4e-5 * scale

@@ -71,6 +71,13 @@ class DwConvItem(C.Structure):
                 ("K", C.c_int32), ("ldy", C.c_int32), ("ldx", C.c_int32), ("B", C.c_int32), ("S", C.c_int32), ("accumulate", C.c_int32)]
 
 
+class DwGemmItem(C.Structure):
+    """Mirror of `ttsk_dwgemm_item` (include/ttsk.h)."""
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("workspace", C.c_void_p), ("lens", C.c_void_p),
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("K", C.c_int32), ("ldy", C.c_int32), ("ldx", C.c_int32), ("B", C.c_int32),
+                ("S", C.c_int32), ("accumulate", C.c_int32), ("splits", C.c_int32)]
+
+
 class AdamItem(C.Structure):
     """Mirror of `ttsk_adam_item` (include/ttsk.h)."""
     _fields_ = [("off", C.c_int64), ("pack", C.c_void_p), ("pack_t", C.c_void_p), ("Cs", C.c_int32), ("K", C.c_int32), ("Ds", C.c_int32),
@@ -131,7 +138,7 @@ def load(path=LIB_PATH):
     lib.ttsk_last_error.restype = C.c_char_p
     for name, argtypes in declared_prototypes().items():
         fn = getattr(lib, name)
-        if name == "ttsk_resblock_pack_elems":
+        if name in ("ttsk_resblock_pack_elems", "ttsk_dwgemm_workspace_floats"):
             fn.restype = C.c_int64
         elif name != "ttsk_last_error":
             fn.restype = C.c_int
@@ -142,6 +149,7 @@ def load(path=LIB_PATH):
     lib.ttsk_colsum_finalize_batch.argtypes = [C.POINTER(FinalizeItem), C.c_int, C.c_void_p]
     lib.ttsk_gemm_reduce_batch.argtypes = [C.POINTER(ReduceItem), C.c_int, C.c_void_p]
     lib.ttsk_dwconv_batch.argtypes = [C.POINTER(DwConvItem), C.c_int, C.c_void_p]
+    lib.ttsk_dwgemm_batch.argtypes = [C.POINTER(DwGemmItem), C.c_int, C.c_void_p]
     lib.ttsk_gemm_plan.argtypes = [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     _lib = lib
     return lib

@@ -603,6 +603,53 @@ def dwconv_batch(items):
         LAUNCH_COUNTS["dwconv"] = LAUNCH_COUNTS.get("dwconv", 0) + 1
 
 
+def dwgemm_supported(Cout, Cin, k):
+    return bool(L.load().ttsk_dwgemm_supported(int(Cout), int(Cin), int(k)))
+
+
+def dwgemm_batch(items):
+    """Weight gradients with Cout, Cin multiples of 256 on the 256x256-tile kernel (ttsk_dwgemm_batch, csrc/dwgemm.hip), one launch per
+    28 problems.  items: [(dy (B,S,Cout) bf16, x (B,S,Cin) bf16, dst (Cout,k,Cin) fp32 or (Cout,Cin), lens int64 (B,) or None, accumulate,
+    splits)].  Returns [(ReduceItem, slabs)] for the problems with splits > 1: run gemm_reduce_batch on them (DeferQueue does)."""
+    lib = L.load()
+    reduce = []
+    for base in range(0, len(items), 28):
+        chunk = items[base:base + 28]
+        arr = (L.DwGemmItem * len(chunk))()
+        keep = []
+        for i, (dy, x, dst, lens, accumulate, splits) in enumerate(chunk):
+            _dev(dy, x, dst, lens)
+            Bsz, S, Cout = dy.shape
+            Cin = x.shape[2]
+            k = dst.shape[1] if dst.dim() == 3 else 1
+            if dst.numel() != Cout * k * Cin or not dst.is_contiguous() or dst.dtype != torch.float32:
+                raise L.TtskError("dwgemm_batch: dst must be a contiguous fp32 (Cout, k, Cin) tensor")
+            if dy.stride(2) != 1 or x.stride(2) != 1 or dy.stride(0) != S * dy.stride(1) or x.stride(0) != S * x.stride(1) or dy.dtype != bf16 or x.dtype != bf16:
+                raise L.TtskError("dwgemm_batch: dy / x must be bf16 (B, S, C) with unit channel stride and utterances back to back")
+            splits = max(1, min(int(splits), Bsz))
+            ws = torch.empty(splits * k * Cout * Cin, dtype=torch.float32, device=dy.device) if splits > 1 else None
+            it = arr[i]
+            it.dy, it.x, it.dw, it.workspace, it.lens = dy.data_ptr(), x.data_ptr(), dst.data_ptr(), _ptr(ws), _ptr(lens)
+            it.Cout, it.Cin, it.K, it.ldy, it.ldx, it.B, it.S = Cout, Cin, k, dy.stride(1), x.stride(1), Bsz, S
+            it.accumulate, it.splits = int(bool(accumulate)), splits
+            if ws is not None:
+                r = L.ReduceItem()
+                r.ws, r.C, r.M, r.N, r.ldc, r.nz, r.splits = ws.data_ptr(), dst.data_ptr(), Cout, Cin, k * Cin, k, splits
+                r.accumulate, r.sC2, r.alpha = int(bool(accumulate)), Cin, 1.0
+                reduce.append((r, ws))
+        if GEMM_TRACE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        check(lib.ttsk_dwgemm_batch(arr, len(chunk), _stream()), "ttsk_dwgemm_batch")
+        if GEMM_TRACE is not None:
+            e1.record()
+            fl = sum(2.0 * it[0].shape[0] * it[0].shape[1] * it[0].shape[2] * it[1].shape[2] * (it[2].shape[1] if it[2].dim() == 3 else 1) for it in chunk)
+            GEMM_TRACE.append((e0, e1, fl, "dwgemm", (len(chunk), 0, 0, 1, 1, 0)))
+        if LAUNCH_COUNTS is not None:
+            LAUNCH_COUNTS["dwgemm"] = LAUNCH_COUNTS.get("dwgemm", 0) + 1
+    return reduce
+
+
 def conv_transpose1d(x, Wp, bias, stride, k, out=None, in_slope=0.0, flags=0, C2=None, out_slope=0.0, **kw):
     """ConvTranspose1d(padding=(k-stride)//2) as `stride` polyphase implicit GEMMs.
     x (B,T,Cin) bf16, Wp (k, Cout, Cin) bf16 (tap-major repack of torch's (Cin,Cout,k)) -> (B,T*stride,Cout).

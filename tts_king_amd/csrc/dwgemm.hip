@@ -90,13 +90,17 @@ __global__ __launch_bounds__(DWG_NT, 1) void dwgemm_kernel(const DwgArgs args) {
     // shift / past the last K step: out-of-range offsets, zeros without a memory access.
     const int p = 2 * wave + (q & 1);
     const int row = ij * DWG_BK + 2 * p + f_row;
+    // (offsets computed unconditionally, then ONE select: with the address arithmetic inside the conditional hipcc built branches
+    // around it and drained vmcnt(0) at their join — every K step waited for the loads it had just issued)
     if (q < 2) {
-      const bool ok = live && row < inb;
-      return __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? ((b0 + ib) * S + row) * ldy * 2 + a_col : DWG_OOB, 0, 0);
+      const int off = ((b0 + ib) * S + row) * ldy * 2 + a_col;
+      const bool ok = live & (row < inb);
+      return __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? off : DWG_OOB, 0, 0);
     } else {
       const int t = row + shift;
-      const bool ok = live && row < inb && t >= 0 && t < S;
-      return __builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? ((b0 + ib) * S + t) * ldx * 2 + b_col : DWG_OOB, 0, 0);
+      const int off = ((b0 + ib) * S + t) * ldx * 2 + b_col;
+      const bool ok = live & (row < inb) & (t >= 0) & (t < S);
+      return __builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? off : DWG_OOB, 0, 0);
     }
   };
   auto load_advance = [&]() __attribute__((always_inline)) {

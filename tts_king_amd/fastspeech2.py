@@ -929,7 +929,7 @@ class FastSpeech2(nn.Module):
         # ---- w_2 (k=1): dW, dX gated by the ReLU
         with self._side_work(dy2, part, h):
             self._finalize_ln(part, nblk, 3 * d, f + "w_2.bias")
-            ops.conv1d_dw(dy2.view(Bn, S, d), h, self._g(f + "w_2.weight"), k=self.k2, defer=self._deferred, accumulate=self._acc)
+            ops.queue_dw(self._deferred, dy2.view(Bn, S, d), h, self._g(f + "w_2.weight"), lens, self._acc, k=self.k2, use_dwgemm=self._use_dwconv)
         if dh is not None:
             pass
         elif pk2 is not None and self.k2 == 1:
@@ -970,7 +970,7 @@ class FastSpeech2(nn.Module):
                                                      self._m(a + "layer_norm.bias"), lens, S, p_pre=p, site_pre=site, rng=rng)
         with self._side_work(dy1, part, o):
             self._finalize_ln(part, nblk, 3 * d, a + "fc.bias")
-            ops.linear_dw(dy1, o, self._g(a + "fc.weight"), defer=self._deferred, accumulate=self._acc)
+            ops.queue_dw(self._deferred, dy1.view(Bn, S, d), o.view(Bn, S, d), self._g(a + "fc.weight"), lens, self._acc, use_dwgemm=self._use_dwconv)
         pkf = self._w1_packed.get(("fcT", a + "fc.weight")) if (self.window_ffn and self._w1_packed) else None
         if do is not None:
             pass
@@ -1004,7 +1004,8 @@ class FastSpeech2(nn.Module):
         # ---- q|k|v projections
         with self._side_work(dqkv, x):
             ops.colsum_into(dqkv, self._g(a + "w_qs.bias", 3 * d), defer=self._deferred_fin, accumulate=self._acc)
-            ops.linear_dw(dqkv, x, self._g(a + "w_qs.weight", 3 * d * d).view(3 * d, d), defer=self._deferred, accumulate=self._acc)
+            ops.queue_dw(self._deferred, dqkv.view(Bn, S, 3 * d), x.view(Bn, S, d), self._g(a + "w_qs.weight", 3 * d * d).view(3 * d, d), lens,
+                         self._acc, use_dwgemm=self._use_dwconv)
         if raw_out and self.raw_slabs:
             pkq = self._w1_packed.get(("qkvT", a + "w_qs.weight")) if (self.window_ffn and self._w1_packed) else None
             if pkq is not None and raw_out == "pre" and d == 256:
@@ -1082,6 +1083,7 @@ class FastSpeech2(nn.Module):
         marks, self._dp_marks = self._dp_marks, []
         with torch.cuda.stream(self._dw_side):
             ops.flush_dwconv(self._deferred)           # all six decoder blocks in ONE launch (a bucket's two would leave the chip idle)
+            ops.flush_dwgemm(self._deferred, reduce_now=True)      # ... and the other weight gradients queued so far, with their reducer
             marks = [(name, ng, nr, 0) for name, ng, nr, nd in marks]
             for i, (name, ng, nr, nd) in enumerate(marks):
                 if launched < 0 or (ready is not None and not ready(name)):
@@ -1187,7 +1189,9 @@ class FastSpeech2(nn.Module):
                             frame_limit=ctx.frame_limit, keep=keep, accumulate=self._acc)
             with self._side_work(dy, xin):
                 ops.colsum_into(dy, self._g(pp + "0.conv.bias"), defer=self._deferred_fin, accumulate=self._acc)
-                ops.conv1d_dw(dy.view(Bn, T, C), xin, self._g(pp + "0.conv.weight"), k=5, defer=self._deferred, accumulate=self._acc)
+                # (no `lens`: the PostNet's BatchNorm runs over the PAD rows too, Layers.py:133-143 — its gradients there are not zero)
+                ops.queue_dw(self._deferred, dy.view(Bn, T, C), xin, self._g(pp + "0.conv.weight"), None, self._acc, k=5,
+                             use_dwgemm=self._use_dwconv)
             pkt = self._w1_packed.get(("pnT", pp + "0.conv.weight")) if (self.window_ffn and self._w1_packed) else None
             if i > 0 and pkt is not None:
                 cw = self._table[pp + "0.conv.weight"].storage_shape

@@ -52,6 +52,7 @@ class DeferQueue(list):
         super().__init__()
         self.group = [] if group_gemms else None
         self.dwconv = []        # weight gradients of convs with taps: (dy, x, dst, lens, accumulate) for dwconv_batch (csrc/dwconv.hip)
+        self.dwgemm = []        # ... of Linear / k = 1 / PostNet layers with 256-multiple channels: (dy, x, dst, lens, accumulate, splits)
 
 
 class GemmGroup:
@@ -147,6 +148,7 @@ def upload_deferred_gemms(items, max_wgs=0, with_dwconv=True):
     def both(streams=None):
         if with_dwconv:
             flush_dwconv(items)
+        flush_dwgemm(items)
         launch(streams)
     return both
 
@@ -171,12 +173,58 @@ def flush_dwconv(items, n=None):
     q[:] = rest
 
 
+def dwgemm_splits(Bsz, S, target_steps=56):
+    """Utterance ranges per problem for dwgemm_batch: workgroups of about `target_steps` 32-row K steps (the 16 x 423-row step: 4)."""
+    steps = Bsz * ((S + 31) // 32)
+    return max(1, min(Bsz, (steps + target_steps // 2) // target_steps))
+
+
+def flush_dwgemm(items, reduce_now=False):
+    """The queued dwgemm problems as ttsk_dwgemm_batch launches on the current stream; the reducer items of the split ones join the
+    queue's split-K items (summed by flush_deferred's batched reducer), or are summed right here (reduce_now)."""
+    q = getattr(items, "dwgemm", None)
+    if not q:
+        return
+    if not hasattr(items, "_keep"):
+        items._keep = []
+    for it in q:
+        items._keep.extend(t for t in it[:4] if t is not None)
+    red = dwgemm_batch(q)
+    q[:] = []
+    if reduce_now and red:
+        arr = (L.ReduceItem * len(red))(*[r for r, _ in red])
+        check(L.load().ttsk_gemm_reduce_batch(arr, len(red), _stream()), "ttsk_gemm_reduce_batch")
+        items._keep.extend(ws for _, ws in red)
+        if LAUNCH_COUNTS is not None:
+            LAUNCH_COUNTS["reduce_batch"] = LAUNCH_COUNTS.get("reduce_batch", 0) + 1
+    else:
+        items.extend(red)
+
+
+def queue_dw(defer, dy, x, dst, lens, accumulate, k=1, use_dwgemm=True):
+    """Queue the weight gradient dst (Cout, k, Cin) (+)= dy (B,S,Cout)^T x (B,S,Cin) [taps: "same" padding]: on the 256x256-tile kernel
+    (dwgemm.hip) when the shape allows, else as a grouped GEMM.  `lens`: rows of each utterance that carry a gradient (or None)."""
+    Bsz, S, Cout = dy.shape
+    Cin = x.shape[2]
+    if (use_dwgemm and getattr(defer, "group", None) is not None and dy.dtype == bf16 and x.dtype == bf16 and dwgemm_supported(Cout, Cin, k)
+            and dst.is_contiguous()):
+        sp = dwgemm_splits(Bsz, S)
+        if (Bsz + sp - 1) // sp <= 64:
+            defer.dwgemm.append((dy, x, dst.view(Cout, k, Cin), lens, accumulate, sp))
+            return
+    if k == 1:
+        linear_dw(dy.reshape(Bsz * S, Cout), x.reshape(Bsz * S, Cin), dst.view(Cout, Cin), defer=defer, accumulate=accumulate)
+    else:
+        conv1d_dw(dy, x, dst, k=k, defer=defer, accumulate=accumulate)
+
+
 def flush_deferred_gemms(items, max_wgs=0, frac=1.0):
     """Only the grouped weight-gradient GEMMs queued in `items` so far, as grouped launches on the current stream (grid capped at
     max_wgs workgroups when > 0); their split-K slabs stay queued for `flush_deferred`'s reducer launch.  frac < 1: only about
     that fraction of the queued FLOPs (the problems queued first); the rest stays queued for the next flush.  The queued dwconv
-    problems (conv weight gradients with taps) go first, all of them."""
+    and dwgemm problems go first, all of them."""
     flush_dwconv(items)
+    flush_dwgemm(items)
     group = getattr(items, "group", None)
     if not group:
         return
@@ -184,10 +232,11 @@ def flush_deferred_gemms(items, max_wgs=0, frac=1.0):
         # a capped launch exists for the 256x128 configuration only; the few 128x128 problems (80-row outputs: mel_linear, the PostNet's
         # last conv) would be a 35 us launch of their own on that stream's critical path: they stay queued for the final flush
         small = [d for d in group if d.kernel != 2]
-        if small and len(small) < len(group):
+        if small:
             group[:] = [d for d in group if d.kernel == 2]
             try:
-                flush_deferred_gemms(items, max_wgs, frac)
+                if group:
+                    flush_deferred_gemms(items, max_wgs, frac)
             finally:
                 group.extend(small)
             return
@@ -231,6 +280,7 @@ def flush_deferred(items):
     """The queued weight-gradient GEMMs as grouped launches, then one ttsk_gemm_reduce_batch launch (per 64 items) for the
     split-K slabs collected in `items` (see gemm(defer=...))."""
     flush_dwconv(items)
+    flush_dwgemm(items)
     group = getattr(items, "group", None)
     if group:
         keep = getattr(items, "_keep")

@@ -595,7 +595,8 @@ typedef struct ttsk_dwgemm_item {
 } ttsk_dwgemm_item;
 int ttsk_dwgemm_supported(int Cout, int Cin, int K);
 int64_t ttsk_dwgemm_workspace_floats(int Cout, int Cin, int K, int splits);
-int ttsk_dwgemm_batch(const ttsk_dwgemm_item* items, int n /* <= 28 */, void* stream);
+/* max_wgs > 0: at most that many workgroups, each walking several tiles (one per CU on part of the chip, the rest left to a concurrent stream) */
+int ttsk_dwgemm_batch(const ttsk_dwgemm_item* items, int n /* <= 28 */, int max_wgs, void* stream);
 
 /* ttsk_optim_step whose Adam launch also writes the window kernels' weight packs (no ttsk_win_conv_pack_table launch after the step).
  * dev_items [n_items] (device memory, sorted by tile0): the packed weights — tap-major storage (Cs, K, Ds) at element offset `off` of the

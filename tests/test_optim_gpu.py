@@ -84,8 +84,9 @@ def test_overwrite_backward_equals_zero_then_accumulate(cfg):
 
 
 def test_dwconv_path_equals_grouped_gemm_path(cfg):
-    """FastSpeech2.dwconv (w_1's weight gradient on csrc/dwconv.hip, rows past each utterance's length skipped) against the grouped
-    GEMM path on the same step: every other gradient bit-identical, w_1's within fp32 summation-order noise."""
+    """FastSpeech2.dwconv (w_1's weight gradient on csrc/dwconv.hip, the other 256-multiple weight gradients on csrc/dwgemm.hip, rows
+    past each utterance's length skipped) against the grouped GEMM path on the same step: the weights those kernels produce within fp32
+    summation-order noise, every other gradient bit-identical."""
     from tests.oracle_util import fs2_state_dict
     from tts_king_amd import ops
     from tts_king_amd.fastspeech2 import FastSpeech2
@@ -113,11 +114,12 @@ def test_dwconv_path_equals_grouped_gemm_path(cfg):
         res.append({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
     worst = 0.0
     for k in res[0]:
-        if k.endswith("pos_ffn.w_1.weight"):
+        if k.endswith(("pos_ffn.w_1.weight", "pos_ffn.w_2.weight", "slf_attn.fc.weight", "slf_attn.w_qs.weight", "slf_attn.w_ks.weight",
+                       "slf_attn.w_vs.weight", "conv1d_1.conv.weight", "conv1d_2.conv.weight")) or (k.startswith("postnet.convolutions.") and k.endswith("0.conv.weight")):
             scale = float(res[0][k].abs().max())
             err = float((res[0][k] - res[1][k]).abs().max()) / scale
             worst = max(worst, err)
             assert err <= 1e-5, (k, err)
         else:
             assert torch.equal(res[0][k], res[1][k]), k
-    print("w_1 gradients, dwconv vs grouped GEMM: max difference %.2e of max |g|" % worst)
+    print("weight gradients, dwconv / dwgemm vs grouped GEMM: max difference %.2e of max |g|" % worst)

@@ -37,25 +37,16 @@ struct DwgArgs {
   int n;
 };
 
-__global__ __launch_bounds__(DWG_NT, 1) void dwgemm_kernel(const DwgArgs args) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[DWG_SMEM];
+__device__ __forceinline__ void dwgemm_tile(const DwgArgs& args, int id, unsigned char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
-
-  // ---- which tile (XCD-major ids: the column tiles and taps that share a dY tile and K range sit on one XCD)
-  int id;
-  {
-    const int G = gridDim.x, wg = blockIdx.x, q = G >> 3, r = G & 7, x = wg & 7;
-    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
-  }
   int pi = 0;
   for (int i = 1; i < args.n; ++i)
     if (id >= args.p[i].wg0) pi = i;
   pi = __builtin_amdgcn_readfirstlane(pi);
   const DwgProblem& P = args.p[pi];
   int local = id - P.wg0;
-  if (local >= P.nwg) return;
   const int tile_n = local % P.tiles_n; local /= P.tiles_n;
   const int tap = local % P.taps; local /= P.taps;
   const int tile_m = local % P.tiles_m;
@@ -235,6 +226,19 @@ __global__ __launch_bounds__(DWG_NT, 1) void dwgemm_kernel(const DwgArgs args) {
   }
 }
 
+// The grid may be smaller than the number of tiles (max_wgs: one workgroup per CU on part of the chip, the rest left to a concurrent
+// stream): a workgroup then walks tiles w, w + gridDim.x, ... in XCD-major order (the tiles that share a dY tile and K range meet in
+// one L2 when the grid is a multiple of 8).
+__global__ __launch_bounds__(DWG_NT, 1) void dwgemm_kernel(const DwgArgs args, int total) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DWG_SMEM];
+  for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    const int q = total >> 3, r = total & 7, x = w & 7;
+    const int id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (w >> 3);
+    dwgemm_tile(args, id, smem);
+    __syncthreads();                   // the next tile's prologue overwrites stages this tile's slower waves may still read
+  }
+}
+
 }  // namespace
 
 extern "C" int ttsk_dwgemm_supported(int Cout, int Cin, int K) {
@@ -245,7 +249,7 @@ extern "C" int64_t ttsk_dwgemm_workspace_floats(int Cout, int Cin, int K, int sp
   return splits > 1 ? (int64_t)splits * K * Cout * Cin : 0;
 }
 
-extern "C" int ttsk_dwgemm_batch(const ttsk_dwgemm_item* items, int n, void* stream) {
+extern "C" int ttsk_dwgemm_batch(const ttsk_dwgemm_item* items, int n, int max_wgs, void* stream) {
   TTSK_REQUIRE(items && n > 0 && n <= DWG_MAXP, "dwgemm_batch: 1..%d items", DWG_MAXP);
   DwgArgs a;
   a.n = n;
@@ -270,7 +274,8 @@ extern "C" int ttsk_dwgemm_batch(const ttsk_dwgemm_item* items, int n, void* str
     p.wg0 = wg;
     wg += p.nwg;
   }
-  hipLaunchKernelGGL(dwgemm_kernel, dim3(wg), dim3(DWG_NT), 0, (hipStream_t)stream, a);
+  TTSK_REQUIRE(max_wgs >= 0, "dwgemm_batch: max_wgs >= 0 (0 = a workgroup per tile)");
+  hipLaunchKernelGGL(dwgemm_kernel, dim3(max_wgs > 0 && max_wgs < wg ? max_wgs : wg), dim3(DWG_NT), 0, (hipStream_t)stream, a, wg);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

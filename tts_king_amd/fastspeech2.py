@@ -1109,21 +1109,20 @@ class FastSpeech2(nn.Module):
             # only activations and gradients the main chain produced: they run now, beside the side stream; the encoder-side dW group
             # queues behind the first one on the side stream; the join comes last, before the split-K reducer.
             cur = torch.cuda.current_stream()
-            launch = ops.upload_deferred_gemms(self._deferred, max_wgs=0, with_dwconv=False)     # the tables now, on this stream (the side stream is busy)
-            if self._deferred.dwconv:
-                # the encoder blocks' w_1 gradients (128 workgroups) beside the grouped launch, on a stream of their own
-                if self._fin_side is None:
-                    self._fin_side = torch.cuda.Stream(device=self.device)
-                self._fin_side.wait_stream(cur)
-                with torch.cuda.stream(self._fin_side):
-                    ops.flush_dwconv(self._deferred)
-                self._fin_pending = True
-            # three branches from here (a replayed graph runs at most three queues side by side: a fourth branch — the two grouped launches
-            # on a stream each — serialised the column sums behind them): the encoder's dwconv (above), the grouped launches one after the
-            # other on the side stream, the column sums on this one
+            launch = ops.upload_deferred_gemms(self._deferred, max_wgs=0, with_dwconv=False, with_dwgemm=False)     # the tables now, on this stream
+            # Three branches from here (a replayed graph runs at most three queues side by side): the encoder blocks' w_1 gradients
+            # (dwconv, 128 workgroups) and behind them the few grouped problems (80-channel outputs) on one stream; the encoder side's
+            # dwgemm problems on the side stream (behind the decoder's work there); the column sums on this one.
+            if self._fin_side is None:
+                self._fin_side = torch.cuda.Stream(device=self.device)
+            self._fin_side.wait_stream(cur)
+            with torch.cuda.stream(self._fin_side):
+                ops.flush_dwconv(self._deferred)
+                launch()
+            self._fin_pending = True
             self._dw_side.wait_stream(cur)
             with torch.cuda.stream(self._dw_side):
-                launch()
+                ops.flush_dwgemm(self._deferred)
             ops.flush_finalize(self._deferred_fin)
             cur.wait_stream(self._dw_side)
             if getattr(self, "_fin_pending", False):

@@ -149,7 +149,7 @@ def load(path=LIB_PATH):
     lib.ttsk_colsum_finalize_batch.argtypes = [C.POINTER(FinalizeItem), C.c_int, C.c_void_p]
     lib.ttsk_gemm_reduce_batch.argtypes = [C.POINTER(ReduceItem), C.c_int, C.c_void_p]
     lib.ttsk_dwconv_batch.argtypes = [C.POINTER(DwConvItem), C.c_int, C.c_void_p]
-    lib.ttsk_dwgemm_batch.argtypes = [C.POINTER(DwGemmItem), C.c_int, C.c_void_p]
+    lib.ttsk_dwgemm_batch.argtypes = [C.POINTER(DwGemmItem), C.c_int, C.c_int, C.c_void_p]
     lib.ttsk_gemm_plan.argtypes = [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     _lib = lib
     return lib

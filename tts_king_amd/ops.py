@@ -139,7 +139,7 @@ def flush_group(descs, keep, max_wgs=0, upload_only=False):
         return launch
 
 
-def upload_deferred_gemms(items, max_wgs=0, with_dwconv=True):
+def upload_deferred_gemms(items, max_wgs=0, with_dwconv=True, with_dwgemm=True):
     """flush_deferred_gemms in two parts: the tables now (current stream), the launches when the returned function is called (the
     queued dwconv problems carry their table in the launch's arguments: with_dwconv, they go with the launches)."""
     group = getattr(items, "group", None)
@@ -148,7 +148,8 @@ def upload_deferred_gemms(items, max_wgs=0, with_dwconv=True):
     def both(streams=None):
         if with_dwconv:
             flush_dwconv(items)
-        flush_dwgemm(items)
+        if with_dwgemm:
+            flush_dwgemm(items)
         launch(streams)
     return both
 
@@ -174,12 +175,15 @@ def flush_dwconv(items, n=None):
 
 
 def dwgemm_splits(Bsz, S, target_steps=56):
-    """Utterance ranges per problem for dwgemm_batch: workgroups of about `target_steps` 32-row K steps (the 16 x 423-row step: 4)."""
+    """Utterance ranges per problem for dwgemm_batch: workgroups of about `target_steps` 32-row K steps (the 16 x 423-row step: 4); short
+    problems (the phoneme side: 2 steps per utterance) of about 16, so that their few tiles still spread over the chip."""
     steps = Bsz * ((S + 31) // 32)
+    if steps <= 64:
+        target_steps = 16
     return max(1, min(Bsz, (steps + target_steps // 2) // target_steps))
 
 
-def flush_dwgemm(items, reduce_now=False):
+def flush_dwgemm(items, reduce_now=False, max_wgs=0):
     """The queued dwgemm problems as ttsk_dwgemm_batch launches on the current stream; the reducer items of the split ones join the
     queue's split-K items (summed by flush_deferred's batched reducer), or are summed right here (reduce_now)."""
     q = getattr(items, "dwgemm", None)
@@ -189,7 +193,7 @@ def flush_dwgemm(items, reduce_now=False):
         items._keep = []
     for it in q:
         items._keep.extend(t for t in it[:4] if t is not None)
-    red = dwgemm_batch(q)
+    red = dwgemm_batch(q, max_wgs)
     q[:] = []
     if reduce_now and red:
         arr = (L.ReduceItem * len(red))(*[r for r, _ in red])
@@ -222,9 +226,10 @@ def flush_deferred_gemms(items, max_wgs=0, frac=1.0):
     """Only the grouped weight-gradient GEMMs queued in `items` so far, as grouped launches on the current stream (grid capped at
     max_wgs workgroups when > 0); their split-K slabs stay queued for `flush_deferred`'s reducer launch.  frac < 1: only about
     that fraction of the queued FLOPs (the problems queued first); the rest stays queued for the next flush.  The queued dwconv
-    and dwgemm problems go first, all of them."""
+    and dwgemm problems go first, all of them (capped likewise; with max_wgs their slabs are summed right behind them: this is the
+    side stream's launch, which has the time)."""
     flush_dwconv(items)
-    flush_dwgemm(items)
+    flush_dwgemm(items, reduce_now=max_wgs > 0, max_wgs=max_wgs)
     group = getattr(items, "group", None)
     if not group:
         return
@@ -358,7 +363,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, flags=0, alpha=1.0, bias=None, R=No
         # grid balanced with 4x-9x fewer slabs (750 MB -> ~50 MB of split-K traffic per train step).
         # Tile configuration: the 256x128 LDS-DMA kernel unless the output has too few rows to fill its tile.
         steps = (K + 63) // 64 * max(taps, 1)
-        d.kernel = 2 if M >= 192 else 1
+        d.kernel = 2 if (M >= 192 and N >= 128) else 1        # (an 80-column output on the 256x128 tile would waste 3/8 of it)
         per1, per2 = DW_STEPS_PER_WG
         d.splits = max(1, (steps + per1 // 2) // per1) if d.kernel == 1 else max(1, (steps + per2 // 2) // per2)
         kernel, splits, ws_bytes = plan(d)
@@ -657,7 +662,7 @@ def dwgemm_supported(Cout, Cin, k):
     return bool(L.load().ttsk_dwgemm_supported(int(Cout), int(Cin), int(k)))
 
 
-def dwgemm_batch(items):
+def dwgemm_batch(items, max_wgs=0):
     """Weight gradients with Cout, Cin multiples of 256 on the 256x256-tile kernel (ttsk_dwgemm_batch, csrc/dwgemm.hip), one launch per
     28 problems.  items: [(dy (B,S,Cout) bf16, x (B,S,Cin) bf16, dst (Cout,k,Cin) fp32 or (Cout,Cin), lens int64 (B,) or None, accumulate,
     splits)].  Returns [(ReduceItem, slabs)] for the problems with splits > 1: run gemm_reduce_batch on them (DeferQueue does)."""
@@ -690,7 +695,7 @@ def dwgemm_batch(items):
         if GEMM_TRACE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        check(lib.ttsk_dwgemm_batch(arr, len(chunk), _stream()), "ttsk_dwgemm_batch")
+        check(lib.ttsk_dwgemm_batch(arr, len(chunk), int(max_wgs), _stream()), "ttsk_dwgemm_batch")
         if GEMM_TRACE is not None:
             e1.record()
             fl = sum(2.0 * it[0].shape[0] * it[0].shape[1] * it[0].shape[2] * it[1].shape[2] * (it[2].shape[1] if it[2].dim() == 3 else 1) for it in chunk)

@@ -607,8 +607,8 @@ class FastSpeech2(nn.Module):
             for g, n in enumerate(names):
                 cg = "variance_adaptor.%s_predictor.conv_layer." % n
                 self._finalize_ln(part[g], nblk, 4 * Fh + 1, cg + "conv1d_2.conv.bias")
-                ops.conv1d_dw(dh2[g].view(Bn, Lp, Fh), a1[g * rows:(g + 1) * rows].view(Bn, Lp, Fh), self._g(cg + "conv1d_2.conv.weight"),
-                              k=self.k_var, defer=self._deferred, accumulate=self._acc)
+                ops.queue_dw(self._deferred, dh2[g].view(Bn, Lp, Fh), a1[g * rows:(g + 1) * rows].view(Bn, Lp, Fh), self._g(cg + "conv1d_2.conv.weight"),
+                             None, self._acc, k=self.k_var, use_dwgemm=self._use_dwconv)
         da1 = torch.empty(3, rows, Fh, dtype=bf16, device=dev)
         ops.conv1d_dx(dh2[0].view(Bn, Lp, Fh), W2, out=da1[0].view(Bn, Lp, Fh), nz1=3, sA=(rows * Fh, 0), sB=(ps, 0), sC=(rows * Fh, 0))
         dh1, part, nblk = ops.layernorm_bwd_grouped(da1.view(3 * rows, Fh), h1.view(3 * rows, Fh), m1, r1, self._m(c + "layer_norm_1.weight"),
@@ -619,8 +619,8 @@ class FastSpeech2(nn.Module):
             for g, n in enumerate(names):
                 cg = "variance_adaptor.%s_predictor.conv_layer." % n
                 self._finalize_ln(part[g], nblk, 3 * Fh, cg + "conv1d_1.conv.bias")
-                ops.conv1d_dw(dh1[g].view(Bn, Lp, Fh), stack[g].view(Bn, Lp, d), self._g(cg + "conv1d_1.conv.weight"), k=self.k_var,
-                              defer=self._deferred, accumulate=self._acc)
+                ops.queue_dw(self._deferred, dh1[g].view(Bn, Lp, Fh), stack[g].view(Bn, Lp, d), self._g(cg + "conv1d_1.conv.weight"), None,
+                             self._acc, k=self.k_var, use_dwgemm=self._use_dwconv)
         dxin = torch.empty(3, rows, d, dtype=torch.float32, device=dev)
         ops.conv1d_dx(dh1[0].view(Bn, Lp, Fh), W1, out=dxin[0].view(Bn, Lp, d), nz1=3, sA=(rows * Fh, 0), sB=(ps, 0), sC=(rows * d, 0))
         return ops.va_combine(dx3, dxin, Lp, row_limit)
@@ -1046,12 +1046,24 @@ class FastSpeech2(nn.Module):
                 ["encoder.%d" % i for i in range(self.n_enc - 1, -1, -1)] + ["embedding"])
 
     def _launch_dw_side(self):
-        """The grouped dW GEMMs queued so far, on the side stream with a capped grid (see `dw_side_wgs`)."""
+        """The weight-gradient work queued so far (PostNet, mel_linear, decoder), after the decoder's backward, beside the encoder-side
+        dX chain on the main stream — two more branches (a replayed graph runs three queues side by side):
+          * second stream: w_1's six gradients (dwconv, 192 workgroups = one per CU on 3/4 of the chip), the other 256-multiple ones
+            (dwgemm, grid capped at `dw_side_wgs`) with their slab reducer, then the few grouped problems (80-channel outputs);
+          * third stream: the bias / LayerNorm column sums queued so far (HBM-bound: they overlap the MFMA-bound kernels beside them)."""
         if self._dw_side is None:
             self._dw_side = torch.cuda.Stream(device=self.device)
-        self._dw_side.wait_stream(torch.cuda.current_stream())
+        if self._fin_side is None:
+            self._fin_side = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream()
+        self._fin_side.wait_stream(cur)
+        self._dp_keep = [k for _, k in self._deferred_fin]       # alive until the final join (the allocator orders frees by the main stream only)
+        with torch.cuda.stream(self._fin_side):
+            ops.flush_finalize(self._deferred_fin)
+        self._fin_pending = True
+        self._dw_side.wait_stream(cur)
         with torch.cuda.stream(self._dw_side):
-            ops.flush_deferred_gemms(self._deferred, max_wgs=self.dw_side_wgs, frac=self.dw_side_frac)
+            ops.flush_deferred_gemms(self._deferred, max_wgs=self.dw_side_wgs, frac=self.dw_side_frac, small_too=True)
         self._dw_side_pending = True
 
     def _mark_bucket(self, name):

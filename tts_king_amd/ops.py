@@ -222,7 +222,7 @@ def queue_dw(defer, dy, x, dst, lens, accumulate, k=1, use_dwgemm=True):
         conv1d_dw(dy, x, dst, k=k, defer=defer, accumulate=accumulate)
 
 
-def flush_deferred_gemms(items, max_wgs=0, frac=1.0):
+def flush_deferred_gemms(items, max_wgs=0, frac=1.0, small_too=False):
     """Only the grouped weight-gradient GEMMs queued in `items` so far, as grouped launches on the current stream (grid capped at
     max_wgs workgroups when > 0); their split-K slabs stay queued for `flush_deferred`'s reducer launch.  frac < 1: only about
     that fraction of the queued FLOPs (the problems queued first); the rest stays queued for the next flush.  The queued dwconv
@@ -234,8 +234,8 @@ def flush_deferred_gemms(items, max_wgs=0, frac=1.0):
     if not group:
         return
     if max_wgs > 0:
-        # a capped launch exists for the 256x128 configuration only; the few 128x128 problems (80-row outputs: mel_linear, the PostNet's
-        # last conv) would be a 35 us launch of their own on that stream's critical path: they stay queued for the final flush
+        # a capped launch exists for the 256x128 configuration only; the few 128x128 problems (80-row / 80-column outputs: mel_linear, the
+        # PostNet's first and last conv) go behind it uncapped (small_too: 168 workgroups, two per CU) or stay queued for the final flush
         small = [d for d in group if d.kernel != 2]
         if small:
             group[:] = [d for d in group if d.kernel == 2]
@@ -244,6 +244,10 @@ def flush_deferred_gemms(items, max_wgs=0, frac=1.0):
                     flush_deferred_gemms(items, max_wgs, frac)
             finally:
                 group.extend(small)
+            if small_too:
+                now = [d for d in group if d.kernel != 2]
+                group[:] = [d for d in group if d.kernel == 2]
+                flush_group(now, getattr(items, "_keep"), 0)
             return
     if frac < 1.0:
         fl = [2.0 * d.M * d.N * d.K * max(d.taps, 1) * d.nz1 * d.nz2 for d in group]

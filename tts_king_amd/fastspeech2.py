@@ -180,6 +180,8 @@ class FastSpeech2(nn.Module):
         #           overlap of wire time with backward, 16 % more compute time per step;
         #   "late"  the single-GPU schedule untouched, every all-reduce after the last flush (no overlap with backward).
         self.dp_schedule = os.environ.get("TTSK_DP_SCHEDULE", "side")
+        self.side_colsum = os.environ.get("TTSK_SIDE_COLSUM", "1") != "0"    # the decoder-side column sums on a third stream at the decoder's end
+        self.side_small = os.environ.get("TTSK_SIDE_SMALL", "1") != "0"      # the 80-channel grouped problems behind dwgemm on the second stream
         self._fin_side = None
         # Does the flat gradient buffer hold an unfinished accumulation (micro-steps of a grad_acc_step cycle)?  False after an optimizer
         # update or zero_grad(): the next backward then overwrites instead of accumulating (see backward_native).
@@ -1056,14 +1058,15 @@ class FastSpeech2(nn.Module):
         if self._fin_side is None:
             self._fin_side = torch.cuda.Stream(device=self.device)
         cur = torch.cuda.current_stream()
-        self._fin_side.wait_stream(cur)
-        self._dp_keep = [k for _, k in self._deferred_fin]       # alive until the final join (the allocator orders frees by the main stream only)
-        with torch.cuda.stream(self._fin_side):
-            ops.flush_finalize(self._deferred_fin)
-        self._fin_pending = True
+        if self.side_colsum:
+            self._fin_side.wait_stream(cur)
+            self._dp_keep = [k for _, k in self._deferred_fin]       # alive until the final join (the allocator orders frees by the main stream only)
+            with torch.cuda.stream(self._fin_side):
+                ops.flush_finalize(self._deferred_fin)
+            self._fin_pending = True
         self._dw_side.wait_stream(cur)
         with torch.cuda.stream(self._dw_side):
-            ops.flush_deferred_gemms(self._deferred, max_wgs=self.dw_side_wgs, frac=self.dw_side_frac, small_too=True)
+            ops.flush_deferred_gemms(self._deferred, max_wgs=self.dw_side_wgs, frac=self.dw_side_frac, small_too=self.side_small)
         self._dw_side_pending = True
 
     def _mark_bucket(self, name):

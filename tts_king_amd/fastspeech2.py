@@ -1066,7 +1066,9 @@ class FastSpeech2(nn.Module):
             self._fin_pending = True
         self._dw_side.wait_stream(cur)
         with torch.cuda.stream(self._dw_side):
+            ops.stamp("side.start")
             ops.flush_deferred_gemms(self._deferred, max_wgs=self.dw_side_wgs, frac=self.dw_side_frac, small_too=self.side_small)
+            ops.stamp("side.end")
         self._dw_side_pending = True
 
     def _mark_bucket(self, name):
@@ -1193,6 +1195,7 @@ class FastSpeech2(nn.Module):
         self._use_dwconv = self.dwconv and (on_bucket is None or dp_side)
         notifier = _GroupNotifier(self.backward_group_order(), on_bucket, self._flush_param_grads, mark=self._mark_bucket if dp_side else None)
         notify = notifier.done
+        ops.stamp("bwd.start")
         # ---- PostNet (last layer first)
         dout = dpost.view(rows, nm)
         for i in range(4, -1, -1):
@@ -1217,6 +1220,7 @@ class FastSpeech2(nn.Module):
                 if ctx.frame_limit is not None:
                     ops.zero_frames_from(dmel_tot, ctx.frame_limit)      # the conv's reach past the batch's own length is not a frame
         notify("postnet")
+        ops.stamp("bwd.postnet_done")
         # ---- mel_linear
         with self._side_work(dmel_tot, ctx.dec_out):
             ops.colsum_into(dmel_tot, self._g("mel_linear.bias"), defer=self._deferred_fin, accumulate=self._acc)
@@ -1227,6 +1231,7 @@ class FastSpeech2(nn.Module):
         for i in range(self.n_dec - 1, -1, -1):
             dx = self._fft_bwd(ctx.blocks[ctx.n_enc_blocks + i], dx, rng, raw_out=self._raw_out_mode() if i > 0 else False)
             notify("decoder.%d" % i)
+        ops.stamp("bwd.decoder_done")
         if dp_side and self.dp_schedule == "side":
             self._launch_dw_side_buckets(on_bucket, notifier.ready)
         elif self.dw_side_wgs > 0 and (on_bucket is None or dp_side) and self.group_param_grads and not self.overlap_param_grads:
@@ -1259,7 +1264,9 @@ class FastSpeech2(nn.Module):
         with self._side_work(dx):
             ops.scatter_sum(dx, ctx.texts.view(-1), self._g("encoder.src_word_emb.weight"), skip_row=0, defer=self._deferred_fin, accumulate=self._acc)   # padding_idx=0
         notify("embedding")
+        ops.stamp("bwd.chain_done")
         self._flush_param_grads()
+        ops.stamp("bwd.flushed")
         if dp_side:
             for name, _, _, _ in self._dp_marks:    # everything is in the buffer now: the remaining buckets, in completion order
                 on_bucket(name)

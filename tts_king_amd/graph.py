@@ -65,8 +65,10 @@ def make_enqueue(model, optimizer, cfg, Loss, step_is_update=True, reducer=None,
     def enqueue(batch):
         dev = model.device
         with torch.no_grad():
+            ops.stamp("step.start")
             out, ctx = model._forward(True, batch[2], batch[3], batch[4], int(batch[5]), batch[7], batch[8], batch[9],
                                       batch[10], batch[11], 1.0, 1.0, 1.0, frame_limit=frame_limit, phoneme_limit=phoneme_limit)
+            ops.stamp("fwd.done")
             mel, pitch, energy, logd = out[0], out[1], out[2], out[3]
             post = out[8]
             losses, dmel_sum, dpost, dp, de, dd = ops.fs2_loss(mel, post, batch[6], batch[7], pitch, energy, logd, batch[11],
@@ -81,5 +83,6 @@ def make_enqueue(model, optimizer, cfg, Loss, step_is_update=True, reducer=None,
                 optimizer.step_and_update_lr(advance_rng=True, keep_grads=True)
             else:
                 ops.rng_advance(model._state())
+            ops.stamp("step.end")
         return losses, out
     return enqueue

@@ -34,7 +34,23 @@ import os as _os
 # K steps one workgroup of a grouped weight-gradient launch walks (128x128 tile, 256x128 tile): more steps = fewer split-K slabs
 DW_STEPS_PER_WG = tuple(int(v) for v in _os.environ.get("TTSK_DW_STEPS", "28,72").split(","))
 LAUNCH_COUNTS = None   # bench.py sets this to a dict: grouped-GEMM / batched-reducer / column-sum launches issued by the flushes
+STAMPS = None       # tools/debug/step_stamps.py (diagnostic library only): (uint64 device buffer, [names]) — `stamp(name)` then launches a
+                    # one-thread kernel that writes the device's 100 MHz clock into the next slot, on the current stream
 GEMM_TRACE = None   # bench.py sets this to a list: every ttsk_gemm launch is then bracketed by HIP events on its stream
+
+
+def stamp(name):
+    """Diagnostic (a no-op unless ops.STAMPS is set, which needs libttsk_hip_stamps.so): mark this point of the current stream."""
+    if STAMPS is None:
+        return
+    buf, names = STAMPS
+    i = len(names)
+    if i >= buf.numel():
+        return
+    names.append(name)
+    fn = L.load().ttsk_debug_stamp
+    fn.argtypes = [C.c_void_p, C.c_void_p]
+    fn(C.c_void_p(buf.data_ptr() + 8 * i), C.c_void_p(_stream()))
 
 
 class Slabs:

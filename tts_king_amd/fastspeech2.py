@@ -180,7 +180,9 @@ class FastSpeech2(nn.Module):
         #           overlap of wire time with backward, 16 % more compute time per step;
         #   "late"  the single-GPU schedule untouched, every all-reduce after the last flush (no overlap with backward).
         self.dp_schedule = os.environ.get("TTSK_DP_SCHEDULE", "side")
-        self.side_colsum = os.environ.get("TTSK_SIDE_COLSUM", "1") != "0"    # the decoder-side column sums on a third stream at the decoder's end
+        # the decoder-side column sums: "after" = behind the GEMM work on the second stream (default); "third" = on a third stream from the
+        # decoder's end (measured: their HBM traffic beside dwconv / dwgemm slows the whole step, 3.06 vs 2.90 ms); "0" = with the final flush
+        self.side_colsum = os.environ.get("TTSK_SIDE_COLSUM", "after")
         self.side_small = os.environ.get("TTSK_SIDE_SMALL", "1") != "0"      # the 80-channel grouped problems behind dwgemm on the second stream
         self._fin_side = None
         # Does the flat gradient buffer hold an unfinished accumulation (micro-steps of a grad_acc_step cycle)?  False after an optimizer
@@ -1058,7 +1060,7 @@ class FastSpeech2(nn.Module):
         if self._fin_side is None:
             self._fin_side = torch.cuda.Stream(device=self.device)
         cur = torch.cuda.current_stream()
-        if self.side_colsum:
+        if self.side_colsum == "third":
             self._fin_side.wait_stream(cur)
             self._dp_keep = [k for _, k in self._deferred_fin]       # alive until the final join (the allocator orders frees by the main stream only)
             with torch.cuda.stream(self._fin_side):
@@ -1068,6 +1070,9 @@ class FastSpeech2(nn.Module):
         with torch.cuda.stream(self._dw_side):
             ops.stamp("side.start")
             ops.flush_deferred_gemms(self._deferred, max_wgs=self.dw_side_wgs, frac=self.dw_side_frac, small_too=self.side_small)
+            if self.side_colsum == "after":
+                self._dp_keep = [k for _, k in self._deferred_fin]
+                ops.flush_finalize(self._deferred_fin)
             ops.stamp("side.end")
         self._dw_side_pending = True
 

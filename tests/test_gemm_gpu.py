@@ -331,7 +331,7 @@ def test_grouped_launch_equals_individual_launches(kern):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        ops.flush_deferred_gemms(q, max_wgs=5)
+        ops.flush_deferred_gemms(q, max_wgs=5, small_too=True)          # small_too: the 128x128 problems go out (uncapped) as well
     assert not q.group and len(q) > 0                      # the GEMMs went out, their split-K slabs still wait for the reducer
     torch.cuda.current_stream().wait_stream(side)
     ops.flush_deferred(q)

@@ -183,6 +183,7 @@ class FastSpeech2(nn.Module):
         # the decoder-side column sums: "after" = behind the GEMM work on the second stream (default); "third" = on a third stream from the
         # decoder's end (measured: their HBM traffic beside dwconv / dwgemm slows the whole step, 3.06 vs 2.90 ms); "0" = with the final flush
         self.side_colsum = os.environ.get("TTSK_SIDE_COLSUM", "after")
+        self.enc_early_at = int(os.environ.get("TTSK_ENC_EARLY_AT", "1"))    # after this encoder block's backward (-1: never)
         self.side_small = os.environ.get("TTSK_SIDE_SMALL", "1") != "0"      # the 80-channel grouped problems behind dwgemm on the second stream
         self._fin_side = None
         # Does the flat gradient buffer hold an unfinished accumulation (micro-steps of a grad_acc_step cycle)?  False after an optimizer
@@ -1266,6 +1267,13 @@ class FastSpeech2(nn.Module):
         for i in range(self.n_enc - 1, -1, -1):
             dx = self._fft_bwd(ctx.blocks[i], dx, rng, raw_out=self._raw_out_mode() if i > 0 else False)
             notify("encoder.%d" % i)
+            if i == self.enc_early_at and self._dw_side_pending and on_bucket is None and self._use_dwconv:
+                # the encoder-side weight gradients queued so far (variance adaptor, blocks n-1 .. i) behind the decoder's on the second
+                # stream, while the last blocks' backward still runs: the final flush is left with the first blocks' only
+                self._dw_side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._dw_side):
+                    ops.flush_dwconv(self._deferred)
+                    ops.flush_dwgemm(self._deferred, reduce_now=True, max_wgs=self.dw_side_wgs)
         with self._side_work(dx):
             ops.scatter_sum(dx, ctx.texts.view(-1), self._g("encoder.src_word_emb.weight"), skip_row=0, defer=self._deferred_fin, accumulate=self._acc)   # padding_idx=0
         notify("embedding")

@@ -190,10 +190,16 @@ def flush_dwconv(items, n=None):
     q[:] = rest
 
 
-def dwgemm_splits(Bsz, S, target_steps=56):
-    """Utterance ranges per problem for dwgemm_batch: workgroups of about `target_steps` 32-row K steps (the 16 x 423-row step: 4); short
-    problems (the phoneme side: 2 steps per utterance) of about 16, so that their few tiles still spread over the chip."""
+DWG_TARGET_STEPS = tuple(int(v) for v in _os.environ.get("TTSK_DWG_STEPS", "56,75").split(","))   # K steps per workgroup: k = 1, taps
+
+
+def dwgemm_splits(Bsz, S, k=1):
+    """Utterance ranges per problem for dwgemm_batch: workgroups of about DWG_TARGET_STEPS 32-row K steps — at the 16 x 423-row step 4
+    ranges for the k = 1 problems (48 tiles x 4) and 3 for the PostNet's k = 5 (60 tiles x 3): 372 workgroups = two rounds of the 192 the
+    side stream's launch is capped at (432 = 2.25 rounds cost a third round); short problems (the phoneme side: 2 steps per utterance) of
+    about 16 steps, so that their few tiles still spread over the chip."""
     steps = Bsz * ((S + 31) // 32)
+    target_steps = DWG_TARGET_STEPS[0] if k == 1 else DWG_TARGET_STEPS[1]
     if steps <= 64:
         target_steps = 16
     return max(1, min(Bsz, (steps + target_steps // 2) // target_steps))
@@ -228,7 +234,7 @@ def queue_dw(defer, dy, x, dst, lens, accumulate, k=1, use_dwgemm=True):
     Cin = x.shape[2]
     if (use_dwgemm and getattr(defer, "group", None) is not None and dy.dtype == bf16 and x.dtype == bf16 and dwgemm_supported(Cout, Cin, k)
             and dst.is_contiguous()):
-        sp = dwgemm_splits(Bsz, S)
+        sp = dwgemm_splits(Bsz, S, k)
         if (Bsz + sp - 1) // sp <= 64:
             defer.dwgemm.append((dy, x, dst.view(Cout, k, Cin), lens, accumulate, sp))
             return

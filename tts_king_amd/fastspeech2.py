@@ -183,7 +183,7 @@ class FastSpeech2(nn.Module):
         # the decoder-side column sums: "after" = behind the GEMM work on the second stream (default); "third" = on a third stream from the
         # decoder's end (measured: their HBM traffic beside dwconv / dwgemm slows the whole step, 3.06 vs 2.90 ms); "0" = with the final flush
         self.side_colsum = os.environ.get("TTSK_SIDE_COLSUM", "after")
-        self.enc_early_at = int(os.environ.get("TTSK_ENC_EARLY_AT", "1"))    # after this encoder block's backward (-1: never)
+        self.enc_early_at = int(os.environ.get("TTSK_ENC_EARLY_AT", "-1"))   # after this encoder block's backward (-1: never; measured 2.87 vs 2.82 ms: the second stream is not free yet)
         self.side_small = os.environ.get("TTSK_SIDE_SMALL", "1") != "0"      # the 80-channel grouped problems behind dwgemm on the second stream
         self._fin_side = None
         # Does the flat gradient buffer hold an unfinished accumulation (micro-steps of a grad_acc_step cycle)?  False after an optimizer

@@ -190,14 +190,14 @@ def flush_dwconv(items, n=None):
     q[:] = rest
 
 
-DWG_TARGET_STEPS = tuple(int(v) for v in _os.environ.get("TTSK_DWG_STEPS", "56,75").split(","))   # K steps per workgroup: k = 1, taps
+DWG_TARGET_STEPS = tuple(int(v) for v in _os.environ.get("TTSK_DWG_STEPS", "56,56").split(","))   # K steps per workgroup: k = 1, taps
 
 
 def dwgemm_splits(Bsz, S, k=1):
     """Utterance ranges per problem for dwgemm_batch: workgroups of about DWG_TARGET_STEPS 32-row K steps — at the 16 x 423-row step 4
-    ranges for the k = 1 problems (48 tiles x 4) and 3 for the PostNet's k = 5 (60 tiles x 3): 372 workgroups = two rounds of the 192 the
-    side stream's launch is capped at (432 = 2.25 rounds cost a third round); short problems (the phoneme side: 2 steps per utterance) of
-    about 16 steps, so that their few tiles still spread over the chip."""
+    ranges for every problem (432 workgroups; 3 ranges for the PostNet's k = 5 — 372 workgroups, two even rounds of the capped 192 —
+    measured the same: 2.816 vs 2.804 ms); short problems (the phoneme side: 2 steps per utterance) of about 16 steps, so that their few
+    tiles still spread over the chip."""
     steps = Bsz * ((S + 31) // 32)
     target_steps = DWG_TARGET_STEPS[0] if k == 1 else DWG_TARGET_STEPS[1]
     if steps <= 64:

@@ -180,6 +180,156 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const FlashArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, P in registers
+// Round 3.  The same tiling as flash_fwd_kernel (64 queries per workgroup, 16 per wave, key tiles of 64), with both products
+// transposed so that P never leaves the registers:
+//   S^T[key][query] = K Q^T        MFMA(A = K rows, B = Q rows): lane (lg, l15) holds keys 16*nt + 4*lg + r of ONE query, l15
+//   O^T[dv][query] += V^T P^T      MFMA(A = V^T from the contraction-major V image, B = P^T): the B operand wants, for query l15, the 8
+//                                  contraction slots 8*lg .. 8*lg+7 — and a contraction may be summed in any order, so slot (lg, e) is
+//                                  DEFINED as key 16*(2u) + 4*lg + e (e < 4) / 16*(2u+1) + 4*lg + e - 4 (e >= 4) of 32-key step u:
+//                                  exactly the eight values the lane already holds (two accumulators of S^T, packed to bf16).  The V^T
+//                                  fragment follows the same slot -> key map through the rows its transposing read addresses.
+// What goes: the 16 two-byte LDS stores of P per tile, the wait for them, their read-back, and 4 x 2 sixteen-lane DPP reductions per
+// tile (a query's keys now sit in one lane's registers and in the three lanes 16, 32, 48 further on: two cross-row exchanges);
+// the epilogue writes O^T as 8-byte (bf16 staging) / 16-byte (fp32 copy) pieces instead of 2- / 4-byte ones.
+// V image for this kernel: [64 keys][128 dv], 32-byte block b of row k at block b ^ (k & 7): one transposing read touches keys
+// 4*lg + (l15>>2) for lg = 0, 1 — eight consecutive rows — conflict-free.
+__device__ __forceinline__ void store_tr8(unsigned char* dst, const uint4 (&r)[4], int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid;
+    const int kr = c >> 4, ts = c & 15;
+    *(uint4*)(dst + kr * 256 + (((ts >> 1) ^ (kr & 7)) << 5) + ((ts & 1) << 4)) = r[i];
+  }
+}
+// A fragment of V^T: 16 dv rows (block nblk), 32-key step u, slots as above: lo = keys 32u + 4lg + 0..3, hi = keys 32u + 16 + 4lg + 0..3
+__device__ __forceinline__ bf16x8 frag_tr8(const unsigned char* base, int nblk, int u, int l15, int lg) {
+  const int k0 = u * 32 + 4 * lg + (l15 >> 2), k1 = k0 + 16;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) bf16x4*)(base + k0 * 256 + ((nblk ^ (k0 & 7)) << 5) + ((l15 & 3) << 3)));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) bf16x4*)(base + k1 * 256 + ((nblk ^ (k1 & 7)) << 5) + ((l15 & 3) << 3)));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// max / sum over the four lanes l15, l15 + 16, l15 + 32, l15 + 48 (the lane groups that share a query)
+__device__ __forceinline__ float cross16_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float cross16_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+__global__ __launch_bounds__(256, 2) void flash_fwd_t_kernel(const FlashArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_KV];      // 64 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  int tile_x, z;
+  xcd_tile(tile_x, z, a.plain_order);
+  const int b = z / a.H, h = z - b * a.H;
+  const int q0 = tile_x * TQ;
+  const int S = a.S, ld = 3 * a.d;
+  const int len = a.lens ? min((int)a.lens[b], S) : S;
+  const int ntk = (len + TK - 1) / TK;
+  const bf16_t* base = a.qkv + (int64_t)b * S * ld + h * DK;
+
+  uint4 rk[4], rv[4];
+  {  // Q goes through the K slot of stage 1 (free until tile 1 is stored); tile 0 of K / V into stage 0
+    uint4 rq[4];
+    load_tile(rq, base, ld, q0, S, tid);
+    if (ntk > 0) { load_tile(rk, base + a.d, ld, 0, S, tid); load_tile(rv, base + 2 * a.d, ld, 0, S, tid); }
+    store_rows(smem + STAGE_KV, rq, tid);
+    if (ntk > 0) { store_rows(smem, rk, tid); store_tr8(smem + KS_BYTES, rv, tid); }
+  }
+  __syncthreads();
+  bf16x8 qa[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qa[ks] = frag_rows(smem + STAGE_KV, wave * 16, ks, l15, lg);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                       // every wave holds its Q fragments: stage 1 may be refilled
+
+  float m = -INFINITY, l = 0.f;                          // running maximum / sum of THIS lane's query (column l15 of the wave's 16)
+  f32x4 oacc[8];                                         // O^T: rows dv = 16*nb + 4*lg + r, column = the query
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) oacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int j = 0; j < ntk; ++j) {
+    const unsigned char* Ks = smem + (j & 1) * STAGE_KV;
+    const unsigned char* Vs = Ks + KS_BYTES;
+    if (j + 1 < ntk) {     // next tile's loads fly during this tile's arithmetic
+      load_tile(rk, base + a.d, ld, (j + 1) * TK, S, tid);
+      load_tile(rv, base + 2 * a.d, ld, (j + 1) * TK, S, tid);
+    }
+    f32x4 s[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, nt * 16, ks, l15, lg), qa[ks], s[nt], 0, 0, 0);
+    float tm = -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j * TK + nt * 16 + lg * 4 + r;
+        s[nt][r] = key < len ? s[nt][r] * a.scale : -INFINITY;
+        tm = fmaxf(tm, s[nt][r]);
+      }
+    // online softmax: every tile j < ntk holds a valid key, so the new maximum is finite
+    tm = cross16_max(tm);
+    const float mn = fmaxf(m, tm);
+    const float corr = __expf(m - mn);                   // exp(-inf) = 0 on the first tile
+    float ts = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float p = __expf(s[nt][r] - mn); s[nt][r] = p; ts += p; }
+    ts = cross16_sum(ts);
+    l = l * corr + ts;
+    m = mn;
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) oacc[nb] *= corr;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      // P^T fragment of 32-key step u, straight from the accumulators (slot order = the order frag_tr8 reads V^T's keys in)
+      const unsigned p0 = pack_bf2(s[2 * u][0], s[2 * u][1]), p1 = pack_bf2(s[2 * u][2], s[2 * u][3]);
+      const unsigned p2 = pack_bf2(s[2 * u + 1][0], s[2 * u + 1][1]), p3 = pack_bf2(s[2 * u + 1][2], s[2 * u + 1][3]);
+      const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(p0, p1, p2, p3));
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) oacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Vs, nb, u, l15, lg), pb, oacc[nb], 0, 0, 0);
+    }
+    if (j + 1 < ntk) {
+      unsigned char* nx = smem + ((j + 1) & 1) * STAGE_KV;   // last read in iteration j-1: every wave passed that iteration's barrier
+      store_rows(nx, rk, tid);
+      store_tr8(nx + KS_BYTES, rv, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- O^T / l: lane holds dv = 16*nb + 4*lg .. +3 of query l15 -> 8-byte bf16 pieces into the staging tile, 16-byte fp32 pieces
+  // straight to memory; LSE from the lanes of group 0
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  const int q = q0 + wave * 16 + l15;
+  if (a.lse && lg == 0 && q < S) a.lse[(int64_t)z * S + q] = l > 0.f ? m + __logf(l) : 0.f;
+  if (a.o32 && q < S) {
+    float* dst = a.o32 + ((int64_t)b * S + q) * a.d + h * DK + 4 * lg;
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) *(f32x4*)(dst + nb * 16) = oacc[nb] * inv;
+  }
+  unsigned char* Os = smem;   // 64 x 272 B = 17 KiB over stage 0 (dead: the loop ended with a barrier)
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+    *(uint2*)(Os + (wave * 16 + l15) * OS_RS + (nb * 16 + 4 * lg) * 2) =
+        make_uint2(pack_bf2(oacc[nb][0] * inv, oacc[nb][1] * inv), pack_bf2(oacc[nb][2] * inv, oacc[nb][3] * inv));
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid, row = c >> 4, ch = c & 15;
+    if (q0 + row < S) *(uint4*)(a.o + ((int64_t)b * S + q0 + row) * a.d + h * DK + ch * 8) = *(const uint4*)(Os + row * OS_RS + ch * 16);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward, query side
 // per (utterance, head, 64 queries): delta, then over the key tiles  P, dP -> dS -> dQ += dS K
 __device__ __forceinline__ void flash_bwd_q_body(const FlashArgs& a, unsigned char* smem) {      // uses 58,368 B of smem
@@ -439,6 +589,10 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashArgs a) {
 
 }  // namespace
 
+static int flash_fwd_variant() {          // TTSK_FLASH_FWD=0: the round-2 forward (P through LDS); default: flash_fwd_t_kernel
+  static const int v = [] { const char* e = getenv("TTSK_FLASH_FWD"); return (e && atoi(e) == 0) ? 0 : 1; }();
+  return v;
+}
 static int flash_plain_order() {
   static const int v = [] { const char* e = getenv("TTSK_FLASH_XCD"); return (e && atoi(e) == 0) ? 1 : 0; }();
   return v;
@@ -451,7 +605,8 @@ extern "C" int ttsk_flash_attention_fwd(const void* qkv_bf16, void* o_bf16, floa
   TTSK_REQUIRE(B * H <= 65535 && (int64_t)S * 3 * d * 2 < ((int64_t)1 << 31), "flash_attention_fwd: sizes out of range");
   FlashArgs a{(const bf16_t*)qkv_bf16, (bf16_t*)o_bf16, o_f32, lse, nullptr, nullptr, nullptr, (const long long*)lens, S, H, d, scale};
   a.plain_order = flash_plain_order();
-  hipLaunchKernelGGL(flash_fwd_kernel, dim3((S + TQ - 1) / TQ, B * H), dim3(256), 0, (hipStream_t)stream, a);
+  if (flash_fwd_variant()) hipLaunchKernelGGL(flash_fwd_t_kernel, dim3((S + TQ - 1) / TQ, B * H), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(flash_fwd_kernel, dim3((S + TQ - 1) / TQ, B * H), dim3(256), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

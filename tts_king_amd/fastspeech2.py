@@ -186,6 +186,13 @@ class FastSpeech2(nn.Module):
         self.enc_early_at = int(os.environ.get("TTSK_ENC_EARLY_AT", "-1"))   # after this encoder block's backward (-1: never; measured 2.87 vs 2.82 ms: the second stream is not free yet)
         self.side_small = os.environ.get("TTSK_SIDE_SMALL", "1") != "0"      # the 80-channel grouped problems behind dwgemm on the second stream
         self._fin_side = None
+        # Training with targets: the three VariancePredictors' outputs feed nothing but the loss (the embeddings are picked by the TARGET
+        # pitch / energy, the length regulator takes the TARGET durations: modules.py:158-205), and their backward needs nothing but the
+        # loss's gradients until its last step.  Both run on a stream of their own: the forward beside the decoder's first block, the
+        # backward beside the PostNet's — 1,024-row kernels of 96 workgroups that the 212-256-workgroup chain kernels leave room for.
+        self.pred_side = os.environ.get("TTSK_PRED_SIDE", "1") != "0"
+        self._pred_stream = None
+        self._pred_fwd_pending = False
         # Does the flat gradient buffer hold an unfinished accumulation (micro-steps of a grad_acc_step cycle)?  False after an optimizer
         # update or zero_grad(): the next backward then overwrites instead of accumulating (see backward_native).
         self.grads_partial = False
@@ -263,7 +270,7 @@ class FastSpeech2(nn.Module):
         self._adam_tables = None
         self._shadow_version = -1
         self._rng_state = None
-        self._side = self._dw_side = self._fin_side = None
+        self._side = self._dw_side = self._fin_side = self._pred_stream = None
         self._rebind()
         if self.window_ffn and self._shadow.is_cuda:
             self._build_packs()
@@ -591,10 +598,18 @@ class FastSpeech2(nn.Module):
             ctx["grouped"] = (stack, h1, m1, r1, a1, h2, m2, r2, Bn, Lp, lens, p, row_limit)
         return out.view(3, Bn, Lp)
 
-    def _predictors_bwd_grouped(self, saved, dstack, rng, dx3):
+    def _predictors_bwd_grouped(self, saved, dstack, rng, dx3, dxin=None):
         """Backward of _predictors_fwd_grouped; dstack (3, B, L) fp32 = gradients of (log-duration, pitch, energy) predictions,
         dx3 = gradient of the LengthRegulator input.  Returns (dx2, dx1, dx): gradients of x2 (what pitch_embedding collects),
-        x1 (speaker_emb) and of the encoder output."""
+        x1 (speaker_emb) and of the encoder output.  `dxin`: the three predictors' input gradients if _predictors_bwd_inputs ran already."""
+        if dxin is None:
+            dxin = self._predictors_bwd_inputs(saved, dstack, rng)
+        Lp, row_limit = saved[9], saved[12]
+        return ops.va_combine(dx3, dxin, Lp, row_limit)
+
+    def _predictors_bwd_inputs(self, saved, dstack, rng):
+        """Everything of the predictors' backward that needs only the loss's gradients: (3, rows, d) fp32 input gradients, and the
+        parameter-gradient work queued."""
         (stack, h1, m1, r1, a1, h2, m2, r2, Bn, Lp, lens, p, row_limit) = saved
         d, rows, ps = self.d, Bn * Lp, self._pred_stride
         names = ("duration", "pitch", "energy")
@@ -602,7 +617,7 @@ class FastSpeech2(nn.Module):
         c = pre + "conv_layer."
         W1, W2 = self._w(c + "conv1d_1.conv.weight"), self._w(c + "conv1d_2.conv.weight")
         Fh = W1.shape[0]
-        dev = dx3.device
+        dev = dstack.device
         dh2, part, nblk = ops.layernorm_bwd_grouped(None, h2.view(3 * rows, Fh), m2, r2, self._m(c + "layer_norm_2.weight"),
                                                     self._m(c + "layer_norm_2.bias"), 3, ps, 2, lens, Lp, relu_in=True, p_post=p,
                                                     site_post=201, rng=rng, dhead=dstack.view(-1),
@@ -628,7 +643,7 @@ class FastSpeech2(nn.Module):
                              self._acc, k=self.k_var, use_dwgemm=self._use_dwconv)
         dxin = torch.empty(3, rows, d, dtype=torch.float32, device=dev)
         ops.conv1d_dx(dh1[0].view(Bn, Lp, Fh), W1, out=dxin[0].view(Bn, Lp, d), nz1=3, sA=(rows * Fh, 0), sB=(ps, 0), sC=(rows * d, 0))
-        return ops.va_combine(dx3, dxin, Lp, row_limit)
+        return dxin
 
     def _forward(self, train, speakers, texts, src_lens, Lp, mel_lens, max_mel_len, e_targets, d_targets, pitches_raw,
                  p_control, e_control, d_control, frame_limit=None, phoneme_limit=None):
@@ -671,7 +686,15 @@ class FastSpeech2(nn.Module):
                                           self.get(va + "pitch_bins"), self._m(va + "pitch_embedding.weight"),
                                           e_targets.to(dev).float().contiguous(), self.get(va + "energy_bins"),
                                           self._m(va + "energy_embedding.weight"), row_limit=phoneme_limit)
-            pred = self._predictors_fwd_grouped(stack, Bn, Lp, src_lens, p_var, rng, preds, row_limit=phoneme_limit)
+            if self.pred_side:
+                if self._pred_stream is None:
+                    self._pred_stream = torch.cuda.Stream(device=dev)
+                self._pred_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._pred_stream):
+                    pred = self._predictors_fwd_grouped(stack, Bn, Lp, src_lens, p_var, rng, preds, row_limit=phoneme_limit)
+                self._pred_fwd_pending = True          # joined at the end of this forward: the loss is the first reader
+            else:
+                pred = self._predictors_fwd_grouped(stack, Bn, Lp, src_lens, p_var, rng, preds, row_limit=phoneme_limit)
             logd, pitch, energy = pred[0], pred[1], pred[2]
         else:
             logd = self._predictor_fwd(va + "duration_predictor.", x, Bn, Lp, src_lens, p_var, 200, rng, preds)
@@ -759,6 +782,9 @@ class FastSpeech2(nn.Module):
             pn.append((pp, xin, yc, mean, rstd, keep))
             xin = nxt.view(Bn, T, C) if not last else nxt
         post = xin
+        if self._pred_fwd_pending:
+            torch.cuda.current_stream().wait_stream(self._pred_stream)
+            self._pred_fwd_pending = False
         if train:
             ctx.blocks, ctx.preds, ctx.pn = blocks, preds, pn
             ctx.n_enc_blocks = n_enc_blocks
@@ -1181,6 +1207,16 @@ class FastSpeech2(nn.Module):
         notifier = _GroupNotifier(self.backward_group_order(), on_bucket, self._flush_param_grads, mark=self._mark_bucket if dp_side else None)
         notify = notifier.done
         ops.stamp("bwd.start")
+        # ---- the predictors' backward up to their input gradients, on a stream of its own beside the PostNet's (see pred_side); not in
+        # the schedules that flush the deferred queue before the decoder is done
+        pred_dxin = None
+        if (self.pred_side and "grouped" in ctx.preds and (on_bucket is None or dp_side) and not self.overlap_param_grads
+                and self.group_param_grads):
+            if self._pred_stream is None:
+                self._pred_stream = torch.cuda.Stream(device=self.device)
+            self._pred_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._pred_stream):
+                pred_dxin = self._predictors_bwd_inputs(ctx.preds["grouped"], self._stack3(dlogd, dpitch, denergy), rng)
         # ---- PostNet (last layer first)
         dout = dpost.view(rows, nm)
         for i in range(4, -1, -1):
@@ -1217,6 +1253,8 @@ class FastSpeech2(nn.Module):
             dx = self._fft_bwd(ctx.blocks[ctx.n_enc_blocks + i], dx, rng, raw_out=self._raw_out_mode() if i > 0 else False)
             notify("decoder.%d" % i)
         ops.stamp("bwd.decoder_done")
+        if pred_dxin is not None:
+            torch.cuda.current_stream().wait_stream(self._pred_stream)    # long done; its queued dW work joins the second stream's
         if dp_side and self.dp_schedule == "side":
             self._launch_dw_side_buckets(on_bucket, notifier.ready)
         elif self.dw_side_wgs > 0 and (on_bucket is None or dp_side) and self.group_param_grads and not self.overlap_param_grads:
@@ -1228,7 +1266,8 @@ class FastSpeech2(nn.Module):
         with self._side_work(dx3):
             ops.scatter_sum(dx3, ctx.eidx.view(-1), self._g(va + "energy_embedding.weight"), defer=self._deferred_fin, accumulate=self._acc)
         if "grouped" in ctx.preds:
-            dx2, dx1, dxe = self._predictors_bwd_grouped(ctx.preds["grouped"], self._stack3(dlogd, dpitch, denergy), rng, dx3)
+            dx2, dx1, dxe = self._predictors_bwd_grouped(ctx.preds["grouped"], None if pred_dxin is not None else
+                                                         self._stack3(dlogd, dpitch, denergy), rng, dx3, dxin=pred_dxin)
             with self._side_work(dx2, dx1):
                 ops.scatter_sum(dx2, ctx.pidx.view(-1), self._g(va + "pitch_embedding.weight"), defer=self._deferred_fin, accumulate=self._acc)
                 ops.scatter_sum(dx1, ctx.speakers, self._g("speaker_emb.weight"), idx_div=Lp, defer=self._deferred_fin, accumulate=self._acc)

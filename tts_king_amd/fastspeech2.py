@@ -182,15 +182,15 @@ class FastSpeech2(nn.Module):
         self.dp_schedule = os.environ.get("TTSK_DP_SCHEDULE", "side")
         # the decoder-side column sums: "after" = behind the GEMM work on the second stream (default); "third" = on a third stream from the
         # decoder's end (measured: their HBM traffic beside dwconv / dwgemm slows the whole step, 3.06 vs 2.90 ms); "0" = with the final flush
-        self.side_colsum = os.environ.get("TTSK_SIDE_COLSUM", "after")
+        self.side_colsum = os.environ.get("TTSK_SIDE_COLSUM", "0")
         self.enc_early_at = int(os.environ.get("TTSK_ENC_EARLY_AT", "-1"))   # after this encoder block's backward (-1: never; measured 2.87 vs 2.82 ms: the second stream is not free yet)
-        self.side_small = os.environ.get("TTSK_SIDE_SMALL", "1") != "0"      # the 80-channel grouped problems behind dwgemm on the second stream
+        self.side_small = os.environ.get("TTSK_SIDE_SMALL", "0") != "0"      # the 80-channel grouped problems behind dwgemm on the second stream
         self._fin_side = None
         # Training with targets: the three VariancePredictors' outputs feed nothing but the loss (the embeddings are picked by the TARGET
         # pitch / energy, the length regulator takes the TARGET durations: modules.py:158-205), and their backward needs nothing but the
         # loss's gradients until its last step.  Both run on a stream of their own: the forward beside the decoder's first block, the
         # backward beside the PostNet's — 1,024-row kernels of 96 workgroups that the 212-256-workgroup chain kernels leave room for.
-        self.pred_side = os.environ.get("TTSK_PRED_SIDE", "1") != "0"
+        self.pred_side = os.environ.get("TTSK_PRED_SIDE", "1")     # "1" both, "f" forward only, "b" backward only, "0" neither
         self._pred_stream = None
         self._pred_fwd_pending = False
         # Does the flat gradient buffer hold an unfinished accumulation (micro-steps of a grad_acc_step cycle)?  False after an optimizer
@@ -686,7 +686,7 @@ class FastSpeech2(nn.Module):
                                           self.get(va + "pitch_bins"), self._m(va + "pitch_embedding.weight"),
                                           e_targets.to(dev).float().contiguous(), self.get(va + "energy_bins"),
                                           self._m(va + "energy_embedding.weight"), row_limit=phoneme_limit)
-            if self.pred_side:
+            if self.pred_side in ("1", "f"):
                 if self._pred_stream is None:
                     self._pred_stream = torch.cuda.Stream(device=dev)
                 self._pred_stream.wait_stream(torch.cuda.current_stream())
@@ -1210,7 +1210,7 @@ class FastSpeech2(nn.Module):
         # ---- the predictors' backward up to their input gradients, on a stream of its own beside the PostNet's (see pred_side); not in
         # the schedules that flush the deferred queue before the decoder is done
         pred_dxin = None
-        if (self.pred_side and "grouped" in ctx.preds and (on_bucket is None or dp_side) and not self.overlap_param_grads
+        if (self.pred_side in ("1", "b") and "grouped" in ctx.preds and (on_bucket is None or dp_side) and not self.overlap_param_grads
                 and self.group_param_grads):
             if self._pred_stream is None:
                 self._pred_stream = torch.cuda.Stream(device=self.device)

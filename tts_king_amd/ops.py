@@ -193,6 +193,9 @@ def flush_dwconv(items, n=None):
 DWG_TARGET_STEPS = tuple(int(v) for v in _os.environ.get("TTSK_DWG_STEPS", "56,56").split(","))   # K steps per workgroup: k = 1, taps
 
 
+DWG_SHORT_STEPS = int(_os.environ.get("TTSK_DWG_SHORT", "16"))
+
+
 def dwgemm_splits(Bsz, S, k=1):
     """Utterance ranges per problem for dwgemm_batch: workgroups of about DWG_TARGET_STEPS 32-row K steps — at the 16 x 423-row step 4
     ranges for every problem (432 workgroups; 3 ranges for the PostNet's k = 5 — 372 workgroups, two even rounds of the capped 192 —
@@ -201,7 +204,7 @@ def dwgemm_splits(Bsz, S, k=1):
     steps = Bsz * ((S + 31) // 32)
     target_steps = DWG_TARGET_STEPS[0] if k == 1 else DWG_TARGET_STEPS[1]
     if steps <= 64:
-        target_steps = 16
+        target_steps = DWG_SHORT_STEPS
     return max(1, min(Bsz, (steps + target_steps // 2) // target_steps))
 
 

@@ -1146,12 +1146,16 @@ class FastSpeech2(nn.Module):
             self._fin_side.wait_stream(cur)
             with torch.cuda.stream(self._fin_side):
                 ops.flush_dwconv(self._deferred)
+                ops.stamp("fin.dwconv")
                 launch()
+                ops.stamp("fin.small")
             self._fin_pending = True
             self._dw_side.wait_stream(cur)
             with torch.cuda.stream(self._dw_side):
                 ops.flush_dwgemm(self._deferred)
+                ops.stamp("fin.dwgemm")
             ops.flush_finalize(self._deferred_fin)
+            ops.stamp("fin.colsum")
             cur.wait_stream(self._dw_side)
             if getattr(self, "_fin_pending", False):
                 cur.wait_stream(self._fin_side)

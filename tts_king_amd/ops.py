@@ -190,7 +190,7 @@ def flush_dwconv(items, n=None):
     q[:] = rest
 
 
-DWG_TARGET_STEPS = tuple(int(v) for v in _os.environ.get("TTSK_DWG_STEPS", "56,56").split(","))   # K steps per workgroup: k = 1, taps
+DWG_TARGET_STEPS = tuple(int(v) for v in _os.environ.get("TTSK_DWG_STEPS", "72,72").split(","))   # K steps per workgroup: k = 1, taps
 
 
 DWG_SHORT_STEPS = int(_os.environ.get("TTSK_DWG_SHORT", "16"))
@@ -254,7 +254,9 @@ def flush_deferred_gemms(items, max_wgs=0, frac=1.0, small_too=False):
     and dwgemm problems go first, all of them (capped likewise; with max_wgs their slabs are summed right behind them: this is the
     side stream's launch, which has the time)."""
     flush_dwconv(items)
+    stamp("dw.dwconv")
     flush_dwgemm(items, reduce_now=max_wgs > 0, max_wgs=max_wgs)
+    stamp("dw.dwgemm")
     group = getattr(items, "group", None)
     if not group:
         return

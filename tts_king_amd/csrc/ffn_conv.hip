@@ -158,11 +158,15 @@ struct ItemChunk {
 __global__ __launch_bounds__(256) void win_pack_kernel(const ttsk_pack_item* __restrict__ items) { pack_one(items[blockIdx.y]); }
 __global__ __launch_bounds__(256) void win_pack_args_kernel(const ItemChunk c) { pack_one(c.it[blockIdx.y]); }
 
-template <int CIN, int TT, bool OUT32, bool PACKED>
-__global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
-  constexpr int C = CIN, RS = CIN * 2 + 32, NT = WC_NT, CH8 = C / 8, KH = WC_KH, CT = WC_CT, NF = TT / 16, NP = CIN / 128;
+// NWV waves x CTV cout tiles of 16: the workgroup's channel group.  8 x 2 = 256 channels everywhere but on the phoneme side, where a
+// 1,024-row problem is 16 tiles x Cout / 256 = 48-64 workgroups that each stream 1.2 MB of weights through one CU's L2 port (22 us
+// for w_1's 4.8 GFLOP): 4 x 1 = 64 channels there — 192-256 workgroups, 0.3 MB each.
+template <int CIN, int TT, bool OUT32, bool PACKED, int NWV = WC_NW, int CTV = WC_CT>
+__global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
+  constexpr int COUT = NWV * CTV * 16;
+  constexpr int C = CIN, RS = CIN * 2 + 32, NT = NWV * 64, CH8 = C / 8, KH = WC_KH, CT = CTV, NF = TT / 16, NP = CIN / 128;
   constexpr int XROWS = TT + 2 * WC_H;
-  constexpr int SRS = OUT32 ? WC_COUT * 4 + 32 : RS;               // row stride of the output staging tile (fp32 rows are 1 KiB)
+  constexpr int SRS = OUT32 ? COUT * 4 + 32 : RS;               // row stride of the output staging tile (fp32 rows are 1 KiB)
   constexpr int SMEM = XROWS * RS > TT * SRS ? XROWS * RS : TT * SRS;
   __shared__ __attribute__((aligned(16))) unsigned char XW[SMEM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -171,12 +175,16 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
   // stay in ONE XCD's 4 MiB L2 instead of all groups in every L2: channel group = f(id % 8), tile = the rest.
   int bi, t0, cg, sp;
   {
-    const int id = blockIdx.x, ncg = (a.Cout / WC_COUT) * a.nsplit, ntile = a.tiles_per_utt * a.B;
+    const int id = blockIdx.x, ncg = (a.Cout / COUT) * a.nsplit, ntile = a.tiles_per_utt * a.B;
     const int xcd = id & 7, per = 8 / (ncg < 8 ? ncg : 8);        // XCDs per channel group (ncg = 1, 2, 4, 8); other counts: plain order
     int tile;
     if ((8 % (ncg < 8 ? ncg : 8)) == 0 && ncg <= 8 && (ntile * ncg) % 8 == 0 && ntile % per == 0) {
       cg = xcd / per;
       tile = (id >> 3) * per + (xcd % per);
+    } else if (ncg % 8 == 0) {                                      // ncg / 8 channel groups per XCD
+      const int gpx = ncg >> 3, slot = id >> 3;
+      tile = slot / gpx;
+      cg = xcd * gpx + (slot - tile * gpx);
     } else {
       cg = id / ntile;
       tile = id - cg * ntile;
@@ -196,8 +204,8 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
   const bf16_t* wrow[CT];
 #pragma unroll
   for (int cc = 0; cc < CT; ++cc)
-    wrow[cc] = PACKED ? wbase + ((int64_t)(cg * (WC_COUT / 16) + wave * CT + cc) * 64 + lane) * 8
-                      : wbase + ((int64_t)(cg * WC_COUT + (wave * CT + cc) * 16 + l15) * K) * C + q * 8;
+    wrow[cc] = PACKED ? wbase + ((int64_t)(cg * (COUT / 16) + wave * CT + cc) * 64 + lane) * 8
+                      : wbase + ((int64_t)(cg * COUT + (wave * CT + cc) * 16 + l15) * K) * C + q * 8;
   const int64_t kstep_stride = (int64_t)(a.Cout / 16) * 512;     // PACKED: elements per (tap, k-step)
   bf16x8 wa[KH][CT], wb[KH][CT], wc[KH][CT];      // three register sets: a step's weights are requested two steps (>= 1 us) ahead
   auto load_w = [&](int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
   f32x4 bv[CT];
 #pragma unroll
   for (int cc = 0; cc < CT; ++cc)
-    bv[cc] = a.bias ? *(const f32x4*)(a.bias + cg * WC_COUT + (wave * CT + cc) * 16 + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bv[cc] = a.bias ? *(const f32x4*)(a.bias + cg * COUT + (wave * CT + cc) * 16 + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   WC_STAMP(1);
   __syncthreads();
   WC_STAMP(2);
@@ -309,29 +317,29 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
   }
   __syncthreads();
   if constexpr (OUT32 && CIN == 512) {
-    static_assert(SMEM >= TT * SRS + 2 * WC_COUT * 4, "room for the two half-sums behind the staging tile");
+    static_assert(SMEM >= TT * SRS + 2 * COUT * 4, "room for the two half-sums behind the staging tile");
     if (a.stats) {
-      constexpr int NH = NT / WC_COUT;                                 // 512 threads: two halves of the tile's rows; 256: one
-      const int c = tid & (WC_COUT - 1), half = tid / WC_COUT;
+      constexpr int NH = NT / COUT;                                 // 512 threads: two halves of the tile's rows; 256: one
+      const int c = tid & (COUT - 1), half = tid / COUT;
       const int lim = a.frame_limit ? (a.frame_limit[0] < S ? a.frame_limit[0] : S) : S;
       float sm = 0.f, sq = 0.f;
       for (int r = half * (TT / NH); r < (half + 1) * (TT / NH); ++r) {
         if (t0 + r < lim) { const float v = *(const float*)(XW + r * SRS + c * 4); sm += v; sq += v * v; }
       }
       float* red = (float*)(XW + TT * SRS);
-      if (NH == 2 && half == 1) { red[c] = sm; red[WC_COUT + c] = sq; }
+      if (NH == 2 && half == 1) { red[c] = sm; red[COUT + c] = sq; }
       if (NH == 2) __syncthreads();
       if (half == 0) {
-        float* P = a.stats + ((int64_t)bi * a.tiles_per_utt + t0 / TT) * 2 * a.Cout + cg * WC_COUT + c;
+        float* P = a.stats + ((int64_t)bi * a.tiles_per_utt + t0 / TT) * 2 * a.Cout + cg * COUT + c;
         P[0] = NH == 2 ? sm + red[c] : sm;
-        P[a.Cout] = NH == 2 ? sq + red[WC_COUT + c] : sq;
+        P[a.Cout] = NH == 2 ? sq + red[COUT + c] : sq;
       }
     }
   }
   constexpr int ESZ = OUT32 ? 4 : 2;
-  constexpr int OCH = WC_COUT * ESZ / 16;                // 16-byte chunks per output row of this channel group
+  constexpr int OCH = COUT * ESZ / 16;                // 16-byte chunks per output row of this channel group
   constexpr int NCO = (TT * OCH + NT - 1) / NT;
-  unsigned char* __restrict__ ob = (unsigned char*)a.out + (sp * a.out_split + (int64_t)bi * S * a.Cout + cg * WC_COUT) * ESZ;
+  unsigned char* __restrict__ ob = (unsigned char*)a.out + (sp * a.out_split + (int64_t)bi * S * a.Cout + cg * COUT) * ESZ;
 #pragma unroll
   for (int it = 0; it < NCO; ++it) {
     const int idx = it * NT + tid;
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
     if (idx < TT * OCH && t < S) {
       uint4 v = *(const uint4*)(XW + rr * SRS + ch * 16);
       if (!OUT32 && a.gate) {
-        const uint4 g = *(const uint4*)(a.gate + ((int64_t)bi * S + t) * a.Cout + cg * WC_COUT + ch * 8);
+        const uint4 g = *(const uint4*)(a.gate + ((int64_t)bi * S + t) * a.Cout + cg * COUT + ch * 8);
         auto keep = [](unsigned w) {      // 0xFFFF per bf16 half that is > 0 (sign clear, not zero)
           const unsigned lo = w & 0xFFFFu, hi = w >> 16;
           return ((lo - 1u) < 0x7FFFu ? 0xFFFFu : 0u) | ((hi - 1u) < 0x7FFFu ? 0xFFFF0000u : 0u);
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
       }
       *(uint4*)(ob + (int64_t)t * a.Cout * ESZ + ch * 16) = v;
       if (!OUT32 && a.delta) {
-        const float* op = a.o32 + ((int64_t)bi * S + t) * a.Cout + cg * WC_COUT + ch * 8;
+        const float* op = a.o32 + ((int64_t)bi * S + t) * a.Cout + cg * COUT + ch * 8;
         const f32x4 y0 = *(const f32x4*)op, y1 = *(const f32x4*)(op + 4);
         dacc = __uint_as_float(v.x << 16) * y0[0] + __uint_as_float(v.x & 0xFFFF0000u) * y0[1] + __uint_as_float(v.y << 16) * y0[2] +
                __uint_as_float(v.y & 0xFFFF0000u) * y0[3] + __uint_as_float(v.z << 16) * y1[0] + __uint_as_float(v.z & 0xFFFF0000u) * y1[1] +
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(WC_NT, 1) void win_conv_kernel(const WcArgs a) {
     }
     if (!OUT32 && a.delta) {          // 16 consecutive lanes hold one (row, head): 16 chunks of 8 columns
       dacc = quad16_sum(dacc);
-      const int hd = (cg * WC_COUT + ch * 8) / 128, nh = a.Cout / 128;
+      const int hd = (cg * COUT + ch * 8) / 128, nh = a.Cout / 128;
       if (idx < TT * OCH && t < S && (ch & 15) == 0) a.delta[((int64_t)bi * nh + hd) * S + t] = dacc;
     }
   }
@@ -385,6 +393,13 @@ int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int pa
   a.B = B;
   a.tiles_per_utt = (S + TT - 1) / TT;
   dim3 grid(a.tiles_per_utt * B * (a.Cout / WC_COUT) * a.nsplit);
+  static const int narrow_ok = [] { const char* e = getenv("TTSK_WIN_NARROW"); return (e && atoi(e) == 0) ? 0 : 1; }();
+  if (short_seq && narrow_ok && !a.delta && (int)grid.x <= 128) {     // few workgroups, each bound by its weight stream: 64-channel groups
+    dim3 g4(grid.x * 4);
+    if (out_f32) hipLaunchKernelGGL((win_conv_kernel<256, 64, true, true, 4, 1>), g4, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((win_conv_kernel<256, 64, false, true, 4, 1>), g4, dim3(256), 0, s, a);
+    return 0;
+  }
   if (Cin == 256 && out_f32) {
     if (short_seq) hipLaunchKernelGGL((win_conv_kernel<256, 64, true, true>), grid, dim3(WC_NT), 0, s, a);
     else hipLaunchKernelGGL((win_conv_kernel<256, 112, true, true>), grid, dim3(WC_NT), 0, s, a);

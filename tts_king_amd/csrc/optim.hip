@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   const float step = lr / bc1;
   const int64_t n4 = n >> 2;
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    f32x4 pp = *(f32x4*)(p + i * 4), gg = *(const f32x4*)(g + i * 4), mm = *(f32x4*)(m + i * 4), vv = *(f32x4*)(v + i * 4);
+    f32x4 pp = __builtin_nontemporal_load((f32x4*)(p + i * 4)), gg = __builtin_nontemporal_load((const f32x4*)(g + i * 4)),
+          mm = __builtin_nontemporal_load((f32x4*)(m + i * 4)), vv = __builtin_nontemporal_load((f32x4*)(v + i * 4));      // streamed once: see adam_pack_kernel
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float ge = gg[e] * coef;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
       vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
       pp[e] -= step * mm[e] / (sqrtf(vv[e]) * isb2 + eps);
     }
-    *(f32x4*)(p + i * 4) = pp; *(f32x4*)(m + i * 4) = mm; *(f32x4*)(v + i * 4) = vv;
+    __builtin_nontemporal_store(pp, (f32x4*)(p + i * 4)); __builtin_nontemporal_store(mm, (f32x4*)(m + i * 4)); __builtin_nontemporal_store(vv, (f32x4*)(v + i * 4));
     if (zero_grad) *(f32x4*)(g + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     if (shadow) *(uint2*)(shadow + i * 4) = make_uint2(pack_bf2(pp[0], pp[1]), pack_bf2(pp[2], pp[3]));
   }
@@ -224,10 +225,12 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(float* __restrict__ p, f
     for (int u = 0; u < 8; ++u) {               // 32 rows x 64 groups of four floats; a wave takes a whole 1 KiB row
       const int idx = u * 256 + tid, r = idx >> 6, c4 = idx & 63;
       const int64_t e = it.off + ((int64_t)(ks * 32 + r) * K + ts) * Ds + cb * 256 + c4 * 4;
-      f32x4 pp = *(f32x4*)(p + e), mm = *(f32x4*)(m + e), vv = *(f32x4*)(v + e);
-      const f32x4 gg = *(const f32x4*)(g + e);
+      // p, m, v and g stream through once per step (1.1 GB): nontemporal, so that they do not evict the shadow and the packs the next
+      // forward reads (measured -25 us on the kernel)
+      f32x4 pp = __builtin_nontemporal_load((f32x4*)(p + e)), mm = __builtin_nontemporal_load((f32x4*)(m + e)), vv = __builtin_nontemporal_load((f32x4*)(v + e));
+      const f32x4 gg = __builtin_nontemporal_load((const f32x4*)(g + e));
       adam4(pp, gg, mm, vv, coef, b1, b2, step, isb2, eps);
-      *(f32x4*)(p + e) = pp; *(f32x4*)(m + e) = mm; *(f32x4*)(v + e) = vv;
+      __builtin_nontemporal_store(pp, (f32x4*)(p + e)); __builtin_nontemporal_store(mm, (f32x4*)(m + e)); __builtin_nontemporal_store(vv, (f32x4*)(v + e));
       if (zero_grad) *(f32x4*)(g + e) = f32x4{0.f, 0.f, 0.f, 0.f};
       const uint2 w = make_uint2(pack_bf2(pp[0], pp[1]), pack_bf2(pp[2], pp[3]));
       *(uint2*)(shadow + e) = w;
@@ -270,10 +273,10 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(float* __restrict__ p, f
       if (tb.gaps[mid * 3 + 2] <= i) lo = mid; else hi = mid;
     }
     const int64_t e = tb.gaps[lo * 3] + (i - tb.gaps[lo * 3 + 2]) * 4;
-    f32x4 pp = *(f32x4*)(p + e), mm = *(f32x4*)(m + e), vv = *(f32x4*)(v + e);
-    const f32x4 gg = *(const f32x4*)(g + e);
+    f32x4 pp = __builtin_nontemporal_load((f32x4*)(p + e)), mm = __builtin_nontemporal_load((f32x4*)(m + e)), vv = __builtin_nontemporal_load((f32x4*)(v + e));
+    const f32x4 gg = __builtin_nontemporal_load((const f32x4*)(g + e));
     adam4(pp, gg, mm, vv, coef, b1, b2, step, isb2, eps);
-    *(f32x4*)(p + e) = pp; *(f32x4*)(m + e) = mm; *(f32x4*)(v + e) = vv;
+    __builtin_nontemporal_store(pp, (f32x4*)(p + e)); __builtin_nontemporal_store(mm, (f32x4*)(m + e)); __builtin_nontemporal_store(vv, (f32x4*)(v + e));
     if (zero_grad) *(f32x4*)(g + e) = f32x4{0.f, 0.f, 0.f, 0.f};
     *(uint2*)(shadow + e) = make_uint2(pack_bf2(pp[0], pp[1]), pack_bf2(pp[2], pp[3]));
   }

@@ -186,6 +186,8 @@ class FastSpeech2(nn.Module):
         self.enc_early_at = int(os.environ.get("TTSK_ENC_EARLY_AT", "-1"))   # after this encoder block's backward (-1: never; measured 2.87 vs 2.82 ms: the second stream is not free yet)
         self.side_small = os.environ.get("TTSK_SIDE_SMALL", "0") != "0"      # the 80-channel grouped problems behind dwgemm on the second stream
         self._fin_side = None
+        self._dp_keep = None
+        self._fin_pending = False
         # Training with targets: the three VariancePredictors' outputs feed nothing but the loss (the embeddings are picked by the TARGET
         # pitch / energy, the length regulator takes the TARGET durations: modules.py:158-205), and their backward needs nothing but the
         # loss's gradients until its last step.  Both run on a stream of their own: the forward beside the decoder's first block, the

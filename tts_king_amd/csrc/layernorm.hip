@@ -744,31 +744,72 @@ __global__ __launch_bounds__(256) void colsum_finalize_batch_kernel(const Finali
   }
 }
 
-// column sums of a [rows][C] matrix (bf16 or fp32) -> partials[nblk][C]; a thread owns 4 contiguous columns
+// column sums of a [rows][C] matrix (bf16 or fp32) -> partials[nblk][C]; a thread owns 16 bytes of a row (8 bf16 / 4 fp32 columns; 4
+// bf16 columns when C or ld is not a multiple of 8) and keeps four rows' loads in flight (nontemporal: the matrix is read for the last
+// time), added in row order.  red: [256 / threads-per-row][C] floats.
+__device__ __forceinline__ int colsum_vec(int C, int ld, const void* x, bool f32) {
+  return (!f32 && (C & 7) == 0 && (ld & 7) == 0 && (((uintptr_t)x) & 15) == 0) ? 8 : 4;
+}
 template <typename T>
 __device__ __forceinline__ void colsum_body(const T* __restrict__ x, int rows, int C, int ld, float* __restrict__ partials, int blk, int nblk,
                                             float* red) {
-  const int tpr = (C + 3) >> 2;                 // threads per row (C % 4 == 0 or C < 4 handled by the host)
+  const int V = colsum_vec(C, ld, x, sizeof(T) == 4);
+  const int tpr = (C + V - 1) / V;              // threads per row (C % 4 == 0 or C < 4 handled by the host)
   const int rpi = 256 / tpr;                    // rows per iteration
-  const int r0 = threadIdx.x / tpr, c4 = (threadIdx.x % tpr) * 4;
+  const int r0 = threadIdx.x / tpr, c0 = (threadIdx.x % tpr) * V;
   const int per = (rows + nblk - 1) / nblk;
   const int rb = blk * per;
   const int re = min(rb + per, rows);
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
-  if (r0 < rpi)
-    for (int r = rb + r0; r < re; r += rpi) {
-      if constexpr (sizeof(T) == 2) {
-        const uint2 u = *(const uint2*)((const bf16_t*)x + (int64_t)r * ld + c4);
-        s[0] += __uint_as_float(u.x << 16); s[1] += __uint_as_float(u.x & 0xFFFF0000u);
-        s[2] += __uint_as_float(u.y << 16); s[3] += __uint_as_float(u.y & 0xFFFF0000u);
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (r0 < rpi) {
+    if constexpr (sizeof(T) == 2) {
+      if (V == 8) {
+        auto add = [&](const uint4 u) __attribute__((always_inline)) {
+          s[0] += __uint_as_float(u.x << 16); s[1] += __uint_as_float(u.x & 0xFFFF0000u);
+          s[2] += __uint_as_float(u.y << 16); s[3] += __uint_as_float(u.y & 0xFFFF0000u);
+          s[4] += __uint_as_float(u.z << 16); s[5] += __uint_as_float(u.z & 0xFFFF0000u);
+          s[6] += __uint_as_float(u.w << 16); s[7] += __uint_as_float(u.w & 0xFFFF0000u);
+        };
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+        const bf16_t* xp = (const bf16_t*)x + c0;
+        int r = rb + r0;
+        for (; r + 3 * rpi < re; r += 4 * rpi) {
+          const u32x4_ a0 = __builtin_nontemporal_load((const u32x4_*)(xp + (int64_t)r * ld));
+          const u32x4_ a1 = __builtin_nontemporal_load((const u32x4_*)(xp + (int64_t)(r + rpi) * ld));
+          const u32x4_ a2 = __builtin_nontemporal_load((const u32x4_*)(xp + (int64_t)(r + 2 * rpi) * ld));
+          const u32x4_ a3 = __builtin_nontemporal_load((const u32x4_*)(xp + (int64_t)(r + 3 * rpi) * ld));
+          add(make_uint4(a0[0], a0[1], a0[2], a0[3])); add(make_uint4(a1[0], a1[1], a1[2], a1[3]));
+          add(make_uint4(a2[0], a2[1], a2[2], a2[3])); add(make_uint4(a3[0], a3[1], a3[2], a3[3]));
+        }
+        for (; r < re; r += rpi) {
+          const u32x4_ a0 = __builtin_nontemporal_load((const u32x4_*)(xp + (int64_t)r * ld));
+          add(make_uint4(a0[0], a0[1], a0[2], a0[3]));
+        }
       } else {
-        const f32x4 u = *(const f32x4*)((const float*)x + (int64_t)r * ld + c4);
-        s[0] += u[0]; s[1] += u[1]; s[2] += u[2]; s[3] += u[3];
+        for (int r = rb + r0; r < re; r += rpi) {
+          const uint2 u = *(const uint2*)((const bf16_t*)x + (int64_t)r * ld + c0);
+          s[0] += __uint_as_float(u.x << 16); s[1] += __uint_as_float(u.x & 0xFFFF0000u);
+          s[2] += __uint_as_float(u.y << 16); s[3] += __uint_as_float(u.y & 0xFFFF0000u);
+        }
+      }
+    } else {
+      const float* xp = (const float*)x + c0;
+      int r = rb + r0;
+      for (; r + 3 * rpi < re; r += 4 * rpi) {
+        const f32x4 a0 = __builtin_nontemporal_load((const f32x4*)(xp + (int64_t)r * ld));
+        const f32x4 a1 = __builtin_nontemporal_load((const f32x4*)(xp + (int64_t)(r + rpi) * ld));
+        const f32x4 a2 = __builtin_nontemporal_load((const f32x4*)(xp + (int64_t)(r + 2 * rpi) * ld));
+        const f32x4 a3 = __builtin_nontemporal_load((const f32x4*)(xp + (int64_t)(r + 3 * rpi) * ld));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += a0[e]; s[e] += a1[e]; s[e] += a2[e]; s[e] += a3[e]; }
+      }
+      for (; r < re; r += rpi) {
+        const f32x4 u = __builtin_nontemporal_load((const f32x4*)(xp + (int64_t)r * ld));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += u[e];
       }
     }
-  if (r0 < rpi) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) red[r0 * C + c4 + e] = s[e];
+    for (int e = 0; e < V; ++e) red[r0 * C + c0 + e] = s[e];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -985,8 +1026,7 @@ extern "C" int ttsk_colsum(const void* x, int is_f32, int rows, int C, int ld, f
   TTSK_REQUIRE(x && partials && rows > 0 && C > 0 && ld >= C, "colsum: bad arguments");
   TTSK_REQUIRE((C & 3) == 0 && C <= 1024 && (ld & 3) == 0, "colsum: C must be a multiple of 4 and <= 1024 (got %d)", C);
   const int nblk = ttsk_colsum_nblocks(rows);
-  const int rpi = 256 / (C >> 2);
-  const size_t shm = (size_t)rpi * C * sizeof(float);
+  const size_t shm = 256 * 8 * sizeof(float);          // [256 / threads-per-row][C]: 4 or 8 columns per thread
   if (is_f32)
     hipLaunchKernelGGL(colsum_kernel<float>, dim3(nblk), dim3(256), shm, (hipStream_t)stream, (const float*)x, rows, C, ld, partials);
   else
@@ -1024,7 +1064,7 @@ extern "C" int ttsk_colsum_batch(const ttsk_colsum_item* items, int n, void* str
       TTSK_REQUIRE(it.x && it.partials && it.rows > 0 && it.C > 0 && (it.C & 3) == 0 && it.C <= 1024 && it.ld >= it.C && (it.ld & 3) == 0 &&
                        it.nblk == ttsk_colsum_nblocks(it.rows), "colsum_batch: bad item %d", base + i);
       if (it.nblk > max_blk) max_blk = it.nblk;
-      const size_t need = (size_t)(256 / (it.C >> 2)) * it.C * sizeof(float);
+      const size_t need = 256 * 8 * sizeof(float);       // [256 / threads-per-row][C]: 4 or 8 columns per thread
       if (need > shm) shm = need;
     }
     hipLaunchKernelGGL(colsum_batch_kernel, dim3(max_blk, m), dim3(256), shm, (hipStream_t)stream, cb);

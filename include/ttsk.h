@@ -191,6 +191,14 @@ int ttsk_win_conv(const void* x_bf16, const void* w_packed, const float* bias /*
 int ttsk_win_conv_stats_rows(int B, int S);
 int ttsk_win_conv_stats(const void* x_bf16, const void* w_packed, const float* bias, float* out_f32, float* stats,
                         const int32_t* frame_limit, int B, int S, int Cin, int Cout, int K, void* stream);
+/* HiFi-GAN's stride-8 upsamplers, ConvTranspose1d(Cin -> Cout, k = 16, stride 8, padding 4) (hifi/models.py:166-176,189 with
+ * upsample_rates[i] = 8), on the window-conv kernel: x16 (B, T, Cin) fp16 -> out16 (B, 8T, Cout) fp16.  Output frame 8t + r reads
+ * x[t] (weight tap r + 4) and x[t - 1] (r < 4: tap r + 12) or x[t + 1] (r >= 4: tap r - 4): a conv with two pseudo-taps and 8 * Cout
+ * phase-major output channels whose rows are the output tensor.  w_packed: ttsk_win_conv_pack_items of the (8 * Cout, 2, Cin) tap-major
+ * pseudo-weight W2[r * Cout + co][slot][ci]; bias8: the bias repeated 8 times.  Replaces the polyphase implicit GEMMs of ttsk_gemm. */
+int ttsk_hifi_upsample8_supported(int Cin, int Cout);
+int ttsk_hifi_upsample8(const void* x16, const void* w_packed, const float* bias8, void* out16, int f16, int B, int T, int Cin, int Cout,
+                        void* stream);
 
 /* Fused sub-layer tail of an FFT block (reference: fs_two/transformer/SubLayers.py:62-63 and :96-99 + Layers.py:29,32):
  *   out = zero_PAD_rows( LayerNorm( dropout_{p_pre, site_pre}( A[M,K] @ W[D,K]^T + bias ) + res ) ),  D = 256 only.

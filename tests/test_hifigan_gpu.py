@@ -311,3 +311,44 @@ def test_stream_upsample_generator_agrees(cfg):
     r = rel_rms(a.cpu(), b.cpu())
     print("streamed vs polyphase-GEMM upsamplers: rel-RMS %.3f%%" % (100 * r))
     assert r <= 2e-3
+
+
+@pytest.mark.parametrize("Cin,Cout,B,T", [(512, 256, 2, 37), (512, 256, 1, 1), (256, 128, 3, 130), (256, 128, 2, 384), (512, 256, 8, 384), (256, 64, 1, 113)])
+def test_window_upsample8_vs_fp64(Cin, Cout, B, T):
+    """ttsk_hifi_upsample8 (stride 8, kernel 16, padding 4 as a two-tap window conv with 8 * Cout phase-major channels: hifi/models.py:166-176
+    with upsample_rates[i] = 8) vs fp64 ConvTranspose1d on the same fp16 inputs — including the sequence ends, where the taps that reach
+    x[-1] / x[T] must see zeros — and vs the polyphase implicit GEMMs it replaces."""
+    from tts_king_amd import ops
+    g = torch.Generator().manual_seed(Cin + Cout + T)
+    x = torch.randn(B, T, Cin, generator=g).half()
+    w = (torch.randn(Cin, Cout, 16, generator=g) * (2 * Cin) ** -0.5).half()         # torch ConvTranspose1d layout
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv_transpose1d(x.double().transpose(1, 2), w.double(), bias.double(), stride=8, padding=4).transpose(1, 2)
+    assert ops.hifi_upsample8_supported(Cin, Cout, 8, 16) and not ops.hifi_upsample8_supported(Cin, Cout, 2, 4)
+    wp = ops.pack_conv_weight(w.float().to(DEV), transposed=True, dtype=torch.float16)           # (16, Cout, Cin)
+    pack, b8 = ops.hifi_upsample8_pack(wp, bias.to(DEV))
+    out = ops.hifi_upsample8(x.to(DEV), pack, b8, Cout)
+    assert out.shape == (B, 8 * T, Cout) and out.dtype == torch.float16
+    r = rel_rms(out.float().cpu(), ref.float())
+    worst = float((out.float().cpu() - ref.float()).abs().max()) / float(ref.abs().max())
+    print("upsample8 %d->%d B=%d T=%d: rel-RMS %.4f%%, max %.2e of max |y|" % (Cin, Cout, B, T, 100 * r, worst))
+    assert r <= 1e-3 and worst <= 2e-3
+    gen = ops.conv_transpose1d(x.to(DEV), wp, bias.to(DEV), 8, 16)                                # polyphase implicit GEMMs
+    assert float((gen.float() - out.float()).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
+def test_window_upsample8_generator_agrees(cfg):
+    from tts_king_amd.hifi_bench import build_generator
+    gen = build_generator(cfg, DEV)
+    mel = make_mel(2, 40, seed=4).to(DEV)
+    gen.window_upsample = True
+    gen._packed = None
+    a = gen(mel)
+    assert any(p is not None for p in gen._packed["ups8"])
+    gen.window_upsample = False
+    gen._packed = None
+    b = gen(mel)
+    assert all(p is None for p in gen._packed["ups8"])
+    r = rel_rms(a.cpu(), b.cpu())
+    print("window-conv vs polyphase-GEMM stride-8 upsamplers: rel-RMS %.3f%%" % (100 * r))
+    assert r <= 2e-3

@@ -54,6 +54,11 @@ struct WcArgs {
   // rows ttsk_bn_train_apply sums, one per (utterance, 64-frame tile), instead of a ttsk_bn_stats_slab launch over the stored rows
   float* stats;
   const int* frame_limit;
+  // Stride-8 ConvTranspose1d (k = 16, padding 4: HiFi-GAN's first two upsamplers) as this conv with K = 2 pseudo-taps over the input
+  // frames: output frame 8t + r takes x[t] (slot 0: weight tap r + 4) and x[t - 1] (r < 4: tap r + 12) or x[t + 1] (r >= 4: tap r - 4),
+  // so with Cout = 8 * C_out "channels" (phase-major) the output rows [B*T][8 * C_out] ARE the (B, 8T, C_out) tensor.  ups_cout =
+  // C_out switches slot 1's row shift to that rule (a channel group lies inside one phase: C_out >= the group's width).
+  int ups_cout;
 #ifdef TTSK_STAMPS
   unsigned long long* stamps;   // diagnostic build only (make stamps; ttsk_win_conv_set_stamps): 8 x s_memrealtime per workgroup
 #endif
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256) void win_pack_args_kernel(const ItemChunk c) {
 // NWV waves x CTV cout tiles of 16: the workgroup's channel group.  8 x 2 = 256 channels everywhere but on the phoneme side, where a
 // 1,024-row problem is 16 tiles x Cout / 256 = 48-64 workgroups that each stream 1.2 MB of weights through one CU's L2 port (22 us
 // for w_1's 4.8 GFLOP): 4 x 1 = 64 channels there — 192-256 workgroups, 0.3 MB each.
-template <int CIN, int TT, bool OUT32, bool PACKED, int NWV = WC_NW, int CTV = WC_CT>
+template <int CIN, int TT, bool OUT32, bool PACKED, int NWV = WC_NW, int CTV = WC_CT, bool F16 = false>
 __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
   constexpr int COUT = NWV * CTV * 16;
   constexpr int C = CIN, RS = CIN * 2 + 32, NT = NWV * 64, CH8 = C / 8, KH = WC_KH, CT = CTV, NF = TT / 16, NP = CIN / 128;
@@ -270,16 +275,18 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
     for (int i = 0; i < NF; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
     const unsigned char* inl = XW + (l15 + WC_H) * RS + q * 16;
+    // row shift of tap slot 1 in the stride-8 transposed-conv mode (slot 0: none)
+    const int ups_shift = a.ups_cout ? ((cg * COUT) / a.ups_cout < 4 ? -1 : 1) : 0;
     auto step = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
       const int tap = g / NP, part = g - tap * NP;
-      const unsigned char* inp = inl + (tap - HK) * RS + part * (KH * 64);
+      const unsigned char* inp = inl + (a.ups_cout ? tap * ups_shift : tap - HK) * RS + part * (KH * 64);
 #pragma unroll
       for (int ks = 0; ks < KH; ++ks) {
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
           const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
 #pragma unroll
-          for (int cc = 0; cc < CT; ++cc) acc[cc][i] = mfma16<false>(w[ks][cc], Bf, acc[cc][i]);
+          for (int cc = 0; cc < CT; ++cc) acc[cc][i] = mfma16<F16>(w[ks][cc], Bf, acc[cc][i]);
         }
       }
     };
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
       }
       const int col = (wave * CT + cc) * 16 + q * 4;
       if (OUT32) *(f32x4*)(XW + (i * 16 + l15) * SRS + col * 4) = v;
-      else *(uint2*)(XW + (i * 16 + l15) * SRS + col * 2) = make_uint2(pack2<false>(v[0], v[1]), pack2<false>(v[2], v[3]));
+      else *(uint2*)(XW + (i * 16 + l15) * SRS + col * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
     }
   }
   __syncthreads();
@@ -383,16 +390,27 @@ extern "C" int ttsk_win_conv_set_stamps(void* dev_buffer) {
 }
 #endif
 
-int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int packed, hipStream_t s) {
+int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int packed, hipStream_t s, int f16 = 0) {
   WcArgs a = a0;
 #ifdef TTSK_STAMPS
   a.stamps = g_wc_stamps;
 #endif
-  const bool short_seq = Cin == 256 && packed && (S <= 64 || (S > 112 && S <= 128));      // phoneme-side sequences: 64-frame tiles waste less
+  const bool short_seq = !f16 && Cin == 256 && packed && (S <= 64 || (S > 112 && S <= 128));      // phoneme-side sequences: 64-frame tiles waste less
   const int TT = Cin == 256 && !short_seq ? 112 : 64;
   a.B = B;
   a.tiles_per_utt = (S + TT - 1) / TT;
   dim3 grid(a.tiles_per_utt * B * (a.Cout / WC_COUT) * a.nsplit);
+  if (f16) {
+    // HiFi-GAN's operand type: the two shapes its stride-8 upsamplers need.  Their contraction is short (2 pseudo-taps x Cin), so a
+    // workgroup's time is its prologue, its weight stream (0.26 / 0.52 MB) and its stores: frame tiles twice as tall as the training
+    // shapes' (224 / 128 frames) halve the number of times each is paid (stage times at B = 8, T = 384: ups1 82 us on the polyphase GEMMs, 53 at 112 frames, 50 at 224; ups0 70 / 46 / 41).
+    const int TTU = Cin == 256 ? 224 : 128;
+    a.tiles_per_utt = (S + TTU - 1) / TTU;
+    const dim3 gu(a.tiles_per_utt * B * (a.Cout / WC_COUT) * a.nsplit);
+    if (Cin == 256) hipLaunchKernelGGL((win_conv_kernel<256, 224, false, true, WC_NW, WC_CT, true>), gu, dim3(WC_NT), 0, s, a);
+    else hipLaunchKernelGGL((win_conv_kernel<512, 128, false, true, WC_NW, WC_CT, true>), gu, dim3(WC_NT), 0, s, a);
+    return 0;
+  }
   static const int narrow_ok = [] { const char* e = getenv("TTSK_WIN_NARROW"); return (e && atoi(e) == 0) ? 0 : 1; }();
   if (short_seq && narrow_ok && !a.delta && (int)grid.x <= 128) {     // few workgroups, each bound by its weight stream: 64-channel groups
     dim3 g4(grid.x * 4);
@@ -470,6 +488,26 @@ extern "C" int ttsk_win_conv(const void* x_bf16, const void* w_packed, const flo
   TTSK_REQUIRE(!delta_out || (delta_o32 && !out_f32 && Cout % 128 == 0 && (((uintptr_t)delta_o32) & 15) == 0),
                "ttsk_win_conv: delta needs o32 (16-byte aligned), bf16 output and Cout = heads * 128");
   launch_win_conv(a, B, S, Cin, out_f32, 1, (hipStream_t)stream);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+extern "C" int ttsk_hifi_upsample8_supported(int Cin, int Cout) {      // a 256-channel group must lie on one side of the phase 3 | 4 boundary
+  return (Cin == 256 || Cin == 512) && Cout > 0 && (Cout % WC_COUT == 0 || Cout == 128 || Cout == 64);
+}
+
+// ConvTranspose1d(Cin -> Cout, k = 16, stride 8, padding 4) on 16-bit rows: see WcArgs::ups_cout.  w_packed: ttsk_win_conv_pack_* of the
+// (8 * Cout, 2, Cin) tap-major pseudo-weight (tts_king_amd/ops.py:hifi_upsample8_pack); bias8: the bias repeated for the 8 phases.
+extern "C" int ttsk_hifi_upsample8(const void* x16, const void* w_packed, const float* bias8, void* out16, int f16, int B, int T, int Cin,
+                                   int Cout, void* stream) {
+  TTSK_REQUIRE(x16 && w_packed && bias8 && out16, "ttsk_hifi_upsample8: null pointer");
+  TTSK_REQUIRE(B > 0 && T > 0 && B <= 65535, "ttsk_hifi_upsample8: bad sizes B=%d T=%d", B, T);
+  TTSK_REQUIRE(ttsk_hifi_upsample8_supported(Cin, Cout), "ttsk_hifi_upsample8: no instance for Cin=%d Cout=%d", Cin, Cout);
+  TTSK_REQUIRE(f16 == 1, "ttsk_hifi_upsample8: built for fp16 rows (HiFi-GAN inference)");
+  TTSK_REQUIRE(((((uintptr_t)x16) | ((uintptr_t)w_packed) | ((uintptr_t)bias8) | ((uintptr_t)out16)) & 15) == 0, "ttsk_hifi_upsample8: 16-byte alignment");
+  TTSK_REQUIRE((int64_t)B * T * 8 * Cout * 2 < ((int64_t)1 << 40), "ttsk_hifi_upsample8: sizes out of range");
+  WcArgs a{(const bf16_t*)x16, (const bf16_t*)w_packed, bias8, out16, T, 2, 8 * Cout, 0, 0, 0, nullptr, 1, Cin, 0, nullptr, nullptr, nullptr, nullptr, Cout};
+  launch_win_conv(a, B, T, Cin, 0, 1, (hipStream_t)stream, 1);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -326,16 +326,17 @@ __device__ __forceinline__ void bn_slab_totals(const float* __restrict__ partial
     const int v0 = q * 4;
     const int col = v0 < slab ? c0 + v0 : C + c0 + (v0 - slab);
     double a[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int b = g0; b < nblk; b += 8 * groups) {
-      f32x4 f[8];
+    // sixteen loads in flight: the 112 partial rows the PostNet's convs emit (16 utterances x 7 tiles) are one batch, not two
+    for (int b = g0; b < nblk; b += 16 * groups) {
+      f32x4 f[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int bb = b + u * groups;
         f[u] = *(const f32x4*)(partials + (int64_t)min(bb, nblk - 1) * 2 * C + col);
         if (bb >= nblk) f[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 16; ++u)
 #pragma unroll
         for (int e = 0; e < 4; ++e) a[e] += f[u][e];
     }

@@ -543,6 +543,13 @@ def main():
             if rank == 0:
                 print("graph capture failed (%s): eager launches" % e, file=sys.stderr)
             use_graph = False
+            # a capture that died half way leaves host-side bookkeeping advanced: put it back (as TrainEngine does)
+            if reducer is not None:
+                reducer.reset()
+            model.grads_partial = False
+            model._dw_side_pending = False
+            model._pred_fwd_pending = False
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         out = step()

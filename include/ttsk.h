@@ -199,6 +199,12 @@ int ttsk_win_conv_stats(const void* x_bf16, const void* w_packed, const float* b
 int ttsk_hifi_upsample8_supported(int Cin, int Cout);
 int ttsk_hifi_upsample8(const void* x16, const void* w_packed, const float* bias8, void* out16, int f16, int B, int T, int Cin, int Cout,
                         void* stream);
+/* The same for any ConvTranspose1d(kernel 2 * stride, padding stride / 2) the kernel is instantiated for: stride 8 as above, stride 2
+ * (k = 4, padding 1) for 128 -> 64 channels (hifi/models.py: ups[2]).  Output frame stride * t + r reads x[t] (tap r + stride / 2) and
+ * x[t - 1] (r < stride / 2: tap r + 3 * stride / 2) or x[t + 1] (tap r - stride / 2); pseudo-weight (stride * Cout, 2, Cin). */
+int ttsk_hifi_upsample_win_supported(int Cin, int Cout, int stride);
+int ttsk_hifi_upsample_win(const void* x16, const void* w_packed, const float* bias_rep, void* out16, int f16, int B, int T, int Cin, int Cout,
+                           int stride, void* stream);
 
 /* Fused sub-layer tail of an FFT block (reference: fs_two/transformer/SubLayers.py:62-63 and :96-99 + Layers.py:29,32):
  *   out = zero_PAD_rows( LayerNorm( dropout_{p_pre, site_pre}( A[M,K] @ W[D,K]^T + bias ) + res ) ),  D = 256 only.

@@ -352,3 +352,27 @@ def test_window_upsample8_generator_agrees(cfg):
     r = rel_rms(a.cpu(), b.cpu())
     print("window-conv vs polyphase-GEMM stride-8 upsamplers: rel-RMS %.3f%%" % (100 * r))
     assert r <= 2e-3
+
+
+@pytest.mark.parametrize("B,T", [(2, 300), (1, 1), (3, 777), (8, 3000)])
+def test_window_upsample2_vs_fp64_and_stream_kernel(B, T):
+    """ttsk_hifi_upsample_win at stride 2 (ConvTranspose1d 128 -> 64, kernel 4, padding 1: out[2t] = x[t] W[1] + x[t-1] W[3], out[2t+1] =
+    x[t] W[2] + x[t+1] W[0]) vs fp64 on the same fp16 inputs and vs ttsk_hifi_upsample2."""
+    from tts_king_amd import ops
+    Cin, Cout = 128, 64
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(B, T, Cin, generator=g).half()
+    w = (torch.randn(Cin, Cout, 4, generator=g) * (2 * Cin) ** -0.5).half()
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv_transpose1d(x.double().transpose(1, 2), w.double(), bias.double(), stride=2, padding=1).transpose(1, 2)
+    assert ops.hifi_upsample_win_supported(Cin, Cout, 2, 4) and not ops.hifi_upsample_win_supported(64, 32, 2, 4)
+    wp = ops.pack_conv_weight(w.float().to(DEV), transposed=True, dtype=torch.float16)
+    pack, brep = ops.hifi_upsample_win_pack(wp, bias.to(DEV), 2)
+    out = ops.hifi_upsample_win(x.to(DEV), pack, brep, Cout, 2)
+    assert out.shape == (B, 2 * T, Cout) and out.dtype == torch.float16
+    r = rel_rms(out.float().cpu(), ref.float())
+    worst = float((out.float().cpu() - ref.float()).abs().max()) / float(ref.abs().max())
+    print("window upsample2 B=%d T=%d: rel-RMS %.4f%%, max %.2e of max |y|" % (B, T, 100 * r, worst))
+    assert r <= 1e-3 and worst <= 2e-3
+    other = ops.hifi_upsample2(x.to(DEV), wp, bias.to(DEV))
+    assert float((other.float() - out.float()).abs().max()) <= 2e-3 * float(ref.abs().max())

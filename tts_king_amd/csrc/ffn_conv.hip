@@ -59,6 +59,7 @@ struct WcArgs {
   // so with Cout = 8 * C_out "channels" (phase-major) the output rows [B*T][8 * C_out] ARE the (B, 8T, C_out) tensor.  ups_cout =
   // C_out switches slot 1's row shift to that rule (a channel group lies inside one phase: C_out >= the group's width).
   int ups_cout;
+  int ups_half;       // phases r < ups_half take x[t - 1] on slot 1, the others x[t + 1] (stride / 2: 4 for stride 8; 1 for stride 2, k = 4, padding 1)
 #ifdef TTSK_STAMPS
   unsigned long long* stamps;   // diagnostic build only (make stamps; ttsk_win_conv_set_stamps): 8 x s_memrealtime per workgroup
 #endif
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
   {
     const unsigned char* inl = XW + (l15 + WC_H) * RS + q * 16;
     // row shift of tap slot 1 in the stride-8 transposed-conv mode (slot 0: none)
-    const int ups_shift = a.ups_cout ? ((cg * COUT) / a.ups_cout < 4 ? -1 : 1) : 0;
+    const int ups_shift = a.ups_cout ? ((cg * COUT + wave * CT * 16) / a.ups_cout < a.ups_half ? -1 : 1) : 0;      // a wave's channels lie in one phase
     auto step = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
       const int tap = g / NP, part = g - tap * NP;
       const unsigned char* inp = inl + (a.ups_cout ? tap * ups_shift : tap - HK) * RS + part * (KH * 64);
@@ -404,8 +405,13 @@ int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int pa
     // HiFi-GAN's operand type: the two shapes its stride-8 upsamplers need.  Their contraction is short (2 pseudo-taps x Cin), so a
     // workgroup's time is its prologue, its weight stream (0.26 / 0.52 MB) and its stores: frame tiles twice as tall as the training
     // shapes' (224 / 128 frames) halve the number of times each is paid (stage times at B = 8, T = 384: ups1 82 us on the polyphase GEMMs, 53 at 112 frames, 50 at 224; ups0 70 / 46 / 41).
-    const int TTU = Cin == 256 ? 224 : 128;
+    const int TTU = Cin == 512 ? 128 : 224;
     a.tiles_per_utt = (S + TTU - 1) / TTU;
+    if (Cin == 128) {          // the stride-2 upsampler 128 -> 64: 128 phase-major channels = one group of 4 waves x 32
+      const dim3 g1(a.tiles_per_utt * B * (a.Cout / 128) * a.nsplit);
+      hipLaunchKernelGGL((win_conv_kernel<128, 224, false, true, 4, 2, true>), g1, dim3(256), 0, s, a);
+      return 0;
+    }
     const dim3 gu(a.tiles_per_utt * B * (a.Cout / WC_COUT) * a.nsplit);
     if (Cin == 256) hipLaunchKernelGGL((win_conv_kernel<256, 224, false, true, WC_NW, WC_CT, true>), gu, dim3(WC_NT), 0, s, a);
     else hipLaunchKernelGGL((win_conv_kernel<512, 128, false, true, WC_NW, WC_CT, true>), gu, dim3(WC_NT), 0, s, a);
@@ -492,24 +498,34 @@ extern "C" int ttsk_win_conv(const void* x_bf16, const void* w_packed, const flo
   return TTSK_OK;
 }
 
-extern "C" int ttsk_hifi_upsample8_supported(int Cin, int Cout) {      // a 256-channel group must lie on one side of the phase 3 | 4 boundary
-  return (Cin == 256 || Cin == 512) && Cout > 0 && (Cout % WC_COUT == 0 || Cout == 128 || Cout == 64);
+extern "C" int ttsk_hifi_upsample_win_supported(int Cin, int Cout, int stride) {
+  // a wave's 32 (or 16) channels must lie in one phase, a workgroup's channel group on whole phases
+  if (stride == 8) return (Cin == 256 || Cin == 512) && Cout > 0 && (Cout % WC_COUT == 0 || Cout == 128 || Cout == 64);
+  if (stride == 2) return Cin == 128 && Cout == 64;
+  return 0;
 }
+extern "C" int ttsk_hifi_upsample8_supported(int Cin, int Cout) { return ttsk_hifi_upsample_win_supported(Cin, Cout, 8); }
 
-// ConvTranspose1d(Cin -> Cout, k = 16, stride 8, padding 4) on 16-bit rows: see WcArgs::ups_cout.  w_packed: ttsk_win_conv_pack_* of the
-// (8 * Cout, 2, Cin) tap-major pseudo-weight (tts_king_amd/ops.py:hifi_upsample8_pack); bias8: the bias repeated for the 8 phases.
-extern "C" int ttsk_hifi_upsample8(const void* x16, const void* w_packed, const float* bias8, void* out16, int f16, int B, int T, int Cin,
-                                   int Cout, void* stream) {
-  TTSK_REQUIRE(x16 && w_packed && bias8 && out16, "ttsk_hifi_upsample8: null pointer");
-  TTSK_REQUIRE(B > 0 && T > 0 && B <= 65535, "ttsk_hifi_upsample8: bad sizes B=%d T=%d", B, T);
-  TTSK_REQUIRE(ttsk_hifi_upsample8_supported(Cin, Cout), "ttsk_hifi_upsample8: no instance for Cin=%d Cout=%d", Cin, Cout);
-  TTSK_REQUIRE(f16 == 1, "ttsk_hifi_upsample8: built for fp16 rows (HiFi-GAN inference)");
-  TTSK_REQUIRE(((((uintptr_t)x16) | ((uintptr_t)w_packed) | ((uintptr_t)bias8) | ((uintptr_t)out16)) & 15) == 0, "ttsk_hifi_upsample8: 16-byte alignment");
-  TTSK_REQUIRE((int64_t)B * T * 8 * Cout * 2 < ((int64_t)1 << 40), "ttsk_hifi_upsample8: sizes out of range");
-  WcArgs a{(const bf16_t*)x16, (const bf16_t*)w_packed, bias8, out16, T, 2, 8 * Cout, 0, 0, 0, nullptr, 1, Cin, 0, nullptr, nullptr, nullptr, nullptr, Cout};
+// ConvTranspose1d(Cin -> Cout, kernel 2 * stride, padding stride / 2) on 16-bit rows: see WcArgs::ups_cout.  w_packed:
+// ttsk_win_conv_pack_* of the (stride * Cout, 2, Cin) tap-major pseudo-weight (tts_king_amd/ops.py:hifi_upsample_win_pack); bias_rep: the
+// bias repeated for the `stride` phases.
+extern "C" int ttsk_hifi_upsample_win(const void* x16, const void* w_packed, const float* bias_rep, void* out16, int f16, int B, int T, int Cin,
+                                      int Cout, int stride, void* stream) {
+  TTSK_REQUIRE(x16 && w_packed && bias_rep && out16, "ttsk_hifi_upsample_win: null pointer");
+  TTSK_REQUIRE(B > 0 && T > 0 && B <= 65535, "ttsk_hifi_upsample_win: bad sizes B=%d T=%d", B, T);
+  TTSK_REQUIRE(ttsk_hifi_upsample_win_supported(Cin, Cout, stride), "ttsk_hifi_upsample_win: no instance for Cin=%d Cout=%d stride=%d", Cin, Cout, stride);
+  TTSK_REQUIRE(f16 == 1, "ttsk_hifi_upsample_win: built for fp16 rows (HiFi-GAN inference)");
+  TTSK_REQUIRE(((((uintptr_t)x16) | ((uintptr_t)w_packed) | ((uintptr_t)bias_rep) | ((uintptr_t)out16)) & 15) == 0, "ttsk_hifi_upsample_win: 16-byte alignment");
+  TTSK_REQUIRE((int64_t)B * T * stride * Cout * 2 < ((int64_t)1 << 40), "ttsk_hifi_upsample_win: sizes out of range");
+  WcArgs a{(const bf16_t*)x16, (const bf16_t*)w_packed, bias_rep, out16, T, 2, stride * Cout, 0, 0, 0, nullptr, 1, Cin, 0, nullptr, nullptr, nullptr, nullptr,
+           Cout, stride / 2};
   launch_win_conv(a, B, T, Cin, 0, 1, (hipStream_t)stream, 1);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
+}
+extern "C" int ttsk_hifi_upsample8(const void* x16, const void* w_packed, const float* bias8, void* out16, int f16, int B, int T, int Cin,
+                                   int Cout, void* stream) {
+  return ttsk_hifi_upsample_win(x16, w_packed, bias8, out16, f16, B, T, Cin, Cout, 8, stream);
 }
 
 extern "C" int ttsk_win_conv_stats_rows(int B, int S) { return B * ((S + 63) / 64); }

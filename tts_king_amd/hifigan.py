@@ -101,7 +101,7 @@ class Generator(nn.Module):
         self.conv_pair_small = True  # ... and at C = 64 / 32, instead of the six-conv fused kernel
         self.fused = True            # fused ResBlock1 kernel where an instance exists (C in {32,64}); False = conv-by-conv
         self.stream_upsample = True  # stride-2 upsamplers (128->64, 64->32) on the streaming kernel; False = polyphase implicit GEMMs
-        self.window_upsample = os.environ.get("TTSK_HIFI_UPS8", "1") != "0"   # stride-8 upsamplers on the window-conv kernel (fp16); 0 = polyphase GEMMs
+        self.window_upsample = os.environ.get("TTSK_HIFI_UPS8", "1") != "0"   # stride-8 upsamplers and 128 -> 64 on the window-conv kernel (fp16); 0 = polyphase GEMMs / streaming kernel
         self.group_resblocks = True  # conv m of the three MRF ResBlocks as one grouped launch where they run conv by conv (C = 256)
 
     # ------------------------------------------------------------------ reference surface
@@ -145,9 +145,10 @@ class Generator(nn.Module):
         pk = {}
         pk["pre"] = (ops.pack_conv_weight(self.conv_pre.folded_weight(), dtype=dt), self.conv_pre.bias.data)
         pk["ups"] = [(ops.pack_conv_weight(u.folded_weight(), transposed=True, dtype=dt), u.bias.data) for u in self.ups]
-        # the stride-8 upsamplers on the window-conv kernel (fp16 rows): a two-tap conv over the input frames with 8 * Cout phase-major channels
-        pk["ups8"] = [ops.hifi_upsample8_pack(w, b) if (self.window_upsample and dt == torch.float16 and
-                                                         ops.hifi_upsample8_supported(w.shape[2], w.shape[1], uu, kk)) else None
+        # the stride-8 upsamplers and the 128 -> 64 stride-2 one on the window-conv kernel (fp16 rows): a two-tap conv over the input frames
+        # with stride * Cout phase-major channels
+        pk["ups8"] = [ops.hifi_upsample_win_pack(w, b, uu) if (self.window_upsample and dt == torch.float16 and
+                                                               ops.hifi_upsample_win_supported(w.shape[2], w.shape[1], uu, kk)) else None
                       for (w, b), uu, kk in zip(pk["ups"], self.h.upsample_rates, self.h.upsample_kernel_sizes)]
         pk["rb"], pk["rbf"], pk["rbw"] = [], [], []
         for rb in self.resblocks:
@@ -286,10 +287,10 @@ class Generator(nn.Module):
                 want_pair = (self.conv_pair and self.window_conv) if C_out >= 128 else (self.conv_pair_small and self.fused and C_out == 64)
                 ppacks = self._pair_packs(pk, i, nk, rbs, C_out) if want_pair else None
                 if ppacks is not None:
-                    if self.stream_upsample and ops.hifi_upsample2_supported(wu.shape[2], wu.shape[1], u, k) and al.is_contiguous():
+                    if pk["ups8"][i] is not None and al.is_contiguous():
+                        a = ops.hifi_upsample_win(al, pk["ups8"][i][0], pk["ups8"][i][1], C_out, u)
+                    elif self.stream_upsample and ops.hifi_upsample2_supported(wu.shape[2], wu.shape[1], u, k) and al.is_contiguous():
                         a = ops.hifi_upsample2(al, wu, bu)
-                    elif pk["ups8"][i] is not None and al.is_contiguous():
-                        a = ops.hifi_upsample8(al, pk["ups8"][i][0], pk["ups8"][i][1], C_out)
                     else:
                         a = ops.conv_transpose1d(al, wu, bu, u, k)                         # raw x: the pair kernels activate it themselves
                     # measured per block at the bench shape (tools/debug/convpair_micro.py): three pair launches beat the six-conv

@@ -1453,33 +1453,46 @@ def hifi_upsample2(x, Wp, bias):
     return out
 
 
+def hifi_upsample_win_supported(Cin, Cout, stride, k):
+    return k == 2 * stride and bool(L.load().ttsk_hifi_upsample_win_supported(Cin, Cout, stride))
+
+
 def hifi_upsample8_supported(Cin, Cout, stride, k):
-    return stride == 8 and k == 16 and bool(L.load().ttsk_hifi_upsample8_supported(Cin, Cout))
+    return stride == 8 and hifi_upsample_win_supported(Cin, Cout, stride, k)
+
+
+def hifi_upsample_win_pack(Wp, bias, stride):
+    """Wp (2*stride, Cout, Cin) 16-bit (pack_conv_weight(..., transposed=True) of a ConvTranspose1d weight, padding stride/2) ->
+    (fragment-major pack of the (stride*Cout, 2, Cin) pseudo-weight, bias repeated for the phases): output frame stride*t + r =
+    x[t] . w[r + h] + (r < h ? x[t - 1] . w[r + h + stride] : x[t + 1] . w[r - h]), h = stride / 2 — include/ttsk.h:ttsk_hifi_upsample_win."""
+    _dev(Wp, bias)
+    k, Cout, Cin = Wp.shape
+    h = stride // 2
+    r = torch.arange(stride, device=Wp.device)
+    slot0 = Wp[r + h]                                             # (stride, Cout, Cin)
+    slot1 = Wp[torch.where(r < h, r + h + stride, r - h)]
+    W2 = torch.stack([slot0, slot1], dim=2).reshape(stride * Cout, 2, Cin).contiguous()      # [(r, co)][slot][ci]
+    pack = torch.empty(W2.numel(), dtype=Wp.dtype, device=Wp.device)
+    win_conv_pack_items([(W2, pack, False)])
+    return pack, bias.float().repeat(stride).contiguous()
 
 
 def hifi_upsample8_pack(Wp, bias):
-    """Wp (16, Cout, Cin) 16-bit (pack_conv_weight(..., transposed=True) of a ConvTranspose1d weight) -> (fragment-major pack of the
-    (8*Cout, 2, Cin) pseudo-weight, bias repeated for the 8 phases): output frame 8t + r = x[t] . w[r + 4] + (r < 4 ? x[t - 1] . w[r + 12]
-    : x[t + 1] . w[r - 4]) — include/ttsk.h:ttsk_hifi_upsample8."""
-    _dev(Wp, bias)
-    k, Cout, Cin = Wp.shape
-    r = torch.arange(8, device=Wp.device)
-    slot0 = Wp[r + 4]                                             # (8, Cout, Cin)
-    slot1 = Wp[torch.where(r < 4, r + 12, r - 4)]
-    W2 = torch.stack([slot0, slot1], dim=2).reshape(8 * Cout, 2, Cin).contiguous()      # [(r, co)][slot][ci]
-    pack = torch.empty(W2.numel(), dtype=Wp.dtype, device=Wp.device)
-    win_conv_pack_items([(W2, pack, False)])
-    return pack, bias.float().repeat(8).contiguous()
+    return hifi_upsample_win_pack(Wp, bias, 8)
+
+
+def hifi_upsample_win(x, pack, bias_rep, Cout, stride):
+    """ConvTranspose1d(kernel 2*stride, padding stride/2) on the window-conv kernel: x (B, T, Cin) fp16 -> (B, stride*T, Cout)."""
+    _dev(x, pack, bias_rep)
+    Bsz, T, Cin = x.shape
+    out = torch.empty(Bsz, stride * T, Cout, dtype=x.dtype, device=x.device)
+    check(L.load().ttsk_hifi_upsample_win(_ptr(x), _ptr(pack), _ptr(bias_rep), _ptr(out), int(x.dtype == f16), Bsz, T, Cin, Cout, stride,
+                                          _stream()), "ttsk_hifi_upsample_win")
+    return out
 
 
 def hifi_upsample8(x, pack, bias8, Cout):
-    """ConvTranspose1d(stride 8, kernel 16, padding 4) on the window-conv kernel: x (B, T, Cin) fp16 -> (B, 8T, Cout)."""
-    _dev(x, pack, bias8)
-    Bsz, T, Cin = x.shape
-    out = torch.empty(Bsz, 8 * T, Cout, dtype=x.dtype, device=x.device)
-    check(L.load().ttsk_hifi_upsample8(_ptr(x), _ptr(pack), _ptr(bias8), _ptr(out), int(x.dtype == f16), Bsz, T, Cin, Cout, _stream()),
-          "ttsk_hifi_upsample8")
-    return out
+    return hifi_upsample_win(x, pack, bias8, Cout, 8)
 
 
 def hifi_conv_post(x, w, bias):

@@ -551,6 +551,213 @@ __device__ __forceinline__ void flash_bwd_kv_body(const FlashArgs& a, unsigned c
   }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, P / dS in registers
+// Round 3: flash_fwd_t_kernel's idiom on both sides of the backward.  Every product is taken transposed so that the tile that is both
+// an MFMA result and the next MFMA's operand (dS for dQ; P and dS for dV and dK) is packed from the accumulators straight into a B
+// operand — under the slot order frag_tr8 reads its transposed A operand in — instead of going through 16 (32 on the key side)
+// two-byte LDS stores, a wait and a read-back per tile:
+//   query side, per (utterance, head, 64 queries), queries on the MFMA COLUMNS (one query per lane column l15):
+//     S^T = K Q^T, dP^T = V dO^T  (A = K / V rows of the tile, B = this wave's Q / dO fragments, held for the whole loop)
+//     dS^T = P^T o (dP^T - delta[q]) * scale           dQ^T[d][q] += K^T dS^T   (A = K^T: transposing reads of the K image)
+//   key side, per (utterance, head, 64 keys), keys on the columns:
+//     S = Q K^T, dP = dO V^T      (A = Q / dO rows of the query tile, B = this wave's K / V fragments)
+//     dV^T[d][k] += dO^T P,   dK^T[d][k] += Q^T dS     (A = dO^T / Q^T: transposing reads)
+// Outputs leave as in flash_fwd_t_kernel: 8-byte bf16 pieces into a staging tile, full rows to memory.  Same sums in a different
+// order (a contraction's slots are permuted, fp32 accumulation): results differ from flash_bwd_kernel's in the last bits only.
+__device__ __forceinline__ void flash_bwd_q_t_body(const FlashArgs& a, unsigned char* smem) {      // uses 49,152 B of smem
+  unsigned char* Kr = smem;                          // K tile, row-major image            (A operand of S^T = K Q^T)
+  unsigned char* Vr = smem + KS_BYTES;               // V tile, row-major image            (A operand of dP^T = V dO^T)
+  unsigned char* Kt = Vr + KS_BYTES;                 // K tile, store_tr8 image            (A operand of dQ^T += K^T dS^T)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  int tile_x, z;
+  xcd_tile(tile_x, z, a.plain_order);
+  const int b = z / a.H, h = z - b * a.H;
+  const int q0 = tile_x * TQ;
+  const int S = a.S, ld = 3 * a.d;
+  const int len = a.lens ? min((int)a.lens[b], S) : S;
+  const int ntk = (len + TK - 1) / TK;
+  const bf16_t* base = a.qkv + (int64_t)b * S * ld + h * DK;
+  const bf16_t* dob = a.dout + (int64_t)b * S * a.d + h * DK;
+
+  uint4 rk[4], rv[4];
+  {
+    uint4 rq[4], rd[4];
+    load_tile(rq, base, ld, q0, S, tid);
+    load_tile(rd, dob, a.d, q0, S, tid);
+    if (ntk > 0) { load_tile(rk, base + a.d, ld, 0, S, tid); load_tile(rv, base + 2 * a.d, ld, 0, S, tid); }
+    store_rows(Kr, rq, tid);
+    store_rows(Vr, rd, tid);
+  }
+  const int qme = q0 + wave * 16 + l15;               // this lane's query
+  const float lse = qme < S ? a.lse[(int64_t)z * S + qme] : 0.f;
+  const float delta = qme < S ? a.delta[(int64_t)z * S + qme] : 0.f;
+  __syncthreads();
+  bf16x8 qb[4], db[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { qb[ks] = frag_rows(Kr, wave * 16, ks, l15, lg); db[ks] = frag_rows(Vr, wave * 16, ks, l15, lg); }
+
+  f32x4 dq[8];                                        // dQ^T: rows d = 16*nb + 4*lg + r, column = the query
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) dq[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int j = 0; j < ntk; ++j) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                  // the previous tile's (or the Q / dO staging's) LDS reads are done
+    store_rows(Kr, rk, tid);
+    store_tr8(Kt, rk, tid);
+    store_rows(Vr, rv, tid);
+    if (j + 1 < ntk) { load_tile(rk, base + a.d, ld, (j + 1) * TK, S, tid); load_tile(rv, base + 2 * a.d, ld, (j + 1) * TK, S, tid); }
+    __syncthreads();
+    f32x4 st[4], dpt[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { st[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        st[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Kr, nt * 16, ks, l15, lg), qb[ks], st[nt], 0, 0, 0);
+        dpt[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vr, nt * 16, ks, l15, lg), db[ks], dpt[nt], 0, 0, 0);
+      }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j * TK + nt * 16 + lg * 4 + r;
+        const float p = key < len ? __expf(st[nt][r] * a.scale - lse) : 0.f;
+        st[nt][r] = a.scale * p * (dpt[nt][r] - delta);
+      }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const bf16x8 sb = __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(st[2 * u][0], st[2 * u][1]), pack_bf2(st[2 * u][2], st[2 * u][3]),
+                                                              pack_bf2(st[2 * u + 1][0], st[2 * u + 1][1]), pack_bf2(st[2 * u + 1][2], st[2 * u + 1][3])));
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) dq[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Kt, nb, u, l15, lg), sb, dq[nb], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  unsigned char* Os = smem;
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+    *(uint2*)(Os + (wave * 16 + l15) * OS_RS + (nb * 16 + 4 * lg) * 2) = make_uint2(pack_bf2(dq[nb][0], dq[nb][1]), pack_bf2(dq[nb][2], dq[nb][3]));
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid, row = c >> 4, ch = c & 15;
+    if (q0 + row < S) *(uint4*)(a.dqkv + ((int64_t)b * S + q0 + row) * ld + h * DK + ch * 8) = *(const uint4*)(Os + row * OS_RS + ch * 16);
+  }
+}
+
+__device__ __forceinline__ void flash_bwd_kv_t_body(const FlashArgs& a, unsigned char* smem) {     // uses 66,048 B of smem
+  unsigned char* Qr = smem;                          // Q tile, row-major image            (A operand of S = Q K^T)
+  unsigned char* Dr = smem + KS_BYTES;               // dO tile, row-major image           (A operand of dP = dO V^T)
+  unsigned char* Qt = Dr + KS_BYTES;                 // Q tile, store_tr8 image            (A operand of dK^T += Q^T dS)
+  unsigned char* Dt = Qt + VS_BYTES;                 // dO tile, store_tr8 image           (A operand of dV^T += dO^T P)
+  float* LD = (float*)(Dt + VS_BYTES);               // [64] LSE | [64] delta of the query tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  int tile_x, z;
+  xcd_tile(tile_x, z, a.plain_order);
+  const int b = z / a.H, h = z - b * a.H;
+  const int k0 = tile_x * TK;
+  const int S = a.S, ld = 3 * a.d;
+  const int len = a.lens ? min((int)a.lens[b], S) : S;
+  const bf16_t* base = a.qkv + (int64_t)b * S * ld + h * DK;
+  const bf16_t* dob = a.dout + (int64_t)b * S * a.d + h * DK;
+  const int ntq = (S + TQ - 1) / TQ;
+  const bool key_live = k0 + wave * 16 + l15 < len;   // this lane's key (column l15 of the wave's 16)
+
+  f32x4 dk[8], dv[8];                                 // dK^T / dV^T: rows d = 16*nb + 4*lg + r, column = the key
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) { dk[nb] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[nb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  if (k0 < len) {        // (a key tile entirely past the utterance gets zero gradients: nothing to compute)
+    uint4 rq[4], rd[4];
+    load_tile(rq, base, ld, 0, S, tid);
+    load_tile(rd, dob, a.d, 0, S, tid);
+    {  // K and V fragments of this wave's 16 keys: through LDS once (Qr / Dr slots), then registers
+      uint4 rk[4], rv[4];
+      load_tile(rk, base + a.d, ld, k0, S, tid);
+      load_tile(rv, base + 2 * a.d, ld, k0, S, tid);
+      store_rows(Qr, rk, tid);
+      store_rows(Dr, rv, tid);
+    }
+    __syncthreads();
+    bf16x8 kb[4], vb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { kb[ks] = frag_rows(Qr, wave * 16, ks, l15, lg); vb[ks] = frag_rows(Dr, wave * 16, ks, l15, lg); }
+
+    for (int i = 0; i < ntq; ++i) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();                            // the previous tile's (or the K / V staging's) LDS reads are done
+      store_rows(Qr, rq, tid);
+      store_tr8(Qt, rq, tid);
+      store_rows(Dr, rd, tid);
+      store_tr8(Dt, rd, tid);
+      if (tid < 128) {
+        const int q = i * TQ + (tid & 63);
+        const float* src = tid < 64 ? a.lse : a.delta;
+        LD[tid] = q < S ? src[(int64_t)z * S + q] : 0.f;
+      }
+      if (i + 1 < ntq) { load_tile(rq, base, ld, (i + 1) * TQ, S, tid); load_tile(rd, dob, a.d, (i + 1) * TQ, S, tid); }
+      __syncthreads();
+      f32x4 s[4], dp[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) { s[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qr, nt * 16, ks, l15, lg), kb[ks], s[nt], 0, 0, 0);
+          dp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Dr, nt * 16, ks, l15, lg), vb[ks], dp[nt], 0, 0, 0);
+        }
+      // rows = queries 16*nt + 4*lg + r of the tile, column = this lane's key
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const f32x4 lq = *(const f32x4*)(LD + nt * 16 + 4 * lg), dq_ = *(const f32x4*)(LD + 64 + nt * 16 + 4 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = i * TQ + nt * 16 + 4 * lg + r;
+          const float p = (key_live && q < S) ? __expf(s[nt][r] * a.scale - lq[r]) : 0.f;
+          s[nt][r] = p;
+          dp[nt][r] = a.scale * p * (dp[nt][r] - dq_[r]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(s[2 * u][0], s[2 * u][1]), pack_bf2(s[2 * u][2], s[2 * u][3]),
+                                                                pack_bf2(s[2 * u + 1][0], s[2 * u + 1][1]), pack_bf2(s[2 * u + 1][2], s[2 * u + 1][3])));
+        const bf16x8 sb = __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(dp[2 * u][0], dp[2 * u][1]), pack_bf2(dp[2 * u][2], dp[2 * u][3]),
+                                                                pack_bf2(dp[2 * u + 1][0], dp[2 * u + 1][1]), pack_bf2(dp[2 * u + 1][2], dp[2 * u + 1][3])));
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+          dv[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Dt, nb, u, l15, lg), pb, dv[nb], 0, 0, 0);
+          dk[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Qt, nb, u, l15, lg), sb, dk[nb], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- dK^T, dV^T -> bf16 -> LDS (8-byte pieces) -> full-row stores into the k / v columns of dqkv
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  unsigned char* Os = smem;                   // two 64 x 272 B tiles = 34 KiB
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) {
+    *(uint2*)(Os + (wave * 16 + l15) * OS_RS + (nb * 16 + 4 * lg) * 2) = make_uint2(pack_bf2(dk[nb][0], dk[nb][1]), pack_bf2(dk[nb][2], dk[nb][3]));
+    *(uint2*)(Os + 64 * OS_RS + (wave * 16 + l15) * OS_RS + (nb * 16 + 4 * lg) * 2) =
+        make_uint2(pack_bf2(dv[nb][0], dv[nb][1]), pack_bf2(dv[nb][2], dv[nb][3]));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid, row = c >> 4, ch = c & 15;
+    if (k0 + row < S) {
+      bf16_t* dst = a.dqkv + ((int64_t)b * S + k0 + row) * ld + h * DK + ch * 8;
+      *(uint4*)(dst + a.d) = *(const uint4*)(Os + row * OS_RS + ch * 16);
+      *(uint4*)(dst + 2 * a.d) = *(const uint4*)(Os + 64 * OS_RS + row * OS_RS + ch * 16);
+    }
+  }
+}
+
 // delta[z][q] = sum_d dO[q][h*128 + d] * O[q][h*128 + d] (O in fp32 when kept): a 16-lane group per (row, head), 16 rows per workgroup
 __global__ __launch_bounds__(256) void flash_delta_kernel(const FlashArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
@@ -586,11 +793,20 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashArgs a) {
   if (blockIdx.z == 0) flash_bwd_q_body(a, smem);
   else flash_bwd_kv_body(a, smem);
 }
+__global__ __launch_bounds__(256, 2) void flash_bwd_t_kernel(const FlashArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KS_BYTES + 2 * VS_BYTES + 512];           // 66,048 B (the key side's)
+  if (blockIdx.z == 0) flash_bwd_q_t_body(a, smem);
+  else flash_bwd_kv_t_body(a, smem);
+}
 
 }  // namespace
 
 static int flash_fwd_variant() {          // TTSK_FLASH_FWD=0: the round-2 forward (P through LDS); default: flash_fwd_t_kernel
   static const int v = [] { const char* e = getenv("TTSK_FLASH_FWD"); return (e && atoi(e) == 0) ? 0 : 1; }();
+  return v;
+}
+static int flash_bwd_variant() {          // TTSK_FLASH_BWD=0: the round-2 backward (P / dS through LDS); default: flash_bwd_t_kernel
+  static const int v = [] { const char* e = getenv("TTSK_FLASH_BWD"); return (e && atoi(e) == 0) ? 0 : 1; }();
   return v;
 }
 static int flash_plain_order() {
@@ -621,7 +837,8 @@ extern "C" int ttsk_flash_attention_bwd(const void* qkv_bf16, const void* o_bf16
               (const long long*)lens, S, H, d, scale};
   a.plain_order = flash_plain_order();
   if (!delta_ready) hipLaunchKernelGGL(flash_delta_kernel, dim3((S + 15) / 16, B * H), dim3(256), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(flash_bwd_kernel, dim3((S + TQ - 1) / TQ, B * H, 2), dim3(256), 0, (hipStream_t)stream, a);
+  if (flash_bwd_variant()) hipLaunchKernelGGL(flash_bwd_t_kernel, dim3((S + TQ - 1) / TQ, B * H, 2), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(flash_bwd_kernel, dim3((S + TQ - 1) / TQ, B * H, 2), dim3(256), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

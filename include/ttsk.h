@@ -191,6 +191,15 @@ int ttsk_win_conv(const void* x_bf16, const void* w_packed, const float* bias /*
 int ttsk_win_conv_stats_rows(int B, int S);
 int ttsk_win_conv_stats(const void* x_bf16, const void* w_packed, const float* bias, float* out_f32, float* stats,
                         const int32_t* frame_limit, int B, int S, int Cin, int Cout, int K, void* stream);
+/* ttsk_win_conv (Cin = 512, bf16 output: the input gradient of a PostNet 512 -> 512 conv, run on the transposed pack) that also emits
+ * the BatchNorm-BACKWARD statistics partials of the layer below — the layer whose upstream gradient `out` is (Layers.py:133-143
+ * backwards: conv_i's input gradient is dL/d(dropout(tanh(BN_{i-1}(yc_{i-1}))))): stats[ttsk_win_conv_stats_rows(B, S)][2*Cout] =
+ * per-channel sum of dy | sum of dy * xhat per (utterance, 64-frame tile) over the rows that exist, dy = out * keep / (1-p) * (1 -
+ * tanh^2(gamma * xhat + beta)) (use_tanh), xhat = (bn_x - mean) * rstd — the `partials` of ttsk_bn_bwd_apply_slab, so that layer needs no
+ * ttsk_bn_bwd_stats_slab launch.  keep: ttsk_bn_train_apply's keep bits (required when p > 0). */
+int ttsk_win_conv_bnb(const void* x_bf16, const void* w_packed, void* out_bf16, float* stats, const float* bn_x_f32, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta, const uint8_t* keep, float p, int use_tanh,
+                      const int32_t* frame_limit, int B, int S, int Cin, int Cout, int K, void* stream);
 /* HiFi-GAN's stride-8 upsamplers, ConvTranspose1d(Cin -> Cout, k = 16, stride 8, padding 4) (hifi/models.py:166-176,189 with
  * upsample_rates[i] = 8), on the window-conv kernel: x16 (B, T, Cin) fp16 -> out16 (B, 8T, Cout) fp16.  Output frame 8t + r reads
  * x[t] (weight tap r + 4) and x[t - 1] (r < 4: tap r + 12) or x[t + 1] (r >= 4: tap r - 4): a conv with two pseudo-taps and 8 * Cout

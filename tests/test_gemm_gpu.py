@@ -623,6 +623,42 @@ def test_win_conv_emits_batchnorm_partials(B, S, limit):
     assert float((o1.float() - o0.float()).abs().max()) <= 2 ** -7
 
 
+@pytest.mark.parametrize("B,S,limit,p", [(16, 423, None, 0.5), (2, 448, 423, 0.5), (3, 70, 61, 0.0), (1, 64, None, 0.5)])
+def test_win_conv_emits_batchnorm_backward_partials(B, S, limit, p):
+    """ttsk_win_conv_bnb (a PostNet 512 -> 512 conv's input gradient on its transposed pack, bf16 out): output bit-identical to
+    ttsk_win_conv, and its statistics partials give ttsk_bn_bwd_apply_slab the sums that ttsk_bn_bwd_stats_slab computes from the stored
+    gradient — so dx, dgamma and dbeta of the layer below agree (tanh, dropout keep bits and the frame limit included)."""
+    from tts_king_amd import ops
+    g = torch.Generator().manual_seed(B * 11 + S)
+    C = 512
+    dy = bf(torch.randn(B, S, C, generator=g)).to(DEV)
+    W = bf(torch.randn(C, 5, C, generator=g) * (5 * C) ** -0.5).to(DEV)
+    pkt = torch.empty(W.numel(), dtype=torch.bfloat16, device=DEV)
+    ops.win_conv_pack_items([(W, pkt, True)])
+    fl = None if limit is None else (torch.tensor([limit], dtype=torch.int32, device=DEV), S)
+    rows = B * S
+    yc = torch.randn(rows, C, generator=g).to(DEV)                      # the layer below: conv output (fp32), statistics, affine, keep bits
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    rng = ops.rng_of(ops.optim_state(DEV, seed=1234)) if p > 0 else None
+    z = lambda: (torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV))
+    _, mean, rstd, keep = ops.bn_train(yc, *z(), gamma, beta, True, p=p, site=301, rng=rng, frame_limit=fl, want_keep=True)
+    want = ops.win_conv(dy, pkt, C, 5)
+    got, stats = ops.win_conv_bnb(dy, pkt, C, 5, yc, mean, rstd, gamma, beta, True, p=p, keep=keep, frame_limit=fl)
+    assert torch.equal(got, want) and stats.shape == (B * ((S + 63) // 64), 2 * C)
+    outs = []
+    for part in (None, stats):
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        dx = ops.bn_bwd(want.view(rows, C), yc, mean, rstd, gamma, beta, True, p=p, site=301, rng=rng, dgamma=dg, dbeta=db, frame_limit=fl,
+                        keep=keep, accumulate=False, partials=part)
+        outs.append((dx.float().cpu(), dg.cpu(), db.cpu()))
+    (dx0, dg0, db0), (dx1, dg1, db1) = outs
+    sc = float(dg0.abs().max()) + float(db0.abs().max())
+    print("BN backward from conv partials: max |dgamma diff| %.2e, |dbeta diff| %.2e of %.2e" % (float((dg1 - dg0).abs().max()), float((db1 - db0).abs().max()), sc))
+    np.testing.assert_allclose(dg1.numpy(), dg0.numpy(), rtol=2e-5, atol=2e-5 * sc)
+    np.testing.assert_allclose(db1.numpy(), db0.numpy(), rtol=2e-5, atol=2e-5 * sc)
+    assert float((dx1 - dx0).abs().max()) <= 2 ** -7 * float(dx0.abs().max())
+
+
 @pytest.mark.parametrize("B,S,K", [(3, 130, 1024), (16, 423, 1024), (2, 33, 256), (16, 64, 1024)])
 def test_win_ln_with_qkv_projection_equals_two_launches(B, S, K):
     """ttsk_win_ln_proj_fwd (w_2 / fc + dropout + residual + LayerNorm, then the NEXT block's q|k|v projection of the output rows in

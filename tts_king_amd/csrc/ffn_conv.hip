@@ -60,6 +60,20 @@ struct WcArgs {
   // C_out switches slot 1's row shift to that rule (a channel group lies inside one phase: C_out >= the group's width).
   int ups_cout;
   int ups_half;       // phases r < ups_half take x[t - 1] on slot 1, the others x[t + 1] (stride / 2: 4 for stride 8; 1 for stride 2, k = 4, padding 1)
+  // BatchNorm backward statistics of the layer BELOW folded into the input-gradient conv that produces its upstream gradient (bf16
+  // output, CIN = 512: the PostNet's 512 -> 512 convs, Layers.py:133-143 backwards): with this conv's output tile = dL/d(dropout(tanh(
+  // BN(yc)))) in hand, bnb_stats[tile][2*Cout] = per-channel sum of dy | sum of dy * xhat over the tile's rows that exist, where xhat =
+  // (yc - mean) * rstd and dy = out * keep * 1/(1-p) * (1 - tanh^2(gamma * xhat + beta)) — the partial rows ttsk_bn_bwd_apply_slab sums,
+  // instead of a ttsk_bn_bwd_stats_slab launch re-reading out and yc (csrc/batchnorm.hip:bn_dy is the same arithmetic).
+  const float* bnb_x;        // yc [B*S][Cout] fp32, or null: no statistics
+  const float* bnb_mean;
+  const float* bnb_rstd;
+  const float* bnb_gamma;
+  const float* bnb_beta;
+  const uint8_t* bnb_keep;   // the forward's dropout keep bits, one byte per (row, channel quad); may be null when bnb_p == 0
+  float* bnb_stats;
+  float bnb_p;
+  int bnb_tanh;
 #ifdef TTSK_STAMPS
   unsigned long long* stamps;   // diagnostic build only (make stamps; ttsk_win_conv_set_stamps): 8 x s_memrealtime per workgroup
 #endif
@@ -306,6 +320,22 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
     }
   }
   WC_STAMP(3);
+  // (BatchNorm-backward statistics, see the end of the kernel: the layer-below rows this thread will need are requested now, so that
+  // they arrive during the staging and the stores)
+  f32x4 bnb_v[8];
+  unsigned bnb_kb[8];
+  if constexpr (!OUT32 && CIN == 512 && !F16 && NWV == 8 && CTV == 2) {
+    if (a.bnb_x) {
+      const int cq = cg * COUT + (tid & 63) * 4, rg = tid >> 6;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {                 // rows past the utterance: clamped here, zeroed where they are used
+        const int t = min(t0 + rg + 8 * k, S - 1);
+        const int64_t row = (int64_t)bi * S + t;
+        bnb_v[k] = *(const f32x4*)(a.bnb_x + row * a.Cout + cq);
+        bnb_kb[k] = (a.bnb_p > 0.f && a.bnb_keep) ? a.bnb_keep[row * (a.Cout >> 2) + (cq >> 2)] : 0xFu;
+      }
+    }
+  }
   __syncthreads();          // every wave is done with the window: its rows become the output staging tile
   WC_STAMP(4);
 
@@ -377,6 +407,47 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
       dacc = quad16_sum(dacc);
       const int hd = (cg * COUT + ch * 8) / 128, nh = a.Cout / 128;
       if (idx < TT * OCH && t < S && (ch & 15) == 0) a.delta[((int64_t)bi * nh + hd) * S + t] = dacc;
+    }
+  }
+  if constexpr (!OUT32 && CIN == 512 && !F16 && NWV == 8 && CTV == 2) {
+    if (a.bnb_x) {
+      // thread = (channel quad of the group's 256 channels, one of 8 row groups); rows rg, rg + 8, ... of the tile
+      static_assert(TT == 64 && NT == 512, "eight rows per thread");
+      const int quad = tid & 63, rg = tid >> 6;
+      const int C = a.Cout, cq = cg * COUT + quad * 4;
+      const int lim = a.frame_limit ? (a.frame_limit[0] < S ? a.frame_limit[0] : S) : S;
+      const float scale = a.bnb_p > 0.f ? 1.f / (1.f - a.bnb_p) : 1.f;
+      const f32x4 m = *(const f32x4*)(a.bnb_mean + cq), rs = *(const f32x4*)(a.bnb_rstd + cq);
+      const f32x4 gmm = *(const f32x4*)(a.bnb_gamma + cq), bt = *(const f32x4*)(a.bnb_beta + cq);
+      float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int rr = rg + 8 * k;
+        const uint2 u = *(const uint2*)(XW + rr * SRS + quad * 8);      // the gradient as stored (bf16)
+        float dy[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
+        const bool live = t0 + rr < lim;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (a.bnb_p > 0.f) dy[e] = ((bnb_kb[k] >> e) & 1u) ? dy[e] * scale : 0.f;
+          float xh = (bnb_v[k][e] - m[e]) * rs[e];
+          if (a.bnb_tanh) { const float tt = 1.f - 2.f * __frcp_rn(__expf(2.f * (xh * gmm[e] + bt[e])) + 1.f); dy[e] *= 1.f - tt * tt; }
+          if (!live) { xh = 0.f; dy[e] = 0.f; }
+          sm[e] += dy[e];
+          sq[e] += dy[e] * xh;
+        }
+      }
+      __syncthreads();                               // every thread is done reading the staged tile: it becomes the reduction buffer
+      float* red = (float*)XW;                       // [8 row groups][2][256]
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { red[(rg * 2 + 0) * COUT + quad * 4 + e] = sm[e]; red[(rg * 2 + 1) * COUT + quad * 4 + e] = sq[e]; }
+      __syncthreads();
+      {
+        const int c = tid & (COUT - 1), half = tid / COUT;           // 512 threads: sums | second sums
+        float acc = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) acc += red[(g * 2 + half) * COUT + c];
+        a.bnb_stats[((int64_t)bi * a.tiles_per_utt + t0 / TT) * 2 * C + half * C + cg * COUT + c] = acc;
+      }
     }
   }
   WC_STAMP(5);
@@ -539,6 +610,24 @@ extern "C" int ttsk_win_conv_stats(const void* x_bf16, const void* w_packed, con
   TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_packed) | ((uintptr_t)bias) | ((uintptr_t)out_f32)) & 15) == 0, "ttsk_win_conv_stats: 16-byte alignment");
   WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, bias, out_f32, S, K, Cout, 0, 0, 0, nullptr, 1, Cin, 0, nullptr, nullptr, stats, frame_limit};
   launch_win_conv(a, B, S, Cin, 1, 1, (hipStream_t)stream);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+// ttsk_win_conv (Cin = 512, bf16 output, no gate / delta) that also emits the BatchNorm-backward statistics partials of the layer whose
+// upstream gradient it produces: see WcArgs::bnb_x.
+extern "C" int ttsk_win_conv_bnb(const void* x_bf16, const void* w_packed, void* out_bf16, float* stats, const float* bn_x_f32,
+                                 const float* mean, const float* rstd, const float* gamma, const float* beta, const uint8_t* keep, float p,
+                                 int use_tanh, const int32_t* frame_limit, int B, int S, int Cin, int Cout, int K, void* stream) {
+  TTSK_REQUIRE(x_bf16 && w_packed && out_bf16 && stats && bn_x_f32 && mean && rstd && gamma && beta, "ttsk_win_conv_bnb: null pointer");
+  TTSK_REQUIRE(B > 0 && S > 0 && B <= 65535, "ttsk_win_conv_bnb: bad sizes B=%d S=%d", B, S);
+  TTSK_REQUIRE(Cin == 512 && ttsk_win_conv_supported(Cin, Cout, K), "ttsk_win_conv_bnb: built for Cin = 512 (got Cin=%d Cout=%d K=%d)", Cin, Cout, K);
+  TTSK_REQUIRE(p >= 0.f && p < 1.f && (p == 0.f || keep), "ttsk_win_conv_bnb: dropout needs the forward's keep bits");
+  TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_packed) | ((uintptr_t)out_bf16) | ((uintptr_t)bn_x_f32) | ((uintptr_t)mean) | ((uintptr_t)rstd) |
+                 ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0, "ttsk_win_conv_bnb: 16-byte alignment");
+  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, nullptr, out_bf16, S, K, Cout, 0, 0, 0, nullptr, 1, Cin, 0, nullptr, nullptr, nullptr, frame_limit,
+           0, 0, bn_x_f32, mean, rstd, gamma, beta, keep, stats, p, use_tanh};
+  launch_win_conv(a, B, S, Cin, 0, 1, (hipStream_t)stream);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

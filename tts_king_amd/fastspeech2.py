@@ -151,6 +151,7 @@ class FastSpeech2(nn.Module):
         self.flash_attention = True     # ... and without the S x S tensors: online softmax forward, recomputing backward (d_k = 128)
         self.fused_ln = True            # fc / w_2 + dropout + residual + LayerNorm + PAD zeroing in one kernel when d = 256
         self.bn_stats_in_conv = os.environ.get("TTSK_BN_STATS_IN_CONV", "1") != "0"   # PostNet 512 -> 512 convs emit their BatchNorm statistics partials
+        self.bn_bwd_stats_in_conv = os.environ.get("TTSK_BN_BWD_STATS_IN_CONV", "1") != "0"   # ... and their input-gradient convs the backward's
         self.fused_qkv_tail = os.environ.get("TTSK_FUSED_QKV_TAIL", "1") != "0"   # a block's last kernel also projects q|k|v for the next block
         self.fused_qkv_dx = os.environ.get("TTSK_FUSED_QKV_DX", "1") != "0"   # ... and the q|k|v input gradient of the block behind in front of it
         self.fused_ln_bwd = os.environ.get("TTSK_FUSED_LN_BWD", "1") != "0"   # LayerNorm backward + the k = 1 dX projection behind it in one kernel
@@ -1225,12 +1226,14 @@ class FastSpeech2(nn.Module):
                 pred_dxin = self._predictors_bwd_inputs(ctx.preds["grouped"], self._stack3(dlogd, dpitch, denergy), rng)
         # ---- PostNet (last layer first)
         dout = dpost.view(rows, nm)
+        bn_partials = None          # BatchNorm-backward statistics of layer i, when conv i+1's input-gradient kernel emitted them
         for i in range(4, -1, -1):
             pp, xin, yc, mean, rstd, keep = ctx.pn[i]
             C = yc.shape[2]
             dy = ops.bn_bwd(dout, yc.view(rows, C), mean, rstd, self._m(pp + "1.weight"), self._m(pp + "1.bias"), i < 4,
                             p=self.p_post, site=300 + i, rng=rng, dgamma=self._g(pp + "1.weight"), dbeta=self._g(pp + "1.bias"),
-                            frame_limit=ctx.frame_limit, keep=keep, accumulate=self._acc)
+                            frame_limit=ctx.frame_limit, keep=keep, accumulate=self._acc, partials=bn_partials)
+            bn_partials = None
             with self._side_work(dy, xin):
                 ops.colsum_into(dy, self._g(pp + "0.conv.bias"), defer=self._deferred_fin, accumulate=self._acc)
                 # (no `lens`: the PostNet's BatchNorm runs over the PAD rows too, Layers.py:133-143 — its gradients there are not zero)
@@ -1239,7 +1242,16 @@ class FastSpeech2(nn.Module):
             pkt = self._w1_packed.get(("pnT", pp + "0.conv.weight")) if (self.window_ffn and self._w1_packed) else None
             if i > 0 and pkt is not None:
                 cw = self._table[pp + "0.conv.weight"].storage_shape
-                dout = ops.win_conv(dy.view(Bn, T, C), pkt, cw[2], cw[1]).view(rows, -1)       # dX as a forward conv on the transposed pack
+                pb, _, ycb, meanb, rstdb, keepb = ctx.pn[i - 1]
+                if (self.bn_bwd_stats_in_conv and C == 512 and cw[2] == 512 and ycb.dtype == torch.float32 and ops.bn_slab_supported(cw[2])
+                        and (keepb is not None or self.p_post == 0.0)):
+                    # ... which also sums the BatchNorm-backward statistics of the layer below over its output tile
+                    dout, bn_partials = ops.win_conv_bnb(dy.view(Bn, T, C), pkt, cw[2], cw[1], ycb.view(rows, cw[2]), meanb, rstdb,
+                                                         self._m(pb + "1.weight"), self._m(pb + "1.bias"), True, p=self.p_post, keep=keepb,
+                                                         frame_limit=ctx.frame_limit)
+                    dout = dout.view(rows, -1)
+                else:
+                    dout = ops.win_conv(dy.view(Bn, T, C), pkt, cw[2], cw[1]).view(rows, -1)   # dX as a forward conv on the transposed pack
             elif i > 0:
                 dout = ops.conv1d_dx(dy.view(Bn, T, C), self._w(pp + "0.conv.weight")).view(rows, -1)
             else:

@@ -607,6 +607,22 @@ def win_conv_stats(x, packed, Cout, k, bias=None, frame_limit=None):
     return out, stats
 
 
+def win_conv_bnb(x, packed, Cout, k, bn_x, mean, rstd, gamma, beta, use_tanh, p=0.0, keep=None, frame_limit=None):
+    """win_conv with bf16 output (Cin = 512: a PostNet conv's input gradient on its transposed pack) that also returns the BatchNorm-
+    backward statistics partials of the layer below, whose upstream gradient the output is ([B * ceil(S/64)][2*Cout] fp32: sum of dy | sum
+    of dy * xhat per tile) for bn_bwd(partials=...) (ttsk_win_conv_bnb).  bn_x (B*S, Cout) fp32: that layer's conv output; keep: its
+    bn_train keep bits."""
+    _dev(x, packed, bn_x, mean, rstd, gamma, beta, keep)
+    Bsz, S, Cin = x.shape
+    lib = L.load()
+    out = torch.empty(Bsz, S, Cout, dtype=bf16, device=x.device)
+    stats = _f32(lib.ttsk_win_conv_stats_rows(Bsz, S), 2 * Cout, device=x.device)
+    lp, _ = _lim(frame_limit)
+    check(lib.ttsk_win_conv_bnb(_ptr(x), _ptr(packed), _ptr(out), _ptr(stats), _ptr(bn_x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
+                                _ptr(keep), float(p), int(use_tanh), lp, Bsz, S, Cin, Cout, k, _stream()), "ttsk_win_conv_bnb")
+    return out, stats
+
+
 def win_conv_split(x, packed, Cout, k):
     """An input-gradient conv with a wide contraction (x (B,S,n*256) bf16) as n window convs over 256-channel slices in one launch:
     fp32 Slabs (n, B*S*Cout) for layernorm_bwd(slabs=...) (ttsk_win_conv_split).  `packed`: the whole transposed pack."""
@@ -1242,17 +1258,18 @@ def bn_train(x, running_mean, running_var, nbt, gamma, beta, use_tanh, p=0.0, si
 
 
 def bn_bwd(dout, x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, dgamma=None, dbeta=None, frame_limit=None, keep=None,
-           accumulate=True):
+           accumulate=True, partials=None):
     """dx (rows,C) bf16; dgamma/dbeta (fp32, accumulated in place when given, or overwritten with accumulate=False).  keep: bn_train's
-    keep bits (slab kernels only)."""
+    keep bits (slab kernels only).  partials: the statistics partial rows when the conv that produced `dout` emitted them (win_conv_bnb)."""
     rows, Cn = x.shape
     lib = L.load()
     if bn_slab_supported(Cn):
-        partials = _f32(lib.ttsk_bn_nchunks(rows), 2 * Cn, device=x.device)
         f32, xf = int(dout.dtype == torch.float32), int(x.dtype == torch.float32)
         lp, seg = _lim(frame_limit)
-        check(lib.ttsk_bn_bwd_stats_slab(_ptr(dout), f32, _ptr(x), xf, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn, int(use_tanh),
-                                         p, site, _ptr(rng), _ptr(keep), _ptr(partials), lp, seg, _stream()), "ttsk_bn_bwd_stats_slab")
+        if partials is None:
+            partials = _f32(lib.ttsk_bn_nchunks(rows), 2 * Cn, device=x.device)
+            check(lib.ttsk_bn_bwd_stats_slab(_ptr(dout), f32, _ptr(x), xf, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn, int(use_tanh),
+                                             p, site, _ptr(rng), _ptr(keep), _ptr(partials), lp, seg, _stream()), "ttsk_bn_bwd_stats_slab")
         dx = torch.empty(rows, Cn, dtype=bf16, device=x.device)
         check(lib.ttsk_bn_bwd_apply_slab(_ptr(dout), f32, _ptr(x), xf, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), rows, Cn, int(use_tanh),
                                          p, site, _ptr(rng), _ptr(keep), _ptr(partials), partials.shape[0], _ptr(dx), _ptr(dgamma), _ptr(dbeta), int(accumulate),

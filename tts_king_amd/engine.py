@@ -135,6 +135,7 @@ class TrainEngine:
                     self.reducer.reset()
                 self.model._ctx = None
                 self.model._dw_side_pending = False
+                self.model._pred_fwd_pending = False
                 self.model.grads_partial = acc
                 torch.cuda.synchronize()
                 self._eager_only.add(key)

@@ -1045,7 +1045,7 @@ extern "C" int ttsk_colsum_finalize_batch(const ttsk_finalize_item* items, int n
       TTSK_REQUIRE(fb.it[i].partials && fb.it[i].dst && fb.it[i].nblk > 0 && fb.it[i].ncols > 0 && fb.it[i].ld >= fb.it[i].ncols,
                    "colsum_finalize_batch: bad item %d", base + i);
     }
-    hipLaunchKernelGGL(colsum_finalize_batch_kernel, dim3(16, m), dim3(256), 0, (hipStream_t)stream, fb);
+    hipLaunchKernelGGL(colsum_finalize_batch_kernel, dim3(64, m), dim3(256), 0, (hipStream_t)stream, fb);      // 64 x 16 columns: one pass for up to 1,024 columns
     TTSK_CHECK_LAUNCH();
   }
   return TTSK_OK;

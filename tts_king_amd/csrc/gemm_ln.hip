@@ -48,7 +48,18 @@ struct GemmLnArgs {
   const float* pbias;
   bf16_t* pout;
   int pCout;
+#ifdef TTSK_STAMPS
+  unsigned long long* stamps;   // diagnostic build only (make stamps; ttsk_win_ln_set_stamps): 8 x s_memrealtime per workgroup
+#endif
 };
+#ifdef TTSK_STAMPS
+#define WL_STAMP(i)                                                                                              \
+  do {                                                                                                           \
+    if (a.stamps && threadIdx.x == 0) a.stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define WL_STAMP(i) do {} while (0)        // the product library carries no stamp code and no global state for it
+#endif
 
 __device__ __forceinline__ void drop4(float v[4], uint64_t seed, uint64_t step, unsigned site, unsigned e4, unsigned thr, float scale) {
   const uint4 b = Philox::gen(make_uint2((unsigned)seed, (unsigned)(seed >> 32)),
@@ -251,6 +262,7 @@ __global__ __launch_bounds__(512, (CIN == 256 && !PROJ) ? 2 : 1) void win_ln_ker
   const int l15 = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.x * BM;
   const int M = a.M;
+  WL_STAMP(0);
   const bf16_t* wrow[CT];
 #pragma unroll
   for (int cc = 0; cc < CT; ++cc) wrow[cc] = a.W + ((int64_t)(wave * CT + cc) * 64 + lane) * 8;
@@ -290,7 +302,9 @@ __global__ __launch_bounds__(512, (CIN == 256 && !PROJ) ? 2 : 1) void win_ln_ker
       if (idx < TT * CH8) *(uint4*)(smem + row * RS + ch * 16) = xv[it];
     }
   }
+  WL_STAMP(1);
   __syncthreads();
+  WL_STAMP(2);
   f32x4 acc[CT][NF];
 #pragma unroll
   for (int cc = 0; cc < CT; ++cc)
@@ -324,9 +338,11 @@ __global__ __launch_bounds__(512, (CIN == 256 && !PROJ) ? 2 : 1) void win_ln_ker
       }
     }
   }
+  WL_STAMP(3);
   Proj32W PW;
   if (PROJ) proj32_prefetch(a.pw, a.pCout, wave, lane, PW);      // the next projection's first fragments arrive behind the LayerNorm rows
   __syncthreads();                         // every wave is done with the rows of A: they become the fp32 tile
+  WL_STAMP(4);
   float* cs = (float*)smem;
 #pragma unroll
   for (int i = 0; i < NF; ++i)
@@ -334,15 +350,26 @@ __global__ __launch_bounds__(512, (CIN == 256 && !PROJ) ? 2 : 1) void win_ln_ker
     for (int cc = 0; cc < CT; ++cc) *(f32x4*)(cs + (i * 16 + l15) * CS_LD + (wave * CT + cc) * 16 + q * 4) = acc[cc][i];
   __syncthreads();
   ln_rows_epilogue<RW>(a, cs, m0, wave, lane, resv, PROJ ? ptile : nullptr);
+  WL_STAMP(5);
   if (PROJ) {
     __syncthreads();
     proj32_run<3>(ptile, ptile + P32_TT * P32_RS, a.pw, a.pCout, a.pbias, PW, tid, [&](int cg, int rr, int ch, uint4 v, int) __attribute__((always_inline)) {
       if (m0 + rr < M) *(uint4*)(a.pout + (int64_t)(m0 + rr) * a.pCout + cg * BN + ch * 8) = v;
     });
   }
+  WL_STAMP(6);
 }
 
 }  // namespace
+
+#ifdef TTSK_STAMPS
+static unsigned long long* g_wl_stamps = nullptr;
+// diagnostic build only (`make stamps`, tools/debug/wl_stamps.py; not declared in ttsk.h, not in the product library)
+extern "C" int ttsk_win_ln_set_stamps(void* dev_buffer) {
+  g_wl_stamps = (unsigned long long*)dev_buffer;
+  return TTSK_OK;
+}
+#endif
 
 extern "C" int ttsk_gemm_ln_fwd(const void* A, int lda, const void* W, int ldw, const float* bias, const void* res,
                                 const float* gamma, const float* beta, void* out, void* z_save, float* mean, float* rstd,
@@ -390,6 +417,9 @@ static int win_ln_launch(const void* A, int lda, const void* W_packed, const flo
   GemmLnArgs a{(const bf16_t*)A, (const bf16_t*)W_packed, bias, (const bf16_t*)res, gamma, beta, (bf16_t*)out, (bf16_t*)z_save, mean, rstd,
                (const long long*)lens, (const uint64_t*)rng, M, K, lda, 0, seg_len > 0 ? seg_len : 1, p_pre, eps, site_pre,
                (const bf16_t*)proj_w, proj_bias, (bf16_t*)proj_out, proj_Cout};
+#ifdef TTSK_STAMPS
+  a.stamps = g_wl_stamps;
+#endif
   const dim3 grid((M + BM - 1) / BM);
   if (proj_w) {
     if (K == 256) hipLaunchKernelGGL((win_ln_kernel<256, true>), grid, dim3(512), 0, (hipStream_t)stream, a);

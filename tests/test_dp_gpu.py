@@ -58,6 +58,58 @@ def test_reducer_step_equals_plain_step(cfg, schedule):
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("schedule", ["side", "late"])
+def test_buckets_are_final_when_announced_full_size(cfg, schedule):
+    """at the training shape (B=16, L=64, T=423) the 80-channel weight gradients (mel_linear, the PostNet's first and
+    last conv) are split-K grouped problems; the "side" schedule used to reduce their slabs and announce their buckets BEFORE their
+    GEMMs had run.  At world size 1 an in-place all-reduce is the identity, so the final buffer cannot show that — this test looks at
+    what a collective would READ: the gradient buffer is poisoned, every bucket is snapshotted at the moment the reducer issues it
+    (after draining the issuing stream, eager launches), and each snapshot must already equal the bucket's final content, which in
+    turn must equal the plain (no reducer) backward bit for bit."""
+    from tests.test_parity_gpu import build
+    from tts_king_amd import ops
+    from tts_king_amd.parallel import GradReducer
+    from tts_king_amd.synthetic import make_batch
+    c = copy.deepcopy(cfg)
+    b = make_batch(16, 64, seed=1234)
+    dev_b = [t.to(DEV) if torch.is_tensor(t) else t for t in b]
+
+    def backward(m, on_bucket=None):
+        with torch.no_grad():
+            out, ctx = m._forward(True, dev_b[2], dev_b[3], dev_b[4], int(b[5]), dev_b[7], b[8], dev_b[9], dev_b[10], dev_b[11], 1.0, 1.0, 1.0)
+            _, dmel_sum, dpost, dp, de, dd = ops.fs2_loss(out[0], out[8], dev_b[6], dev_b[7], out[1], out[2], out[3], dev_b[11],
+                                                          dev_b[9], dev_b[10], dev_b[4], grad_scale=1.0)
+            m.flat_buffers()[1].fill_(1e30)                       # poison: the overwriting backward must leave none of it
+            m.backward_native(ctx, dmel_sum, dpost, dp, de, dd, on_bucket=on_bucket, accumulate=False)
+        torch.cuda.synchronize()
+        return m.flat_buffers()[1].clone()
+
+    m = build(c, 7, dropout=False).train()
+    m.dp_schedule = schedule
+    plain = backward(m)
+    assert float(plain.abs().max()) < 1e20
+    red = GradReducer(m.flat_buffers()[1], m.grad_buckets(24), m.group_offsets())
+    snaps = []
+
+    def on_group_done(name):
+        n0 = len(red.launched)
+        red.on_group_done(name)
+        if len(red.launched) > n0:
+            torch.cuda.current_stream().synchronize()            # the stream the collective would be issued from
+            for s, e in red.launched[n0:]:
+                snaps.append((name, s, e, m.flat_buffers()[1][s:e].clone()))
+
+    m.train()
+    final = backward(m, on_bucket=on_group_done)
+    red.finish()
+    assert red.launched == list(red.buckets)
+    assert len(snaps) == len(red.buckets)
+    assert torch.equal(final, plain), "data-parallel %s schedule: gradients differ from the plain backward" % schedule
+    for name, s, e, snap in snaps:
+        bad = int((snap != final[s:e]).sum())
+        assert bad == 0, "bucket [%d, %d) announced with group %r held %d elements that changed afterwards" % (s, e, name, bad)
+
+
 def test_reducer_step_is_graph_capturable(cfg):
     """The RCCL all-reduces are captured into the step's hipGraph (bench.py replays the data-parallel step too): three
     replays leave exactly the weights of three eager steps."""

@@ -10,6 +10,7 @@ wandb / matplotlib logging is replaced by a plain print (no network on the GPU b
 restores the optimizer state the reference saves but never reloads.
 """
 import os
+import sys
 
 import torch
 from torch.utils.data import DataLoader
@@ -137,4 +138,12 @@ def main(cfg, max_steps=None):
 
 
 if __name__ == "__main__":
-    main(load_config("./config.yaml"))
+    _cfg = load_config("./config.yaml")
+    # `mi355x.gpus: N` (N > 1) without a torch.distributed.run wrapper: this process starts its own N ranks — before anything here
+    # touches the GPU — and only relays their output (tts_king_amd/launch.py); under torch.distributed.run the rank environment is
+    # already there and `main` runs as one of the ranks.
+    from tts_king_amd import launch as _launch
+    _n = int((_cfg.get("mi355x", {}) or {}).get("gpus", 1)) if hasattr(_cfg, "get") else 1
+    if _launch.wants_spawn(_n):
+        raise SystemExit(_launch.spawn_ranks(_n, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+    main(_cfg)

@@ -1079,12 +1079,15 @@ class FastSpeech2(nn.Module):
         return (["postnet", "mel_linear"] + ["decoder.%d" % i for i in range(self.n_dec - 1, -1, -1)] + ["variance_adaptor"] +
                 ["encoder.%d" % i for i in range(self.n_enc - 1, -1, -1)] + ["embedding"])
 
-    def _launch_dw_side(self):
+    def _launch_dw_side(self, everything=False):
         """The weight-gradient work queued so far (PostNet, mel_linear, decoder), after the decoder's backward, beside the encoder-side
         dX chain on the main stream — two more branches (a replayed graph runs three queues side by side):
           * second stream: w_1's six gradients (dwconv, 192 workgroups = one per CU on 3/4 of the chip), the other 256-multiple ones
             (dwgemm, grid capped at `dw_side_wgs`) with their slab reducer, then the few grouped problems (80-channel outputs);
-          * third stream: the bias / LayerNorm column sums queued so far (HBM-bound: they overlap the MFMA-bound kernels beside them)."""
+          * third stream: the bias / LayerNorm column sums queued so far (HBM-bound: they overlap the MFMA-bound kernels beside them).
+        `everything` (the data-parallel "side" schedule): nothing may stay queued — neither the share `dw_side_frac` leaves for the
+        final flush nor the 128 x 128-tile problems (mel_linear, the PostNet's 80-channel ends) that `side_small = 0` leaves there:
+        the caller reduces every split-K slab and announces the buckets right behind this."""
         if self._dw_side is None:
             self._dw_side = torch.cuda.Stream(device=self.device)
         if self._fin_side is None:
@@ -1099,7 +1102,8 @@ class FastSpeech2(nn.Module):
         self._dw_side.wait_stream(cur)
         with torch.cuda.stream(self._dw_side):
             ops.stamp("side.start")
-            ops.flush_deferred_gemms(self._deferred, max_wgs=self.dw_side_wgs, frac=self.dw_side_frac, small_too=self.side_small)
+            ops.flush_deferred_gemms(self._deferred, max_wgs=self.dw_side_wgs, frac=1.0 if everything else self.dw_side_frac,
+                                     small_too=True if everything else self.side_small)
             if self.side_colsum == "after":
                 self._dp_keep = [k for _, k in self._deferred_fin]
                 ops.flush_finalize(self._deferred_fin)
@@ -1118,7 +1122,12 @@ class FastSpeech2(nn.Module):
         STREAM, the all-reduce of every bucket those groups complete — beside the encoder-side dX chain on the main stream, ahead of the
         final flush, which announces the encoder-side groups.  (Round 3 first cut this work at the bucket boundaries, a launch set per
         bucket: with dwconv / dwgemm covering all six blocks in one launch each that only added launches: 3.47 vs 3.09 ms on one GPU.)"""
-        self._launch_dw_side()
+        self._launch_dw_side(everything=True)
+        q = self._deferred
+        if q.group or q.dwconv or q.dwgemm:
+            # a problem still queued would write its gradient (or its split-K slabs) AFTER the reduce / all-reduce below read them
+            raise RuntimeError("data-parallel side schedule: %d grouped / %d dwconv / %d dwgemm weight-gradient problems still queued "
+                               "before the buckets are announced" % (len(q.group or ()), len(q.dwconv), len(q.dwgemm)))
         # the split-K slabs of the grouped problems just launched: summed here, not with the final flush (the buckets must be final)
         marks, self._dp_marks = self._dp_marks, []
         with torch.cuda.stream(self._dw_side):

@@ -10,6 +10,7 @@ reference: the reference has no launcher (train.py:104 is a commented-out nn.Dat
 `torchrun` wrapper the driver would otherwise have to supply.
 """
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -17,11 +18,22 @@ import time
 
 
 def free_port():
+    """A port nobody listens on right now.  (Bind-and-close leaves a window in which another process may take it; spawn_ranks
+    retries the whole job once on another port when rank 0 dies of EADDRINUSE before any rank has produced output.)"""
     s = socket.socket()
+    s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     return port
+
+
+class _Terminated(Exception):
+    pass
+
+
+def _raise_terminated(signum, frame):
+    raise _Terminated(signum)
 
 
 def under_profiler(env=None):
@@ -44,6 +56,23 @@ def visible_devices():
         return 0
 
 
+def threading_main():
+    import threading
+    return threading.current_thread() is threading.main_thread()
+
+
+def _signal_group(p, sig):
+    """Signal the rank's whole session (it was started with start_new_session: its pgid is its pid); the exact group we started,
+    never a pattern."""
+    try:
+        os.killpg(p.pid, sig)
+    except (ProcessLookupError, PermissionError):
+        try:
+            p.send_signal(sig)
+        except ProcessLookupError:
+            pass
+
+
 def spawn_ranks(n, argv, env=None, timeout=None, n_devices=None, stdout=None):
     """Start `argv` n times (rank r gets RANK=LOCAL_RANK=r), wait for all, write rank 0's stdout to `stdout` (default
     sys.stdout) and return the exit status: 0 only if every rank returned 0.  Ranks other than 0 have their stdout sent to
@@ -62,13 +91,21 @@ def spawn_ranks(n, argv, env=None, timeout=None, n_devices=None, stdout=None):
     base.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
                  "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
     procs = []
-    for r in range(n):
-        e = dict(base)
-        e.update({"RANK": str(r), "LOCAL_RANK": str(r)})
-        procs.append(subprocess.Popen(list(argv), env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None))
+    # SIGTERM / SIGINT / SIGHUP of the parent (`timeout N python bench.py`, a scheduler's kill) must not orphan the ranks — they would
+    # keep their GPUs and hang in the rendezvous or a collective: the handlers raise into the `finally` below, which ends every rank;
+    # the ranks live in a session of their own so that the whole tree of each (a rank's own helpers) can be signalled as a group.
+    old = {}
+    if threading_main():
+        for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+            old[sig] = signal.signal(sig, _raise_terminated)
     t_end = None if timeout is None else time.time() + timeout
     rc, out0 = 0, b""
     try:
+        for r in range(n):
+            e = dict(base)
+            e.update({"RANK": str(r), "LOCAL_RANK": str(r)})
+            procs.append(subprocess.Popen(list(argv), env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None,
+                                          start_new_session=True))
         pending = set(range(n))
         while pending:
             for r in sorted(pending):
@@ -92,15 +129,20 @@ def spawn_ranks(n, argv, env=None, timeout=None, n_devices=None, stdout=None):
                 break
             if pending and 0 not in pending:
                 time.sleep(0.1)
+    except _Terminated as t:
+        rc = 128 + int(t.args[0])
     finally:
+        for sig, h in old.items():
+            signal.signal(sig, h)
         for p in procs:
             if p.poll() is None:
-                p.terminate()
+                _signal_group(p, signal.SIGTERM)
         for p in procs:
             try:
                 p.wait(timeout=10)
             except subprocess.TimeoutExpired:
-                p.kill()
+                _signal_group(p, signal.SIGKILL)
+                p.wait()
     (stdout or sys.stdout.buffer).write(out0)
     (stdout or sys.stdout.buffer).flush()
     return rc

@@ -488,6 +488,17 @@ int ttsk_hifi_resblock1(const void* x16, void* out16, int f16, const void* const
                         const int32_t* dilations, int B, int len, int C, int K, int mode, float scale, float slope,
                         float final_slope, void* stream);
 int ttsk_hifi_resblock1_supported(int C, int K);
+/* The WHOLE last stage of the generator in one launch (hifi/models.py:190-199, csrc/mrf32.hip): the three ResBlock1s of the C = 32
+ * multi-receptive-field fusion (kernel sizes k0, k1, k2 = 3, 7, 11) on the same raw input x16 (B, len, 32), their sum * scale (1/3),
+ * LeakyReLU(final_slope = 0.01: F.leaky_relu's default, :197), conv_post (32 -> 1, k_post = 7; w_post16 (1, 7, 32) tap-major 16-bit as
+ * for ttsk_hifi_conv_post) and tanh: out (B, 1, len) fp32.  weights / biases: 18 entries, block j's six convs at [6 j ..] in
+ * ttsk_hifi_resblock1's order and packs; dilations: 3 x 3.  stage_out16 (optional, (B, len, 32)): the activated average that
+ * conv_post reads, for tests.  Bit-identical to three ttsk_hifi_resblock1 launches (modes 0, 1, 2) + ttsk_hifi_conv_post; one read of
+ * x and one write of the waveform instead of nine tensor passes. */
+int ttsk_hifi_mrf32_post_supported(int C, int k0, int k1, int k2, int k_post);
+int ttsk_hifi_mrf32_post(const void* x16, float* out, void* stage_out16, int f16, const void* const* weights, const float* const* biases,
+                         const int32_t* dilations, const void* w_post16, const float* b_post, int B, int len, int C, int k0, int k1, int k2,
+                         int k_post, float slope, float final_slope, float scale, void* stream);
 
 /* rows (u, t) with t >= frame_limit[0] of x [rows][C] (elem_bytes 2 or 4, row = u*seg_len + t) are set to zero: the mel
  * frames / mel gradients past the batch's own longest utterance under shape-bucketed training (see BatchNorm below). */

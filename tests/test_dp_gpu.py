@@ -86,8 +86,13 @@ def test_buckets_are_final_when_announced_full_size(cfg, schedule):
 
     m = build(c, 7, dropout=False).train()
     m.dp_schedule = schedule
+    from tts_king_amd import params as P
+    owned = torch.zeros(m.flat_buffers()[1].numel(), dtype=torch.bool, device=DEV)      # (the alignment padding between parameters is never written)
+    for en in m._table.values():
+        if en.kind == P.TRAIN:
+            owned[en.offset:en.offset + en.numel] = True
     plain = backward(m)
-    assert float(plain.abs().max()) < 1e20
+    assert float(plain[owned].abs().max()) < 1e20
     red = GradReducer(m.flat_buffers()[1], m.grad_buckets(24), m.group_offsets())
     snaps = []
 
@@ -104,9 +109,9 @@ def test_buckets_are_final_when_announced_full_size(cfg, schedule):
     red.finish()
     assert red.launched == list(red.buckets)
     assert len(snaps) == len(red.buckets)
-    assert torch.equal(final, plain), "data-parallel %s schedule: gradients differ from the plain backward" % schedule
+    assert torch.equal(final[owned], plain[owned]), "data-parallel %s schedule: gradients differ from the plain backward" % schedule
     for name, s, e, snap in snaps:
-        bad = int((snap != final[s:e]).sum())
+        bad = int(((snap != final[s:e]) & owned[s:e]).sum())
         assert bad == 0, "bucket [%d, %d) announced with group %r held %d elements that changed afterwards" % (s, e, name, bad)
 
 

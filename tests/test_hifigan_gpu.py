@@ -376,3 +376,66 @@ def test_window_upsample2_vs_fp64_and_stream_kernel(B, T):
     assert r <= 1e-3 and worst <= 2e-3
     other = ops.hifi_upsample2(x.to(DEV), wp, bias.to(DEV))
     assert float((other.float() - out.float()).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
+def _mrf32_inputs(dtype, B, ln, seed):
+    """Seeded stage input and the 18 conv packs / biases + conv_post of a C = 32 last stage (kernel sizes 3, 7, 11)."""
+    from tts_king_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(B, ln, 32, generator=g) * 0.5).to(dtype).to(DEV)
+    ks, dil = (3, 7, 11), ((1, 3, 5),) * 3
+    ws, bs = [], []
+    for k in ks:
+        for _ in range(6):
+            w = torch.randn(32, 32, k, generator=g) / (32 * k) ** 0.5
+            ws.append(ops.pack_resblock_weight(w.to(DEV), dtype=dtype))
+            bs.append((0.02 * torch.randn(32, generator=g)).to(DEV))
+    wpost = ops.pack_conv_weight((torch.randn(1, 32, 7, generator=g) / 15.0).to(DEV), dtype=dtype)
+    bpost = (0.02 * torch.randn(1, generator=g)).to(DEV)
+    return x, ks, dil, ws, bs, wpost, bpost
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,ln", [(2, 1000), (1, 386), (1, 387), (3, 5), (1, 1), (2, 4099)])
+def test_fused_last_stage_equals_four_launches(B, ln, dtype):
+    """ttsk_hifi_mrf32_post (csrc/mrf32.hip: three ResBlock1s + average + LeakyReLU(0.01) + conv_post + tanh in one launch;
+    hifi/models.py:190-199) against the launches it replaces — ttsk_hifi_resblock1 x 3 in modes 0 / 1 / 2 and ttsk_hifi_conv_post —
+    on the same input and packs: the activated average and the waveform BIT-identical (same MFMA order per conv, same 16-bit roundings
+    of every block output and partial sum, same conv_post summation order).  Lengths around the 386-frame tile, shorter than the halo,
+    and one frame."""
+    from tts_king_amd import ops
+    x, ks, dil, ws, bs, wpost, bpost = _mrf32_inputs(dtype, B, ln, 5 + ln)
+    ref = torch.empty_like(x)
+    for j, k in enumerate(ks):
+        ops.hifi_resblock1(x, ws[6 * j:6 * j + 6], bs[6 * j:6 * j + 6], dil[j], ref, k, mode=0 if j == 0 else (2 if j == 2 else 1),
+                           scale=1.0 / 3.0, slope=0.1, final_slope=0.01 if j == 2 else 1.0)
+    want = ops.hifi_conv_post(ref, wpost, bpost)
+    stage = torch.full_like(x, 7.0)
+    got = ops.hifi_mrf32_post(x, ws, bs, dil, ks, wpost, bpost, stage_out=stage)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (B, 1, ln)
+    assert torch.equal(stage.view(torch.int16), ref.view(torch.int16)), "activated MRF average differs: %d of %d elements" % (
+        int((stage.view(torch.int16) != ref.view(torch.int16)).sum()), stage.numel())
+    assert torch.equal(got, want), "waveform differs: max abs %.3e" % float((got - want).abs().max())
+
+
+def test_fused_last_stage_full_size_and_generator(cfg):
+    """The same at the BASELINE.json configs[2] size (8 x 98,304 frames), and the generator with and without the fused last stage:
+    identical waveforms."""
+    from tts_king_amd import ops
+    x, ks, dil, ws, bs, wpost, bpost = _mrf32_inputs(torch.float16, 8, 98304, 77)
+    ref = torch.empty_like(x)
+    for j, k in enumerate(ks):
+        ops.hifi_resblock1(x, ws[6 * j:6 * j + 6], bs[6 * j:6 * j + 6], dil[j], ref, k, mode=0 if j == 0 else (2 if j == 2 else 1),
+                           scale=1.0 / 3.0, slope=0.1, final_slope=0.01 if j == 2 else 1.0)
+    want = ops.hifi_conv_post(ref, wpost, bpost)
+    got = ops.hifi_mrf32_post(x, ws, bs, dil, ks, wpost, bpost)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    gen = build(cfg, 11)
+    mel = make_mel(2, 50, seed=9).to(DEV)
+    assert gen.mrf_fused
+    a = gen(mel)
+    gen.mrf_fused = False
+    b = gen(mel)
+    assert torch.equal(a, b)

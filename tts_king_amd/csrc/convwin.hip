@@ -589,7 +589,7 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
 // carries 8 guard rows each side that only those discarded edge rows read.  Against the six-conv fused kernel
 // (resblock.hip): that one reads x once per block but multiplies 1.23-1.45x redundant halo rows and synchronises its eight
 // waves per weight stage; three pair launches move 3x its HBM bytes (still one read + one write of x per pair) and win on the
-// MFMA side.  Row stride C*2 + 16 bytes: 16 consecutive rows start on 16 different 16-byte bank groups.
+// MFMA side.
 template <int C> struct FsGeom {
   static constexpr int NW = 4, NT = 256, GU = 8, CROWS = 192;       // 192 rows computed by both convs
   // wave = (cout group, frame group): C = 64: 2 x 2 — 32 output channels x 96 frames per wave (6 MFMAs per weight fragment loaded, the
@@ -599,10 +599,16 @@ template <int C> struct FsGeom {
   static constexpr int TT = CROWS - 2 * GU;             // 176 frames stored
   static constexpr int XROWS = CROWS + 50;              // 242: c1 reaches 25 rows either side
   static constexpr int TROWS = CROWS + 2 * GU;          // 208
-  static constexpr int RS = C * 2 + 16;
+  // Row stride C * 2 + 32 bytes = 2 mod 4 sixteen-byte units, like the C = 128 / 256 kernels: a ds_read_b128 is served in groups of 16
+  // lanes that mix 8 rows at k-chunk q with the 8 OTHER rows at q + 1; with an odd stride in units (C * 2 + 16: what this kernel had)
+  // rows l and l' with 9 l = 9 l' + 1 (mod 16) collide for every such pair — every fragment read two-way conflicted, 48 % of the
+  // kernel's LDS cycles (profiles/r03_mfma_util.json), and at 64 channels the LDS pipe, not the MFMA pipe, set the pace.  A stride of
+  // 2 mod 4 units sends q-even chunks to even units and q-odd ones to odd units, 8 rows each over the 8 units of a parity: conflict-free
+  // at every tap shift.
+  static constexpr int RS = C * 2 + 32;
   static constexpr int NC = C / 16, KS = C / 32, CH8 = C / 8;
   static constexpr int TAP = NC * KS * 1024;
-  static constexpr int SMEM = (XROWS + TROWS) * RS;     // 64,800 B (C = 64) / 36,000 B (C = 32)
+  static constexpr int SMEM = (XROWS + TROWS) * RS;     // 72,000 B (C = 64: two workgroups per CU) / 43,200 B (C = 32)
 };
 
 template <int C, bool F16>

@@ -1,6 +1,7 @@
 // hifigan.hip — HiFi-GAN V1 generator support kernels: weight-norm folding, weight repacking for the implicit-GEMM
 // conv kernels, and the MRF average.  reference: hifi/models.py:146-210 (Generator), :12-95 (ResBlock1).
 #include "common.h"
+#include "conv_post.h"
 
 namespace {
 
@@ -98,10 +99,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const bf16_t* __restrict
     const float* wj = wf + j * C;
     for (int ch = 0; ch < CH8; ++ch) {
       const uint4 v = *(const uint4*)(row + ch * 16);
-      float a0, a1, a2, a3, a4, a5, a6, a7;
-      unpack2<F16>(v.x, a0, a1); unpack2<F16>(v.y, a2, a3); unpack2<F16>(v.z, a4, a5); unpack2<F16>(v.w, a6, a7);
-      const f32x4 w0 = *(const f32x4*)(wj + ch * 8), w1 = *(const f32x4*)(wj + ch * 8 + 4);
-      acc += a0 * w0[0] + a1 * w0[1] + a2 * w0[2] + a3 * w0[3] + a4 * w1[0] + a5 * w1[1] + a6 * w1[2] + a7 * w1[3];
+      acc += conv_post_dot8<F16>(v, wj + ch * 8);
     }
   }
   out[(int64_t)b * len + t] = tanhf(acc);

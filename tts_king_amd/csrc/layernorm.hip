@@ -418,28 +418,41 @@ __device__ __forceinline__ float rows4_sum(float v) {
 }
 
 // the four row groups of a wave, then the waves, in a fixed order (deterministic) -> partials[blockIdx.x][dbias | dgamma | dbeta]
-__device__ __forceinline__ void lnb256_partials(const LnBwdArgs& a, float sbias[16], float sgam[16], float sbeta[16], float (*red)[3 * 256],
+// LDS image: column c = 16 l + e of each 256-column array sits at e * 17 + l (LNB_RED floats per wave).  Lane l owns 16 CONSECUTIVE
+// columns, so in column order the 16 lanes of a store hit two banks (stride 16 floats: 28-38 % of this kernel family's LDS cycles were
+// bank conflicts, profiles/r03_mfma_util.json); here a store's lanes are consecutive floats, and the read-back (lane = column) walks
+// e * 17 + l with 17 odd: conflict-free both ways.  After rows4_sum every row group holds the totals: group g stores e = 4 g .. 4 g + 3.
+constexpr int LNB_RED_LD = 16 * 17, LNB_RED = 3 * LNB_RED_LD;
+__device__ __forceinline__ void lnb256_partials(const LnBwdArgs& a, float sbias[16], float sgam[16], float sbeta[16], float (*red)[LNB_RED],
                                                 int wave, int grp, int c0) {
   constexpr int D = 256;
 #pragma unroll
   for (int e = 0; e < 16; ++e) { sbias[e] = rows4_sum(sbias[e]); sgam[e] = rows4_sum(sgam[e]); sbeta[e] = rows4_sum(sbeta[e]); }
-  if (grp == 0) {
+  const int l = c0 >> 4;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { red[wave][c0 + e] = sbias[e]; red[wave][D + c0 + e] = sgam[e]; red[wave][2 * D + c0 + e] = sbeta[e]; }
+  for (int g = 0; g < 4; ++g) {
+    if (grp == g) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = 4 * g + j;          // (compile-time register index inside the unrolled g / j loops)
+        red[wave][e * 17 + l] = sbias[e]; red[wave][LNB_RED_LD + e * 17 + l] = sgam[e]; red[wave][2 * LNB_RED_LD + e * 17 + l] = sbeta[e];
+      }
+    }
   }
   __syncthreads();
   float* P = a.partials + (int64_t)blockIdx.x * 3 * D;
   for (int c = threadIdx.x; c < 3 * D; c += LNB_WAVES * 64) {
+    const int pos = (c >> 8) * LNB_RED_LD + (c & 15) * 17 + ((c & 255) >> 4);
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < LNB_WAVES; ++w) t += red[w][c];
+    for (int w = 0; w < LNB_WAVES; ++w) t += red[w][pos];
     P[c] = t;
   }
 }
 
 __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd256_kernel(const LnBwdArgs a) {
   constexpr int D = 256;
-  __shared__ float red[LNB_WAVES][3 * D];
+  __shared__ float red[LNB_WAVES][LNB_RED];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = lane >> 4, l = lane & 15, c0 = l * 16;
   const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
@@ -590,12 +603,12 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const
   constexpr int D = 256;
   static_assert(LNB_WAVES * 64 == P32_NT && P32_D == D, "proj32.h is built for 8 waves and 256 channels");
   constexpr int PRS = PRE_RS, DT_LD = PRE_DT_LD;                          // PRE: LDS row stride of the dqkv rows, fp32 tile stride
-  constexpr int MAIN_BYTES = LNB_WAVES * 3 * D * 4 + 2 * P32_TT * P32_RS;  // red | xs | os
+  constexpr int MAIN_BYTES = LNB_WAVES * LNB_RED * 4 + 2 * P32_TT * P32_RS;  // red | xs | os
   constexpr int PRE_BYTES = P32_TT * PRS;                                  // dqkv rows: dead before red / xs / os are written
   __shared__ __attribute__((aligned(16))) unsigned char smem[(PRE && PRE_BYTES > MAIN_BYTES) ? PRE_BYTES : MAIN_BYTES];
   __shared__ __attribute__((aligned(16))) float dtile[PRE ? P32_TT * DT_LD : 4];
-  float (*red)[3 * D] = (float (*)[3 * D])smem;
-  unsigned char* xs = smem + LNB_WAVES * 3 * D * 4;       // dy rows (bf16): the GEMM's B operand
+  float (*red)[LNB_RED] = (float (*)[LNB_RED])smem;
+  unsigned char* xs = smem + LNB_WAVES * LNB_RED * 4;     // dy rows (bf16): the GEMM's B operand
   unsigned char* os = xs + P32_TT * P32_RS;               // one channel group's output rows (bf16)
   const LnBwdArgs& a = p.ln;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

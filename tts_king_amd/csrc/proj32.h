@@ -80,9 +80,11 @@ __device__ __forceinline__ void proj32_run(const unsigned char* xs, unsigned cha
       f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
       if (bias) bv = *(const f32x4*)(bias + cg * P32_D + col);
 #pragma unroll
+      // 8-byte units XOR-swizzled by (row >> 2) & 3: the 16 lanes of a store (16 rows, one unit column; row stride 136 dwords = 8
+      // mod 32) would hit 4 bank pairs four deep; with the swizzle they cover all 32 banks once
       for (int i = 0; i < NF; ++i) {
         const f32x4 v = acc[cc][i] + bv;
-        *(uint2*)(os + (i * 16 + l15) * P32_RS + col * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        *(uint2*)(os + (i * 16 + l15) * P32_RS + ((col * 2) ^ (((l15 >> 2) & 3) << 3))) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
       }
     }
     __syncthreads();
@@ -91,7 +93,9 @@ __device__ __forceinline__ void proj32_run(const unsigned char* xs, unsigned cha
     for (int it = 0; it < P32_TT * OCH / P32_NT; ++it) {
       const int idx = it * P32_NT + tid;
       const int rr = idx / OCH, ch = idx - rr * OCH;
-      const uint4 v = *(const uint4*)(os + rr * P32_RS + ch * 16);
+      const int sw = (rr >> 2) & 3;                // the row's unit swizzle: bit 1 moves the chunk, bit 0 swaps its halves
+      uint4 v = *(const uint4*)(os + rr * P32_RS + ((ch ^ (sw >> 1)) << 4));
+      if (sw & 1) v = make_uint4(v.z, v.w, v.x, v.y);
       epi(cg, rr, ch, v, it);
     }
     if (cg + 1 < NG) __syncthreads();          // the next group overwrites the staging rows

@@ -15,7 +15,7 @@ STAGE_MFLOP = {"conv_pre": 0.573, "ups0": 4.194, "ups1": 8.389, "ups2": 4.194, "
 # rocprofv3 symbols of each stage's kernels (profiles/r*_pmc_traffic_hifi.json is keyed by symbol): (substring, launches per forward)
 STAGE_KERNELS = {"mrf0": [("conv_pair256_kernel", 9)], "mrf1": [("conv_pair_kernel", 9)],
                  "mrf2": [("conv_pair_fs_kernel<64", 6), ("resblock1_kernel<64, 3", 1)],
-                 "mrf3": [("resblock1_kernel<32, 3", 1), ("resblock1_kernel<32, 7", 1), ("resblock1_kernel<32, 11", 1), ("mrf32_kernel", 1)],
+                 "mrf3": [("resblock1_kernel<32, 3", 1), ("resblock1_kernel<32, 7", 1), ("resblock1_kernel<32, 11", 1), ("mrf32_post_kernel", 1)],
                  "ups0": [("win_conv_kernel<512, 128", 1)], "ups1": [("win_conv_kernel<256, 224", 1)],
                  "ups2": [("ups2_kernel<128, 64", 1)], "ups3": [("ups2_kernel<64, 32", 1)], "conv_post": [("conv_post_kernel", 1)]}
 # tensor elements per mel frame at each stage's resolution (channels x frames-per-mel-frame), 2 bytes each: the algorithmic

@@ -103,6 +103,7 @@ class Generator(nn.Module):
         self.stream_upsample = True  # stride-2 upsamplers (128->64, 64->32) on the streaming kernel; False = polyphase implicit GEMMs
         self.window_upsample = os.environ.get("TTSK_HIFI_UPS8", "1") != "0"   # stride-8 upsamplers and 128 -> 64 on the window-conv kernel (fp16); 0 = polyphase GEMMs / streaming kernel
         self.group_resblocks = True  # conv m of the three MRF ResBlocks as one grouped launch where they run conv by conv (C = 256)
+        self.mrf_fused = True        # the last stage (C = 32: three ResBlock1s + average + LeakyReLU + conv_post + tanh) as ONE launch (csrc/mrf32.hip)
 
     # ------------------------------------------------------------------ reference surface
     def remove_weight_norm(self):
@@ -306,8 +307,19 @@ class Generator(nn.Module):
                         a = ops.hifi_upsample2(al, wu, bu)                                 # both phases from one read of `al`
                     else:
                         a = ops.conv_transpose1d(al, wu, bu, u, k)                         # raw x: the fused blocks activate it themselves
-                    out = torch.empty_like(a)
                     self._mark("ups%d" % i)
+                    if (self.mrf_fused and i + 1 == self.num_upsamples and nk == 3 and a.is_contiguous() and
+                            ops.hifi_mrf32_post_supported(C_out, [rb.k for rb in rbs], pk["post"][0].shape[1])):
+                        # the whole last stage — three blocks, their average, LeakyReLU(0.01), conv_post, tanh — in one launch: x is
+                        # read once, the waveform written once (hifi/models.py:190-199)
+                        ws = [w for j in range(nk) for w in pk["rbf"][i * nk + j][0]]
+                        bs = [b for j in range(nk) for b in pk["rbf"][i * nk + j][1]]
+                        y = ops.hifi_mrf32_post(a, ws, bs, [rb.dilation for rb in rbs], [rb.k for rb in rbs], pk["post"][0], pk["post"][1],
+                                                slope=LRELU_SLOPE, final_slope=nxt_slope, scale=1.0 / nk)
+                        self._mark("mrf%d" % i)
+                        self._mark("conv_post")
+                        return y
+                    out = torch.empty_like(a)
                     for j, rb in enumerate(rbs):
                         ws, bs = pk["rbf"][i * nk + j]
                         lastb = j == nk - 1

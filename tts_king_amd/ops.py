@@ -1455,6 +1455,28 @@ def hifi_resblock1(x, weights, biases, dilations, out, K, mode=0, scale=1.0, slo
     return out
 
 
+def hifi_mrf32_post_supported(C_, ks, k_post):
+    return len(ks) == 3 and bool(L.load().ttsk_hifi_mrf32_post_supported(C_, int(ks[0]), int(ks[1]), int(ks[2]), int(k_post)))
+
+
+def hifi_mrf32_post(x, weights, biases, dilations, ks, w_post, b_post, slope=0.1, final_slope=0.01, scale=1.0 / 3.0, stage_out=None):
+    """The generator's whole last stage in one launch (reference: hifi/models.py:190-199; csrc/mrf32.hip): x (B, len, 32) 16-bit raw
+    stage input -> (B, 1, len) fp32 waveform = tanh(conv_post(leaky_relu(mean_j ResBlock1_j(x), 0.01))).  weights / biases: 18 packs /
+    (32,) fp32 vectors, block j's six convs at [6 j ..] in hifi_resblock1's order; dilations: three triples; ks: the three kernel sizes;
+    w_post (1, 7, 32) tap-major 16-bit.  stage_out (optional, like x): receives the activated average conv_post reads."""
+    _dev(x, w_post, b_post, stage_out, *weights, *biases)
+    Bn, ln, Cn = x.shape
+    assert len(weights) == 18 and len(biases) == 18 and x.is_contiguous()
+    wp = (C.c_void_p * 18)(*[w.data_ptr() for w in weights])
+    bp = (C.c_void_p * 18)(*[b.data_ptr() for b in biases])
+    dl = (C.c_int32 * 9)(*[int(d) for tri in dilations for d in tri])
+    out = torch.empty(Bn, 1, ln, dtype=torch.float32, device=x.device)
+    check(L.load().ttsk_hifi_mrf32_post(_ptr(x), _ptr(out), _ptr(stage_out), int(x.dtype == f16), C.cast(wp, C.c_void_p), C.cast(bp, C.c_void_p),
+                                        C.cast(dl, C.c_void_p), _ptr(w_post), _ptr(b_post), Bn, ln, Cn, int(ks[0]), int(ks[1]), int(ks[2]),
+                                        int(w_post.shape[-2]), slope, final_slope, scale, _stream()), "ttsk_hifi_mrf32_post")
+    return out
+
+
 def hifi_upsample2_supported(Cin, Cout, stride, k):
     return bool(L.load().ttsk_hifi_upsample2_supported(Cin, Cout, stride, k))
 

@@ -590,30 +590,33 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
 // (resblock.hip): that one reads x once per block but multiplies 1.23-1.45x redundant halo rows and synchronises its eight
 // waves per weight stage; three pair launches move 3x its HBM bytes (still one read + one write of x per pair) and win on the
 // MFMA side.
-template <int C> struct FsGeom {
-  static constexpr int NW = 4, NT = 256, GU = 8, CROWS = 192;       // 192 rows computed by both convs
-  // wave = (cout group, frame group): C = 64: 2 x 2 — 32 output channels x 96 frames per wave (6 MFMAs per weight fragment loaded, the
-  // weights of a tap fetched twice per workgroup); all 64 channels x 48 frames per wave measured 29 % MFMA busy (3 MFMAs per fragment,
-  // four fetches).  C = 32: one cout group, four frame groups of 48.
-  static constexpr int CG = C == 64 ? 2 : 1, FG = NW / CG, FW = CROWS / FG, NF = FW / 16;
-  static constexpr int TT = CROWS - 2 * GU;             // 176 frames stored
-  static constexpr int XROWS = CROWS + 50;              // 242: c1 reaches 25 rows either side
-  static constexpr int TROWS = CROWS + 2 * GU;          // 208
+template <int C, int NW_> struct FsGeom {
+  static constexpr int NW = NW_, NT = NW * 64, GU = 8;
+  // wave = (cout group of 32 channels, frame group): C = 64, 4 waves: 2 x 2 — 32 output channels x 96 frames per wave (6 MFMAs per weight
+  // fragment loaded, the weights of a tap fetched twice per workgroup); all 64 channels x 48 frames per wave measured 29 % MFMA busy (3
+  // MFMAs per fragment, four fetches).  C = 32: one cout group, four frame groups of 48.  (Round 4 measured 8-wave variants — C = 128:
+  // 4 cout groups x 2 frame halves, C = 64: 2 x 4, one workgroup per CU, twice the frames behind each weight fetch: 1.07 vs 0.87 ms and
+  // 0.66 vs 0.60 ms per stage.  Two independent 4-wave workgroups per CU in different phases beat one 8-wave workgroup in lockstep.)
+  static constexpr int CG = C >= 64 ? C / 32 : 1, FG = NW / CG, FW = C >= 64 ? 96 : 48, NF = FW / 16;
+  static constexpr int CROWS = FG * FW;                 // rows computed by both convs
+  static constexpr int TT = CROWS - 2 * GU;             // frames stored
+  static constexpr int XROWS = CROWS + 50;              // c1 reaches 25 rows either side
+  static constexpr int TROWS = CROWS + 2 * GU;
   // Row stride C * 2 + 32 bytes = 2 mod 4 sixteen-byte units, like the C = 128 / 256 kernels: a ds_read_b128 is served in groups of 16
   // lanes that mix 8 rows at k-chunk q with the 8 OTHER rows at q + 1; with an odd stride in units (C * 2 + 16: what this kernel had)
   // rows l and l' with 9 l = 9 l' + 1 (mod 16) collide for every such pair — every fragment read two-way conflicted, 48 % of the
-  // kernel's LDS cycles (profiles/r03_mfma_util.json), and at 64 channels the LDS pipe, not the MFMA pipe, set the pace.  A stride of
-  // 2 mod 4 units sends q-even chunks to even units and q-odd ones to odd units, 8 rows each over the 8 units of a parity: conflict-free
-  // at every tap shift.
+  // kernel's LDS cycles (profiles/r03_mfma_util.json).  A stride of 2 mod 4 units sends q-even chunks to even units and q-odd ones to
+  // odd units, 8 rows each over the 8 units of a parity: conflict-free at every tap shift.
   static constexpr int RS = C * 2 + 32;
   static constexpr int NC = C / 16, KS = C / 32, CH8 = C / 8;
   static constexpr int TAP = NC * KS * 1024;
-  static constexpr int SMEM = (XROWS + TROWS) * RS;     // 72,000 B (C = 64: two workgroups per CU) / 43,200 B (C = 32)
+  static constexpr int SMEM = (XROWS + TROWS) * RS;     // 72,000 B (C = 64, 4 waves: two workgroups per CU) / 43,200 B (C = 32)
+  static constexpr int OCC = SMEM <= 80 * 1024 ? 2 : 1; // workgroups per CU the LDS allows (at most two are asked for)
 };
 
-template <int C, bool F16>
-__global__ __launch_bounds__(256, 2) void conv_pair_fs_kernel(const PairArgs a) {
-  using Gm = FsGeom<C>;
+template <int C, int NW, bool F16>
+__global__ __launch_bounds__(NW * 64, (FsGeom<C, NW>::OCC * NW) / 4) void conv_pair_fs_kernel(const PairArgs a) {
+  using Gm = FsGeom<C, NW>;
   constexpr int NT = Gm::NT, FW = Gm::FW, NF = Gm::NF, GU = Gm::GU, TT = Gm::TT, XROWS = Gm::XROWS, RS = Gm::RS, NC = Gm::NC, KS = Gm::KS,
                 CH8 = Gm::CH8, TAP = Gm::TAP, XH = GU + 25, CG = Gm::CG, CT = NC / CG;
   __shared__ __attribute__((aligned(16))) unsigned char smem[Gm::SMEM];
@@ -847,13 +850,13 @@ extern "C" int ttsk_hifi_conv_pair(const void* x16, const void* w1_pack, const f
     if (f16) hipLaunchKernelGGL(conv_pair_kernel<true>, grid, dim3(C2_NT), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(conv_pair_kernel<false>, grid, dim3(C2_NT), 0, (hipStream_t)stream, a);
   } else {
-    dim3 grid((len + FsGeom<64>::TT - 1) / FsGeom<64>::TT, B);
+    dim3 grid((len + FsGeom<64, 4>::TT - 1) / FsGeom<64, 4>::TT, B);
     if (C == 64) {
-      if (f16) hipLaunchKernelGGL((conv_pair_fs_kernel<64, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
-      else hipLaunchKernelGGL((conv_pair_fs_kernel<64, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      if (f16) hipLaunchKernelGGL((conv_pair_fs_kernel<64, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((conv_pair_fs_kernel<64, 4, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     } else {
-      if (f16) hipLaunchKernelGGL((conv_pair_fs_kernel<32, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
-      else hipLaunchKernelGGL((conv_pair_fs_kernel<32, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      if (f16) hipLaunchKernelGGL((conv_pair_fs_kernel<32, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((conv_pair_fs_kernel<32, 4, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     }
   }
   TTSK_CHECK_LAUNCH();

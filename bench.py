@@ -22,6 +22,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from tts_king_amd import switches  # noqa: E402
 
 PEAK_MFMA_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
@@ -40,7 +41,7 @@ def host_threads():
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(n, int(os.environ.get("TTSK_CPU_THREADS", "16"))))
+    return max(1, min(n, int(switches.get("TTSK_CPU_THREADS"))))
 
 
 def cpu_baseline(cfg, B, L, n_steps=5):
@@ -199,47 +200,78 @@ def e2e_synth_leg(cfg, dev, L=64, iters=20, with_cpu=True):
     return rec
 
 
-def pmc_traffic(symbol):
-    """HBM bytes per launch of `symbol` from the newest committed PMC summary (profiles/r*_pmc_traffic.json, written by
-    tools/pmc_bench.sh + tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
-    bench command; counters cannot be collected from inside the timed process).  None when there is no summary for it."""
+def _profile_docs(pattern):
+    """(doc, relative path) of the committed PMC summaries matching profiles/<pattern>, newest round first."""
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
-    for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(here, "profiles", pattern)), reverse=True):
         try:
-            doc = json.load(open(f))
+            yield json.load(open(f)), os.path.relpath(f, here)
         except (OSError, ValueError):
             continue
-        for r in doc.get("kernels", []):
-            if symbol in r["kernel"]:
-                return {"hbm_bytes_per_launch": r["hbm_bytes_per_launch"],
-                        "source": "%s: FETCH_SIZE x2 %.1f MB + WRITE_SIZE %.1f MB per launch, %d dispatches" % (
-                            os.path.relpath(f, here), r["fetch_bytes_per_launch"] / 1e6, r["write_bytes_per_launch"] / 1e6, r["dispatches"])}
+
+
+def profile_is_stale(doc):
+    """A committed profile is stale when the kernel sources changed after it was taken: its `csrc_fingerprint` (tools/pmc_summary.py,
+    tts_king_amd/lib.py:source_fingerprint) differs from this tree's.  Profiles of earlier rounds carry no fingerprint: stale."""
+    from tts_king_amd.lib import source_fingerprint
+    return doc.get("csrc_fingerprint") != source_fingerprint()
+
+
+def pmc_traffic(symbol):
+    """HBM bytes per launch of the kernels whose symbol contains `symbol` (dispatch-weighted mean) from the newest committed PMC
+    summary (profiles/r*_pmc_traffic.json, written by tools/pmc_bench.sh + tools/pmc_summary.py from separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes over this same bench command; counters cannot be collected from inside the timed process).
+    None when there is no summary for it."""
+    for doc, rel in _profile_docs("r*_pmc_traffic.json"):
+        rows = [r for r in doc.get("kernels", []) if symbol in r["kernel"]]
+        if rows:
+            n = sum(r["dispatches"] for r in rows)
+            mean = lambda key: sum(r[key] * r["dispatches"] for r in rows) / n
+            return {"hbm_bytes_per_launch": mean("hbm_bytes_per_launch"), "stale": profile_is_stale(doc),
+                    "source": "%s: FETCH_SIZE x2 %.1f MB + WRITE_SIZE %.1f MB per launch, %d dispatches of %d symbol(s)" % (
+                        rel, mean("fetch_bytes_per_launch") / 1e6, mean("write_bytes_per_launch") / 1e6, n, len(rows))}
     return None
 
 
 def pmc_mfma_busy(symbol, section="fs2_train_step"):
-    """mfma_busy_frac of `symbol` from the newest committed profiles/r*_mfma_util.json (tools/pmc_mfma.sh: a separate rocprofv3 --pmc
-    pass over this bench command; counters cannot be read from inside the timed process).  None when there is no summary."""
-    import glob
-    here = os.path.dirname(os.path.abspath(__file__))
-    for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_mfma_util.json")), reverse=True):
-        try:
-            doc = json.load(open(f))
-        except (OSError, ValueError):
-            continue
-        for r in doc.get(section, []):
-            if symbol in r["kernel"] and r.get("mfma_busy_frac") is not None:
-                return {"mfma_busy_frac": r["mfma_busy_frac"], "source": os.path.relpath(f, here)}
+    """mfma_busy_frac (cycle-weighted over the symbols containing `symbol`) from the newest committed profiles/r*_mfma_util.json
+    (tools/pmc_mfma.sh: a separate rocprofv3 --pmc pass over this bench command).  None when there is no summary."""
+    for doc, rel in _profile_docs("r*_mfma_util.json"):
+        rows = [r for r in doc.get(section, []) if symbol in r["kernel"] and r.get("mfma_busy_frac") is not None]
+        if rows:
+            w = [r["avg_cycles"] * r["dispatches"] for r in rows]
+            return {"mfma_busy_frac": sum(r["mfma_busy_frac"] * wi for r, wi in zip(rows, w)) / sum(w),
+                    "lds_conflict_frac": sum((r.get("lds_conflict_frac") or 0.0) * wi for r, wi in zip(rows, w)) / sum(w),
+                    "stale": profile_is_stale(doc), "source": rel}
     return None
 
 
-def gemm_roofline(enqueue, batch, steps=3):
-    """Roofline of the dominant kernel of the step.  Every ttsk_gemm launch of `steps` eager train steps is bracketed by
-    HIP events on its launch stream (tts_king_amd/ops.py:GEMM_TRACE); launches are grouped by kernel symbol (tile
-    configuration x operand layout, the names rocprofv3 reports) and the symbol that carries the most algorithmic FLOPs is
-    reported (under hipGraph replay no single symbol dominates the step's time): achieved = its algorithmic FLOPs (2*M*N*K*taps*batch per launch) / its measured time.  A split-K launch includes
-    its reducer kernel in the bracket."""
+# kernel families of the train step: trace kind (tts_king_amd/ops.py: GEMM_TRACE entries) -> (family, rocprofv3 symbol substring, source)
+FAMILIES = {"win_conv": ("win_conv_kernel", "tts_king_amd/csrc/ffn_conv.hip"), "win_ln": ("win_ln_kernel", "tts_king_amd/csrc/gemm_ln.hip"),
+            "ln_bwd_proj": ("ln_bwd256_proj_kernel", "tts_king_amd/csrc/layernorm.hip"), "flash_attention": ("flash_", "tts_king_amd/csrc/flash_attn.hip"),
+            "dwconv": ("dwconv_kernel", "tts_king_amd/csrc/dwconv.hip"), "dwgemm": ("dwgemm_kernel", "tts_king_amd/csrc/dwgemm.hip"),
+            "gemm": ("gemm", "tts_king_amd/csrc/gemm.hip, gemm2.hip"), "batchnorm": ("bn_", "tts_king_amd/csrc/batchnorm.hip"),
+            "clip_adam": ("adam_", "tts_king_amd/csrc/optim.hip")}
+
+
+def _family_of(kind):
+    if kind in FAMILIES:
+        return kind
+    if kind.startswith("dwconv"):
+        return "dwconv"
+    return "gemm"            # NT / TT / grouped tile configurations of ttsk_gemm
+
+
+def step_roofline(enqueue, batch, steps=3):
+    """Roofline of the train step by kernel FAMILY.  Every launch of the MFMA families (window convs, fused projection + LayerNorm,
+    LayerNorm-backward + projection, flash attention, dwconv, dwgemm, the ttsk_gemm tiles) and of the two HBM-bound passes with real
+    time share (BatchNorm, clip + Adam) in `steps` eager train steps is bracketed by HIP events on its launch stream
+    (tts_king_amd/ops.py: GEMM_TRACE / _family); per family: launches, device time, algorithmic FLOPs (2*M*N*K*taps: the reference's
+    counts) -> fraction of the dense bf16 MFMA peak, and the HBM bytes per step by PMC where a committed summary has the
+    family's kernels.  The headline `achieved` / `frac` are the family that takes the most TIME; `dominant_by_flops` is reported
+    beside it.  Eager brackets: a launch's bracket can include the tail of a kernel on another stream, never another launch of
+    its own stream."""
     from tts_king_amd import ops
     enqueue(batch)
     torch.cuda.synchronize()
@@ -247,41 +279,54 @@ def gemm_roofline(enqueue, batch, steps=3):
     ops.GEMM_TRACE = trace
     try:
         for _ in range(steps):
+            # Park the GPU behind a spin kernel while the host enqueues the whole step (~4 ms of Python): the launches then run back to
+            # back, as in the replayed graph, and a bracket holds its kernel — not the host time between recording its first event
+            # and enqueueing the launch (eager launches are host-bound: brackets measured 10-50 % long without this).
+            torch.cuda._sleep(int(60e6))
             enqueue(batch)
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
     finally:
         ops.GEMM_TRACE = None
-    sym = {"NT1": "gemm_kernel<false, false, false>", "NT_btr1": "gemm_kernel<false, true, false>", "TT1": "gemm_kernel<true, true, false>",
-           "NT2": "gemm2_kernel<256, false, false, false>", "NT_btr2": "gemm2_kernel<256, false, true, false>", "TT2": "gemm2_kernel<256, true, true, false>",
-           "TT1g": "gemm_group_kernel<true, true, false>", "TT2g": "gemm2_group_kernel<256, true, true, false>",
-           "NT3": "gemm64_kernel<false, false>", "NT_btr3": "gemm64_kernel<true, false>", "dwconv9": "dwconv_kernel<9, 2, 2>"}
-    src = lambda k: "tts_king_amd/csrc/dwconv.hip" if k.startswith("dwconv") else "tts_king_amd/csrc/gemm%s.hip" % ("2" if "2" in k else "")
-    by_sym, by_shape = {}, {}
+    fam = {}
     for e0, e1, fl, kind, shape in trace:
-        ms = e0.elapsed_time(e1)
-        d = by_sym.setdefault(kind, [0.0, 0.0, 0]); d[0] += ms; d[1] += fl; d[2] += 1
-        d = by_shape.setdefault((kind,) + shape, [0.0, 0.0, 0]); d[0] += ms; d[1] += fl; d[2] += 1
-    tot_ms = sum(v[0] for v in by_sym.values())
-    tot_fl = sum(v[1] for v in by_sym.values())
-    dk, dv = max(by_sym.items(), key=lambda kv: kv[1][1])      # dominant = most algorithmic FLOPs (decoder FFN / PostNet convs)
-    tk, tv = max(by_sym.items(), key=lambda kv: kv[1][0])      # and the symbol that takes the most TIME (eager brackets incl. reducers)
-    sk, sv = max(((k, v) for k, v in by_shape.items() if k[0] == dk), key=lambda kv: kv[1][0])
-    ach = dv[1] / (dv[0] * 1e-3) / 1e12
-    traffic = pmc_traffic(sym.get(dk, dk))
-    return {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_BF16_TFLOPS,
-            "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
-            "traffic_source": traffic["source"] if traffic else None,
-            "mfma_busy_frac": (pmc_mfma_busy(sym.get(dk, dk)) or {}).get("mfma_busy_frac"),
-            "mfma_busy_source": (pmc_mfma_busy(sym.get(dk, dk)) or {}).get("source"),
-            "kernel": "%s (%s)" % (sym.get(dk, dk), src(dk)),
-            "launches_per_step": dv[2] // steps, "avg_launch_us": 1e3 * dv[0] / dv[2], "avg_launch_gflop": dv[1] / dv[2] / 1e9,
-            "kernel_ms_per_step": dv[0] / steps,
-            "dominant_by_time": {"kernel": sym.get(tk, tk), "launches_per_step": tv[2] // steps, "ms_per_step": tv[0] / steps,
-                                 "tflops": tv[1] / (tv[0] * 1e-3) / 1e12, "frac_of_peak": tv[1] / (tv[0] * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS},
-            "all_gemm": {"launches_per_step": len(trace) // steps, "ms_per_step": tot_ms / steps, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12},
-            "largest_shape": ({"grouped_problems": sk[1], "workgroups": sk[6]} if (dk.endswith("g") or dk.startswith("dwconv")) else
-                              {"M,N,K,taps,batch,splits": list(sk[1:]), "launches_per_step": sv[2] // steps,
-                               "avg_us": 1e3 * sv[0] / sv[2], "tflops": sv[1] / (sv[0] * 1e-3) / 1e12})}
+        d = fam.setdefault(_family_of(kind), [0.0, 0.0, 0])
+        d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += 1
+    rows = []
+    stale = False
+    for name, (ms, fl, n) in fam.items():
+        sym, src = FAMILIES[name]
+        tr, mb = pmc_traffic(sym), pmc_mfma_busy(sym)
+        stale = stale or bool(tr and tr["stale"]) or bool(mb and mb["stale"])
+        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        rows.append({"family": name, "kernels": "%s* (%s)" % (sym, src), "launches": n // steps, "ms_per_step": ms / steps,
+                     "gflop": fl / steps / 1e9, "tflops": tf, "frac_of_peak": tf / PEAK_MFMA_BF16_TFLOPS,
+                     "hbm_bytes_pmc": tr["hbm_bytes_per_launch"] * (n // steps) if tr else None,
+                     "hbm_frac_of_peak": (tr["hbm_bytes_per_launch"] * n / (ms * 1e-3) / 8e12) if (tr and ms > 0) else None,
+                     "mfma_busy_frac": mb["mfma_busy_frac"] if mb else None, "lds_conflict_frac": mb["lds_conflict_frac"] if mb else None,
+                     "pmc_source": (tr or mb or {}).get("source")})
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    top = rows[0]
+    byfl = max(rows, key=lambda r: r["gflop"])
+    tot_ms = sum(r["ms_per_step"] for r in rows)
+    tot_gf = sum(r["gflop"] for r in rows)
+    mfma = top["gflop"] > 0
+    tr = pmc_traffic(FAMILIES[top["family"]][0])
+    rec = {"bound": "mfma" if mfma else "hbm",
+           "achieved": top["tflops"] if mfma else (top["hbm_bytes_pmc"] or 0.0) / (top["ms_per_step"] * 1e-3) / 1e9,
+           "peak": PEAK_MFMA_BF16_TFLOPS if mfma else 8000.0, "unit": "TFLOP/s" if mfma else "GB/s",
+           "kernel": top["kernels"], "family": top["family"], "launches_per_step": top["launches"],
+           "avg_launch_us": 1e3 * top["ms_per_step"] / max(top["launches"], 1), "avg_launch_gflop": top["gflop"] / max(top["launches"], 1),
+           "kernel_ms_per_step": top["ms_per_step"],
+           "traffic": tr["hbm_bytes_per_launch"] if tr else None, "traffic_source": tr["source"] if tr else None,
+           "mfma_busy_frac": top["mfma_busy_frac"],
+           "dominant_by_time": {k: top[k] for k in ("family", "launches", "ms_per_step", "gflop", "tflops", "frac_of_peak")},
+           "dominant_by_flops": {k: byfl[k] for k in ("family", "launches", "ms_per_step", "gflop", "tflops", "frac_of_peak", "mfma_busy_frac")},
+           "families": rows[:6],
+           "traced": {"launches_per_step": len(trace) // steps, "ms_per_step": tot_ms, "gflop_per_step": tot_gf,
+                      "tflops": tot_gf / tot_ms if tot_ms > 0 else 0.0},
+           "profile_stale": stale}
+    rec["frac"] = rec["achieved"] / rec["peak"]
+    return rec
 
 
 def _time_loop(fn, n, sync=True):
@@ -391,7 +436,7 @@ def dp1_leg_isolated(args):
 
 
 def dp1_leg(cfg, dev, B, L, steps=30):
-    """The data-parallel schedules (FastSpeech2.dp_schedule: "side" = the default, "early" = round 2's, "late") on ONE GPU: the full
+    """The data-parallel schedules (FastSpeech2.dp_schedule: "side" = the default, "late") on ONE GPU: the full
     step with GradReducer issuing its bucketed all-reduces over RCCL at world
     size 1 (a collective per gradient bucket on RCCL's stream, backward_native flushing its deferred weight-gradient work whenever
     a bucket completes) — captured in a hipGraph and eager — beside the plain step, and how many grouped-GEMM / reducer / column-sum
@@ -416,8 +461,8 @@ def dp1_leg(cfg, dev, B, L, steps=30):
         loss_fn = FastSpeech2Loss(c1.preprocess_config, c1.model_config)
         batch = to_device(make_batch(B, L, seed=1234), dev)
         out = None
-        default = os.environ.get("TTSK_DP_SCHEDULE", "side")
-        for sched in [default] + [x for x in ("side", "early", "late") if x != default]:
+        default = switches.get("TTSK_DP_SCHEDULE")
+        for sched in [default] + [x for x in ("side", "late") if x != default]:
             model = FastSpeech2(c1.preprocess_config, c1.model_config, 65, device=dev, seed=1234).train()
             model.dp_schedule = sched
             opt = ScheduledOptim(model, c1.train_config, c1.model_config, 0)
@@ -526,7 +571,7 @@ def main():
         reducer = GradReducer(model.flat_buffers()[1], model.grad_buckets(cfg.mi355x.dp_bucket_mb), model.group_offsets())
     enqueue = make_enqueue(model, opt, cfg, loss_fn, reducer=reducer,
                            grad_scale=reducer.grad_scale(1) if reducer else None)
-    use_graph = not args.no_graph and (world == 1 or os.environ.get("TTSK_DP_GRAPH", "1") != "0")
+    use_graph = not args.no_graph and (world == 1 or switches.get("TTSK_DP_GRAPH") != "0")
     step = lambda: enqueue(batch)
     if use_graph:
         # the data-parallel step (RCCL bucket all-reduces included) is captured as well; two eager steps first so that
@@ -596,30 +641,18 @@ def main():
             "step_mfma_roofline_frac": flops / (ms * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS,
             "final_losses": {"total": losses[0], "mel": losses[1], "pitch": losses[2], "energy": losses[3], "duration": losses[4]},
         }
+        if switches.unknown_in_environment():
+            rec["unknown_switches"] = switches.unknown_in_environment()      # TTSK_* variables nothing reads (tts_king_amd/switches.py)
         if not args.no_roofline:
             eager = make_enqueue(model, opt, cfg, loss_fn, reducer=None)
-            rec["roofline"] = gemm_roofline(eager, batch)
-            if "dwconv" in rec["roofline"]["kernel"]:
-                # Two launches per step: the six decoder weights = 192 workgroups (one per CU, by construction: 4 output-channel tiles x 8
-                # input-channel slices per weight) on the second stream beside the encoder-side dX chain, which runs on the CUs they leave;
-                # the four encoder weights = 128 workgroups beside the final grouped launch.  `achieved` / `frac` are over both, against
-                # the whole chip's peak; on the CUs the kernel occupies the decoder launch runs at frac * 256 / 192.
-                rec["roofline"]["grid"] = {"decoder_launch_workgroups": 192, "encoder_launch_workgroups": 128, "cus": 256,
-                                           "concurrent_with": "length regulator, variance adaptor and encoder backward (main stream)",
-                                           "rows_walked": "sum over utterances of ceil(mel_len / 32) * 32 (PAD rows skipped); FLOPs counted for all B*T rows"}
-            if model.dw_side_wgs > 0 and "gemm2_group" in rec["roofline"]["kernel"]:
-                # The shipped step runs this kernel on a second stream with its grid capped (192 of 256 CUs) beside the encoder-side
-                # dX chain: its launch is longer than on the whole chip and the step shorter.  `achieved` / `frac` above are what runs
-                # (and what rocprofv3 shows); `whole_chip` is the same kernel uncapped, alone, for the kernel's own quality.
-                cap = model.dw_side_wgs
-                rec["roofline"]["grid_cap"] = {"workgroups": cap, "cus": 256, "frac_of_peak_on_its_cus": rec["roofline"]["frac"] * 256.0 / cap,
-                                               "concurrent_with": "length regulator, variance adaptor and encoder backward (main stream)"}
-                model.dw_side_wgs = 0
-                try:
-                    whole = gemm_roofline(eager, batch)
-                finally:
-                    model.dw_side_wgs = cap
-                rec["roofline"]["whole_chip"] = {k: whole[k] for k in ("achieved", "frac", "avg_launch_us", "kernel_ms_per_step", "kernel")}
+            rec["roofline"] = step_roofline(eager, batch)
+            # the family with the most FLOPs behind one symbol's worth of launches (round 3's headline kernel), kept for continuity:
+            # dwconv runs as two launches per step — six decoder weights = 192 workgroups (one per CU) beside the encoder-side dX
+            # chain, four encoder weights = 128 workgroups in the final phase; FLOPs counted for all B*T rows, PAD rows are skipped
+            dwc = [r for r in rec["roofline"]["families"] if r["family"] == "dwconv"]
+            if dwc:
+                rec["roofline"]["dwconv_grid"] = {"decoder_launch_workgroups": 192, "encoder_launch_workgroups": 128, "cus": 256,
+                                                  "frac_of_peak": dwc[0]["frac_of_peak"]}
         if world == 1 and not args.no_extra:
             rec.update(extra_train_legs(cfg, dev, B, L, steps=args.steps))
             rec["dp_schedule_1gpu"] = dp1_rec

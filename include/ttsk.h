@@ -372,8 +372,9 @@ int ttsk_softmax_fwd(const float* scores, void* probs_bf16, const int64_t* lens,
 int ttsk_softmax_bwd(const void* probs_bf16, const float* dprobs, void* dscores_bf16, int nz, int S, int Sp, float alpha,
                      void* stream);
 
-/* ---------------------------------------------------------------------------- flash attention (d_k = 128), round 2
- * The same math as ttsk_attention_fwd / _bwd_q below (reference: fs_two/transformer/Modules.py:14-24 + SubLayers.py:44-60)
+/* ---------------------------------------------------------------------------- flash attention (d_k = 128)
+ * softmax(q k^T * scale, keys >= lens[b] masked) v per (utterance, head) on the fused projection output qkv [B*S][3*d] (q | k | v, head h =
+ * columns h*128.. of each part), heads merged back in o [B*S][d] (reference: fs_two/transformer/Modules.py:14-24 + SubLayers.py:44-60)
  * without any S x S tensor in HBM: the forward keeps a running row max / sum over 64-key tiles and returns O and, for the
  * backward, lse [B*H][S] = log sum_k exp(score); the backward recomputes P = exp(score - lse) per tile.
  * bwd: delta_ws [B*H][S] fp32 scratch; writes ALL of dqkv [B*S][3*d] (dQ | dK | dV, head h at columns h*128 of each part),
@@ -386,19 +387,6 @@ int ttsk_flash_attention_fwd(const void* qkv_bf16, void* o_bf16, float* o_f32 /*
 int ttsk_flash_attention_bwd(const void* qkv_bf16, const void* o_bf16, const float* o_f32 /* may be NULL */, const void* dout_bf16,
                              const float* lse, float* delta_ws, int delta_ready, void* dqkv_bf16, const int64_t* lens, int B, int H, int S,
                              int d, float scale, void* stream);
-
-/* ------------------------------------------------------------------------------------- fused attention (d_k = 128)
- * reference: fs_two/transformer/Modules.py:14-24 + SubLayers.py:44-60.  qkv is the fused projection output
- * [B*S][3*d] (q | k | v, head h = columns h*128.. of each part), o [B*S][d] has the heads merged back.
- * fwd: o = softmax(q k^T * scale, keys >= lens[b] masked) v; probs (optional, [B*H][S][Sp] bf16, Sp % 8 == 0) receives P;
- *      o_f32 (optional, [B*S][d]) the un-rounded sum_k P v, from which the backward forms rowsum(P o dP) = dO . o_f32
- *      consistently with the bf16 P it multiplies by.
- * bwd_q: dS = scale * P o (dO V^T - dO . o_f32) -> ds [B*H][S][Sp]; dQ = dS K -> columns h*128.. of dqkv [B*S][3*d].
- *        (dK = dS^T Q and dV = P^T dO are batched ttsk_gemm launches.) */
-int ttsk_attention_fwd(const void* qkv_bf16, void* o_bf16, float* o_f32, void* probs_bf16, const int64_t* lens, int B, int H, int S,
-                       int Sp, int d, float scale, void* stream);
-int ttsk_attention_bwd_q(const void* qkv_bf16, const float* o_f32, const void* dout_bf16, const void* probs_bf16, void* ds_bf16,
-                         void* dqkv_bf16, int B, int H, int S, int Sp, int d, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------- embeddings / variance adaptor
  * bucketize: idx = #{bins < v*scale} (torch.bucketize right=False; reference: model/modules.py:95-100,134-139)
@@ -586,6 +574,12 @@ int ttsk_optim_state_bytes(void);
 int ttsk_optim_advance(void* state, float d_model, float warmup, const float* anneal_steps_host, int n_anneal,
                        float anneal_rate, float beta1, float beta2, void* stream);
 int ttsk_rng_advance(void* state, void* stream);
+/* The keep-mask of dropout site `site` at the state `rng` points to ({uint64 seed, uint64 step}): keep[e] = 1 iff element e (row-major
+ * index into the site's [rows][C] tensor) survives with drop probability p — the very function of (seed, step, site, e) every kernel of
+ * the step evaluates (masks are regenerated, never stored).  Sites of the FS2 step: encoder block i: 2 i (fc), 2 i + 1 (w_2); decoder
+ * block i: 100 + 2 i, 101 + 2 i; predictor g in (duration, pitch, energy): 200 + 2 g, 201 + 2 g; PostNet layer i: 300 + i
+ * (reference sites: SubLayers.py:62,98; modules.py:283,295; Layers.py:137-140).  n % 4 == 0.  For parity tests. */
+int ttsk_dropout_keep_mask(const uint64_t* rng, uint32_t site, int64_t n, float p, uint8_t* keep, void* stream);
 int ttsk_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n,
                         void* state, float* partials, float max_norm, float beta1, float beta2, float eps, int zero_grad,
                         void* stream);

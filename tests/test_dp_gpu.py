@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("schedule", ["side", "early", "late"])
+@pytest.mark.parametrize("schedule", ["side", "late", "per_bucket"])
 def test_reducer_step_equals_plain_step(cfg, schedule):
     """Every data-parallel schedule (FastSpeech2.dp_schedule) leaves the plain step's losses and weights, bit for bit, and launches
     every bucket exactly once, from the end of the buffer."""
@@ -39,8 +39,11 @@ def test_reducer_step_equals_plain_step(cfg, schedule):
             m = FastSpeech2(c.preprocess_config, c.model_config, 65, device=DEV)
             m.load_state_dict(fs2_state_dict(c, 7))
             m.p_enc = m.p_dec = m.p_var = m.p_post = 0.0
-            m.dp_schedule = schedule
-            m.dwconv = schedule != "early"      # the "early" schedule keeps the grouped GEMMs (its flushes are small); compare like with like
+            if schedule == "per_bucket":        # no second stream: buckets are flushed one by one on the main stream as they complete
+                m.dw_side_wgs = 0               # (the grouped GEMMs carry every weight gradient there: compare like with like)
+                m.dwconv = False
+            else:
+                m.dp_schedule = schedule
             m.train()
             opt = ScheduledOptim(m, c.train_config, c.model_config, 0)
             red = GradReducer(m.flat_buffers()[1], m.grad_buckets(8), m.group_offsets(), force_collectives=True) if use_reducer else None

@@ -16,7 +16,7 @@ for (B, L, dur_hi, seed) in ((2, 200, 12, 77), (2, 200, 9, 77), (2, 100, 12, 5),
     b = make_batch(B, L, seed=seed, ragged=True, dur_hi=dur_hi)
     with torch.no_grad():
         o = ofs2.fs2_forward(sd, mc0, *b[2:], train=True, bn_buffers={})
-    for name, kw in (("default", {}), ("no fused_ln", {"fused_ln": False}), ("no fused attn", {"fused_attention": False}), ("no grouped pred", {"group_predictors": False})):
+    for name, kw in (("default", {}), ("no fused_ln", {"fused_ln": False}), ("no flash attn", {"flash_attention": False}), ("no grouped pred", {"group_predictors": False})):
         m = FastSpeech2(cfg.preprocess_config, cfg.model_config, 65, device=DEV)
         m.load_state_dict(sd); m.p_enc = m.p_dec = m.p_var = m.p_post = 0.0; m.train()
         for k, v in kw.items(): setattr(m, k, v)

@@ -52,7 +52,10 @@ def summarise(rows):
 
 def main():
     src, dst = sys.argv[1], sys.argv[2]
-    doc = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY "
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tts_king_amd.lib import source_fingerprint
+    doc = {"csrc_fingerprint": source_fingerprint(),
+           "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY "
                      "SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace (tools/pmc_mfma.sh); ratios: see tools/pmc_mfma_summary.py",
            "fs2_train_step": summarise(load(os.path.join(src, "fs2"))), "hifi_gan": summarise(load(os.path.join(src, "hifi")))}
     json.dump(doc, open(dst, "w"), indent=1)

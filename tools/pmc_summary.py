@@ -7,6 +7,13 @@ exact for 16-byte-per-lane stores.  Infinity-Cache hits are counted by both (the
 import csv, glob, json, os, sys
 
 
+def _fingerprint():
+    """Identity of the kernel sources the counters were taken with (tts_king_amd/lib.py:source_fingerprint); bench.py compares it."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tts_king_amd.lib import source_fingerprint
+    return source_fingerprint()
+
+
 def per_kernel(d, counter):
     out = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -32,7 +39,8 @@ def main():
     for r in rows:
         r["hbm_bytes_per_launch"] = r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"]
     rows.sort(key=lambda r: -r["hbm_bytes_per_launch"] * r["dispatches"])
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 3 --warmup 2",
+    json.dump({"csrc_fingerprint": _fingerprint(),
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 3 --warmup 2",
                "unit": "bytes per launch (FETCH_SIZE x2 per the gfx950 rule, + WRITE_SIZE)", "kernels": rows}, open(dst, "w"), indent=1)
     for r in rows[:16]:
         print("%-70s n=%5d  fetch %8.2f MB  write %8.2f MB" % (r["kernel"][:70], r["dispatches"], r["fetch_bytes_per_launch"] / 1e6, r["write_bytes_per_launch"] / 1e6))

@@ -488,8 +488,7 @@ int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int pa
     else hipLaunchKernelGGL((win_conv_kernel<512, 128, false, true, WC_NW, WC_CT, true>), gu, dim3(WC_NT), 0, s, a);
     return 0;
   }
-  static const int narrow_ok = [] { const char* e = getenv("TTSK_WIN_NARROW"); return (e && atoi(e) == 0) ? 0 : 1; }();
-  if (short_seq && narrow_ok && !a.delta && (int)grid.x <= 128) {     // few workgroups, each bound by its weight stream: 64-channel groups
+  if (short_seq && !a.delta && (int)grid.x <= 128) {     // few workgroups, each bound by its weight stream: 64-channel groups
     dim3 g4(grid.x * 4);
     if (out_f32) hipLaunchKernelGGL((win_conv_kernel<256, 64, true, true, 4, 1>), g4, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((win_conv_kernel<256, 64, false, true, 4, 1>), g4, dim3(256), 0, s, a);

@@ -17,7 +17,6 @@
 // Fragment / LDS idioms (XOR-swizzled row-major images, ds_read_b64_tr_b16 images for operands whose contraction index is the
 // memory row) are those of attn.hip (attn_common.h).  Two workgroups fit a CU (<= 80 KB of LDS each).
 #include "attn_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -33,7 +32,6 @@ struct FlashArgs {
   const long long* lens;  // [B] valid keys per utterance (null = S)
   int S, H, d;
   float scale;
-  int plain_order;        // 1 = (blockIdx.x, blockIdx.y) as launched (diagnostic: TTSK_FLASH_XCD=0); 0 = xcd_tile's mapping
 };
 
 constexpr int STAGE_KV = KS_BYTES + VS_BYTES;            // one K tile (row-major image) + one V tile (contraction-major image)
@@ -43,140 +41,15 @@ constexpr int STAGE_KV = KS_BYTES + VS_BYTES;            // one K tile (row-majo
 // with an L2 of its own, so the plain (blockIdx.x, blockIdx.y) order spreads the query tiles that share a head's K / V (or the key
 // tiles that share its Q / dO) over all eight and every one of them fetches its own copy from memory.  Bijective when the number of
 // (batch, head) pairs is a multiple of 8; otherwise the plain order.
-__device__ __forceinline__ void xcd_tile(int& tile, int& z, int plain) {
+__device__ __forceinline__ void xcd_tile(int& tile, int& z) {
   const int nx = gridDim.x, ny = gridDim.y;
   tile = blockIdx.x;
   z = blockIdx.y;
-  if ((ny & 7) == 0 && !plain) {
+  if ((ny & 7) == 0) {
     const int L = blockIdx.x + nx * blockIdx.y;
     const int xcd = L & 7, slot = L >> 3;
     z = (slot / nx) * 8 + xcd;
     tile = slot - (slot / nx) * nx;
-  }
-}
-
-__global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const FlashArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_KV + PS_BYTES];      // 73,728 B
-  unsigned char* Ps = smem + 2 * STAGE_KV;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  int tile_x, z;
-  xcd_tile(tile_x, z, a.plain_order);
-  const int b = z / a.H, h = z - b * a.H;
-  const int q0 = tile_x * TQ;
-  const int S = a.S, ld = 3 * a.d;
-  const int len = a.lens ? min((int)a.lens[b], S) : S;
-  const int ntk = (len + TK - 1) / TK;                       // key tiles that hold at least one valid key
-  const bf16_t* base = a.qkv + (int64_t)b * S * ld + h * DK;
-  unsigned char* Pw = Ps + wave * 16 * PS_RS;
-
-  uint4 rk[4], rv[4];
-  {  // Q goes through the K slot of stage 1 (free until tile 1 is stored); tile 0 of K / V into stage 0
-    uint4 rq[4];
-    load_tile(rq, base, ld, q0, S, tid);
-    if (ntk > 0) { load_tile(rk, base + a.d, ld, 0, S, tid); load_tile(rv, base + 2 * a.d, ld, 0, S, tid); }
-    store_rows(smem + STAGE_KV, rq, tid);
-    if (ntk > 0) { store_rows(smem, rk, tid); store_tr(smem + KS_BYTES, rv, tid); }
-  }
-  __syncthreads();
-  bf16x8 qa[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qa[ks] = frag_rows(smem + STAGE_KV, wave * 16, ks, l15, lg);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __syncthreads();                                       // every wave holds its Q fragments: stage 1 may be refilled
-
-  float m[4], l[4];
-  f32x4 oacc[8];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
-#pragma unroll
-  for (int nb = 0; nb < 8; ++nb) oacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  for (int j = 0; j < ntk; ++j) {
-    const unsigned char* Ks = smem + (j & 1) * STAGE_KV;
-    const unsigned char* Vs = Ks + KS_BYTES;
-    if (j + 1 < ntk) {     // next tile's loads fly during this tile's arithmetic
-      load_tile(rk, base + a.d, ld, (j + 1) * TK, S, tid);
-      load_tile(rv, base + 2 * a.d, ld, (j + 1) * TK, S, tid);
-    }
-    f32x4 s[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], frag_rows(Ks, nt * 16, ks, l15, lg), s[nt], 0, 0, 0);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int key = j * TK + nt * 16 + l15;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s[nt][r] = key < len ? s[nt][r] * a.scale : -INFINITY;
-    }
-    // online softmax: every tile j < ntk holds a valid key, so the new row maximum is finite
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float tm = fmaxf(fmaxf(s[0][r], s[1][r]), fmaxf(s[2][r], s[3][r]));
-      tm = quad16_max(tm);
-      const float mn = fmaxf(m[r], tm);
-      const float corr = __expf(m[r] - mn);              // exp(-inf) = 0 on the first tile
-      float ts = 0.f;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) { const float p = __expf(s[nt][r] - mn); s[nt][r] = p; ts += p; }
-      ts = quad16_sum(ts);
-      l[r] = l[r] * corr + ts;
-      m[r] = mn;
-#pragma unroll
-      for (int nb = 0; nb < 8; ++nb) oacc[nb][r] *= corr;
-    }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) *(bf16_t*)(Pw + (lg * 4 + r) * PS_RS + (nt * 16 + l15) * 2) = f2bf(s[nt][r]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the P tile is private to the wave
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 pa = *(const bf16x8*)(Pw + l15 * PS_RS + (ks * 32 + lg * 8) * 2);
-#pragma unroll
-      for (int nb = 0; nb < 8; ++nb) oacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, frag_tr(Vs, nb, ks, l15, lg), oacc[nb], 0, 0, 0);
-    }
-    if (j + 1 < ntk) {
-      unsigned char* nx = smem + ((j + 1) & 1) * STAGE_KV;   // last read in iteration j-1: every wave passed that iteration's barrier
-      store_rows(nx, rk, tid);
-      store_tr(nx + KS_BYTES, rv, tid);
-    }
-    __syncthreads();
-  }
-
-  // ---- O / l -> bf16 -> LDS -> full-row stores (heads merged: column h*128); LSE per row
-  float inv[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) inv[r] = l[r] > 0.f ? 1.f / l[r] : 0.f;
-  if (a.lse && l15 == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int q = q0 + wave * 16 + lg * 4 + r;
-      if (q < S) a.lse[(int64_t)z * S + q] = l[r] > 0.f ? m[r] + __logf(l[r]) : 0.f;
-    }
-  }
-  if (a.o32) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int q = q0 + wave * 16 + lg * 4 + r;
-      if (q >= S) continue;
-      float* dst = a.o32 + ((int64_t)b * S + q) * a.d + h * DK + l15;
-#pragma unroll
-      for (int nb = 0; nb < 8; ++nb) dst[nb * 16] = oacc[nb][r] * inv[r];
-    }
-  }
-  unsigned char* Os = smem;   // 64 x 272 B = 17 KiB over stage 0 (dead: the loop ended with a barrier)
-#pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) *(bf16_t*)(Os + (wave * 16 + lg * 4 + r) * OS_RS + (nb * 16 + l15) * 2) = f2bf(oacc[nb][r] * inv[r]);
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = i * 256 + tid, row = c >> 4, ch = c & 15;
-    if (q0 + row < S) *(uint4*)(a.o + ((int64_t)b * S + q0 + row) * a.d + h * DK + ch * 8) = *(const uint4*)(Os + row * OS_RS + ch * 16);
   }
 }
 
@@ -225,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_t_kernel(const FlashArgs a) 
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_KV];      // 64 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   int tile_x, z;
-  xcd_tile(tile_x, z, a.plain_order);
+  xcd_tile(tile_x, z);
   const int b = z / a.H, h = z - b * a.H;
   const int q0 = tile_x * TQ;
   const int S = a.S, ld = 3 * a.d;
@@ -330,228 +203,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_t_kernel(const FlashArgs a) 
   }
 }
 
-// ------------------------------------------------------------------------------------------------ backward, query side
-// per (utterance, head, 64 queries): delta, then over the key tiles  P, dP -> dS -> dQ += dS K
-__device__ __forceinline__ void flash_bwd_q_body(const FlashArgs& a, unsigned char* smem) {      // uses 58,368 B of smem
-  unsigned char* Kr = smem;                          // K tile, row-major image  (B operand of S = Q K^T)
-  unsigned char* Kt = smem + KS_BYTES;               // K tile, contraction-major image (B operand of dQ = dS K)
-  unsigned char* Vr = Kt + VS_BYTES;                 // V tile, row-major image  (B operand of dP = dO V^T)
-  unsigned char* Ss = Vr + KS_BYTES;                 // per-wave dS tile
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  int tile_x, z;
-  xcd_tile(tile_x, z, a.plain_order);
-  const int b = z / a.H, h = z - b * a.H;
-  const int q0 = tile_x * TQ;
-  const int S = a.S, ld = 3 * a.d;
-  const int len = a.lens ? min((int)a.lens[b], S) : S;
-  const int ntk = (len + TK - 1) / TK;
-  const bf16_t* base = a.qkv + (int64_t)b * S * ld + h * DK;
-  const bf16_t* dob = a.dout + (int64_t)b * S * a.d + h * DK;
-  const bf16_t* ob = a.o + (int64_t)b * S * a.d + h * DK;
-  unsigned char* Sw = Ss + wave * 16 * PS_RS;
-
-  uint4 rk[4], rv[4];
-  // Q and dO fragments of this wave's 16 rows: through LDS once (Kr / Vr slots), then registers for the whole loop.  Requested before
-  // the first K / V tile (loads return in order; Q and dO are consumed first and do not wait for the utterance length).
-  {
-    uint4 rq[4], rd[4];
-    load_tile(rq, base, ld, q0, S, tid);
-    load_tile(rd, dob, a.d, q0, S, tid);
-    if (ntk > 0) { load_tile(rk, base + a.d, ld, 0, S, tid); load_tile(rv, base + 2 * a.d, ld, 0, S, tid); }
-    store_rows(Kr, rq, tid);
-    store_rows(Vr, rd, tid);
-  }
-  // delta[q] = sum_d dO[q][d] * O[q][d] (flash_delta_kernel) and LSE for rows lg*4 + r of the wave
-  float delta[4], lse[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int q = q0 + wave * 16 + lg * 4 + r;
-    delta[r] = q < S ? a.delta[(int64_t)z * S + q] : 0.f;
-    lse[r] = q < S ? a.lse[(int64_t)z * S + q] : 0.f;
-  }
-  __syncthreads();
-  bf16x8 qa[4], da[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) { qa[ks] = frag_rows(Kr, wave * 16, ks, l15, lg); da[ks] = frag_rows(Vr, wave * 16, ks, l15, lg); }
-
-  f32x4 dq[8];
-#pragma unroll
-  for (int nb = 0; nb < 8; ++nb) dq[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  for (int j = 0; j < ntk; ++j) {
-    __syncthreads();                              // the previous tile's (or the Q / dO staging's) LDS reads are done
-    store_rows(Kr, rk, tid);
-    store_tr(Kt, rk, tid);
-    store_rows(Vr, rv, tid);
-    if (j + 1 < ntk) { load_tile(rk, base + a.d, ld, (j + 1) * TK, S, tid); load_tile(rv, base + 2 * a.d, ld, (j + 1) * TK, S, tid); }
-    __syncthreads();
-    f32x4 s[4], dp[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { s[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], frag_rows(Kr, nt * 16, ks, l15, lg), s[nt], 0, 0, 0);
-        dp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[ks], frag_rows(Vr, nt * 16, ks, l15, lg), dp[nt], 0, 0, 0);
-      }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int key = j * TK + nt * 16 + l15;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = key < len ? __expf(s[nt][r] * a.scale - lse[r]) : 0.f;
-        *(bf16_t*)(Sw + (lg * 4 + r) * PS_RS + (nt * 16 + l15) * 2) = f2bf(a.scale * p * (dp[nt][r] - delta[r]));
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 sa = *(const bf16x8*)(Sw + l15 * PS_RS + (ks * 32 + lg * 8) * 2);
-#pragma unroll
-      for (int nb = 0; nb < 8; ++nb) dq[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, frag_tr(Kt, nb, ks, l15, lg), dq[nb], 0, 0, 0);
-    }
-  }
-  __syncthreads();
-  unsigned char* Os = smem;
-#pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) *(bf16_t*)(Os + (wave * 16 + lg * 4 + r) * OS_RS + (nb * 16 + l15) * 2) = f2bf(dq[nb][r]);
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = i * 256 + tid, row = c >> 4, ch = c & 15;
-    if (q0 + row < S) *(uint4*)(a.dqkv + ((int64_t)b * S + q0 + row) * ld + h * DK + ch * 8) = *(const uint4*)(Os + row * OS_RS + ch * 16);
-  }
-}
-
-// -------------------------------------------------------------------------------------------------- backward, key side
-// per (utterance, head, 64 keys): over the query tiles, with keys on the MFMA rows:
-//   S^T = K Q^T, dP^T = V dO^T  ->  P^T = exp(S^T * scale - LSE[query]),  dS^T = P^T o (dP^T - delta[query]) * scale
-//   dV += P^T dO,  dK += dS^T Q          (dO and Q as contraction-major images: the contraction index is the query row)
-__device__ __forceinline__ void flash_bwd_kv_body(const FlashArgs& a, unsigned char* smem) {     // uses 74,752 B of smem
-  unsigned char* Qr = smem;                          // Q tile, row-major image           (B operand of S^T = K Q^T)
-  unsigned char* Dr = smem + KS_BYTES;               // dO tile, row-major image          (B operand of dP^T = V dO^T)
-  unsigned char* Qt = Dr + KS_BYTES;                 // Q tile, contraction-major image   (B operand of dK += dS^T Q)
-  unsigned char* Dt = Qt + VS_BYTES;                 // dO tile, contraction-major image  (B operand of dV += P^T dO)
-  unsigned char* Ps = Dt + VS_BYTES;                 // per-wave P^T, then dS^T tile [16 keys][64 queries]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  int tile_x, z;
-  xcd_tile(tile_x, z, a.plain_order);
-  const int b = z / a.H, h = z - b * a.H;
-  const int k0 = tile_x * TK;
-  const int S = a.S, ld = 3 * a.d;
-  const int len = a.lens ? min((int)a.lens[b], S) : S;
-  const bf16_t* base = a.qkv + (int64_t)b * S * ld + h * DK;
-  const bf16_t* dob = a.dout + (int64_t)b * S * a.d + h * DK;
-  unsigned char* Pw = Ps + wave * 16 * PS_RS;
-  const int ntq = (S + TQ - 1) / TQ;
-
-  f32x4 dk[8], dv[8];
-#pragma unroll
-  for (int nb = 0; nb < 8; ++nb) { dk[nb] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[nb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-  if (k0 < len) {        // (a key tile entirely past the utterance gets zero gradients: nothing to compute)
-    uint4 rq[4], rd[4];
-    load_tile(rq, base, ld, 0, S, tid);
-    load_tile(rd, dob, a.d, 0, S, tid);
-    {  // K and V fragments of this wave's 16 keys: through LDS once (Qr / Dr slots), then registers
-      uint4 rk[4], rv[4];
-      load_tile(rk, base + a.d, ld, k0, S, tid);
-      load_tile(rv, base + 2 * a.d, ld, k0, S, tid);
-      store_rows(Qr, rk, tid);
-      store_rows(Dr, rv, tid);
-    }
-    __syncthreads();
-    bf16x8 ka[4], va[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) { ka[ks] = frag_rows(Qr, wave * 16, ks, l15, lg); va[ks] = frag_rows(Dr, wave * 16, ks, l15, lg); }
-
-    for (int i = 0; i < ntq; ++i) {
-      __syncthreads();                            // the previous tile's (or the K / V staging's) LDS reads are done
-      store_rows(Qr, rq, tid);
-      store_tr(Qt, rq, tid);
-      store_rows(Dr, rd, tid);
-      store_tr(Dt, rd, tid);
-      if (i + 1 < ntq) { load_tile(rq, base, ld, (i + 1) * TQ, S, tid); load_tile(rd, dob, a.d, (i + 1) * TQ, S, tid); }
-      // LSE / delta of this lane's query columns (nt*16 + l15)
-      float lq[4], dq_[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int q = i * TQ + nt * 16 + l15;
-        lq[nt] = q < S ? a.lse[(int64_t)z * S + q] : 0.f;
-        dq_[nt] = q < S ? a.delta[(int64_t)z * S + q] : 0.f;
-      }
-      __syncthreads();
-      f32x4 st[4], dpt[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) { st[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          st[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[ks], frag_rows(Qr, nt * 16, ks, l15, lg), st[nt], 0, 0, 0);
-          dpt[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[ks], frag_rows(Dr, nt * 16, ks, l15, lg), dpt[nt], 0, 0, 0);
-        }
-      // P^T tile (rows = this wave's keys lg*4 + r, columns = queries)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int q = i * TQ + nt * 16 + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = k0 + wave * 16 + lg * 4 + r;
-          const float p = (key < len && q < S) ? __expf(st[nt][r] * a.scale - lq[nt]) : 0.f;
-          st[nt][r] = p;
-          *(bf16_t*)(Pw + (lg * 4 + r) * PS_RS + (nt * 16 + l15) * 2) = f2bf(p);
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      bf16x8 pa[2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) pa[ks] = *(const bf16x8*)(Pw + l15 * PS_RS + (ks * 32 + lg * 8) * 2);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // P^T fragments are in registers: the tile can take dS^T
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          *(bf16_t*)(Pw + (lg * 4 + r) * PS_RS + (nt * 16 + l15) * 2) = f2bf(a.scale * st[nt][r] * (dpt[nt][r] - dq_[nt]));
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int nb = 0; nb < 8; ++nb) dv[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[ks], frag_tr(Dt, nb, ks, l15, lg), dv[nb], 0, 0, 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 sa = *(const bf16x8*)(Pw + l15 * PS_RS + (ks * 32 + lg * 8) * 2);
-#pragma unroll
-        for (int nb = 0; nb < 8; ++nb) dk[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, frag_tr(Qt, nb, ks, l15, lg), dk[nb], 0, 0, 0);
-      }
-    }
-  }
-  // ---- dK, dV tiles -> bf16 -> LDS -> full-row stores into the k / v columns of dqkv
-  __syncthreads();
-  unsigned char* Os = smem;                   // two 64 x 272 B tiles = 34 KiB
-#pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      *(bf16_t*)(Os + (wave * 16 + lg * 4 + r) * OS_RS + (nb * 16 + l15) * 2) = f2bf(dk[nb][r]);
-      *(bf16_t*)(Os + 64 * OS_RS + (wave * 16 + lg * 4 + r) * OS_RS + (nb * 16 + l15) * 2) = f2bf(dv[nb][r]);
-    }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = i * 256 + tid, row = c >> 4, ch = c & 15;
-    if (k0 + row < S) {
-      bf16_t* dst = a.dqkv + ((int64_t)b * S + k0 + row) * ld + h * DK + ch * 8;
-      *(uint4*)(dst + a.d) = *(const uint4*)(Os + row * OS_RS + ch * 16);
-      *(uint4*)(dst + 2 * a.d) = *(const uint4*)(Os + 64 * OS_RS + row * OS_RS + ch * 16);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ backward, P / dS in registers
+// ------------------------------------------------------------------------------------------------ backward
 // Round 3: flash_fwd_t_kernel's idiom on both sides of the backward.  Every product is taken transposed so that the tile that is both
 // an MFMA result and the next MFMA's operand (dS for dQ; P and dS for dV and dK) is packed from the accumulators straight into a B
 // operand — under the slot order frag_tr8 reads its transposed A operand in — instead of going through 16 (32 on the key side)
@@ -570,7 +222,7 @@ __device__ __forceinline__ void flash_bwd_q_t_body(const FlashArgs& a, unsigned 
   unsigned char* Kt = Vr + KS_BYTES;                 // K tile, store_tr8 image            (A operand of dQ^T += K^T dS^T)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   int tile_x, z;
-  xcd_tile(tile_x, z, a.plain_order);
+  xcd_tile(tile_x, z);
   const int b = z / a.H, h = z - b * a.H;
   const int q0 = tile_x * TQ;
   const int S = a.S, ld = 3 * a.d;
@@ -656,7 +308,7 @@ __device__ __forceinline__ void flash_bwd_kv_t_body(const FlashArgs& a, unsigned
   float* LD = (float*)(Dt + VS_BYTES);               // [64] LSE | [64] delta of the query tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   int tile_x, z;
-  xcd_tile(tile_x, z, a.plain_order);
+  xcd_tile(tile_x, z);
   const int b = z / a.H, h = z - b * a.H;
   const int k0 = tile_x * TK;
   const int S = a.S, ld = 3 * a.d;
@@ -788,11 +440,6 @@ __global__ __launch_bounds__(256) void flash_delta_kernel(const FlashArgs a) {
 // The query side (dQ) and the key side (dK, dV) as ONE grid (blockIdx.z = side): with delta precomputed neither needs the other, and a
 // side alone is 7 x 32 workgroups for the decoder — one per CU, a single wave per SIMD on a chain of dependent loads, LDS round trips
 // and VALU work; together two workgroups share a CU and fill each other's stalls.
-__global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KS_BYTES + 2 * VS_BYTES + PS_BYTES];      // 74,752 B (the key side's)
-  if (blockIdx.z == 0) flash_bwd_q_body(a, smem);
-  else flash_bwd_kv_body(a, smem);
-}
 __global__ __launch_bounds__(256, 2) void flash_bwd_t_kernel(const FlashArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KS_BYTES + 2 * VS_BYTES + 512];           // 66,048 B (the key side's)
   if (blockIdx.z == 0) flash_bwd_q_t_body(a, smem);
@@ -801,28 +448,13 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_t_kernel(const FlashArgs a) 
 
 }  // namespace
 
-static int flash_fwd_variant() {          // TTSK_FLASH_FWD=0: the round-2 forward (P through LDS); default: flash_fwd_t_kernel
-  static const int v = [] { const char* e = getenv("TTSK_FLASH_FWD"); return (e && atoi(e) == 0) ? 0 : 1; }();
-  return v;
-}
-static int flash_bwd_variant() {          // TTSK_FLASH_BWD=0: the round-2 backward (P / dS through LDS); default: flash_bwd_t_kernel
-  static const int v = [] { const char* e = getenv("TTSK_FLASH_BWD"); return (e && atoi(e) == 0) ? 0 : 1; }();
-  return v;
-}
-static int flash_plain_order() {
-  static const int v = [] { const char* e = getenv("TTSK_FLASH_XCD"); return (e && atoi(e) == 0) ? 1 : 0; }();
-  return v;
-}
-
 extern "C" int ttsk_flash_attention_fwd(const void* qkv_bf16, void* o_bf16, float* o_f32, float* lse, const int64_t* lens, int B, int H,
                                         int S, int d, float scale, void* stream) {
   TTSK_REQUIRE(qkv_bf16 && o_bf16, "flash_attention_fwd: null pointer");
   TTSK_REQUIRE(B > 0 && H > 0 && S > 0 && d == H * DK, "flash_attention_fwd: head size must be 128 (d = %d, H = %d)", d, H);
   TTSK_REQUIRE(B * H <= 65535 && (int64_t)S * 3 * d * 2 < ((int64_t)1 << 31), "flash_attention_fwd: sizes out of range");
   FlashArgs a{(const bf16_t*)qkv_bf16, (bf16_t*)o_bf16, o_f32, lse, nullptr, nullptr, nullptr, (const long long*)lens, S, H, d, scale};
-  a.plain_order = flash_plain_order();
-  if (flash_fwd_variant()) hipLaunchKernelGGL(flash_fwd_t_kernel, dim3((S + TQ - 1) / TQ, B * H), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(flash_fwd_kernel, dim3((S + TQ - 1) / TQ, B * H), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(flash_fwd_t_kernel, dim3((S + TQ - 1) / TQ, B * H), dim3(256), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }
@@ -835,10 +467,8 @@ extern "C" int ttsk_flash_attention_bwd(const void* qkv_bf16, const void* o_bf16
   TTSK_REQUIRE(B * H <= 65535 && (int64_t)S * 3 * d * 2 < ((int64_t)1 << 31), "flash_attention_bwd: sizes out of range");
   FlashArgs a{(const bf16_t*)qkv_bf16, (bf16_t*)o_bf16, (float*)o_f32, (float*)lse, (const bf16_t*)dout_bf16, delta_ws, (bf16_t*)dqkv_bf16,
               (const long long*)lens, S, H, d, scale};
-  a.plain_order = flash_plain_order();
   if (!delta_ready) hipLaunchKernelGGL(flash_delta_kernel, dim3((S + 15) / 16, B * H), dim3(256), 0, (hipStream_t)stream, a);
-  if (flash_bwd_variant()) hipLaunchKernelGGL(flash_bwd_t_kernel, dim3((S + TQ - 1) / TQ, B * H, 2), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(flash_bwd_kernel, dim3((S + TQ - 1) / TQ, B * H, 2), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(flash_bwd_t_kernel, dim3((S + TQ - 1) / TQ, B * H, 2), dim3(256), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -12,7 +12,6 @@
 // LDS-DMA into a 4-stage ring (see the comment at the kernel), XOR-swizzled 128-byte rows (conflict-free fragment reads),
 // one barrier per K step.  Epilogue: accumulators -> fp32 LDS tile -> one wave per row (4 columns per
 // lane, exactly ln_fwd_kernel's row code: same Philox indexing, so ln_bwd_kernel regenerates the same dropout mask).
-#include <cstdlib>
 #include "gemm_common.h"
 #include "proj32.h"
 
@@ -385,16 +384,8 @@ extern "C" int ttsk_gemm_ln_fwd(const void* A, int lda, const void* W, int ldw, 
   TTSK_REQUIRE(!lens || (seg_len > 0 && M % seg_len == 0), "ttsk_gemm_ln_fwd: lens needs M %% seg_len == 0");
   GemmLnArgs a{(const bf16_t*)A, (const bf16_t*)W, bias, (const bf16_t*)res, gamma, beta, (bf16_t*)out, (bf16_t*)z_save, mean, rstd,
                (const long long*)lens, (const uint64_t*)rng, M, K, lda, ldw, seg_len > 0 ? seg_len : 1, p_pre, eps, site_pre};
-  static const int variant = [] { const char* e = getenv("TTSK_GEMM_LN_VARIANT"); return e ? atoi(e) : 3; }();   // tuning knob (tools/debug)
-  const dim3 grid((M + BM - 1) / BM);
-  switch (variant) {
-    case 0: hipLaunchKernelGGL((gemm_ln_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    case 1: hipLaunchKernelGGL((gemm_ln_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    case 2: hipLaunchKernelGGL((gemm_ln_kernel<8, false>), grid, dim3(512), 0, (hipStream_t)stream, a); break;
-    case 4: hipLaunchKernelGGL((gemm_ln_kernel<16, false>), grid, dim3(1024), 0, (hipStream_t)stream, a); break;
-    case 5: hipLaunchKernelGGL((gemm_ln_kernel<16, true>), grid, dim3(1024), 0, (hipStream_t)stream, a); break;
-    default: hipLaunchKernelGGL((gemm_ln_kernel<8, true>), grid, dim3(512), 0, (hipStream_t)stream, a); break;
-  }
+  // 8 waves, staggered weight stream: the measured optimum of (4 | 8 | 16 waves) x (plain | staggered) on the step's shapes
+  hipLaunchKernelGGL((gemm_ln_kernel<8, true>), dim3((M + BM - 1) / BM), dim3(512), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

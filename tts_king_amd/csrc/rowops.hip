@@ -500,3 +500,26 @@ extern "C" int ttsk_zero_frames_from(void* x, int elem_bytes, int rows, int C, i
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }
+
+// ---- the dropout keep-mask of one site, as every kernel of the step draws it: element e of the site's [rows][C] tensor (row-major,
+// e = row * C + c) is kept iff word (e & 3) of Philox4x32-10(key = seed, counter = (e >> 2, site, step)) >= keep_threshold(p).
+// Parity tests hand these masks to the oracle (tests/test_parity_gpu.py: one full-size step with dropout ON on both sides).
+namespace {
+__global__ __launch_bounds__(256) void dropout_keep_mask_kernel(const uint64_t* __restrict__ rng, unsigned site, int64_t n4, float p,
+                                                                uint8_t* __restrict__ keep) {
+  const uint64_t seed = rng[0], step = rng[1];
+  const unsigned thr = keep_threshold(p);
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const uint4 b = Philox::gen(make_uint2((unsigned)seed, (unsigned)(seed >> 32)), make_uint4((unsigned)i, site, (unsigned)step, (unsigned)(step >> 32)));
+    *(uchar4*)(keep + i * 4) = make_uchar4(b.x >= thr, b.y >= thr, b.z >= thr, b.w >= thr);
+  }
+}
+}  // namespace
+
+extern "C" int ttsk_dropout_keep_mask(const uint64_t* rng, uint32_t site, int64_t n, float p, uint8_t* keep, void* stream) {
+  TTSK_REQUIRE(rng && keep && n > 0 && (n & 3) == 0 && p >= 0.f && p < 1.f, "dropout_keep_mask: n must be a positive multiple of 4, 0 <= p < 1");
+  TTSK_REQUIRE(n / 4 <= 0xFFFFFFFFll && (((uintptr_t)keep) & 3) == 0, "dropout_keep_mask: element index exceeds the 32-bit counter word / alignment");
+  hipLaunchKernelGGL(dropout_keep_mask_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, rng, site, n / 4, p, keep);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}

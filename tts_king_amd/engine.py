@@ -101,7 +101,10 @@ class TrainEngine:
             self.model.train()             # (nn.Module.train() walks every sub-module: 7 ms here, so not once per step)
         # longer than the position tables (frames: the train-mode truncation path; phonemes: sinusoid_table(...).to(dev) is a pageable
         # H2D copy, not capturable, and the grouped predictor path with its phoneme_limit is off there): plain launches
-        if not self.use_graph or int(batch[8]) > self.model.max_seq_len or int(batch[5]) > self.model.max_seq_len:
+        # ... and so does an update step whose gradient reducer goes through the host (parallel.GradReducer.host_staged: the host
+        # waits for the collective inside the step); the accumulate-only micro-steps of such a run still replay
+        staged = is_update and self.reducer is not None and getattr(self.reducer, "host_staged", False)
+        if not self.use_graph or staged or int(batch[8]) > self.model.max_seq_len or int(batch[5]) > self.model.max_seq_len:
             self.stats["eager"] += 1
             losses, out = self._enqueue(is_update, fl, pl)(batch)
             return losses, out

@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from . import ops
 from . import params as P
+from . import switches
 from .ops import bf16
 
 N_VOCAB = 207  # len(symbols) + 1 — reference: fs_two/transformer/Models.py:40, fs_two/text/symbols.py
@@ -139,23 +140,23 @@ class FastSpeech2(nn.Module):
         self._deferred = None           # split-K slabs awaiting the batched reducer (backward only)
         self._deferred_fin = None       # gradient column-sum partials awaiting the batched finalize
         self._side = None               # second HIP stream for parameter-gradient work (see _SideWork)
-        self.fused_attention = True     # one kernel for scores + softmax + P.V (and dP + softmax' + dQ) when d_k = 128
         # The FFT blocks' w_1 forward, q|k|v projection, fc and w_2 input gradients, and the PostNet's 512 -> 512 convs (forward and
         # input gradient) run on the window kernel (csrc/ffn_conv.hip).  It wants the weights in MFMA-fragment order (1 KiB contiguous
         # per fragment; from the tap-major shadow it is no faster than the implicit GEMM): `_w1_packed` holds such copies — for an input
         # gradient the transposed, tap-flipped weight — all rewritten by ONE launch whenever the bf16 shadow is (sync_shadow, the
         # optimizer step).
-        self.window_ffn = os.environ.get("TTSK_WINDOW_FFN", "1") != "0"
+        self.window_ffn = switches.get("TTSK_WINDOW_FFN") != "0"
         self._w1_packed = None
         self._adam_tables = None
-        self.flash_attention = True     # ... and without the S x S tensors: online softmax forward, recomputing backward (d_k = 128)
+        self.adam_packs = True          # the optimizer's Adam launch writes the window kernels' weight packs itself (ttsk_optim_step_packed)
+        self.flash_attention = True     # attention without the S x S tensors when d_k = 128 (csrc/flash_attn.hip); False / other head sizes: scores GEMM + softmax + P V GEMM
         self.fused_ln = True            # fc / w_2 + dropout + residual + LayerNorm + PAD zeroing in one kernel when d = 256
-        self.bn_stats_in_conv = os.environ.get("TTSK_BN_STATS_IN_CONV", "1") != "0"   # PostNet 512 -> 512 convs emit their BatchNorm statistics partials
-        self.bn_bwd_stats_in_conv = os.environ.get("TTSK_BN_BWD_STATS_IN_CONV", "1") != "0"   # ... and their input-gradient convs the backward's
-        self.fused_qkv_tail = os.environ.get("TTSK_FUSED_QKV_TAIL", "1") != "0"   # a block's last kernel also projects q|k|v for the next block
-        self.fused_qkv_dx = os.environ.get("TTSK_FUSED_QKV_DX", "1") != "0"   # ... and the q|k|v input gradient of the block behind in front of it
-        self.fused_ln_bwd = os.environ.get("TTSK_FUSED_LN_BWD", "1") != "0"   # LayerNorm backward + the k = 1 dX projection behind it in one kernel
-        self.dwconv = os.environ.get("TTSK_DWCONV", "1") != "0"   # w_1's weight gradient on the tap-sharing kernel (csrc/dwconv.hip)
+        self.bn_stats_in_conv = True        # PostNet 512 -> 512 convs emit their BatchNorm statistics partials
+        self.bn_bwd_stats_in_conv = True    # ... and their input-gradient convs the backward's
+        self.fused_qkv_tail = True          # a block's last kernel also projects q|k|v for the next block
+        self.fused_qkv_dx = True            # ... and the q|k|v input gradient of the block behind in front of it
+        self.fused_ln_bwd = True            # LayerNorm backward + the k = 1 dX projection behind it in one kernel
+        self.dwconv = switches.get("TTSK_DWCONV") != "0"   # w_1's weight gradient on the tap-sharing kernel (csrc/dwconv.hip), the other 256-multiple ones on dwgemm.hip
         self.group_predictors = True    # training with targets: the three VariancePredictors run as grouped launches
         self.raw_slabs = True           # dX GEMMs that feed a LayerNorm backward leave their split-K tiles for it to sum
         self.group_param_grads = True      # weight-gradient GEMMs of a backward pass share grouped launches (ops.DeferQueue)
@@ -165,27 +166,23 @@ class FastSpeech2(nn.Module):
         # what follows on the dX path (length regulator, variance adaptor, encoder: ~0.5 ms of 32-128-workgroup kernels) fills a
         # fraction of the chip.  So that group is launched there on a second stream with its grid capped at `dw_side_wgs` workgroups
         # (one per CU: the other CUs stay free for the dX chain) and joined before the optimizer.  0 = launch it at the end instead.
-        self.dw_side_wgs = int(os.environ.get("TTSK_DW_SIDE_WGS", "192"))
+        self.dw_side_wgs = int(switches.get("TTSK_DW_SIDE_WGS"))
         # ... and only `dw_side_frac` of that group's FLOPs go there: the dX chain that runs beside it is shorter (0.39 ms) than the
         # capped group (0.57 ms), the rest joins the encoder-side group that runs on the whole chip once the dX chain is done
         # (measured: 1.0 -> 3.03 ms/step, 0.85 / 0.75 -> 3.00, 0.65 -> 3.02, 0.55 -> 3.11)
         # (round 3: w_1's gradients left the grouped queue for csrc/dwconv.hip, which runs first on that stream: re-measured below)
-        self.dw_side_frac = float(os.environ.get("TTSK_DW_SIDE_FRAC", "1.0"))
+        self.dw_side_frac = float(switches.get("TTSK_DW_SIDE_FRAC"))
         self._dw_side = None
         self._dw_side_pending = False
         # Data-parallel schedule (backward_native(on_bucket=...)), TTSK_DP_SCHEDULE:
         #   "side"  (default) the single-GPU schedule kept: nothing is flushed during the PostNet / decoder backward; after it the queued
-        #           weight-gradient work runs on the second stream BUCKET BY BUCKET (capped grid, its split-K reducer behind it) and each
-        #           bucket's all-reduce is issued from there, beside the encoder-side dX chain; the rest after the chain;
-        #   "early" round 2's: flush on the main stream whenever a bucket completes (7 grouped launches, no second stream): the most
-        #           overlap of wire time with backward, 16 % more compute time per step;
+        #           weight-gradient work runs on the second stream (capped grid, its split-K reducer behind it) and the all-reduces of
+        #           the buckets it completes are issued from there, beside the encoder-side dX chain; the rest after the chain;
         #   "late"  the single-GPU schedule untouched, every all-reduce after the last flush (no overlap with backward).
-        self.dp_schedule = os.environ.get("TTSK_DP_SCHEDULE", "side")
-        # the decoder-side column sums: "after" = behind the GEMM work on the second stream (default); "third" = on a third stream from the
-        # decoder's end (measured: their HBM traffic beside dwconv / dwgemm slows the whole step, 3.06 vs 2.90 ms); "0" = with the final flush
-        self.side_colsum = os.environ.get("TTSK_SIDE_COLSUM", "0")
-        self.enc_early_at = int(os.environ.get("TTSK_ENC_EARLY_AT", "-1"))   # after this encoder block's backward (-1: never; measured 2.87 vs 2.82 ms: the second stream is not free yet)
-        self.side_small = os.environ.get("TTSK_SIDE_SMALL", "0") != "0"      # the 80-channel grouped problems behind dwgemm on the second stream
+        # (Round 2's "early" schedule — a flush on the main stream whenever a bucket completes — measured 22 % more compute per step and
+        # was deleted in round 4; without a second stream, dw_side_wgs = 0, buckets are still flushed one by one as they complete.)
+        self.dp_schedule = switches.get("TTSK_DP_SCHEDULE")
+        self.side_small = False             # the 80-channel grouped problems behind dwgemm on the second stream (measured: they belong in the final phase)
         self._fin_side = None
         self._dp_keep = None
         self._fin_pending = False
@@ -193,7 +190,7 @@ class FastSpeech2(nn.Module):
         # pitch / energy, the length regulator takes the TARGET durations: modules.py:158-205), and their backward needs nothing but the
         # loss's gradients until its last step.  Both run on a stream of their own: the forward beside the decoder's first block, the
         # backward beside the PostNet's — 1,024-row kernels of 96 workgroups that the 212-256-workgroup chain kernels leave room for.
-        self.pred_side = os.environ.get("TTSK_PRED_SIDE", "1")     # "1" both, "f" forward only, "b" backward only, "0" neither
+        self.pred_side = switches.get("TTSK_PRED_SIDE")     # "1" both, "f" forward only, "b" backward only, "0" neither
         self._pred_stream = None
         self._pred_fwd_pending = False
         # Does the flat gradient buffer hold an unfinished accumulation (micro-steps of a grad_acc_step cycle)?  False after an optimizer
@@ -413,7 +410,7 @@ class FastSpeech2(nn.Module):
         # flat offset, storage shape and its plain / transposed packs.  A weight with more than one pack of a kind (w_1's transposed
         # pack exists once) or one that does not tile leaves `_adam_tables` None: the optimizer then calls refresh_packed as before.
         self._adam_tables = None
-        if self._pack_items and os.environ.get("TTSK_ADAM_PACKS", "1") != "0":
+        if self._pack_items and self.adam_packs:
             by_key, ok = {}, True
             for key, fr, out, tr in self._pack_items:
                 W = self._pack_source(key, fr)
@@ -493,9 +490,6 @@ class FastSpeech2(nn.Module):
             # (2)-(4) one kernel, no S x S tensor: scores, key-padding mask, online softmax, P V, heads merged (Modules.py:15-22,
             # SubLayers.py:57-60); the backward recomputes P from the per-row log-sum-exp kept in `probs`'s slot
             o, probs, o32 = ops.flash_attention_fwd(qkv, lens, Bn, H, S, want_lse=ctx_list is not None)
-        elif self.fused_attention and dk == 128:
-            # (2)-(4) one kernel: scores, key-padding mask, softmax, P V, heads merged (Modules.py:15-22, SubLayers.py:57-60)
-            o, probs, o32 = ops.attention_fwd(qkv, lens, Bn, H, S, want_probs=ctx_list is not None)
         else:
             o32 = None
             # (2) scores = Q K^T / sqrt(dk) per (batch, head), head h = columns [h*dk, (h+1)*dk): Modules.py:15-16
@@ -664,15 +658,17 @@ class FastSpeech2(nn.Module):
         blocks = [] if train else None
         preds = {} if train else None
 
-        # ---- masks: fastspeech2.py:62-69
-        src_masks = ops.length_mask(src_lens, Lp)
+        # ---- masks: fastspeech2.py:62-69.  Nothing on the device reads them (every kernel takes the lengths): when the training forward
+        # has its predictor stream, they are produced there (below) instead of opening the main chain with two dependent launches
+        grouped = (train and self.group_predictors and pitches_raw is not None and e_targets is not None and Lp <= self.max_seq_len)
+        masks_aside = grouped and self.pred_side in ("1", "f") and mel_lens is not None and d_targets is not None and max_mel_len is not None
+        src_masks = None if masks_aside else ops.length_mask(src_lens, Lp)
         # ---- encoder: phoneme embedding + position table, 4 FFT blocks: Models.py:79-112
         if Lp > self.max_seq_len:
             pe_enc = sinusoid_table(Lp, d).to(dev)        # eval-only long input: Models.py:88-99
         else:
             pe_enc = self.get("encoder.position_enc")[0]
         x = ops.gather_add(None, self._m("encoder.src_word_emb.weight"), texts, pe=pe_enc, pe_mod=Lp, rows=Bn * Lp)
-        grouped = (train and self.group_predictors and pitches_raw is not None and e_targets is not None and Lp <= self.max_seq_len)
         stack = torch.empty(3, Bn * Lp, d, dtype=bf16, device=dev) if grouped else None
         qkv = None
         for i in range(self.n_enc):
@@ -693,8 +689,13 @@ class FastSpeech2(nn.Module):
                 if self._pred_stream is None:
                     self._pred_stream = torch.cuda.Stream(device=dev)
                 self._pred_stream.wait_stream(torch.cuda.current_stream())
+                mel_masks_aside = None
                 with torch.cuda.stream(self._pred_stream):
                     pred = self._predictors_fwd_grouped(stack, Bn, Lp, src_lens, p_var, rng, preds, row_limit=phoneme_limit)
+                    if masks_aside:
+                        T_m = min(int(max_mel_len), self.max_seq_len)
+                        src_masks = ops.length_mask(src_lens, Lp)
+                        mel_masks_aside = ops.length_mask(mel_lens.to(dev).long().contiguous(), T_m)
                 self._pred_fwd_pending = True          # joined at the end of this forward: the loss is the first reader
             else:
                 pred = self._predictors_fwd_grouped(stack, Bn, Lp, src_lens, p_var, rng, preds, row_limit=phoneme_limit)
@@ -731,7 +732,10 @@ class FastSpeech2(nn.Module):
         pe_dec = sinusoid_table(T, d).to(dev) if eval_long else self.get("decoder.position_enc")[0]
         dec_in, _, cs, mel_lens_out = ops.length_regulator_fwd(x3.view(Bn, Lp, d), dur, T, pe=pe_dec, want_idx=False)
         mlens = mel_lens.to(dev).long().contiguous() if mel_lens is not None else mel_lens_out
-        mel_masks = ops.length_mask(mlens, T)
+        if masks_aside and mel_masks_aside is not None and mel_masks_aside.shape[1] == T:
+            mel_masks = mel_masks_aside
+        else:
+            mel_masks = ops.length_mask(mlens, T)
         # ---- decoder: Models.py:157-189
         y = dec_in.view(Bn * T, d)
         n_enc_blocks = len(blocks) if train else 0
@@ -1020,15 +1024,12 @@ class FastSpeech2(nn.Module):
             dqkv = ops.flash_attention_bwd(qkv, o, do, probs, lens, Bn, H, S, o32=o32, delta=delta)      # P recomputed per tile; dQ, dK, dV in two launches
         else:
             dqkv = torch.empty(rows, 3 * d, dtype=bf16, device=dev)
-            if self.fused_attention and dk == 128:
-                dS = ops.attention_bwd_q(qkv, o32, do, probs, dqkv, Bn, H, S)       # dP, softmax backward and dQ in one kernel
-            else:
-                dP = torch.empty(Bn * H, S, Sp, dtype=torch.float32, device=dev)
-                ops.gemm(do, qkv[:, 2 * d:], dP, S, S, dk, d, 3 * d, Sp, nz1=Bn, nz2=H, sA=(S * d, dk), sB=(S * 3 * d, dk),
-                         sC=(H * S * Sp, S * Sp))
-                dS = ops.softmax_bwd(probs, dP, dk ** -0.5)
-                ops.gemm(dS, qkv[:, d:], dqkv, S, dk, S, Sp, 3 * d, 3 * d, flags=ops.B_TR, nz1=Bn, nz2=H,
-                         sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * 3 * d, dk))
+            dP = torch.empty(Bn * H, S, Sp, dtype=torch.float32, device=dev)
+            ops.gemm(do, qkv[:, 2 * d:], dP, S, S, dk, d, 3 * d, Sp, nz1=Bn, nz2=H, sA=(S * d, dk), sB=(S * 3 * d, dk),
+                     sC=(H * S * Sp, S * Sp))
+            dS = ops.softmax_bwd(probs, dP, dk ** -0.5)
+            ops.gemm(dS, qkv[:, d:], dqkv, S, dk, S, Sp, 3 * d, 3 * d, flags=ops.B_TR, nz1=Bn, nz2=H,
+                     sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * 3 * d, dk))
             kv = ops.GemmGroup()         # dK and dV are independent: one grouped launch
             ops.gemm(dS, qkv, dqkv[:, d:], S, dk, S, Sp, 3 * d, 3 * d, flags=ops.A_TR | ops.B_TR, nz1=Bn, nz2=H,
                      sA=(H * S * Sp, S * Sp), sB=(S * 3 * d, dk), sC=(S * 3 * d, dk), group=kv)
@@ -1080,33 +1081,20 @@ class FastSpeech2(nn.Module):
                 ["encoder.%d" % i for i in range(self.n_enc - 1, -1, -1)] + ["embedding"])
 
     def _launch_dw_side(self, everything=False):
-        """The weight-gradient work queued so far (PostNet, mel_linear, decoder), after the decoder's backward, beside the encoder-side
-        dX chain on the main stream — two more branches (a replayed graph runs three queues side by side):
-          * second stream: w_1's six gradients (dwconv, 192 workgroups = one per CU on 3/4 of the chip), the other 256-multiple ones
-            (dwgemm, grid capped at `dw_side_wgs`) with their slab reducer, then the few grouped problems (80-channel outputs);
-          * third stream: the bias / LayerNorm column sums queued so far (HBM-bound: they overlap the MFMA-bound kernels beside them).
+        """The weight-gradient work queued so far (PostNet, mel_linear, decoder, predictors), after the decoder's backward, on the second
+        stream beside the encoder-side dX chain on the main stream: w_1's six gradients (dwconv, 192 workgroups = one per CU on 3/4 of
+        the chip), then the other 256-multiple ones (dwgemm, grid capped at `dw_side_wgs`) with their slab reducer.  The column sums and
+        the few 128 x 128-tile grouped problems (80-channel outputs) wait for the final phase (measured: beside dwconv / dwgemm their HBM
+        traffic slows the whole step).
         `everything` (the data-parallel "side" schedule): nothing may stay queued — neither the share `dw_side_frac` leaves for the
-        final flush nor the 128 x 128-tile problems (mel_linear, the PostNet's 80-channel ends) that `side_small = 0` leaves there:
-        the caller reduces every split-K slab and announces the buckets right behind this."""
+        final flush nor those grouped problems: the caller reduces every split-K slab and announces the buckets right behind this."""
         if self._dw_side is None:
             self._dw_side = torch.cuda.Stream(device=self.device)
-        if self._fin_side is None:
-            self._fin_side = torch.cuda.Stream(device=self.device)
-        cur = torch.cuda.current_stream()
-        if self.side_colsum == "third":
-            self._fin_side.wait_stream(cur)
-            self._dp_keep = [k for _, k in self._deferred_fin]       # alive until the final join (the allocator orders frees by the main stream only)
-            with torch.cuda.stream(self._fin_side):
-                ops.flush_finalize(self._deferred_fin)
-            self._fin_pending = True
-        self._dw_side.wait_stream(cur)
+        self._dw_side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._dw_side):
             ops.stamp("side.start")
             ops.flush_deferred_gemms(self._deferred, max_wgs=self.dw_side_wgs, frac=1.0 if everything else self.dw_side_frac,
                                      small_too=True if everything else self.side_small)
-            if self.side_colsum == "after":
-                self._dp_keep = [k for _, k in self._deferred_fin]
-                ops.flush_finalize(self._deferred_fin)
             ops.stamp("side.end")
         self._dw_side_pending = True
 
@@ -1132,11 +1120,9 @@ class FastSpeech2(nn.Module):
         marks, self._dp_marks = self._dp_marks, []
         with torch.cuda.stream(self._dw_side):
             ops.flush_deferred_prefix(self._deferred, 0, len(self._deferred))
-            if self._deferred_fin:                                  # (side_colsum = "0": the column sums would wait for the final flush)
+            if self._deferred_fin:                                  # the column sums queued so far belong to these buckets too
                 self._dp_keep = (self._dp_keep or []) + [k for _, k in self._deferred_fin]
                 ops.flush_finalize(self._deferred_fin)
-            if getattr(self, "_fin_pending", False):               # (side_colsum = "third")
-                self._dw_side.wait_stream(self._fin_side)
             for name, _, _, _ in marks:
                 on_bucket(name)               # groups in completion order: a bucket goes out when its lowest group has been announced
         self._dw_side_pending = True
@@ -1214,11 +1200,12 @@ class FastSpeech2(nn.Module):
         self._deferred_fin = []
         if self.overlap_param_grads and self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
-        dp_side = on_bucket is not None and self.dp_schedule in ("side", "late") and self.dw_side_wgs > 0 and self.group_param_grads \
-            and not self.overlap_param_grads
+        if self.dp_schedule not in ("side", "late"):
+            raise ValueError("dp_schedule must be 'side' or 'late' (got %r)" % (self.dp_schedule,))
+        dp_side = on_bucket is not None and self.dw_side_wgs > 0 and self.group_param_grads and not self.overlap_param_grads
         self._dp_marks = []
         # w_1's weight gradients on the tap-sharing kernel: one launch for the six decoder blocks (192 workgroups) and one for the encoder's;
-        # not in the "early" data-parallel schedule, whose per-bucket flushes would launch them two at a time
+        # not when buckets are flushed one by one (no second stream): those flushes would launch them two at a time
         self._use_dwconv = self.dwconv and (on_bucket is None or dp_side)
         notifier = _GroupNotifier(self.backward_group_order(), on_bucket, self._flush_param_grads, mark=self._mark_bucket if dp_side else None)
         notify = notifier.done
@@ -1312,13 +1299,6 @@ class FastSpeech2(nn.Module):
         for i in range(self.n_enc - 1, -1, -1):
             dx = self._fft_bwd(ctx.blocks[i], dx, rng, raw_out=self._raw_out_mode() if i > 0 else False)
             notify("encoder.%d" % i)
-            if i == self.enc_early_at and self._dw_side_pending and on_bucket is None and self._use_dwconv:
-                # the encoder-side weight gradients queued so far (variance adaptor, blocks n-1 .. i) behind the decoder's on the second
-                # stream, while the last blocks' backward still runs: the final flush is left with the first blocks' only
-                self._dw_side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self._dw_side):
-                    ops.flush_dwconv(self._deferred)
-                    ops.flush_dwgemm(self._deferred, reduce_now=True, max_wgs=self.dw_side_wgs)
         with self._side_work(dx):
             ops.scatter_sum(dx, ctx.texts.view(-1), self._g("encoder.src_word_emb.weight"), skip_row=0, defer=self._deferred_fin, accumulate=self._acc)   # padding_idx=0
         notify("embedding")

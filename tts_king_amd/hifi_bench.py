@@ -35,8 +35,10 @@ def _pmc_hifi():
             doc = json.load(open(f))
         except (OSError, ValueError):
             continue
-        return {r["kernel"]: r["hbm_bytes_per_launch"] for r in doc.get("kernels", [])}, os.path.relpath(f, root)
-    return {}, None
+        from .lib import source_fingerprint
+        return ({r["kernel"]: r["hbm_bytes_per_launch"] for r in doc.get("kernels", [])}, os.path.relpath(f, root),
+                doc.get("csrc_fingerprint") != source_fingerprint())
+    return {}, None, False
 
 
 def stage_rooflines(gen, mel, B, T, iters=5):
@@ -56,7 +58,7 @@ def stage_rooflines(gen, mel, B, T, iters=5):
         torch.cuda.synchronize()
         for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
             acc.setdefault(n1, []).append(e0.elapsed_time(e1))
-    pmc, src = _pmc_hifi()
+    pmc, src, stale = _pmc_hifi()
     out = {}
     for name, ms_list in acc.items():
         ms = sorted(ms_list)[len(ms_list) // 2]
@@ -76,6 +78,7 @@ def stage_rooflines(gen, mel, B, T, iters=5):
                 rec["hbm_bytes_pmc"] = tot
                 rec["hbm_roofline_frac"] = tot / (ms * 1e-3) / 8e12
                 rec["pmc_source"] = src
+                rec["profile_stale"] = stale      # the kernel sources changed after the PMC passes were taken (lib.source_fingerprint)
         out[name] = rec
     return out
 

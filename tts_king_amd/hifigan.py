@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import switches
 from .ops import bf16, f16
 
 LRELU_SLOPE = 0.1          # reference: hifi/models.py:9
@@ -101,7 +102,7 @@ class Generator(nn.Module):
         self.conv_pair_small = True  # ... and at C = 64 / 32, instead of the six-conv fused kernel
         self.fused = True            # fused ResBlock1 kernel where an instance exists (C in {32,64}); False = conv-by-conv
         self.stream_upsample = True  # stride-2 upsamplers (128->64, 64->32) on the streaming kernel; False = polyphase implicit GEMMs
-        self.window_upsample = os.environ.get("TTSK_HIFI_UPS8", "1") != "0"   # stride-8 upsamplers and 128 -> 64 on the window-conv kernel (fp16); 0 = polyphase GEMMs / streaming kernel
+        self.window_upsample = switches.get("TTSK_HIFI_UPS8") != "0"   # stride-8 upsamplers and 128 -> 64 on the window-conv kernel (fp16); 0 = polyphase GEMMs / streaming kernel
         self.group_resblocks = True  # conv m of the three MRF ResBlocks as one grouped launch where they run conv by conv (C = 256)
         self.mrf_fused = True        # the last stage (C = 32: three ResBlock1s + average + LeakyReLU + conv_post + tanh) as ONE launch (csrc/mrf32.hip)
 

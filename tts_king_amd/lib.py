@@ -8,7 +8,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("TTSK_LIB_PATH") or os.path.join(_HERE, "libttsk_hip.so")   # the override is for diagnostic builds (tools/debug)
+LIB_PATH = os.environ.get("TTSK_LIB_PATH") or os.path.join(_HERE, "libttsk_hip.so")   # the override is for diagnostic builds (switches.py)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ttsk.h")
 
 
@@ -117,6 +117,21 @@ def declared_prototypes(header_path=HEADER_PATH):
         args = [a for a in (_ctype_of(x) for x in m.group(2).split(",")) if a is not None]
         out[m.group(1)] = args
     return out
+
+
+def source_fingerprint():
+    """sha256 (first 16 hex digits) over csrc/*.hip, csrc/*.h and include/ttsk.h, by file name then content: the identity of the
+    kernel sources a profile was taken with.  tools/pmc_summary.py / pmc_mfma_summary.py store it in profiles/*.json, and bench.py
+    flags a committed profile as stale when it differs from the tree it runs in."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [HEADER_PATH]):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 _lib = None

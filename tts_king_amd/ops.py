@@ -32,11 +32,36 @@ def _ptr(t):
 
 import os as _os
 # K steps one workgroup of a grouped weight-gradient launch walks (128x128 tile, 256x128 tile): more steps = fewer split-K slabs
-DW_STEPS_PER_WG = tuple(int(v) for v in _os.environ.get("TTSK_DW_STEPS", "28,72").split(","))
+DW_STEPS_PER_WG = (28, 72)
 LAUNCH_COUNTS = None   # bench.py sets this to a dict: grouped-GEMM / batched-reducer / column-sum launches issued by the flushes
 STAMPS = None       # tools/debug/step_stamps.py (diagnostic library only): (uint64 device buffer, [names]) — `stamp(name)` then launches a
                     # one-thread kernel that writes the device's 100 MHz clock into the next slot, on the current stream
 GEMM_TRACE = None   # bench.py sets this to a list: every ttsk_gemm launch is then bracketed by HIP events on its stream
+                    # (and, through `_family`, every launch of the other MFMA kernel families and of the step's HBM-bound passes)
+
+
+def _family(kind, flops):
+    """Decorator: when GEMM_TRACE is set, bracket the wrapped launch with HIP events on its stream and record (events, algorithmic
+    FLOPs = flops(*args, **kwargs), family name) — bench.py's per-family roofline (`roofline.families`).  No cost otherwise."""
+    def deco(fn):
+        import functools
+
+        @functools.wraps(fn)
+        def wrapped(*a, **kw):
+            if GEMM_TRACE is None:
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            GEMM_TRACE.append((e0, e1, float(flops(*a, **kw)), kind, (0, 0, 0, 1, 1, 0)))
+            return out
+        return wrapped
+    return deco
+
+
+def _conv_flops(x, packed, Cout, k, *a, **kw):
+    return 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * Cout * k
 
 
 def stamp(name):
@@ -190,10 +215,10 @@ def flush_dwconv(items, n=None):
     q[:] = rest
 
 
-DWG_TARGET_STEPS = tuple(int(v) for v in _os.environ.get("TTSK_DWG_STEPS", "72,72").split(","))   # K steps per workgroup: k = 1, taps
+DWG_TARGET_STEPS = (72, 72)   # K steps per workgroup: k = 1, taps (3 ranges at B = 16, T = 423: the measured optimum of 2 / 3 / 4)
 
 
-DWG_SHORT_STEPS = int(_os.environ.get("TTSK_DWG_SHORT", "16"))
+DWG_SHORT_STEPS = 16
 
 
 def dwgemm_splits(Bsz, S, k=1):
@@ -581,6 +606,7 @@ def win_conv_pack_run(table, n):
     check(L.load().ttsk_win_conv_pack_table(_ptr(table), n, _stream()), "ttsk_win_conv_pack_table")
 
 
+@_family("win_conv", _conv_flops)
 def win_conv(x, packed, Cout, k, bias=None, relu=False, out_dtype=None, gate=None, delta_o32=None, delta_out=None):
     """[relu](Conv1d(Cin -> Cout, k)(x) + bias) on the window kernel, weights = a win_conv_pack_batch pack (ttsk_win_conv); `gate`
     (B,S,Cout) bf16: result zeroed where gate <= 0.  x (B,S,Cin) bf16 -> (B,S,Cout) bf16 or fp32."""
@@ -593,6 +619,7 @@ def win_conv(x, packed, Cout, k, bias=None, relu=False, out_dtype=None, gate=Non
     return out
 
 
+@_family("win_conv", _conv_flops)
 def win_conv_stats(x, packed, Cout, k, bias=None, frame_limit=None):
     """win_conv with fp32 output (Cin = 512) that also returns the BatchNorm statistics partials of its output
     ([B * ceil(S/64)][2*Cout] fp32: sum | sum of squares per tile) for bn_train(partials=...) (ttsk_win_conv_stats)."""
@@ -607,6 +634,7 @@ def win_conv_stats(x, packed, Cout, k, bias=None, frame_limit=None):
     return out, stats
 
 
+@_family("win_conv", _conv_flops)
 def win_conv_bnb(x, packed, Cout, k, bn_x, mean, rstd, gamma, beta, use_tanh, p=0.0, keep=None, frame_limit=None):
     """win_conv with bf16 output (Cin = 512: a PostNet conv's input gradient on its transposed pack) that also returns the BatchNorm-
     backward statistics partials of the layer below, whose upstream gradient the output is ([B * ceil(S/64)][2*Cout] fp32: sum of dy | sum
@@ -623,6 +651,7 @@ def win_conv_bnb(x, packed, Cout, k, bn_x, mean, rstd, gamma, beta, use_tanh, p=
     return out, stats
 
 
+@_family("win_conv", _conv_flops)
 def win_conv_split(x, packed, Cout, k):
     """An input-gradient conv with a wide contraction (x (B,S,n*256) bf16) as n window convs over 256-channel slices in one launch:
     fp32 Slabs (n, B*S*Cout) for layernorm_bwd(slabs=...) (ttsk_win_conv_split).  `packed`: the whole transposed pack."""
@@ -634,6 +663,7 @@ def win_conv_split(x, packed, Cout, k):
     return Slabs(ws, n, Bsz * S * Cout)
 
 
+@_family("win_conv", lambda x, W, *a, **kw: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * W.shape[0] * W.shape[1])
 def ffn_conv_fwd(x, W, bias, relu=True, packed=None):
     """relu(Conv1d(256 -> Cout, k)(x) + bias) on the window kernel (ttsk_ffn_conv_fwd; SubLayers.py:93-101, w_1).
     x (B,S,256) bf16, W (Cout,k,256) bf16 tap-major -> (B,S,Cout) bf16; `packed`: ffn_pack_weight(W), read instead of W."""
@@ -828,6 +858,7 @@ def win_ln_supported(K, D):
     return bool(L.load().ttsk_win_ln_supported(K, D))
 
 
+@_family("win_ln", lambda x, *a, **kw: 2.0 * x.shape[0] * x.shape[1] * 256 + (2.0 * x.shape[0] * 256 * 768 if kw.get("proj") is not None else 0.0))
 def win_ln_fwd(x, packed, bias, res, gamma, beta, lens=None, seg_len=0, p_pre=0.0, site_pre=0, rng=None, save_z=True, eps=1e-5, out=None,
                proj=None):
     """gemm_ln_fwd with the weight as a fragment-major pack (win_conv_pack_*; ttsk_win_ln_fwd): x (rows, K) bf16, K = 256 or 1024.
@@ -880,6 +911,7 @@ def layernorm_bwd(dout, z, mean, rstd, gamma, beta, lens=None, seg_len=0, relu_i
     return dz, (dy if dy is not None else dz), partials, nblk
 
 
+@_family("ln_bwd_proj", lambda dout, z, mean, rstd, gamma, packed, Cout, *a, **kw: 2.0 * z.shape[0] * 256 * Cout + (2.0 * z.shape[0] * 768 * 256 if kw.get("pre") is not None else 0.0))
 def layernorm_bwd_proj(dout, z, mean, rstd, gamma, packed, Cout, lens=None, seg_len=0, p_pre=0.0, site_pre=0, rng=None, slabs=None, R=None,
                        gate=None, delta_o32=None, delta_out=None, pre=None):
     """layernorm_bwd (D = 256) and the k = 1 window conv on its dy in ONE launch (ttsk_layernorm_bwd_proj): `packed` is the
@@ -906,6 +938,7 @@ def layernorm_bwd_proj(dout, z, mean, rstd, gamma, packed, Cout, lens=None, seg_
     return dz, (dy if dy is not None else dz), partials, nblk, out
 
 
+@_family("ln_bwd_proj", lambda dqkv, *a, **kw: 2.0 * dqkv.shape[0] * dqkv.shape[1] * 256)
 def qkv_dx(dqkv, packed, R=None):
     """dqkv (rows, 768) bf16 x the packed transposed q|k|v weight (+ R) -> (rows, 256) bf16 (ttsk_qkv_dx)."""
     _dev(dqkv, packed, R)
@@ -1023,30 +1056,7 @@ def colsum_into(x, dst, accumulate=True, defer=None):
     return colsum_finalize(partials, nblk, Cn, Cn, dst, accumulate, defer=defer)
 
 
-def attention_fwd(qkv, lens, Bn, H, S, want_probs):
-    """Fused softmax(Q K^T / sqrt(128) + key mask) V on the q|k|v buffer (rows, 3d) -> (o (rows, d) bf16, probs, o32);
-    probs (bf16) and o32 (fp32 copy of o before rounding) are produced only for the backward (want_probs)."""
-    _dev(qkv, lens)
-    d = qkv.shape[1] // 3
-    Sp = (S + 7) // 8 * 8
-    o = torch.empty(Bn * S, d, dtype=bf16, device=qkv.device)
-    probs = torch.empty(Bn * H, S, Sp, dtype=bf16, device=qkv.device) if want_probs else None
-    o32 = torch.empty(Bn * S, d, dtype=torch.float32, device=qkv.device) if want_probs else None
-    check(L.load().ttsk_attention_fwd(_ptr(qkv), _ptr(o), _ptr(o32), _ptr(probs), _ptr(lens), Bn, H, S, Sp, d, (d // H) ** -0.5,
-                                      _stream()), "ttsk_attention_fwd")
-    return o, probs, o32
-
-
-def attention_bwd_q(qkv, o32, do, probs, dqkv, Bn, H, S):
-    """dS (returned) and dQ (written into dqkv[:, :d]) of the fused attention."""
-    _dev(qkv, o32, do, probs, dqkv)
-    d = qkv.shape[1] // 3
-    ds = torch.empty_like(probs)
-    check(L.load().ttsk_attention_bwd_q(_ptr(qkv), _ptr(o32), _ptr(do), _ptr(probs), _ptr(ds), _ptr(dqkv), Bn, H, S, probs.shape[2], d,
-                                        (d // H) ** -0.5, _stream()), "ttsk_attention_bwd_q")
-    return ds
-
-
+@_family("flash_attention", lambda qkv, lens, Bn, H, S, *a, **kw: 4.0 * Bn * S * S * (qkv.shape[1] // 3))
 def flash_attention_fwd(qkv, lens, Bn, H, S, want_lse):
     """softmax(Q K^T / sqrt(128) + key mask) V on the q|k|v buffer (rows, 3d) -> (o (rows, d) bf16, lse (B*H, S) fp32 or None,
     o32 (rows, d) fp32 or None) with no S x S tensor in HBM (ttsk_flash_attention_fwd); lse and o32 are what the backward needs."""
@@ -1060,6 +1070,7 @@ def flash_attention_fwd(qkv, lens, Bn, H, S, want_lse):
     return o, lse, o32
 
 
+@_family("flash_attention", lambda qkv, o, do, lse, lens, Bn, H, S, *a, **kw: 8.0 * Bn * S * S * (qkv.shape[1] // 3))
 def flash_attention_bwd(qkv, o, do, lse, lens, Bn, H, S, o32=None, delta=None):
     """dqkv (rows, 3d) bf16 = gradients of q | k | v (ttsk_flash_attention_bwd: delta, then dQ and dK/dV sides as one grid; P
     recomputed from lse).  `delta` (B*H, S) fp32: already computed by the producer of `do` (win_conv(delta_out=...)): no delta launch."""
@@ -1196,7 +1207,7 @@ def zero_frames_from(x, frame_limit):
     return x
 
 
-BN_SLAB = _os.environ.get("TTSK_BN_SLAB", "1") != "0"      # two-launch BatchNorm (channel slabs); 0 = the three-launch kernels
+BN_SLAB = True      # two-launch BatchNorm (channel slabs) where the channel count allows; the three-launch kernels serve the rest and inference
 
 
 def bn_train_stats(x, running_mean=None, running_var=None, nbt=None, eps=1e-5, momentum=0.1, frame_limit=None):
@@ -1233,6 +1244,7 @@ def bn_slab_supported(Cn):
     return BN_SLAB and Cn % 4 == 0 and (Cn % 64 == 0 or Cn <= 128)
 
 
+@_family("batchnorm", lambda *a, **kw: 0.0)
 def bn_train(x, running_mean, running_var, nbt, gamma, beta, use_tanh, p=0.0, site=0, rng=None, resid=None, out_f32=False,
              frame_limit=None, eps=1e-5, momentum=0.1, partials=None, want_keep=False):
     """Training-mode BatchNorm forward in two launches: batch statistics partials, then normalise (+tanh, dropout, residual)
@@ -1257,6 +1269,7 @@ def bn_train(x, running_mean, running_var, nbt, gamma, beta, use_tanh, p=0.0, si
     return ((o32 if out_f32 else o16), mean, rstd, keep) if want_keep else ((o32 if out_f32 else o16), mean, rstd)
 
 
+@_family("batchnorm", lambda *a, **kw: 0.0)
 def bn_bwd(dout, x, mean, rstd, gamma, beta, use_tanh, p=0.0, site=0, rng=None, dgamma=None, dbeta=None, frame_limit=None, keep=None,
            accumulate=True, partials=None):
     """dx (rows,C) bf16; dgamma/dbeta (fp32, accumulated in place when given, or overwritten with accumulate=False).  keep: bn_train's
@@ -1324,6 +1337,14 @@ def rng_of(state):
     return state[2:4]
 
 
+def dropout_keep_mask(state, site, n, p):
+    """uint8[n] keep-mask of dropout site `site` at the current (seed, step) of the device state block (ttsk_dropout_keep_mask): what
+    every kernel of the step draws for that site; element order = row-major over the site's [rows][C] tensor."""
+    keep = torch.empty(n, dtype=torch.uint8, device=state.device)
+    check(L.load().ttsk_dropout_keep_mask(_ptr(rng_of(state)), int(site), int(n), float(p), _ptr(keep), _stream()), "ttsk_dropout_keep_mask")
+    return keep
+
+
 def optim_advance(state, d_model, warmup, anneal_steps, anneal_rate, beta1, beta2):
     arr = (C.c_float * 4)(*([float(a) for a in anneal_steps] + [0.0] * (4 - len(anneal_steps))))
     check(L.load().ttsk_optim_advance(_ptr(state), float(d_model), float(warmup), C.cast(arr, C.c_void_p), len(anneal_steps),
@@ -1341,6 +1362,7 @@ def clip_adam_step(params, grads, m, v, shadow, state, partials, max_norm, beta1
           "ttsk_clip_adam_step")
 
 
+@_family("clip_adam", lambda *a, **kw: 0.0)
 def optim_step(params, grads, m, v, shadow, state, partials, max_norm, beta1, beta2, eps, d_model, warmup, anneal_steps, anneal_rate,
                zero_grad=True, advance_rng=False):
     """optim_advance (+ rng_advance) + clip_adam_step in two launches (ttsk_optim_step)."""
@@ -1381,6 +1403,7 @@ def adam_pack_tables(items, n_flat, device):
     return {"items": dev_items, "n_items": len(items), "n_tiles": tile0, "gaps": dev_gaps, "n_gaps": len(gaps), "gap_floats": acc * 4}
 
 
+@_family("clip_adam", lambda *a, **kw: 0.0)
 def optim_step_packed(params, grads, m, v, shadow, state, partials, max_norm, beta1, beta2, eps, d_model, warmup, anneal_steps, anneal_rate,
                       tables, zero_grad=True, advance_rng=False):
     """optim_step whose Adam launch also writes the window kernels' weight packs (ttsk_optim_step_packed): no pack launch afterwards."""

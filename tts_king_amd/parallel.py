@@ -36,13 +36,22 @@ class GradReducer:
     `group_offsets`: name -> lowest flat offset of the parameter group whose completion `on_group_done(name)`
     announces (groups complete in reverse forward order, so everything at or above that offset is final)."""
 
-    def __init__(self, flat_grad, buckets, group_offsets, process_group=None, force_collectives=False):
+    def __init__(self, flat_grad, buckets, group_offsets, process_group=None, force_collectives=False, host_staged=None):
         self.flat_grad = flat_grad
         self.buckets = list(buckets)
         self.group_offsets = dict(group_offsets)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.force = bool(force_collectives) and dist.is_initialized()    # issue the all-reduces even at world size 1 (bench: DP schedule cost)
+        # A process group that cannot take device tensors directly (gloo: two ranks sharing ONE GPU, which RCCL refuses — the only
+        # cross-process run a 1-GPU box allows, tests/test_00_two_ranks_one_gpu.py): each bucket goes through a pinned host buffer —
+        # an event behind its last writer, D2H, the collective on the host copy, H2D on the step's stream.  Same interface, same
+        # bucket order on every rank, no overlap with backward; not capturable (the host waits inside `finish`).
+        if host_staged is None:
+            host_staged = dist.is_initialized() and flat_grad.is_cuda and dist.get_backend(process_group) == "gloo"
+        self.host_staged = bool(host_staged)
+        self._host = None
+        self._staged = []           # (start, end, event recorded behind the bucket's last writer)
         self._next = 0
         self._handles = []
         self.launched = []          # (start, end) in launch order, for tests / tracing
@@ -51,9 +60,28 @@ class GradReducer:
         while self._next < len(self.buckets) and self.buckets[self._next][0] >= watermark:
             s, e = self.buckets[self._next]
             if self.world > 1 or self.force:
-                self._handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                if self.host_staged:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError("a host-staged gradient reducer cannot be captured in a hipGraph")
+                    ev = torch.cuda.Event()
+                    ev.record()          # on the stream that announced the bucket: everything that wrote it is ahead of this
+                    self._staged.append((s, e, ev))
+                else:
+                    self._handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
             self.launched.append((s, e))
             self._next += 1
+
+    def _finish_staged(self):
+        if self._host is None:
+            self._host = torch.empty(self.flat_grad.numel(), dtype=self.flat_grad.dtype).pin_memory()
+        for s, e, ev in self._staged:
+            ev.synchronize()
+            self._host[s:e].copy_(self.flat_grad[s:e])                       # D2H (synchronous for a pinned destination + sync below)
+            torch.cuda.current_stream().synchronize()
+            dist.all_reduce(self._host[s:e], op=dist.ReduceOp.SUM, group=self.pg)
+            self.flat_grad[s:e].copy_(self._host[s:e], non_blocking=True)    # H2D on the step's stream: clip + Adam queue behind it
+        torch.cuda.current_stream().synchronize()                            # the pinned buffer is reused by the next step
+        self._staged = []
 
     def ready(self, name):
         """Would `on_group_done(name)` launch a bucket?  backward_native flushes its deferred weight-gradient work (one grouped
@@ -66,6 +94,8 @@ class GradReducer:
     def finish(self):
         """Issue whatever is left and make the current stream wait for every collective (no host block on NCCL)."""
         self._launch_down_to(0)
+        if self._staged:
+            self._finish_staged()
         for h in self._handles:
             h.wait()
         self._handles = []
@@ -74,6 +104,7 @@ class GradReducer:
     def reset(self):
         """Forget a half-issued step (a hipGraph capture of it was aborted): no handles, first bucket next."""
         self._handles = []
+        self._staged = []
         self._next = 0
 
     def grad_scale(self, grad_acc_step=1):

@@ -22,6 +22,11 @@ class FSTWOapi:
         self.speakers_dict, self.speaker_names = load_speakers_json(config.preprocess_config.path.preprocessed_path)
         if isinstance(device, int):
             device = "cuda:%d" % device
+        if not str(device).startswith("cuda"):
+            # the reference's shipped default (config.yaml:2 `gpu: 'cpu'`): this build has no CPU path — say so here, not at the first forward
+            from tts_king_amd.lib import TtskError
+            raise TtskError("gpu: %r — this build runs FastSpeech2 on hand-written MI355X kernels only; set gpu: 'cuda:0' in config.yaml "
+                            "(PyTorch-ROCm names HIP devices cuda:N)" % (device,))
         self.model = FastSpeech2(config.preprocess_config, config.model_config, len(self.speaker_names), device=device)
         self.weights_path = weights_path
         if weights_path is not None:

@@ -71,3 +71,33 @@ def test_dataset_files_and_feeder(tmp_path):
     dev = list(D.DeviceFeeder(batches, "cpu"))
     assert len(dev) == 3 and torch.is_tensor(dev[0][6]) and dev[0][6].dtype == torch.float32 and dev[0][10].dtype == torch.int64
     assert torch.equal(dev[1][3], torch.from_numpy(batches[1][3]).long())
+
+
+def test_packed_bucket_staging_equals_pad_to_bucket():
+    """The feeder's one-buffer staging (dataset.packed_layout / pack_into with engine.bucket_plan's target shapes: the bucket's zero
+    padding written while packing) holds exactly the arrays engine.pad_to_bucket produces."""
+    import numpy as np
+    import torch
+    from tts_king_amd.dataset import _FIELD_DTYPE, pack_into, packed_layout, views_of
+    from tts_king_amd.engine import bucket_plan, pad_to_bucket
+    from tts_king_amd.synthetic import make_batch
+    for seed, L in ((3, 61), (4, 64), (5, 37)):
+        b = tuple(x.numpy() if torch.is_tensor(x) else x for x in make_batch(5, L, seed=seed, ragged=True))
+        want = pad_to_bucket(b, 8, 32, 1000)
+        Lb, Tb, t_true, l_true, axis1 = bucket_plan(b, 8, 32, 1000)
+        assert (Lb, Tb, t_true, l_true) == (want[5], want[8], want.t_true, want.l_true)
+        arrays = []
+        for i, x in enumerate(b):
+            if isinstance(x, np.ndarray) and x.dtype != object:
+                a = x.astype(_FIELD_DTYPE[i], copy=False) if i in _FIELD_DTYPE else x
+                shp = a.shape if i not in axis1 else (a.shape[0], axis1[i]) + tuple(a.shape[2:])
+                arrays.append((i, a, tuple(shp)))
+        layout, total = packed_layout(arrays)
+        assert total % 256 == 0 and all(o % 256 == 0 for _, o, _, _, _ in layout)
+        buf = np.full(total, 0xAB, dtype=np.uint8)          # stale bytes of the slot's previous batch must not survive
+        pack_into(buf, layout, arrays)
+        got = views_of(torch.from_numpy(buf), layout)
+        for i, _, _ in arrays:
+            w = np.asarray(want[i])
+            assert tuple(got[i].shape) == w.shape, (i, got[i].shape, w.shape)
+            assert np.array_equal(got[i].numpy(), w.astype(got[i].numpy().dtype)), i

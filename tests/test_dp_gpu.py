@@ -275,7 +275,7 @@ def test_train_engine_with_reducer_capture_and_fallback(cfg):
             keep = G.GraphedTrainStep
             if mode == "capture_fails":
                 class Boom(keep):
-                    def __init__(self, enqueue, example_batch, warmup=2, pool=None):
+                    def __init__(self, enqueue, example_batch, warmup=2, pool=None, **kw):
                         enqueue(example_batch)          # runs part of a step's Python (and its launches), then fails like a refused capture
                         raise RuntimeError("capture refused (test)")
                 import tts_king_amd.engine as E

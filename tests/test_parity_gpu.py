@@ -166,23 +166,24 @@ def test_full_size_step_vs_oracle(cfg, dropout):
         r = rel_rms(named[k].grad.float().cpu(), tr.sd[k].grad)
         print("  grad %-64s rel-RMS vs oracle %.2f%%" % (k, 100 * r))
         rels[k] = r
-    if dropout and rels["postnet.convolutions.4.0.conv.weight"] > 0.08:
-        # With half the PostNet's activations dropped, the last conv's weight gradient is the reference's own soft spot: train-mode
-        # BatchNorm divides by batch deviations that shrink with the kept half, and a 2^-9 rounding of the operands turns into >10 %
-        # of this tensor (its NORM stays within 0.1 %).  Calibrate instead of guessing: the oracle against ITSELF with its weights
-        # rounded to bf16 — the HIP path's operand precision — under the same masks; the HIP path must stay within 1.5 x that.
+    bars = {k: 0.08 for k in rels}
+    if dropout:
+        # With half of the predictors' and the PostNet's activations dropped (p = 0.5), a whole-tensor comparison is at the mercy of the
+        # reference's own soft spots: e.g. train-mode BatchNorm divides by batch deviations that shrink with the kept half, and a 2^-9
+        # rounding of the operands turns into > 10 % of the last PostNet conv's weight gradient (whose NORM stays within 0.1 %).
+        # Calibrate instead of guessing: the oracle against ITSELF with its matrices rounded to bf16 — the HIP path's operand precision
+        # — under the same masks; per tensor the bar is max(8 %, 1.5 x that).
         sd16 = {k: (v.to(torch.bfloat16).float() if (v.is_floating_point() and v.dim() >= 2) else v.clone()) for k, v in sd.items()}
         tr16 = ofs2.OracleTrainer(sd16, copy.deepcopy(cfg.model_config), cfg.train_config, 0)
         with oracle_with_masks(masks):
             o16 = ofs2.fs2_forward(tr16.sd, tr16.mc, *b[2:], train=True, bn_buffers={})
             ofs2.fs2_loss(b, o16)[0].sum().backward()
-        k4 = "postnet.convolutions.4.0.conv.weight"
-        own = rel_rms(tr16.sd[k4].grad, tr.sd[k4].grad)
-        print("  grad %-64s oracle with bf16-rounded weights vs oracle: rel-RMS %.2f%%" % (k4, 100 * own))
-        assert rels[k4] <= max(0.08, 1.5 * own), (k4, rels[k4], own)
-        rels.pop(k4)
+        for k in rels:
+            own = rel_rms(tr16.sd[k].grad, tr.sd[k].grad)
+            bars[k] = max(0.08, 1.5 * own)
+            print("  grad %-64s oracle with bf16-rounded matrices vs oracle: rel-RMS %.2f%% -> bar %.1f%%" % (k, 100 * own, 100 * bars[k]))
     for k, r in rels.items():
-        assert r <= 0.08, (k, r)
+        assert r <= bars[k], (k, r, bars[k])
     gn, on = math.sqrt(gsq), math.sqrt(osq)
     assert abs(on - tr.grad_norm()) <= 1e-6 * on          # the groups cover every trainable key
     print("global grad norm HIP %.5f oracle %.5f; worst group %s" % (gn, on, worst))

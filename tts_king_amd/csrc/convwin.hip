@@ -225,8 +225,11 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
   };
   TTSK_STAMP(0);
 
-  {  // ---- x window: lrelu(x) rows t0 - 33 .. t0 + 129, zeros outside the utterance
+  {  // ---- x window: lrelu(x) rows t0 - 33 .. t0 + 129, zeros outside the utterance.  The window is sized for dilation 5 (c1 reaches 25
+     // rows beyond the 112 it computes); a smaller dilation reads HK * d rows either side only — the others are never fetched (they
+     // stay zero, nobody reads them): 122 / 142 / 162 rows for d = 1 / 3 / 5 at k = 11.
     constexpr int NCH = (CP_XROWS * CH8 + NT - 1) / NT;     // 11
+    const int xlo = CP_XH - CP_TH - HK * d, xhi = CP_XH - CP_TH + CP_TROWS + HK * d;
     uint4 xv[NCH];
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
       const int row = idx / CH8, ch = idx - row * CH8;
       const int t = t0 - CP_XH + row;
       xv[it] = make_uint4(0, 0, 0, 0);
-      if (idx < CP_XROWS * CH8 && t >= 0 && t < len) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
+      if (idx < CP_XROWS * CH8 && t >= 0 && t < len && row >= xlo && row < xhi) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
     }
     // the weight fragments are requested BEHIND the window: loads return in order, and nothing starts before the window is in LDS
     load_w(0, wa);
@@ -430,8 +433,11 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
       for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(src + (ks * NC + cc) * 1024);
   };
 
-  {  // ---- x window: lrelu(x) rows t0 - 33 .. t0 + 129, zeros outside the utterance
+  {  // ---- x window: lrelu(x) rows t0 - 33 .. t0 + 129, zeros outside the utterance.  The window is sized for dilation 5 (c1 reaches 25
+     // rows beyond the 112 it computes); a smaller dilation reads HK * d rows either side only — the others are never fetched (they
+     // stay zero, nobody reads them): 122 / 142 / 162 rows for d = 1 / 3 / 5 at k = 11.
     constexpr int NCH = (CP_XROWS * CH8 + NT - 1) / NT;     // 11
+    const int xlo = CP_XH - CP_TH - HK * d, xhi = CP_XH - CP_TH + CP_TROWS + HK * d;
     uint4 xv[NCH];
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
       const int row = idx / CH8, ch = idx - row * CH8;
       const int t = t0 - CP_XH + row;
       xv[it] = make_uint4(0, 0, 0, 0);
-      if (idx < CP_XROWS * CH8 && t >= 0 && t < len) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
+      if (idx < CP_XROWS * CH8 && t >= 0 && t < len && row >= xlo && row < xhi) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
     }
     // the weight fragments are requested BEHIND the window: loads return in order, and nothing starts before the window is in LDS
     load_w(0, wa);
@@ -642,6 +648,7 @@ __global__ __launch_bounds__(NW * 64, (FsGeom<C, NW>::OCC * NW) / 4) void conv_p
 
   {  // ---- x window: lrelu(x) rows t0 - 33 .. t0 + 209, zeros outside the utterance
     constexpr int NCH = (XROWS * CH8 + NT - 1) / NT;
+    const int xlo = 25 - HK * d, xhi = 25 + Gm::CROWS + HK * d;      // the rows c1 reads at this dilation (the window is sized for d = 5)
     uint4 xv[NCH];
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(NW * 64, (FsGeom<C, NW>::OCC * NW) / 4) void conv_p
       const int row = idx / CH8, ch = idx - row * CH8;
       const int t = t0 - XH + row;
       xv[it] = make_uint4(0, 0, 0, 0);
-      if (idx < XROWS * CH8 && t >= 0 && t < len) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
+      if (idx < XROWS * CH8 && t >= 0 && t < len && row >= xlo && row < xhi) xv[it] = *(const uint4*)(xb + (int64_t)t * C + ch * 8);
     }
     // the weight fragments are requested BEHIND the window: loads return in order, and nothing starts before the window is in LDS
     load_w(0, wa);

@@ -100,7 +100,11 @@ class _PinnedPool:
     but only an event says so to the HOST (the training stream waiting for the copy stream orders the device, not this thread):
     `copied(...)` records one on the copy stream after the slot's `.to()`, and `stage` waits for it before overwriting the slot."""
 
-    def __init__(self, depth=3):
+    def __init__(self, depth=6):
+        # depth: a slot comes round again `depth` batches later.  Round 4 measured what 3 costs: the H2D copy of a slot shares a hardware
+        # queue with branches of the replayed step graph and can sit behind them for whole steps — the host found the slot's event
+        # unfinished in 10 of 33 waits and then blocked 1.3 ms per batch on average (up to 9.5 ms), 0.3 ms of every trainer step.  At 6+
+        # every wait found its event complete (tools/debug/loop_ab.py).
         self.depth, self.slots, self.turn = depth, {}, {}
 
     def stage(self, field, arr):
@@ -119,6 +123,38 @@ class _PinnedPool:
         self._last = lst[i]
         return lst[i][0]
 
+    def to_device_packed(self, arrays, device):
+        """Every array of a batch through ONE pinned buffer and ONE H2D copy: arrays = [(tag, ndarray, target shape)] — an array
+        smaller than its target shape is zero-padded on the way in.  Returns (packed uint8 device
+        tensor, {tag: device tensor view}, layout) — layout = ((tag, byte offset, byte length, numpy dtype str, shape), ...) with
+        256-byte aligned offsets: the same shapes give the same layout, so a consumer that holds a buffer of this layout (a captured
+        graph's static inputs, tts_king_amd/graph.py) takes the next batch with one device copy instead of one per field."""
+        layout, total = packed_layout(arrays)
+        key = ("packed", total)
+        lst = self.slots.setdefault(key, [])
+        i = self.turn.get(key, 0)
+        if len(lst) <= i:
+            t = torch.empty(total, dtype=torch.uint8).pin_memory()
+            lst.append([t, t.numpy(), None])
+        self.turn[key] = (i + 1) % self.depth
+        slot = lst[i]
+        if slot[2] is not None:
+            if _DEBUG_EVENTS is not None:
+                import time as _t
+                q = slot[2].query()
+                t0 = _t.perf_counter()
+                slot[2].synchronize()
+                _DEBUG_EVENTS.append((q, _t.perf_counter() - t0))
+            else:
+                slot[2].synchronize()
+        host = slot[1]
+        pack_into(host, layout, arrays)
+        packed = slot[0].to(device, non_blocking=True)
+        if slot[2] is None:
+            slot[2] = torch.cuda.Event()
+        slot[2].record()
+        return packed, views_of(packed, layout), tuple(layout)
+
     def to_device(self, field, arr, device):
         """stage + the non-blocking H2D copy on the current (copy) stream + the slot's completion event."""
         t = self.stage(field, arr).to(device, non_blocking=True)
@@ -129,7 +165,42 @@ class _PinnedPool:
         return t
 
 
+def packed_layout(arrays):
+    """((tag, byte offset, byte length, numpy dtype str, target shape), ...) and the total byte count (a multiple of 256) for
+    arrays = [(tag, ndarray, target shape)], 256-byte aligned offsets in the given order."""
+    layout, off = [], 0
+    for tag, a, shp in arrays:
+        nb = int(np.prod(shp)) * a.dtype.itemsize
+        layout.append((tag, off, nb, a.dtype.str, tuple(shp)))
+        off = (off + nb + 255) // 256 * 256
+    return layout, max(off, 256)
+
+
+def pack_into(host_u8, layout, arrays):
+    """Write the arrays into a uint8 numpy buffer at their layout positions; an array smaller than its target shape is zero-padded on the
+    way in (the shape bucket's padding: no np.pad copy of the array first)."""
+    for (tag, o, nb, dt, shp), (_, a, _s) in zip(layout, arrays):
+        if not nb:
+            continue
+        dst = host_u8[o:o + nb].view(dt).reshape(shp)
+        if a.shape == shp:
+            np.copyto(dst, a)
+        else:
+            dst[...] = 0
+            dst[tuple(slice(0, n) for n in a.shape)] = a
+
+
+def views_of(packed, layout):
+    """{tag: typed view} into a packed batch buffer (see _PinnedPool.to_device_packed)."""
+    out = {}
+    for tag, o, nb, dt, shp in layout:
+        tdt = torch.from_numpy(np.empty(0, dtype=np.dtype(dt))).dtype
+        out[tag] = packed[o:o + nb].view(tdt).view(shp)
+    return out
+
+
 _POOLS = {}
+_DEBUG_EVENTS = None
 
 # dtypes `to_device` gives the batch fields (reference: fs_two/utils/tools.py:15-83): speakers / texts / durations long, mels / pitches
 # float, pitches_cwt float with NaN -> 0, the others as stored
@@ -144,13 +215,15 @@ class DeviceFeeder:
     def __init__(self, batches, device, bucket=None):
         self.it, self.device = iter(batches), torch.device(device)
         self.bucket = bucket
+        # (a high-priority copy stream was tried so that the copies would not queue behind the step graph's branches: every slot event
+        # was then complete on time, but the replayed step itself took 6.2 ms instead of 2.7 — plain priority)
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self.pool = _POOLS.setdefault(str(self.device), _PinnedPool()) if self.stream is not None else None
         self._next = None
         self._preload()
 
     def _preload(self):
-        from .engine import PaddedBatch, pad_to_bucket
+        from .engine import PaddedBatch, bucket_plan, pad_to_bucket
         from .train_step import to_device
         try:
             b = next(self.it)
@@ -158,31 +231,41 @@ class DeviceFeeder:
             self._next = None
             return
         t_true = l_true = None
-        if self.bucket is not None:
-            b = pad_to_bucket(b, *self.bucket)
-            t_true, l_true = b.t_true, b.l_true
         nb = len(b[0])
         if self.stream is None:
+            if self.bucket is not None:
+                b = pad_to_bucket(b, *self.bucket)
+                t_true, l_true = b.t_true, b.l_true
             dev_b = to_device(b, self.device)
             fl = torch.tensor([t_true], dtype=torch.int32, device=self.device) if t_true is not None else None
             pl = torch.full((nb,), l_true, dtype=torch.int64, device=self.device) if l_true is not None else None
         else:
-            fields = []
+            # the whole batch (bucket padding included) and its frame / phoneme limits through one pinned buffer and one H2D copy
+            axis1, b = {}, list(b)
+            if self.bucket is not None:
+                Lb, Tb, t_true, l_true, axis1 = bucket_plan(b, *self.bucket)
+                b[5], b[8] = Lb, Tb
+            arrays = []
+            for i, x in enumerate(b):
+                if isinstance(x, np.ndarray) and x.dtype != object:
+                    a = x.astype(_FIELD_DTYPE[i], copy=False) if i in _FIELD_DTYPE else x
+                    if i == 12:
+                        a = np.nan_to_num(a, nan=0.0)
+                    shp = a.shape if i not in axis1 else (a.shape[0], axis1[i]) + tuple(a.shape[2:])
+                    arrays.append((i, a, tuple(shp)))
+            if t_true is not None:
+                arrays.append(("fl", np.array([t_true], dtype=np.int32), (1,)))
+            if l_true is not None:
+                arrays.append(("pl", np.full((nb,), l_true, dtype=np.int64), (nb,)))
             with torch.cuda.stream(self.stream):
-                for i, x in enumerate(b):
-                    if isinstance(x, np.ndarray) and x.dtype != object:
-                        a = x.astype(_FIELD_DTYPE[i], copy=False) if i in _FIELD_DTYPE else x
-                        if i == 12:
-                            a = np.nan_to_num(a, nan=0.0)
-                        fields.append(self.pool.to_device(i, a, self.device))
-                    else:
-                        fields.append(x)
-                fl = self.pool.to_device("fl", np.array([t_true], dtype=np.int32), self.device) if t_true is not None else None
-                pl = self.pool.to_device("pl", np.full((nb,), l_true, dtype=np.int64), self.device) if l_true is not None else None
-            dev_b = tuple(fields)
-        if self.bucket is not None:
+                packed, views, layout = self.pool.to_device_packed(arrays, self.device)
+            dev_b = tuple(views[i] if i in views else x for i, x in enumerate(b))
+            fl, pl = views.get("fl"), views.get("pl")
+        if self.bucket is not None or self.stream is not None:
             dev_b = PaddedBatch(dev_b)
             dev_b.t_true, dev_b.l_true, dev_b.frame_limit, dev_b.phoneme_limit = t_true, l_true, fl, pl
+            if self.stream is not None:
+                dev_b.packed, dev_b.layout = packed, layout
         self._next = dev_b
 
     def __iter__(self):
@@ -194,8 +277,12 @@ class DeviceFeeder:
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
         batch = self._next
-        for t in tuple(batch) + (getattr(batch, "frame_limit", None), getattr(batch, "phoneme_limit", None)):
-            if torch.is_tensor(t) and t.is_cuda:
-                t.record_stream(torch.cuda.current_stream())
+        pk = getattr(batch, "packed", None)
+        if pk is not None:
+            pk.record_stream(torch.cuda.current_stream())      # (every field is a view of it)
+        else:
+            for t in tuple(batch) + (getattr(batch, "frame_limit", None), getattr(batch, "phoneme_limit", None)):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(torch.cuda.current_stream())
         self._preload()
         return batch

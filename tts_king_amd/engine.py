@@ -25,22 +25,24 @@ from .graph import GraphedTrainStep, make_enqueue
 
 class PaddedBatch(tuple):
     """The 15-tuple batch plus `t_true` / `l_true` (frames / phonemes of the batch's own longest utterance; None when the bucket adds
-    no padding) and, on the device, `frame_limit` (int32[1]) / `phoneme_limit` (int64[B], every entry l_true)."""
+    no padding) and, on the device, `frame_limit` (int32[1]) / `phoneme_limit` (int64[B], every entry l_true).  From the DeviceFeeder
+    every device field (the limits included) is a view of ONE buffer, `packed`, laid out as `layout` says (dataset.views_of)."""
     t_true = None
     l_true = None
     frame_limit = None
     phoneme_limit = None
+    packed = None
+    layout = None
 
 
 def bucket_up(n, step):
     return (int(n) + step - 1) // step * step
 
 
-def pad_to_bucket(batch, l_bucket=8, t_bucket=32, max_seq_len=1000):
-    """numpy 15-tuple (fs_two/dataset.py:188-204 layout) -> PaddedBatch with texts / durations / pitch / energy padded to a
-    multiple of `l_bucket` phonemes and mels to a multiple of `t_bucket` frames (zeros = the reference's PAD values).  Batches
-    longer than `max_seq_len` frames keep their length (the train-mode decoder truncation path, Models.py:172-180)."""
-    (ids, raw, spk, texts, src_lens, max_src, mels, mel_lens, max_mel, energies, durations, pitches, cwt, pmean, pstd) = batch
+def bucket_plan(batch, l_bucket=8, t_bucket=32, max_seq_len=1000):
+    """What `pad_to_bucket` will do to a numpy 15-tuple, without doing it: (Lb, Tb, t_true, l_true, {field index: padded length of its
+    axis 1}).  Batches longer than `max_seq_len` frames keep their length (the train-mode decoder truncation path, Models.py:172-180)."""
+    max_src, max_mel = batch[5], batch[8]
     Lb = bucket_up(max_src, l_bucket)
     if Lb > max_seq_len >= int(max_src):
         Lb = max(int(max_src), max_seq_len)        # never pad a text past the position table (the eval-only long-input path)
@@ -48,22 +50,31 @@ def pad_to_bucket(batch, l_bucket=8, t_bucket=32, max_seq_len=1000):
     Tb = bucket_up(t_true, t_bucket) if t_true <= max_seq_len else t_true
     if Tb > max_seq_len >= t_true:
         Tb = max(t_true, max_seq_len)
+    frame_level_p = np.asarray(batch[11]).shape[1] == int(max_mel) and int(max_mel) != int(max_src)
+    frame_level_e = np.asarray(batch[9]).shape[1] == int(max_mel) and int(max_mel) != int(max_src)
+    axis1 = {3: Lb, 6: Tb, 9: Tb if frame_level_e else Lb, 10: Lb, 11: Tb if frame_level_p else Lb, 12: Lb}
+    return Lb, Tb, (t_true if Tb != t_true else None), (int(max_src) if Lb != int(max_src) else None), axis1
 
-    def pad(a, n, axis=1):
+
+def pad_to_bucket(batch, l_bucket=8, t_bucket=32, max_seq_len=1000):
+    """numpy 15-tuple (fs_two/dataset.py:188-204 layout) -> PaddedBatch with texts / durations / pitch / energy padded to a
+    multiple of `l_bucket` phonemes and mels to a multiple of `t_bucket` frames (zeros = the reference's PAD values)."""
+    Lb, Tb, t_true, l_true, axis1 = bucket_plan(batch, l_bucket, t_bucket, max_seq_len)
+
+    def pad(a, n):
         a = np.asarray(a)
-        if a.shape[axis] == n:
+        if a.shape[1] == n:
             return a
         w = [(0, 0)] * a.ndim
-        w[axis] = (0, n - a.shape[axis])
+        w[1] = (0, n - a.shape[1])
         return np.pad(a, w, mode="constant", constant_values=0)
 
-    frame_level_p = np.asarray(pitches).shape[1] == int(max_mel) and int(max_mel) != int(max_src)
-    frame_level_e = np.asarray(energies).shape[1] == int(max_mel) and int(max_mel) != int(max_src)
-    out = PaddedBatch((ids, raw, spk, pad(texts, Lb), src_lens, Lb, pad(mels, Tb), mel_lens, Tb,
-                       pad(energies, Tb if frame_level_e else Lb), pad(durations, Lb), pad(pitches, Tb if frame_level_p else Lb),
-                       pad(cwt, Lb), pmean, pstd))
-    out.t_true = t_true if Tb != t_true else None
-    out.l_true = int(max_src) if Lb != int(max_src) else None
+    fields = list(batch)
+    for i, n in axis1.items():
+        fields[i] = pad(fields[i], n)
+    fields[5], fields[8] = Lb, Tb
+    out = PaddedBatch(fields)
+    out.t_true, out.l_true = t_true, l_true
     return out
 
 
@@ -122,15 +133,25 @@ class TrainEngine:
         if g is None:
             if len(self._graphs) >= self.max_graphs:
                 self._graphs.popitem(last=False)
-            static = [t.clone() if torch.is_tensor(t) else t for t in batch]
-            static_fl = fl.clone() if fl is not None else None
-            static_pl = pl.clone() if pl is not None else None
+            static_packed = None
+            if getattr(batch, "packed", None) is not None:
+                # the graph's static inputs as views of one buffer with the feeder's layout: a replay takes its batch with ONE copy
+                from .dataset import views_of
+                static_packed = batch.packed.clone()
+                views = views_of(static_packed, batch.layout)
+                static = [views[i] if i in views else t for i, t in enumerate(batch)]
+                static_fl, static_pl = views.get("fl"), views.get("pl")
+            else:
+                static = [t.clone() if torch.is_tensor(t) else t for t in batch]
+                static_fl = fl.clone() if fl is not None else None
+                static_pl = pl.clone() if pl is not None else None
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()
             host_step = self.optimizer._host_step
             torch.cuda.synchronize()
             try:
-                g = GraphedTrainStep(self._enqueue(is_update, static_fl, static_pl, accumulate=acc), static, warmup=0, pool=self._pool)
+                g = GraphedTrainStep(self._enqueue(is_update, static_fl, static_pl, accumulate=acc), static, warmup=0, pool=self._pool,
+                                     static_packed=static_packed, layout=getattr(batch, "layout", None))
             except Exception as e:      # e.g. RCCL refusing to have a collective captured: this shape runs with plain launches
                 # the aborted capture ran part of one step's Python: put the host-side bookkeeping back where it was
                 self.optimizer._host_step = host_step
@@ -153,10 +174,11 @@ class TrainEngine:
         else:
             self._graphs.move_to_end(key)
             self.stats["replayed"] += 1
-        if g.frame_limit is not None:
-            g.frame_limit.copy_(fl, non_blocking=True)
-        if g.phoneme_limit is not None:
-            g.phoneme_limit.copy_(pl, non_blocking=True)
+        if not g.takes_packed(batch):       # (a packed batch carries its limits inside the one buffer g.run copies)
+            if g.frame_limit is not None:
+                g.frame_limit.copy_(fl, non_blocking=True)
+            if g.phoneme_limit is not None:
+                g.phoneme_limit.copy_(pl, non_blocking=True)
         losses, out = g.run(batch)
         self.model.grads_partial = not is_update      # what the replayed step's Python would have left
         if is_update:

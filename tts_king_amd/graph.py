@@ -17,8 +17,11 @@ class GraphedTrainStep:
     `enqueue` must only enqueue device work on the current stream (no host reads); it returns device tensors
     (e.g. the losses) that are valid after each replay."""
 
-    def __init__(self, enqueue, example_batch, warmup=2, pool=None):
-        self.static = [t.clone() if torch.is_tensor(t) else t for t in example_batch]
+    def __init__(self, enqueue, example_batch, warmup=2, pool=None, static_packed=None, layout=None):
+        # `static_packed` / `layout`: the example batch's tensors are already the graph's own static inputs — views of one buffer laid
+        # out like the DeviceFeeder's packed batches (tts_king_amd/dataset.py): `run` then takes a batch with one device copy
+        self.static_packed, self.layout = static_packed, layout
+        self.static = list(example_batch) if static_packed is not None else [t.clone() if torch.is_tensor(t) else t for t in example_batch]
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -40,13 +43,21 @@ class GraphedTrainStep:
     def key(self):
         return tuple(tuple(t.shape) for t in self.static if torch.is_tensor(t))
 
+    def takes_packed(self, batch):
+        pk = getattr(batch, "packed", None)
+        return (self.static_packed is not None and pk is not None and getattr(batch, "layout", None) == self.layout
+                and pk.numel() == self.static_packed.numel())
+
     def run(self, batch=None):
         """Copy `batch` into the static inputs (when given) and replay.  The replay runs none of the step's Python: host-side
         bookkeeping a step would have done (optimizer._host_step, model.grads_partial) is the caller's."""
         if batch is not None:
-            for dst, src in zip(self.static, batch):
-                if torch.is_tensor(dst) and src is not dst:
-                    dst.copy_(src, non_blocking=True)
+            if self.takes_packed(batch):
+                self.static_packed.copy_(batch.packed, non_blocking=True)
+            else:
+                for dst, src in zip(self.static, batch):
+                    if torch.is_tensor(dst) and src is not dst:
+                        dst.copy_(src, non_blocking=True)
         self.graph.replay()
         return self.outputs
 

@@ -15,5 +15,7 @@ find $O/hifi_trace -name "*kernel_trace.csv" -size +20M -delete
 cd $R
 bash tools/pmc_bench.sh > $O/pmc_bench.log 2>&1; cp gpurun_out/pmc_bench/pmc_traffic.json $O/ 2>/dev/null; echo "pmc traffic rc=$?"
 bash tools/pmc_mfma.sh > $O/pmc_mfma.log 2>&1; cp gpurun_out/pmc_mfma/mfma_util.json $O/ 2>/dev/null; echo "pmc mfma rc=$?"
+bash tools/pmc_hifi.sh > $O/pmc_hifi.log 2>&1; cp gpurun_out/pmc_hifi/pmc_traffic.json $O/pmc_traffic_hifi.json 2>/dev/null; echo "pmc hifi rc=$?"
+rm -rf gpurun_out/pmc_hifi/fetch gpurun_out/pmc_hifi/write
 rm -rf gpurun_out/pmc_bench/fetch gpurun_out/pmc_bench/write gpurun_out/pmc_mfma/fs2 gpurun_out/pmc_mfma/hifi
 ls -la $O

@@ -630,8 +630,16 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const
     for (int e = 0; e < 16; ++e) sbias[e] = sgam[e] = sbeta[e] = 0.f;
     const int rl = wave * 4 + grp;
     lnb256_row(a, m0 + rl, c0, gam, seed, step, thr, dscale, sbias, sgam, sbeta, dzv, PRE ? dtile + rl * DT_LD : nullptr);
-    *(uint4*)(xs + rl * P32_RS + c0 * 2) = pack8f(dzv);
-    *(uint4*)(xs + rl * P32_RS + c0 * 2 + 16) = pack8f(dzv + 8);
+    {
+      // a lane's 32 bytes as two 16-byte stores: lanes l and l + 4 of a store's 8-lane group are 128 bytes apart — the same banks
+      // (a two-way conflict on every store: 16 % of this kernel's LDS cycles at NG = 1).  Lanes 4-7 of a group store their upper half
+      // first: the eight lanes then cover all 32 banks
+      const uint4 lo = pack8f(dzv), hi = pack8f(dzv + 8);
+      const int up = (l >> 2) & 1;
+      unsigned char* dst = xs + rl * P32_RS + c0 * 2;
+      *(uint4*)(dst + up * 16) = up ? hi : lo;
+      *(uint4*)(dst + (up ^ 1) * 16) = up ? lo : hi;
+    }
     LNB_STAMP(2);
     // group 0's weight fragments: requested behind the rows' own loads (loads return in order: in front of them they delayed every
     // row), with the partial sums and their barrier (~3 us) to arrive

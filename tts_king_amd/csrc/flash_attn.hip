@@ -84,6 +84,14 @@ __device__ __forceinline__ bf16x8 frag_tr8(const unsigned char* base, int nblk, 
       (__attribute__((address_space(3))) bf16x4*)(base + k1 * 256 + ((nblk ^ (k1 & 7)) << 5) + ((l15 & 3) << 3)));
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
+// A row-major fragment (rows r0 + l15, r0 a multiple of 16; k step ks = 32 contraction elements) read from a store_tr8 IMAGE: the
+// 16-byte chunk c = 4 ks + lg of row k sits in 32-byte block (c >> 1) ^ (k & 7), half c & 1 — a group of 16 lanes (8 rows at chunk
+// c, the 8 other rows at c + 1) covers 16 distinct 16-byte units: conflict-free (tools/debug/lds_bank_model.py).  So an operand that
+// is multiplied BOTH ways (K on the query side of the backward, Q and dO on its key side) needs one LDS image, not two.
+__device__ __forceinline__ bf16x8 frag_rows8(const unsigned char* base, int r0, int ks, int l15, int lg) {
+  const int row = r0 + l15, c = ks * 4 + lg;
+  return *(const bf16x8*)(base + row * 256 + ((((c >> 1) ^ (row & 7)) << 5) | ((c & 1) << 4)));
+}
 // max / sum over the four lanes l15, l15 + 16, l15 + 32, l15 + 48 (the lane groups that share a query)
 __device__ __forceinline__ float cross16_max(float v) {
   v = fmaxf(v, __shfl_xor(v, 16, 64));
@@ -217,9 +225,9 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_t_kernel(const FlashArgs a) 
 // Outputs leave as in flash_fwd_t_kernel: 8-byte bf16 pieces into a staging tile, full rows to memory.  Same sums in a different
 // order (a contraction's slots are permuted, fp32 accumulation): results differ from flash_bwd_kernel's in the last bits only.
 __device__ __forceinline__ void flash_bwd_q_t_body(const FlashArgs& a, unsigned char* smem) {      // uses 49,152 B of smem
-  unsigned char* Kr = smem;                          // K tile, row-major image            (A operand of S^T = K Q^T)
-  unsigned char* Vr = smem + KS_BYTES;               // V tile, row-major image            (A operand of dP^T = V dO^T)
-  unsigned char* Kt = Vr + KS_BYTES;                 // K tile, store_tr8 image            (A operand of dQ^T += K^T dS^T)
+  unsigned char* Kr = smem;                          // staging of the workgroup's Q rows (before the loop)
+  unsigned char* Vr = smem + KS_BYTES;               // V tile, row-major image            (A operand of dP^T = V dO^T); dO staging before the loop
+  unsigned char* Kt = Vr + KS_BYTES;                 // K tile, store_tr8 image            (A operand of S^T = K Q^T as rows, of dQ^T += K^T dS^T transposed)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   int tile_x, z;
   xcd_tile(tile_x, z);
@@ -255,8 +263,7 @@ __device__ __forceinline__ void flash_bwd_q_t_body(const FlashArgs& a, unsigned 
   for (int j = 0; j < ntk; ++j) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                                  // the previous tile's (or the Q / dO staging's) LDS reads are done
-    store_rows(Kr, rk, tid);
-    store_tr8(Kt, rk, tid);
+    store_tr8(Kt, rk, tid);                           // ONE image of K: read as rows for S^T (frag_rows8) and transposed for dQ^T (frag_tr8)
     store_rows(Vr, rv, tid);
     if (j + 1 < ntk) { load_tile(rk, base + a.d, ld, (j + 1) * TK, S, tid); load_tile(rv, base + 2 * a.d, ld, (j + 1) * TK, S, tid); }
     __syncthreads();
@@ -267,7 +274,7 @@ __device__ __forceinline__ void flash_bwd_q_t_body(const FlashArgs& a, unsigned 
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        st[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Kr, nt * 16, ks, l15, lg), qb[ks], st[nt], 0, 0, 0);
+        st[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows8(Kt, nt * 16, ks, l15, lg), qb[ks], st[nt], 0, 0, 0);
         dpt[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vr, nt * 16, ks, l15, lg), db[ks], dpt[nt], 0, 0, 0);
       }
 #pragma unroll
@@ -301,10 +308,10 @@ __device__ __forceinline__ void flash_bwd_q_t_body(const FlashArgs& a, unsigned 
 }
 
 __device__ __forceinline__ void flash_bwd_kv_t_body(const FlashArgs& a, unsigned char* smem) {     // uses 66,048 B of smem
-  unsigned char* Qr = smem;                          // Q tile, row-major image            (A operand of S = Q K^T)
-  unsigned char* Dr = smem + KS_BYTES;               // dO tile, row-major image           (A operand of dP = dO V^T)
-  unsigned char* Qt = Dr + KS_BYTES;                 // Q tile, store_tr8 image            (A operand of dK^T += Q^T dS)
-  unsigned char* Dt = Qt + VS_BYTES;                 // dO tile, store_tr8 image           (A operand of dV^T += dO^T P)
+  unsigned char* Qr = smem;                          // staging of the workgroup's K rows (before the loop)
+  unsigned char* Dr = smem + KS_BYTES;               // staging of its V rows
+  unsigned char* Qt = Dr + KS_BYTES;                 // Q tile, store_tr8 image            (A operand of S = Q K^T as rows, of dK^T += Q^T dS transposed)
+  unsigned char* Dt = Qt + VS_BYTES;                 // dO tile, store_tr8 image           (A operand of dP = dO V^T as rows, of dV^T += dO^T P transposed)
   float* LD = (float*)(Dt + VS_BYTES);               // [64] LSE | [64] delta of the query tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   int tile_x, z;
@@ -341,9 +348,7 @@ __device__ __forceinline__ void flash_bwd_kv_t_body(const FlashArgs& a, unsigned
     for (int i = 0; i < ntq; ++i) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __syncthreads();                            // the previous tile's (or the K / V staging's) LDS reads are done
-      store_rows(Qr, rq, tid);
-      store_tr8(Qt, rq, tid);
-      store_rows(Dr, rd, tid);
+      store_tr8(Qt, rq, tid);                       // one image each of Q and dO, read both ways (frag_rows8 / frag_tr8)
       store_tr8(Dt, rd, tid);
       if (tid < 128) {
         const int q = i * TQ + (tid & 63);
@@ -359,8 +364,8 @@ __device__ __forceinline__ void flash_bwd_kv_t_body(const FlashArgs& a, unsigned
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-          s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qr, nt * 16, ks, l15, lg), kb[ks], s[nt], 0, 0, 0);
-          dp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Dr, nt * 16, ks, l15, lg), vb[ks], dp[nt], 0, 0, 0);
+          s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows8(Qt, nt * 16, ks, l15, lg), kb[ks], s[nt], 0, 0, 0);
+          dp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows8(Dt, nt * 16, ks, l15, lg), vb[ks], dp[nt], 0, 0, 0);
         }
       // rows = queries 16*nt + 4*lg + r of the tile, column = this lane's key
 #pragma unroll

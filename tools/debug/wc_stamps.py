@@ -25,16 +25,29 @@ cases = {
     "w_1 forward (256 -> 1024, k = 9, ReLU)": (lambda: ops.ffn_conv_fwd(x, W1, b1, relu=True, packed=pk), 256),
     "w_1 input gradient (4 slices of 256 -> 256, k = 9, fp32 slabs)": (lambda: ops.win_conv_split(dh, pkT, d, 9), 256),
 }
+xp = bf(torch.randn(B, S, 512, generator=g)).to(DEV)
+Wp = bf(torch.randn(512, 5, 512, generator=g) * 0.02).to(DEV)
+bp = (0.1 * torch.randn(512, generator=g)).to(DEV)
+pp, ppT = (torch.empty(Wp.numel(), dtype=torch.bfloat16, device=DEV) for _ in range(2))
+ops.win_conv_pack_items([(Wp, pp, False), (Wp, ppT, True)])
+npost = 256 if os.environ.get("WC_POST") else 224
+cases["PostNet forward (512 -> 512, k = 5, fp32 out)"] = (lambda: ops.win_conv(xp, pp, 512, 5, bias=bp, out_dtype=torch.float32), npost)
+cases["PostNet input gradient (512 -> 512, k = 5)"] = (lambda: ops.win_conv(xp, ppT, 512, 5), npost)
 for name, (fn, nwg) in cases.items():
-    for _ in range(3):
+    for _ in range(int(os.environ.get("WARM", "3"))):
         fn()
-    st = torch.zeros(nwg * 8, dtype=torch.int64, device=DEV)
+    st = torch.zeros(nwg * 16, dtype=torch.int64, device=DEV)
     torch.cuda.synchronize()
     lib.ttsk_win_conv_set_stamps(C.c_void_p(st.data_ptr()))
     fn()
     torch.cuda.synchronize()
     lib.ttsk_win_conv_set_stamps(C.c_void_p(0))
-    s = st.cpu().numpy().reshape(nwg, 8)[:, :6].astype(np.float64) * 0.01
+    raw = st.cpu().numpy().reshape(nwg, 16).astype(np.float64)
+    wv = (raw[:, 8:16] - raw[:, 2:3]) * 0.01
+    print("   tap loop per wave (us after the barrier, mean over workgroups): " + " ".join("%.1f" % v for v in wv.mean(axis=0)))
+    clk = np.median((raw[:, 7] - raw[:, 6]) / (raw[:, 3] - raw[:, 2])) * 0.1        # GHz: shader-clock ticks per 100 MHz tick over the tap loop
+    print("   in-kernel clock over the tap loop: %.2f GHz (median over workgroups)" % clk)
+    s = raw[:, :6] * 0.01
     s -= s[:, 0].min()
     dd = np.diff(s, axis=1)
     print("%s: %d workgroups, span %.1f us, lifetime mean %.1f (max %.1f); phases mean [window %.2f | barrier %.2f | taps %.2f | barrier %.2f | staging + stores %.2f] us; starts up to %.1f us"

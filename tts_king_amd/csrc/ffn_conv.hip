@@ -16,6 +16,7 @@
 // contiguous; from the tap-major shadow (16 rows x 64 B per fragment) the kernel only ties the GEMM (kept for Cin = 256 as the
 // unpacked variant of ttsk_ffn_conv_fwd).
 #include "common.h"
+#include "tapring.h"
 
 namespace {
 
@@ -75,14 +76,17 @@ struct WcArgs {
   float bnb_p;
   int bnb_tanh;
 #ifdef TTSK_STAMPS
-  unsigned long long* stamps;   // diagnostic build only (make stamps; ttsk_win_conv_set_stamps): 8 x s_memrealtime per workgroup
+  unsigned long long* stamps;   // diagnostic build only (make stamps; ttsk_win_conv_set_stamps): 16 slots per workgroup
 #endif
 };
 #ifdef TTSK_STAMPS
 #define WC_STAMP(i)                                                                                              \
   do {                                                                                                           \
-    if (a.stamps && threadIdx.x == 0) a.stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
-  } while (0)
+    if (a.stamps && threadIdx.x == 0) {                                                                          \
+      a.stamps[(int64_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime();                               \
+      if ((i) == 2 || (i) == 3) a.stamps[(int64_t)blockIdx.x * 16 + 4 + (i)] = __builtin_amdgcn_s_memtime();     \
+    }                                                                                                            \
+  } while (0)        // slots 6, 7: the shader clock's counter on either side of the tap loop (in-kernel clock = its delta / the 100 MHz delta)
 #else
 #define WC_STAMP(i) do {} while (0)        // the product library carries no stamp code and no global state for it
 #endif
@@ -221,33 +225,27 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
   const bf16_t* __restrict__ wbase = a.w;
   const int ks_total = ldx / 32, ks_base = sp * (C / 32);
 
-  const bf16_t* wrow[CT];
-#pragma unroll
-  for (int cc = 0; cc < CT; ++cc)
-    wrow[cc] = PACKED ? wbase + ((int64_t)(cg * (COUT / 16) + wave * CT + cc) * 64 + lane) * 8
-                      : wbase + ((int64_t)(cg * COUT + (wave * CT + cc) * 16 + l15) * K) * C + q * 8;
-  const int64_t kstep_stride = (int64_t)(a.Cout / 16) * 512;     // PACKED: elements per (tap, k-step)
+  // weight fragments by buffer loads (tapring.h): one per-lane byte offset for the whole kernel, the step's distance in a scalar register
+  const __amdgpu_buffer_rsrc_t wres = weights_rsrc(wbase, K * ldx * a.Cout * 2);
+  const int wlane = PACKED ? (cg * (COUT / 16) + wave * CT) * 1024 + lane * 16 : ((cg * COUT + wave * CT * 16 + l15) * K * C + q * 8) * 2;
+  const int kstep_bytes = (a.Cout / 16) * 1024;                  // PACKED: bytes per (tap, k-step)
   bf16x8 wa[KH][CT], wb[KH][CT], wc[KH][CT];      // three register sets: a step's weights are requested two steps (>= 1 us) ahead
   auto load_w = [&](int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
     const int tap = g / NP, part = g - tap * NP;
     if (PACKED) {
-      const int64_t off = (int64_t)(tap * ks_total + ks_base + part * KH) * kstep_stride;
-#pragma unroll
-      for (int ks = 0; ks < KH; ++ks)
-#pragma unroll
-        for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(wrow[cc] + off + ks * kstep_stride);
+      frags_load<KH, CT>(w, wres, wlane, (tap * ks_total + ks_base + part * KH) * kstep_bytes, kstep_bytes);
     } else {
-      const int off = tap * C + part * (KH * 32);
+      const int soff = (tap * C + part * (KH * 32)) * 2;
 #pragma unroll
       for (int ks = 0; ks < KH; ++ks)
 #pragma unroll
-        for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(wrow[cc] + off + ks * 32);
+        for (int cc = 0; cc < CT; ++cc) w[ks][cc] = frag_load(wres, wlane, soff + ks * 64 + cc * (16 * K * C * 2));
     }
   };
 #if !WC_XFIRST
   load_w(0, wa);
-  if (1 < NS) load_w(1, wb);
-  if (2 < NS) load_w(2, wc);
+  load_w(min(1, NS - 1), wb);
+  load_w(min(2, NS - 1), wc);
 #endif
 
   {  // ---- activation window: rows t0 - 4 .. t0 + TT + 4 of the utterance, zeros outside it (the conv's zero padding).
@@ -265,8 +263,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
     }
 #if WC_XFIRST
     load_w(0, wa);
-    if (1 < NS) load_w(1, wb);
-    if (2 < NS) load_w(2, wc);
+    load_w(min(1, NS - 1), wb);
+    load_w(min(2, NS - 1), wc);
 #endif
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
@@ -291,35 +289,49 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
   {
     const unsigned char* inl = XW + (l15 + WC_H) * RS + q * 16;
     // row shift of tap slot 1 in the stride-8 transposed-conv mode (slot 0: none)
-    const int ups_shift = a.ups_cout ? ((cg * COUT + wave * CT * 16) / a.ups_cout < a.ups_half ? -1 : 1) : 0;      // a wave's channels lie in one phase
-    auto step = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
+    // (only HiFi-GAN's fp16 instances have that mode: the training instances carry no test for it in their step code)
+    const int ups_shift = F16 && a.ups_cout ? ((cg * COUT + wave * CT * 16) / a.ups_cout < a.ups_half ? -1 : 1) : 0;      // a wave's channels lie in one phase
+    // Activation fragments through a ring of NF registers, refilled NF * CT MFMAs ahead of their use (tapring.h).  14 tiles — the
+    // HiFi-GAN upsamplers' 224-frame tiles — hold 112 accumulator + 96 weight registers: no room for a ring, the fragments are read
+    // where they are used.
+    constexpr bool RING = NF <= 8;
+    auto inp_of = [&](int g) __attribute__((always_inline)) {
       const int tap = g / NP, part = g - tap * NP;
-      const unsigned char* inp = inl + (a.ups_cout ? tap * ups_shift : tap - HK) * RS + part * (KH * 64);
+      return inl + (F16 && a.ups_cout ? tap * ups_shift : tap - HK) * RS + part * (KH * 64);
+    };
+    bf16x8 ring[RING ? NF : 1];
+    if constexpr (RING) ring_prime<NF, RS>(ring, inp_of(0));
+    auto step = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
+      const unsigned char* inp = inp_of(g);
+      if constexpr (RING) {
+        tap_ring<F16, KH, CT, NF, RS>(acc, ring, w, inp, inp_of(g + 1 < NS ? g + 1 : g));
+      } else {
 #pragma unroll
-      for (int ks = 0; ks < KH; ++ks) {
+        for (int ks = 0; ks < KH; ++ks) {
 #pragma unroll
-        for (int i = 0; i < NF; ++i) {
-          const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
+          for (int i = 0; i < NF; ++i) {
+            const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
 #pragma unroll
-          for (int cc = 0; cc < CT; ++cc) acc[cc][i] = mfma16<F16>(w[ks][cc], Bf, acc[cc][i]);
+            for (int cc = 0; cc < CT; ++cc) acc[cc][i] = mfma16<F16>(w[ks][cc], Bf, acc[cc][i]);
+          }
         }
       }
     };
+    // the weight requests are unconditional (past the last step they fetch its fragments again, into registers nobody reads): exact wait counts
 #pragma unroll 1
     for (int g = 0; g < NS; g += 3) {
       step(g, wa);
-      if (g + 3 < NS) load_w(g + 3, wa);
-      if (g + 1 < NS) {
-        step(g + 1, wb);
-        if (g + 4 < NS) load_w(g + 4, wb);
-      }
-      if (g + 2 < NS) {
-        step(g + 2, wc);
-        if (g + 5 < NS) load_w(g + 5, wc);
-      }
+      load_w(min(g + 3, NS - 1), wa);
+      if (g + 1 < NS) step(g + 1, wb);
+      load_w(min(g + 4, NS - 1), wb);
+      if (g + 2 < NS) step(g + 2, wc);
+      load_w(min(g + 5, NS - 1), wc);
     }
   }
   WC_STAMP(3);
+#ifdef TTSK_STAMPS
+  if (a.stamps && lane == 0 && wave < 8) a.stamps[(int64_t)blockIdx.x * 16 + 8 + wave] = __builtin_amdgcn_s_memrealtime();      // slots 8..15: each wave's end of the tap loop
+#endif
   // (BatchNorm-backward statistics, see the end of the kernel: the layer-below rows this thread will need are requested now, so that
   // they arrive during the staging and the stores)
   f32x4 bnb_v[8];

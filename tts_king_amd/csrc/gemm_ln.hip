@@ -14,6 +14,7 @@
 // lane, exactly ln_fwd_kernel's row code: same Philox indexing, so ln_bwd_kernel regenerates the same dropout mask).
 #include "gemm_common.h"
 #include "proj32.h"
+#include "tapring.h"
 
 namespace {
 
@@ -262,17 +263,12 @@ __global__ __launch_bounds__(512, (CIN == 256 && !PROJ) ? 2 : 1) void win_ln_ker
   const int m0 = blockIdx.x * BM;
   const int M = a.M;
   WL_STAMP(0);
-  const bf16_t* wrow[CT];
-#pragma unroll
-  for (int cc = 0; cc < CT; ++cc) wrow[cc] = a.W + ((int64_t)(wave * CT + cc) * 64 + lane) * 8;
-  constexpr int64_t kstep_stride = (BN / 16) * 512;            // elements per k-step of the pack
+  // weight fragments by buffer loads, activation fragments a step ahead of their MFMAs (tapring.h)
+  const __amdgpu_buffer_rsrc_t wres = weights_rsrc(a.W, CIN * BN * 2);
+  const int wlane = (wave * CT) * 1024 + lane * 16;
+  constexpr int kstep_bytes = (BN / 16) * 1024;                // bytes per k-step of the pack
   bf16x8 wa[KH][CT], wb[KH][CT], wc[KH][CT];
-  auto load_w = [&](int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int ks = 0; ks < KH; ++ks)
-#pragma unroll
-      for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(wrow[cc] + (int64_t)(g * KH + ks) * kstep_stride);
-  };
+  auto load_w = [&](int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) { frags_load<KH, CT>(w, wres, wlane, g * KH * kstep_bytes, kstep_bytes); };
   uint2 resv[RW];
   {
     // request order = arrival order: the rows of A (nothing starts before they are in LDS), the first three steps' weight fragments,
@@ -311,29 +307,30 @@ __global__ __launch_bounds__(512, (CIN == 256 && !PROJ) ? 2 : 1) void win_ln_ker
     for (int i = 0; i < NF; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
     const unsigned char* inl = smem + l15 * RS + q * 16;
+    bf16x8 ring[KH][NF];
+    ring_prime_step<NF, RS, KH>(ring, inl);
     auto step = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
-      const unsigned char* inp = inl + g * (KH * 64);
-#pragma unroll
-      for (int ks = 0; ks < KH; ++ks) {
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-          const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
-#pragma unroll
-          for (int cc = 0; cc < CT; ++cc) acc[cc][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][cc], Bf, acc[cc][i], 0, 0, 0);
-        }
-      }
+      tap_ring_step<false, KH, CT, NF, RS>(acc, ring, w, inl + (g + 1 < NS ? g + 1 : g) * (KH * 64));
     };
-#pragma unroll 1
+    // NS = 2 or 8 steps, unrolled: every `if` below is decided at compile time, so the wait counts of the weight requests are exact
+    // (the scheduling barriers keep each request where it is written: right behind the step that frees its registers, two steps ahead of its use)
+#pragma unroll
     for (int g = 0; g < NS; g += 3) {
       step(g, wa);
+      __builtin_amdgcn_sched_barrier(0);
       if (g + 3 < NS) load_w(g + 3, wa);
+      __builtin_amdgcn_sched_barrier(0);
       if (g + 1 < NS) {
         step(g + 1, wb);
+        __builtin_amdgcn_sched_barrier(0);
         if (g + 4 < NS) load_w(g + 4, wb);
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (g + 2 < NS) {
         step(g + 2, wc);
+        __builtin_amdgcn_sched_barrier(0);
         if (g + 5 < NS) load_w(g + 5, wc);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
 #pragma unroll
     for (int i = 0; i < NF; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
-    const unsigned char* inl = XW + (l15 + WC_H) * RS + q * 16;
+    const int inl = (l15 + WC_H) * RS + q * 16;               // this lane's window position at tap shift 0 (byte offset into XW)
     // row shift of tap slot 1 in the stride-8 transposed-conv mode (slot 0: none)
     // (only HiFi-GAN's fp16 instances have that mode: the training instances carry no test for it in their step code)
     const int ups_shift = F16 && a.ups_cout ? ((cg * COUT + wave * CT * 16) / a.ups_cout < a.ups_half ? -1 : 1) : 0;      // a wave's channels lie in one phase
@@ -300,17 +300,17 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
       return inl + (F16 && a.ups_cout ? tap * ups_shift : tap - HK) * RS + part * (KH * 64);
     };
     bf16x8 ring[RING ? NF : 1];
-    if constexpr (RING) ring_prime<NF, RS>(ring, inp_of(0));
+    if constexpr (RING) ring_prime<NF, RS>(ring, XW, inp_of(0));
     auto step = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
-      const unsigned char* inp = inp_of(g);
+      const int inp = inp_of(g);
       if constexpr (RING) {
-        tap_ring<F16, KH, CT, NF, RS>(acc, ring, w, inp, inp_of(g + 1 < NS ? g + 1 : g));
+        tap_ring<F16, KH, CT, NF, RS>(acc, ring, w, XW, inp, inp_of(g + 1 < NS ? g + 1 : g));
       } else {
 #pragma unroll
         for (int ks = 0; ks < KH; ++ks) {
 #pragma unroll
           for (int i = 0; i < NF; ++i) {
-            const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
+            const bf16x8 Bf = *(const bf16x8*)(XW + inp + i * 16 * RS + ks * 64);
 #pragma unroll
             for (int cc = 0; cc < CT; ++cc) acc[cc][i] = mfma16<F16>(w[ks][cc], Bf, acc[cc][i]);
           }

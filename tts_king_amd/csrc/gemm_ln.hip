@@ -306,11 +306,11 @@ __global__ __launch_bounds__(512, (CIN == 256 && !PROJ) ? 2 : 1) void win_ln_ker
 #pragma unroll
     for (int i = 0; i < NF; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
-    const unsigned char* inl = smem + l15 * RS + q * 16;
+    const int inl = l15 * RS + q * 16;
     bf16x8 ring[KH][NF];
-    ring_prime_step<NF, RS, KH>(ring, inl);
+    ring_prime_step<NF, RS, KH>(ring, smem, inl);
     auto step = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
-      tap_ring_step<false, KH, CT, NF, RS>(acc, ring, w, inl + (g + 1 < NS ? g + 1 : g) * (KH * 64));
+      tap_ring_step<false, KH, CT, NF, RS>(acc, ring, w, smem, inl + (g + 1 < NS ? g + 1 : g) * (KH * 64));
     };
     // NS = 2 or 8 steps, unrolled: every `if` below is decided at compile time, so the wait counts of the weight requests are exact
     // (the scheduling barriers keep each request where it is written: right behind the step that frees its registers, two steps ahead of its use)

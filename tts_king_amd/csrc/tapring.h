@@ -35,24 +35,46 @@ __device__ __forceinline__ void frags_load(bf16x8 (&w)[KS][CT], __amdgpu_buffer_
     for (int cc = 0; cc < CT; ++cc) w[ks][cc] = frag_load(r, lane_off + cc * 1024, step_off + ks * kstep_bytes);
 }
 
-// ring[i] = frame tile i's fragment of the first k-step at `inp` (this lane's row and 16-byte column of the window, rows RS bytes apart)
-template <int NF, int RS>
-__device__ __forceinline__ void ring_prime(bf16x8 (&ring)[NF], const unsigned char* inp) {
+// A window position is a byte offset into the workgroup's LDS array (this lane's row and 16-byte column of the window, rows RS bytes
+// apart).  LdsPos turns it into address registers that go through an empty asm, so that they stay THE address registers of the step's
+// reads and every (frame tile, k-step) distance lands in the instruction's 16-bit offset field (one register per TPB frame tiles: what
+// the field reaches).  Left alone, the compiler re-bases the reads on some other register and spends a v_add_u32 per ds_read_b128 —
+// one more instruction between every two MFMAs of a wave that already issues five there.
+template <int NF, int RS, int KS>
+struct LdsPos {
+  static constexpr int TPB = (65536 - KS * 64) / (16 * RS) < NF ? (65536 - KS * 64) / (16 * RS) : NF, NB = (NF + TPB - 1) / TPB;
+  unsigned base[NB];
+  __device__ __forceinline__ explicit LdsPos(unsigned off) {
 #pragma unroll
-  for (int i = 0; i < NF; ++i) ring[i] = *(const bf16x8*)(inp + i * 16 * RS);
+    for (int j = 0; j < NB; ++j) {
+      base[j] = off + j * TPB * 16 * RS;
+      asm volatile("" : "+v"(base[j]));
+    }
+  }
+  __device__ __forceinline__ bf16x8 frag(const unsigned char* lds, int i, int ks) const {
+    return *(const bf16x8*)(lds + base[i / TPB] + (i % TPB) * 16 * RS + ks * 64);
+  }
+};
+// ring[i] = frame tile i's fragment of the first k-step at position `inp`
+template <int NF, int RS>
+__device__ __forceinline__ void ring_prime(bf16x8 (&ring)[NF], const unsigned char* lds, unsigned inp) {
+  const LdsPos<NF, RS, 1> p(inp);
+#pragma unroll
+  for (int i = 0; i < NF; ++i) ring[i] = p.frag(lds, i, 0);
 }
 // acc += w (x) window at `inp`; on return the ring holds the first k-step's fragments at `nxt` (the next step's window position; the
 // last step passes any readable position)
 template <bool F16, int KS, int CT, int NF, int RS>
-__device__ __forceinline__ void tap_ring(f32x4 (&acc)[CT][NF], bf16x8 (&ring)[NF], const bf16x8 (&w)[KS][CT], const unsigned char* inp,
-                                         const unsigned char* nxt) {
+__device__ __forceinline__ void tap_ring(f32x4 (&acc)[CT][NF], bf16x8 (&ring)[NF], const bf16x8 (&w)[KS][CT], const unsigned char* lds, unsigned inp,
+                                         unsigned nxt) {
+  const LdsPos<NF, RS, KS> pi(inp), pn(nxt);
 #pragma unroll
   for (int idx = 0; idx < KS * NF; ++idx) {
     const int ks = idx / NF, i = idx % NF;
     const bf16x8 Bf = ring[i];
 #pragma unroll
     for (int cc = 0; cc < CT; ++cc) acc[cc][i] = mfma16<F16>(w[ks][cc], Bf, acc[cc][i]);
-    ring[i] = ks + 1 < KS ? *(const bf16x8*)(inp + i * 16 * RS + (ks + 1) * 64) : *(const bf16x8*)(nxt + i * 16 * RS);
+    ring[i] = ks + 1 < KS ? pi.frag(lds, i, ks + 1) : pn.frag(lds, i, 0);
   }
 #pragma unroll
   for (int idx = 0; idx < KS * NF; ++idx) {
@@ -64,14 +86,17 @@ __device__ __forceinline__ void tap_ring(f32x4 (&acc)[CT][NF], bf16x8 (&ring)[NF
 // The same with a whole step of fragments in flight (KS x NF registers): for short tiles (NF = 2: the 32-row tiles of gemm_ln.hip) one
 // k-step ahead would be 2 * CT MFMAs, less than the LDS latency.  On return the ring holds the step at `nxt`.
 template <int NF, int RS, int KS>
-__device__ __forceinline__ void ring_prime_step(bf16x8 (&ring)[KS][NF], const unsigned char* inp) {
+__device__ __forceinline__ void ring_prime_step(bf16x8 (&ring)[KS][NF], const unsigned char* lds, unsigned inp) {
+  const LdsPos<NF, RS, KS> p(inp);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int i = 0; i < NF; ++i) ring[ks][i] = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
+    for (int i = 0; i < NF; ++i) ring[ks][i] = p.frag(lds, i, ks);
 }
 template <bool F16, int KS, int CT, int NF, int RS>
-__device__ __forceinline__ void tap_ring_step(f32x4 (&acc)[CT][NF], bf16x8 (&ring)[KS][NF], const bf16x8 (&w)[KS][CT], const unsigned char* nxt) {
+__device__ __forceinline__ void tap_ring_step(f32x4 (&acc)[CT][NF], bf16x8 (&ring)[KS][NF], const bf16x8 (&w)[KS][CT], const unsigned char* lds,
+                                              unsigned nxt) {
+  const LdsPos<NF, RS, KS> pn(nxt);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -79,7 +104,7 @@ __device__ __forceinline__ void tap_ring_step(f32x4 (&acc)[CT][NF], bf16x8 (&rin
       const bf16x8 Bf = ring[ks][i];
 #pragma unroll
       for (int cc = 0; cc < CT; ++cc) acc[cc][i] = mfma16<F16>(w[ks][cc], Bf, acc[cc][i]);
-      ring[ks][i] = *(const bf16x8*)(nxt + i * 16 * RS + ks * 64);
+      ring[ks][i] = pn.frag(lds, i, ks);
     }
 #pragma unroll
   for (int idx = 0; idx < KS * NF; ++idx) {

@@ -8,6 +8,7 @@
 // Same k-step order as win_conv_kernel<256, ...>: bit-identical results.
 #pragma once
 #include "common.h"
+#include "tapring.h"
 
 constexpr int P32_TT = 32, P32_D = 256, P32_RS = P32_D * 2 + 32, P32_KH = 4, P32_CT = 2, P32_NT = 512;
 
@@ -15,13 +16,11 @@ struct Proj32W {
   bf16x8 a[P32_KH][P32_CT], b[P32_KH][P32_CT];      // the two 128-channel steps of a group
 };
 
+// (buffer loads: one per-lane byte offset, the group's and step's distance in a scalar register — tapring.h)
 __device__ __forceinline__ void proj32_load(const bf16_t* __restrict__ w, int Cout, int cg, int g, int wave, int lane, bf16x8 (&dst)[P32_KH][P32_CT]) {
-  const int64_t kstep_stride = (int64_t)(Cout / 16) * 512;
-#pragma unroll
-  for (int ks = 0; ks < P32_KH; ++ks)
-#pragma unroll
-    for (int cc = 0; cc < P32_CT; ++cc)
-      dst[ks][cc] = *(const bf16x8*)(w + ((int64_t)(cg * 16 + wave * P32_CT + cc) * 64 + lane) * 8 + (int64_t)(g * P32_KH + ks) * kstep_stride);
+  const int kstep_bytes = (Cout / 16) * 1024;
+  frags_load<P32_KH, P32_CT>(dst, weights_rsrc(w, (P32_D / 32) * kstep_bytes), (wave * P32_CT) * 1024 + lane * 16, cg * 16 * 1024 + g * P32_KH * kstep_bytes,
+                             kstep_bytes);
 }
 __device__ __forceinline__ void proj32_prefetch(const bf16_t* __restrict__ w, int Cout, int wave, int lane, Proj32W& W) {
   proj32_load(w, Cout, 0, 0, wave, lane, W.a);
@@ -45,6 +44,10 @@ __device__ __forceinline__ void proj32_run(const unsigned char* xs, unsigned cha
   const unsigned char* inl = xs + l15 * P32_RS + q * 16;
   Proj32W V;                                     // the other register pair: group cg + 1 is requested when group cg STARTS, so it has
                                                  // the whole group (contraction, staging, barrier, stores: ~2 us) to arrive, not just its tail
+  // the B fragments of a step (4 k-steps x 2 row tiles) run a step ahead of their MFMAs (tapring.h); every group reads the same rows,
+  // so the ring is carried from one group into the next
+  bf16x8 ring[P32_KH][NF];
+  ring_prime_step<NF, P32_RS, P32_KH>(ring, inl, 0);
 #pragma unroll
   for (int cg = 0; cg < NG; ++cg) {
     Proj32W& cur = (cg & 1) ? V : W;
@@ -54,22 +57,14 @@ __device__ __forceinline__ void proj32_run(const unsigned char* xs, unsigned cha
       proj32_load(w, Cout, cg + 1, 0, wave, lane, nxt.a);
       proj32_load(w, Cout, cg + 1, 1, wave, lane, nxt.b);
     }
+    __builtin_amdgcn_sched_barrier(0);             // the requests stay ahead of the contraction
     f32x4 acc[P32_CT][NF];
 #pragma unroll
     for (int cc = 0; cc < P32_CT; ++cc)
 #pragma unroll
       for (int i = 0; i < NF; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto step = [&](int g, const bf16x8 (&wf)[P32_KH][P32_CT]) __attribute__((always_inline)) {
-      const unsigned char* inp = inl + g * (P32_KH * 64);
-#pragma unroll
-      for (int ks = 0; ks < P32_KH; ++ks) {
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-          const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * P32_RS + ks * 64);
-#pragma unroll
-          for (int cc = 0; cc < P32_CT; ++cc) acc[cc][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][cc], Bf, acc[cc][i], 0, 0, 0);
-        }
-      }
+      tap_ring_step<false, P32_KH, P32_CT, NF, P32_RS>(acc, ring, wf, inl, (g ^ 1) * (P32_KH * 64));      // step 1 refills with step 0's fragments
     };
     step(0, cur.a);
     step(1, cur.b);

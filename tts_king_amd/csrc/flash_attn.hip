@@ -144,10 +144,17 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_t_kernel(const FlashArgs a) 
     f32x4 s[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, nt * 16, ks, l15, lg), qa[ks], s[nt], 0, 0, 0);
+    {  // S^T: operand i = K rows of key block i & 3, k-step i >> 2, eight reads ahead of their MFMAs (FragStream, attn_common.h)
+      FragStream<16, 8, 1> ks_;
+      auto kfrag = [&](int i) __attribute__((always_inline)) { return frag_rows(Ks, (i & 3) * 16, i >> 2, l15, lg); };
+      ks_.prime(kfrag);
+      ks_.run(kfrag, [&](int i, bf16x8 f) __attribute__((always_inline)) { s[i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, qa[i >> 2], s[i & 3], 0, 0, 0); });
+    }
+    // the first eight V^T operands are requested here: they arrive under the softmax arithmetic
+    FragStream<16, 8, 2> vs_;
+    auto vfrag = [&](int i) __attribute__((always_inline)) { return frag_tr8(Vs, i & 7, i >> 3, l15, lg); };
+    vs_.prime(vfrag);
+    __builtin_amdgcn_sched_barrier(0);
     float tm = -INFINITY;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -171,15 +178,16 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_t_kernel(const FlashArgs a) 
     m = mn;
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) oacc[nb] *= corr;
+    bf16x8 pb[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       // P^T fragment of 32-key step u, straight from the accumulators (slot order = the order frag_tr8 reads V^T's keys in)
       const unsigned p0 = pack_bf2(s[2 * u][0], s[2 * u][1]), p1 = pack_bf2(s[2 * u][2], s[2 * u][3]);
       const unsigned p2 = pack_bf2(s[2 * u + 1][0], s[2 * u + 1][1]), p3 = pack_bf2(s[2 * u + 1][2], s[2 * u + 1][3]);
-      const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(p0, p1, p2, p3));
-#pragma unroll
-      for (int nb = 0; nb < 8; ++nb) oacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Vs, nb, u, l15, lg), pb, oacc[nb], 0, 0, 0);
+      pb[u] = __builtin_bit_cast(bf16x8, make_uint4(p0, p1, p2, p3));
     }
+    __builtin_amdgcn_sched_barrier(0);
+    vs_.run(vfrag, [&](int i, bf16x8 f) __attribute__((always_inline)) { oacc[i & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, pb[i >> 3], oacc[i & 7], 0, 0, 0); });
     if (j + 1 < ntk) {
       unsigned char* nx = smem + ((j + 1) & 1) * STAGE_KV;   // last read in iteration j-1: every wave passed that iteration's barrier
       store_rows(nx, rk, tid);
@@ -270,13 +278,22 @@ __device__ __forceinline__ void flash_bwd_q_t_body(const FlashArgs& a, unsigned 
     f32x4 st[4], dpt[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) { st[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dpt[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        st[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows8(Kt, nt * 16, ks, l15, lg), qb[ks], st[nt], 0, 0, 0);
-        dpt[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vr, nt * 16, ks, l15, lg), db[ks], dpt[nt], 0, 0, 0);
-      }
+    {  // operand i: bit 0 = S^T (K image) | dP^T (V rows), bits 1-2 = key block, bits 3-4 = k-step; eight reads ahead (FragStream)
+      FragStream<32, 8, 1> ab;
+      auto frag = [&](int i) __attribute__((always_inline)) {
+        return (i & 1) ? frag_rows(Vr, ((i >> 1) & 3) * 16, i >> 3, l15, lg) : frag_rows8(Kt, ((i >> 1) & 3) * 16, i >> 3, l15, lg);
+      };
+      ab.prime(frag);
+      ab.run(frag, [&](int i, bf16x8 f) __attribute__((always_inline)) {
+        const int nt = (i >> 1) & 3, ks = i >> 3;
+        if (i & 1) dpt[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, db[ks], dpt[nt], 0, 0, 0);
+        else st[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, qb[ks], st[nt], 0, 0, 0);
+      });
+    }
+    // the first eight K^T operands of dQ^T are requested here: they arrive under the exponentials
+    FragStream<16, 8, 2> kt;
+    auto ktfrag = [&](int i) __attribute__((always_inline)) { return frag_tr8(Kt, i & 7, i >> 3, l15, lg); };
+    kt.prime(ktfrag);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -285,13 +302,13 @@ __device__ __forceinline__ void flash_bwd_q_t_body(const FlashArgs& a, unsigned 
         const float p = key < len ? __expf(st[nt][r] * a.scale - lse) : 0.f;
         st[nt][r] = a.scale * p * (dpt[nt][r] - delta);
       }
+    bf16x8 sb[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const bf16x8 sb = __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(st[2 * u][0], st[2 * u][1]), pack_bf2(st[2 * u][2], st[2 * u][3]),
-                                                              pack_bf2(st[2 * u + 1][0], st[2 * u + 1][1]), pack_bf2(st[2 * u + 1][2], st[2 * u + 1][3])));
-#pragma unroll
-      for (int nb = 0; nb < 8; ++nb) dq[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Kt, nb, u, l15, lg), sb, dq[nb], 0, 0, 0);
-    }
+    for (int u = 0; u < 2; ++u)
+      sb[u] = __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(st[2 * u][0], st[2 * u][1]), pack_bf2(st[2 * u][2], st[2 * u][3]),
+                                                    pack_bf2(st[2 * u + 1][0], st[2 * u + 1][1]), pack_bf2(st[2 * u + 1][2], st[2 * u + 1][3])));
+    __builtin_amdgcn_sched_barrier(0);
+    kt.run(ktfrag, [&](int i, bf16x8 f) __attribute__((always_inline)) { dq[i & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, sb[i >> 3], dq[i & 7], 0, 0, 0); });
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
@@ -360,13 +377,20 @@ __device__ __forceinline__ void flash_bwd_kv_t_body(const FlashArgs& a, unsigned
       f32x4 s[4], dp[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) { s[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows8(Qt, nt * 16, ks, l15, lg), kb[ks], s[nt], 0, 0, 0);
-          dp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows8(Dt, nt * 16, ks, l15, lg), vb[ks], dp[nt], 0, 0, 0);
-        }
+      {  // operand i: bit 0 = S (Q image) | dP (dO image), bits 1-2 = query block, bits 3-4 = k-step; eight reads ahead (FragStream)
+        FragStream<32, 8, 1> ab;
+        auto frag = [&](int i) __attribute__((always_inline)) { return frag_rows8((i & 1) ? Dt : Qt, ((i >> 1) & 3) * 16, i >> 3, l15, lg); };
+        ab.prime(frag);
+        ab.run(frag, [&](int i, bf16x8 f) __attribute__((always_inline)) {
+          const int nt = (i >> 1) & 3, ks = i >> 3;
+          if (i & 1) dp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, vb[ks], dp[nt], 0, 0, 0);
+          else s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, kb[ks], s[nt], 0, 0, 0);
+        });
+      }
+      // the first eight transposed operands of dV^T / dK^T are requested here: they arrive under the exponentials
+      FragStream<32, 8, 2> tq;
+      auto tfrag = [&](int i) __attribute__((always_inline)) { return frag_tr8((i & 1) ? Qt : Dt, (i >> 1) & 7, i >> 4, l15, lg); };
+      tq.prime(tfrag);
       // rows = queries 16*nt + 4*lg + r of the tile, column = this lane's key
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -379,18 +403,20 @@ __device__ __forceinline__ void flash_bwd_kv_t_body(const FlashArgs& a, unsigned
           dp[nt][r] = a.scale * p * (dp[nt][r] - dq_[r]);
         }
       }
+      bf16x8 pb[2], sb[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const bf16x8 pb = __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(s[2 * u][0], s[2 * u][1]), pack_bf2(s[2 * u][2], s[2 * u][3]),
-                                                                pack_bf2(s[2 * u + 1][0], s[2 * u + 1][1]), pack_bf2(s[2 * u + 1][2], s[2 * u + 1][3])));
-        const bf16x8 sb = __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(dp[2 * u][0], dp[2 * u][1]), pack_bf2(dp[2 * u][2], dp[2 * u][3]),
-                                                                pack_bf2(dp[2 * u + 1][0], dp[2 * u + 1][1]), pack_bf2(dp[2 * u + 1][2], dp[2 * u + 1][3])));
-#pragma unroll
-        for (int nb = 0; nb < 8; ++nb) {
-          dv[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Dt, nb, u, l15, lg), pb, dv[nb], 0, 0, 0);
-          dk[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr8(Qt, nb, u, l15, lg), sb, dk[nb], 0, 0, 0);
-        }
+        pb[u] = __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(s[2 * u][0], s[2 * u][1]), pack_bf2(s[2 * u][2], s[2 * u][3]),
+                                                      pack_bf2(s[2 * u + 1][0], s[2 * u + 1][1]), pack_bf2(s[2 * u + 1][2], s[2 * u + 1][3])));
+        sb[u] = __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(dp[2 * u][0], dp[2 * u][1]), pack_bf2(dp[2 * u][2], dp[2 * u][3]),
+                                                      pack_bf2(dp[2 * u + 1][0], dp[2 * u + 1][1]), pack_bf2(dp[2 * u + 1][2], dp[2 * u + 1][3])));
       }
+      __builtin_amdgcn_sched_barrier(0);
+      tq.run(tfrag, [&](int i, bf16x8 f) __attribute__((always_inline)) {        // operand i: bit 0 = dV^T (dO^T) | dK^T (Q^T), bits 1-3 = d block, bit 4 = 32-query step
+        const int nb = (i >> 1) & 7, u = i >> 4;
+        if (i & 1) dk[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, sb[u], dk[nb], 0, 0, 0);
+        else dv[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, pb[u], dv[nb], 0, 0, 0);
+      });
     }
   }
   // ---- dK^T, dV^T -> bf16 -> LDS (8-byte pieces) -> full-row stores into the k / v columns of dqkv

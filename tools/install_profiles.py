@@ -1,0 +1,27 @@
+"""Copy one tools/round_profiles.sh output directory into profiles/<tag>_* and stamp the JSON summaries with the source fingerprint they
+were measured on and the git head.  usage: python tools/install_profiles.py gpurun_out/round_r04c r04"""
+import glob, json, os, shutil, subprocess, sys
+sys.path.insert(0, os.getcwd())
+from tts_king_amd import lib as L
+src, tag = sys.argv[1], sys.argv[2]
+fp = L.source_fingerprint()
+head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+def one(pattern):
+    m = sorted(glob.glob(os.path.join(src, pattern)))
+    if not m: raise SystemExit("missing " + pattern)
+    return m[0]
+copies = {
+    "bench.json": "%s_bench.json", "fs2_trace/*kernel_stats.csv": "%s_bench_kernel_stats.csv", "hifi_trace/*kernel_stats.csv": "%s_hifigan_kernel_stats.csv",
+    "mfma_util.json": "%s_mfma_util.json", "pmc_traffic.json": "%s_pmc_traffic.json", "pmc_traffic_hifi.json": "%s_pmc_traffic_hifi.json",
+    "step_timeline.txt": "%s_step_timeline.txt", "step_timeline_real.txt": "%s_step_timeline_real.txt",
+}
+for pat, dst in copies.items():
+    d = os.path.join("profiles", dst % tag)
+    shutil.copyfile(one(pat), d)
+    if d.endswith(".json") and "bench.json" not in d:
+        j = json.load(open(d))
+        if j.get("csrc_fingerprint") != fp:
+            raise SystemExit("%s was measured on source %s, the tree is %s" % (d, j.get("csrc_fingerprint"), fp))
+        j["git_head"] = head
+        json.dump(j, open(d, "w"), indent=1)
+    print("installed", d)

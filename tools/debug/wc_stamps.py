@@ -36,13 +36,16 @@ cases["PostNet input gradient (512 -> 512, k = 5)"] = (lambda: ops.win_conv(xp, 
 for name, (fn, nwg) in cases.items():
     for _ in range(int(os.environ.get("WARM", "3"))):
         fn()
-    st = torch.zeros(nwg * 16, dtype=torch.int64, device=DEV)
+    st = torch.zeros(nwg * 24, dtype=torch.int64, device=DEV)
     torch.cuda.synchronize()
     lib.ttsk_win_conv_set_stamps(C.c_void_p(st.data_ptr()))
     fn()
     torch.cuda.synchronize()
     lib.ttsk_win_conv_set_stamps(C.c_void_p(0))
-    raw = st.cpu().numpy().reshape(nwg, 16).astype(np.float64)
+    rawi = st.cpu().numpy().reshape(nwg, 24)
+    hw = rawi[:, 16:24]
+    print("   SIMD of waves 0..7 (first workgroups): " + " | ".join(" ".join(str(int(v >> 4) & 3) for v in hw[k]) for k in range(3)) + "; wave slots: " + " ".join(str(int(v) & 15) for v in hw[0]))
+    raw = rawi.astype(np.float64)
     wv = (raw[:, 8:16] - raw[:, 2:3]) * 0.01
     print("   tap loop per wave (us after the barrier, mean over workgroups): " + " ".join("%.1f" % v for v in wv.mean(axis=0)))
     clk = np.median((raw[:, 7] - raw[:, 6]) / (raw[:, 3] - raw[:, 2])) * 0.1        # GHz: shader-clock ticks per 100 MHz tick over the tap loop

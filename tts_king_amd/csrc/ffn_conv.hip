@@ -76,15 +76,15 @@ struct WcArgs {
   float bnb_p;
   int bnb_tanh;
 #ifdef TTSK_STAMPS
-  unsigned long long* stamps;   // diagnostic build only (make stamps; ttsk_win_conv_set_stamps): 16 slots per workgroup
+  unsigned long long* stamps;   // diagnostic build only (make stamps; ttsk_win_conv_set_stamps): 24 slots per workgroup
 #endif
 };
 #ifdef TTSK_STAMPS
 #define WC_STAMP(i)                                                                                              \
   do {                                                                                                           \
     if (a.stamps && threadIdx.x == 0) {                                                                          \
-      a.stamps[(int64_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime();                               \
-      if ((i) == 2 || (i) == 3) a.stamps[(int64_t)blockIdx.x * 16 + 4 + (i)] = __builtin_amdgcn_s_memtime();     \
+      a.stamps[(int64_t)blockIdx.x * 24 + (i)] = __builtin_amdgcn_s_memrealtime();                               \
+      if ((i) == 2 || (i) == 3) a.stamps[(int64_t)blockIdx.x * 24 + 4 + (i)] = __builtin_amdgcn_s_memtime();     \
     }                                                                                                            \
   } while (0)        // slots 6, 7: the shader clock's counter on either side of the tap loop (in-kernel clock = its delta / the 100 MHz delta)
 #else
@@ -330,7 +330,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
   }
   WC_STAMP(3);
 #ifdef TTSK_STAMPS
-  if (a.stamps && lane == 0 && wave < 8) a.stamps[(int64_t)blockIdx.x * 16 + 8 + wave] = __builtin_amdgcn_s_memrealtime();      // slots 8..15: each wave's end of the tap loop
+  if (a.stamps && lane == 0 && wave < 8) {
+    a.stamps[(int64_t)blockIdx.x * 24 + 8 + wave] = __builtin_amdgcn_s_memrealtime();      // slots 8..15: each wave's end of the tap loop
+    a.stamps[(int64_t)blockIdx.x * 24 + 16 + wave] = __builtin_amdgcn_s_getreg(63492);      // slots 16..23: HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], ...)
+  }
 #endif
   // (BatchNorm-backward statistics, see the end of the kernel: the layer-below rows this thread will need are requested now, so that
   // they arrive during the staging and the stores)

@@ -13,7 +13,9 @@
 //   * callers issue their weight requests unconditionally (clamped past the end) so that the wait counts are exact.
 // Same-box A/B (tools/ab_libs.sh): FS2 step 2.670 -> 2.644 ms.  In cycles the tap loop of w_1 went 41.1k -> 36.5k (32.3k = its MFMAs
 // alone), in time less: the loop runs at the clock the chip holds under this load (1.66-1.94 GHz across boxes, never 2.4), and the
-// older wave of a SIMD's two still finishes 7 us before the younger one, which then has the SIMD to itself.  HiFi-GAN's pair kernels
+// wave in slot 0 of a SIMD finishes 7 us before the one in slot 1 (HW_ID stamps: waves w and w + 4 share a SIMD; slot 0 issues whenever it
+// can, whatever s_setprio says), which then has the SIMD to itself.  Splitting the pair's four channel tiles 3 : 1 made both end
+// together — at the same 36 k cycles: the loop is at the rate the pipe sustains with an LDS read per two MFMAs, not losing a tail.  HiFi-GAN's pair kernels
 // (convwin.hip: two 4-wave workgroups per CU, unconditional requests in c1 already) measured the same with the buffer loads and 1 %
 // slower with the ring — they keep their plain loops.
 #pragma once

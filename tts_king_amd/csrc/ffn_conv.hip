@@ -244,8 +244,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
   };
 #if !WC_XFIRST
   load_w(0, wa);
-  load_w(min(1, NS - 1), wb);
-  load_w(min(2, NS - 1), wc);
+  if (!F16 || 1 < NS) load_w(min(1, NS - 1), wb);
+  if (!F16 || 2 < NS) load_w(min(2, NS - 1), wc);
 #endif
 
   {  // ---- activation window: rows t0 - 4 .. t0 + TT + 4 of the utterance, zeros outside it (the conv's zero padding).
@@ -263,8 +263,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
     }
 #if WC_XFIRST
     load_w(0, wa);
-    load_w(min(1, NS - 1), wb);
-    load_w(min(2, NS - 1), wc);
+    if (!F16 || 1 < NS) load_w(min(1, NS - 1), wb);      // (fp16 instances: no repeated requests, see the tap loop)
+    if (!F16 || 2 < NS) load_w(min(2, NS - 1), wc);
 #endif
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
@@ -317,15 +317,18 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
         }
       }
     };
-    // the weight requests are unconditional (past the last step they fetch its fragments again, into registers nobody reads): exact wait counts
+    // the weight requests are unconditional (past the last step they fetch its fragments again, into registers nobody reads): exact wait
+    // counts.  Not in the fp16 instances: HiFi-GAN's upsamplers have 2-8 steps, the repeats would be half their weight traffic (the
+    // 128 -> 64 upsampler measured 47 -> 52 us with them).
+    constexpr bool UNCOND = !F16;
 #pragma unroll 1
     for (int g = 0; g < NS; g += 3) {
       step(g, wa);
-      load_w(min(g + 3, NS - 1), wa);
+      if (UNCOND || g + 3 < NS) load_w(min(g + 3, NS - 1), wa);
       if (g + 1 < NS) step(g + 1, wb);
-      load_w(min(g + 4, NS - 1), wb);
+      if (UNCOND || g + 4 < NS) load_w(min(g + 4, NS - 1), wb);
       if (g + 2 < NS) step(g + 2, wc);
-      load_w(min(g + 5, NS - 1), wc);
+      if (UNCOND || g + 5 < NS) load_w(min(g + 5, NS - 1), wc);
     }
   }
   WC_STAMP(3);

@@ -1,6 +1,7 @@
 // attn_common.h — tile staging / fragment helpers shared by the attention kernels (attn.hip, flash_attn.hip), d_k = 128.
 #pragma once
 #include "common.h"
+#include "tapring.h"
 
 namespace {
 
@@ -64,34 +65,5 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned char* base, int nblk, i
       (__attribute__((address_space(3))) bf16x4*)(base + k1 * 256 + ((nblk ^ tr_sw(k1)) << 5) + ((l15 & 3) << 3)));
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
-
-// A run of N MFMAs whose LDS operand i is `frag(i)`: the operands go through a ring of D registers, each refilled right after its MFMA
-// with operand i + D, and sched_group_barrier holds the scheduler to that order (READS = LDS instructions per operand: 1 for a
-// ds_read_b128, 2 for a pair of transposing reads).  Left to the compiler every operand is read just before its MFMA and waited for
-// with lgkmcnt(0): an LDS round trip per MFMA.  prime() may be called early (before a stretch of VALU work the first D reads can fly under).
-template <int N, int D, int READS>
-struct FragStream {
-  bf16x8 ring[D];
-  template <class Frag>
-  __device__ __forceinline__ void prime(Frag&& frag) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) ring[d] = frag(d);
-    __builtin_amdgcn_sched_barrier(0);      // (the reads of the run must not be mistaken for these by the scheduler's groups, nor these for theirs)
-  }
-  template <class Frag, class Mma>
-  __device__ __forceinline__ void run(Frag&& frag, Mma&& mma) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      mma(i, ring[i % D]);
-      if (i + D < N) ring[i % D] = frag(i + D);
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (i + D < N) __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-};
 
 }  // namespace

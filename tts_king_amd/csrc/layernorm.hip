@@ -516,21 +516,19 @@ __device__ __forceinline__ void pre768_gemm(const bf16_t* __restrict__ pre_x, co
   for (int cc = 0; cc < CT; ++cc)
 #pragma unroll
     for (int i = 0; i < NF; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the 48 B fragments (6 steps x 4 k-steps x 2 row tiles) four ahead of their two MFMAs each (FragStream, tapring.h: 240 of the 256
+  // registers are the weights, the accumulators and this ring)
   const unsigned char* inl = as + l15 * PRS + q * 16;
-  auto step = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
-    const unsigned char* inp = inl + g * (KH * 64);
+  {
+    FragStream<NS * KH * NF, 4, 1, CT> bs;
+    auto frag = [&](int i) __attribute__((always_inline)) { return *(const bf16x8*)(inl + (i % NF) * 16 * PRS + (i / NF) * 64); };
+    bs.prime(frag);
+    bs.run(frag, [&](int i, bf16x8 Bf) __attribute__((always_inline)) {
+      const int nf = i % NF, ks = (i / NF) % KH, g = i / (NF * KH);
 #pragma unroll
-    for (int ks = 0; ks < KH; ++ks) {
-#pragma unroll
-      for (int i = 0; i < NF; ++i) {
-        const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * PRS + ks * 64);
-#pragma unroll
-        for (int cc = 0; cc < CT; ++cc) acc[cc][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][cc], Bf, acc[cc][i], 0, 0, 0);
-      }
-    }
-  };
-#pragma unroll
-  for (int g = 0; g < NS; ++g) step(g, wv[g]);
+      for (int cc = 0; cc < CT; ++cc) acc[cc][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[g][ks][cc], Bf, acc[cc][nf], 0, 0, 0);
+    });
+  }
 #pragma unroll
   for (int i = 0; i < NF; ++i)
 #pragma unroll

@@ -63,6 +63,7 @@ __device__ __forceinline__ void ring_prime(bf16x8 (&ring)[NF], const unsigned ch
   const LdsPos<NF, RS, 1> p(inp);
 #pragma unroll
   for (int i = 0; i < NF; ++i) ring[i] = p.frag(lds, i, 0);
+  __builtin_amdgcn_sched_barrier(0);      // all of them in flight before the first MFMA (the scheduler otherwise sinks each to its use)
 }
 // acc += w (x) window at `inp`; on return the ring holds the first k-step's fragments at `nxt` (the next step's window position; the
 // last step passes any readable position)
@@ -94,6 +95,7 @@ __device__ __forceinline__ void ring_prime_step(bf16x8 (&ring)[KS][NF], const un
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
     for (int i = 0; i < NF; ++i) ring[ks][i] = p.frag(lds, i, ks);
+  __builtin_amdgcn_sched_barrier(0);
 }
 template <bool F16, int KS, int CT, int NF, int RS>
 __device__ __forceinline__ void tap_ring_step(f32x4 (&acc)[CT][NF], bf16x8 (&ring)[KS][NF], const bf16x8 (&w)[KS][CT], const unsigned char* lds,
@@ -114,3 +116,32 @@ __device__ __forceinline__ void tap_ring_step(f32x4 (&acc)[CT][NF], bf16x8 (&rin
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
   }
 }
+
+// A run of N LDS operands `frag(i)`, each feeding MPF MFMAs (`mma(i, operand)` issues them): the operands go through a ring of D
+// registers, each refilled right after its MFMAs with operand i + D, and sched_group_barrier holds the scheduler to that order (READS =
+// LDS instructions per operand: 1 for a ds_read_b128, 2 for a pair of transposing reads).  Left to the compiler every operand is read just before its MFMA and waited for
+// with lgkmcnt(0): an LDS round trip per MFMA.  prime() may be called early (before a stretch of VALU work the first D reads can fly under).
+template <int N, int D, int READS, int MPF = 1>
+struct FragStream {
+  bf16x8 ring[D];
+  template <class Frag>
+  __device__ __forceinline__ void prime(Frag&& frag) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) ring[d] = frag(d);
+    __builtin_amdgcn_sched_barrier(0);      // (the reads of the run must not be mistaken for these by the scheduler's groups, nor these for theirs)
+  }
+  template <class Frag, class Mma>
+  __device__ __forceinline__ void run(Frag&& frag, Mma&& mma) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      mma(i, ring[i % D]);
+      if (i + D < N) ring[i % D] = frag(i + D);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, MPF, 0);
+      if (i + D < N) __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+};

@@ -36,12 +36,9 @@ def fs2_flops_per_step(B, L, T):
 
 def host_threads():
     """Threads for the CPU baseline: the cores this process may actually use (a 1-GPU box gives a 16-core share of a much
-    larger host; os.cpu_count() would oversubscribe it)."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(n, int(switches.get("TTSK_CPU_THREADS"))))
+    larger host through its cgroup quota; os.cpu_count() and the affinity mask say 256), at most TTSK_CPU_THREADS."""
+    from tts_king_amd.hostcpu import host_cores
+    return host_cores(cap=int(switches.get("TTSK_CPU_THREADS")))
 
 
 def cpu_baseline(cfg, B, L, n_steps=5):
@@ -515,6 +512,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the eager / grad_acc_step=4 / trainer-loop / DP-schedule legs")
     ap.add_argument("--dp1-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    from tts_king_amd.hostcpu import fit_torch_threads
+    fit_torch_threads()           # the host-side legs (eager launches, the trainer's loop) on the cores this process is granted
     if args.dp1_child:            # the DP-schedule leg in a process of its own (see dp1_leg_isolated)
         real_stdout = os.dup(1)
         os.dup2(2, 1)

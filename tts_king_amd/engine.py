@@ -95,6 +95,8 @@ class TrainEngine:
         self._eager_only = set()          # shapes whose capture failed: plain launches from then on
         self._pool = None
         self.stats = {"eager": 0, "captured": 0, "replayed": 0}
+        from .hostcpu import fit_torch_threads
+        fit_torch_threads()       # host-side staging copies on the cores this process is granted, not on every core the host shows
 
     @staticmethod
     def _key(batch, is_update, limited):

@@ -8,6 +8,7 @@
 // 25-28 % MFMA utilisation).  Here a workgroup loads its frames x channels ONCE and per tap only the weights (fragment-major
 // pack, coalesced).  D[cout][frame] orientation, fragment layouts and padding are those of resblock.hip.
 #include "common.h"
+#include "tapring.h"
 #include <cstdlib>
 
 namespace {
@@ -473,17 +474,13 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
     for (int i = 0; i < NF1; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
     const unsigned char* inl = XW + (l15 + CP_XH - CP_TH) * RS + q * 16;
+    // (one 8-wave workgroup per CU: the two waves of a SIMD are in the same phase and hide nothing for each other — the activation
+    // fragments go through tapring.h's ring, one k-step ahead of their MFMAs; the 2-workgroup pair kernels measured slower with it)
+    auto inp1 = [&](int g) __attribute__((always_inline)) { return (unsigned)(inl - smem) + ((g >> 1) - HK) * d * RS + (g & 1) * (KH * 64); };
+    bf16x8 ring[NF1];
+    ring_prime<NF1, RS>(ring, smem, inp1(0));
     auto tap1 = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
-      const unsigned char* inp = inl + ((g >> 1) - HK) * d * RS + (g & 1) * (KH * 64);
-#pragma unroll
-      for (int ks = 0; ks < KH; ++ks) {
-#pragma unroll
-        for (int i = 0; i < NF1; ++i) {
-          const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
-#pragma unroll
-          for (int cc = 0; cc < CT; ++cc) acc[cc][i] = mfma16<F16>(w[ks][cc], Bf, acc[cc][i]);
-        }
-      }
+      tap_ring<F16, KH, CT, NF1, RS>(acc, ring, w, smem, inp1(g), inp1(min(g + 1, K2 - 1)));
     };
 #pragma unroll 1
     for (int g = 0; g < K2; g += 2) {      // the last two loads are c2's first two half-taps
@@ -527,17 +524,11 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
     for (int i = 0; i < NF2; ++i) acc2[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
     const unsigned char* inl = TW + (l15 + CP_TH) * RS + q * 16;
+    auto inp2 = [&](int g) __attribute__((always_inline)) { return (unsigned)(inl - smem) + ((g >> 1) - HK) * RS + (g & 1) * (KH * 64); };
+    bf16x8 ring[NF2];
+    ring_prime<NF2, RS>(ring, smem, inp2(0));
     auto tap2 = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
-      const unsigned char* inp = inl + ((g >> 1) - HK) * RS + (g & 1) * (KH * 64);
-#pragma unroll
-      for (int ks = 0; ks < KH; ++ks) {
-#pragma unroll
-        for (int i = 0; i < NF2; ++i) {
-          const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
-#pragma unroll
-          for (int cc = 0; cc < CT; ++cc) acc2[cc][i] = mfma16<F16>(w[ks][cc], Bf, acc2[cc][i]);
-        }
-      }
+      tap_ring<F16, KH, CT, NF2, RS>(acc2, ring, w, smem, inp2(g), inp2(min(g + 1, K2 - 1)));
     };
 #pragma unroll 1
     for (int g = 0; g < K2; g += 2) {

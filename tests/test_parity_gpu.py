@@ -277,6 +277,43 @@ def test_trajectory_20_steps_vs_oracle(cfg):
     assert opt.current_step == 120
 
 
+def test_trajectory_with_dropout_on_vs_oracle(cfg):
+    """Eight consecutive full train steps WITH dropout (what the trainer and bench.py run), the oracle fed, step by step, the keep-masks
+    the HIP kernels are about to draw (ttsk_dropout_keep_mask at the device's current (seed, step)): the masks change from step to step
+    (the end-of-step tick of the dropout counter rides in the optimizer launch), all 31 sites are consumed in every step, and the losses
+    follow the oracle's as closely as in the dropout-off trajectory."""
+    from tts_king_amd.loss import FastSpeech2Loss
+    from tts_king_amd.optimizer import ScheduledOptim
+    from tts_king_amd.train_step import main_train_step, to_device
+    c = copy.deepcopy(cfg)
+    c.train_config["optimizer"]["grad_acc_step"] = 1
+    m = build(c, 7, dropout=True)
+    opt = ScheduledOptim(m, c.train_config, c.model_config, 100)
+    loss_fn = FastSpeech2Loss(c.preprocess_config, c.model_config)
+    tr = ofs2.OracleTrainer(fs2_state_dict(c, 7), copy.deepcopy(c.model_config), c.train_config, current_step=100)
+    batches = [make_batch(2, 48, seed=300 + i, ragged=True) for i in range(2)]
+    dev_batches = [to_device(b, DEV) for b in batches]
+    errs, prev_first = [], None
+    for s in range(8):
+        b = batches[s % 2]
+        masks = hip_dropout_masks(m, 2, int(b[5]), int(b[8]))
+        first = masks[0][0].clone()
+        if prev_first is not None and prev_first.shape == first.shape:
+            assert not torch.equal(prev_first, first), "step %d drew the masks of the step before: the dropout counter did not advance" % (s + 1)
+        prev_first = first if s % 2 == 1 else prev_first      # (same batch shape two steps apart)
+        vals, _ = main_train_step(m, dev_batches[s % 2], s + 1, opt, c, loss_fn)
+        with oracle_with_masks(masks) as feeder:
+            ovals, _ = tr.train_step(b, s + 1)
+        assert feeder.pos == len(masks) == 31, (s, feeder.pos)
+        tot, otot = sum(vals[:4]), sum(ovals[:4])
+        comp = max(abs(a - w) / abs(w) for a, w in zip(vals[:4], ovals[:4]))
+        errs.append(abs(tot - otot) / otot)
+        print("step %d total HIP %.5f oracle %.5f (%.2f%%)  worst component %.2f%%" % (s + 1, tot, otot, 100 * errs[-1], 100 * comp))
+        assert comp <= 0.30, (s, vals, ovals)
+    assert max(errs) <= 0.05 and sum(errs) / len(errs) <= 0.02, errs
+    assert opt.current_step == 108
+
+
 def test_train_mode_truncates_decoder_at_max_seq_len(cfg):
     """reference: transformer/Models.py:172-180 (train mode: decoder input, mask and output cut to max_seq_len = 1000 frames)
     with loss.py:57-58 (mel targets cropped to the mask's length; `mel_lens` stay uncropped).  One utterance longer than

@@ -191,27 +191,37 @@ def test_full_size_step_vs_oracle(cfg, dropout):
     assert worst[0] <= 0.06, worst
 
 
-def test_grad_acc_step_4_cycle_vs_oracle(cfg):
+@pytest.mark.parametrize("dropout", [False, True])
+def test_grad_acc_step_4_cycle_vs_oracle(cfg, dropout):
     """The reference's default `grad_acc_step: 4` (config.yaml:51, train.py:33,43-54): four micro-steps on four different
     batches accumulate (loss / 4) gradients, the fourth call clips, updates the LR, runs Adam and zeroes the gradients —
-    against OracleTrainer on the same four batches (dropout off)."""
+    against OracleTrainer on the same four batches.  dropout = True (the reference's own configuration): the oracle takes, micro-step
+    by micro-step, the keep-masks the HIP path is about to draw — the dropout counter ticks after EVERY micro-step, update or not."""
     from tts_king_amd.loss import FastSpeech2Loss
     from tts_king_amd.optimizer import ScheduledOptim
     from tts_king_amd.train_step import main_train_step, to_device
     c = copy.deepcopy(cfg)
     assert c.train_config["optimizer"]["grad_acc_step"] == 4
-    m = build(c, 7, dropout=False)
+    m = build(c, 7, dropout=dropout)
     opt = ScheduledOptim(m, c.train_config, c.model_config, 1000)
     loss_fn = FastSpeech2Loss(c.preprocess_config, c.model_config)
     sd0 = fs2_state_dict(c, 7)
-    tr = ofs2.OracleTrainer(sd0, no_dropout_config(c), c.train_config, current_step=1000)
+    tr = ofs2.OracleTrainer(sd0, copy.deepcopy(c.model_config) if dropout else no_dropout_config(c), c.train_config, current_step=1000)
     batches = [make_batch(3, 40 + 8 * i, seed=50 + i, ragged=True) for i in range(4)]
     flat0 = m.flat_buffers()[0].clone()
+    seen = []
     for step in range(1, 5):
         b = batches[step - 1]
+        masks = hip_dropout_masks(m, 3, int(b[5]), int(b[8])) if dropout else None
+        if dropout:
+            key = masks[-1][0][:, :, :32].clone()               # (the PostNet's last site: the same shape prefix in every batch)
+            assert all(not torch.equal(key, k) for k in seen), "micro-step %d drew an earlier micro-step's masks" % step
+            seen.append(key)
         vals, _ = main_train_step(m, to_device(b, DEV), step, opt, c, loss_fn)
-        with oracle_without_dropout():
+        with (oracle_with_masks(masks) if dropout else oracle_without_dropout()) as feeder:
             ovals, _ = tr.train_step(b, step)
+        if dropout:
+            assert feeder.pos == 31
         print("micro-step %d losses" % step, [round(v, 5) for v in vals[:4]], [round(v, 5) for v in ovals[:4]])
         np.testing.assert_allclose(vals[:4], ovals[:4], rtol=0.01)          # both report loss / grad_acc_step
         if step < 4:

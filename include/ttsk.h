@@ -189,6 +189,13 @@ int ttsk_win_conv(const void* x_bf16, const void* w_packed, const float* bias /*
  * exist (t < S, t < frame_limit[0] when given) — the `partials` of ttsk_bn_train_apply, so the PostNet's 512 -> 512 layers need no
  * ttsk_bn_stats_slab launch (reference: Layers.py:133-143, Conv1d -> BatchNorm1d). */
 int ttsk_win_conv_stats_rows(int B, int S);
+/* Round 5: the PostNet's ends on the same kernel (reference: Layers.py:85-129, convolutions 0 and 4 = Conv1d(80 -> 512, k 5) and
+ * Conv1d(512 -> 80, k 5); their input gradients are the mirrored shapes on transposed packs).  Cin = 80: rows of 80 channels, the
+ * window and the pack zero-padded to three 32-channel k-steps (ttsk_win_conv_pack_* pads such a pack itself); Cout = 80: five waves
+ * of 16 channels.  ttsk_win_conv / _stats / _bnb accept both.  ttsk_win_conv_resid: bf16 output = conv + resid_f32 [B*S][Cout], the
+ * sum rounded once more — conv 0's input gradient + the mel terms' own gradient (fastspeech2.py:104, postnet(output) + output). */
+int ttsk_win_conv_resid(const void* x_bf16, const void* w_packed, const float* resid_f32, void* out_bf16, int B, int S, int Cin, int Cout,
+                        int K, void* stream);
 int ttsk_win_conv_stats(const void* x_bf16, const void* w_packed, const float* bias, float* out_f32, float* stats,
                         const int32_t* frame_limit, int B, int S, int Cin, int Cout, int K, void* stream);
 /* ttsk_win_conv (Cin = 512, bf16 output: the input gradient of a PostNet 512 -> 512 conv, run on the transposed pack) that also emits

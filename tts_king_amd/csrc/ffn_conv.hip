@@ -75,6 +75,12 @@ struct WcArgs {
   float* bnb_stats;
   float bnb_p;
   int bnb_tanh;
+  // The PostNet's ends (round 5): Conv1d(80 -> 512) and Conv1d(512 -> 80), k = 5, and their input gradients (Layers.py:85-129).
+  // cin_valid: the rows of x hold this many channels (ldx of them per row); the window and the pack are padded with zeros to CIN = 96
+  // (0: CIN itself).  resid32 [B*S][Cout] fp32 or null: added to the output before it is rounded (bf16 output: the PostNet's first
+  // conv's input gradient + the mel loss's own gradient, fastspeech2.py:104).
+  int cin_valid;
+  const float* resid32;
 #ifdef TTSK_STAMPS
   unsigned long long* stamps;   // diagnostic build only (make stamps; ttsk_win_conv_set_stamps): 24 slots per workgroup
 #endif
@@ -102,7 +108,22 @@ __device__ __forceinline__ void pack_one(const ttsk_pack_item& it) {
   const bf16_t* __restrict__ src = (const bf16_t*)it.src;
   bf16_t* __restrict__ dst = (bf16_t*)it.dst;
   const int Cs = it.Cs, K = it.K, Ds = it.Ds;
-  if (!it.transpose) {
+  if ((it.transpose ? Cs : Ds) % 32 != 0) {
+    // contraction not a multiple of 32 (the PostNet's 80 mel channels): k-steps padded with zeros, element by element (small weights)
+    const int Co = it.transpose ? Ds : Cs, Ci = it.transpose ? Cs : Ds, nks = (Ci + 31) / 32;
+    const int64_t n = (int64_t)K * nks * (Co / 16) * 512;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+      int64_t f = i >> 9;
+      const int c = (int)(f % (Co / 16)); f /= (Co / 16);
+      const int ks = (int)(f % nks);
+      const int tap = (int)(f / nks);
+      const int co = c * 16 + (l & 15), ci = ks * 32 + (l >> 4) * 8 + j;
+      bf16_t v = 0;
+      if (ci < Ci) v = it.transpose ? src[((int64_t)ci * K + (K - 1 - tap)) * Ds + co] : src[((int64_t)co * K + tap) * Ds + ci];
+      dst[i] = v;
+    }
+  } else if (!it.transpose) {
     const int Co = Cs, Ci = Ds;
     const int64_t n8 = (int64_t)Co * K * (Ci / 8);                 // 16-byte pieces of the pack
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
@@ -188,10 +209,18 @@ __global__ __launch_bounds__(256) void win_pack_args_kernel(const ItemChunk c) {
 template <int CIN, int TT, bool OUT32, bool PACKED, int NWV = WC_NW, int CTV = WC_CT, bool F16 = false>
 __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
   constexpr int COUT = NWV * CTV * 16;
-  constexpr int C = CIN, RS = CIN * 2 + 32, NT = NWV * 64, CH8 = C / 8, KH = WC_KH, CT = CTV, NF = TT / 16, NP = CIN / 128;
+  // a step = one tap x KH k-steps of 32 input channels: 128-channel parts, or the whole (padded) contraction when it is shorter
+  constexpr int C = CIN, RS = CIN * 2 + 32, NT = NWV * 64, CH8 = C / 8, KH = CIN % 128 == 0 ? WC_KH : CIN / 32, CT = CTV, NF = TT / 16,
+                NP = CIN / (KH * 32);
+  static_assert(CIN % 32 == 0 && NP * KH * 32 == CIN, "CIN = parts of KH k-steps");
   constexpr int XROWS = TT + 2 * WC_H;
-  constexpr int SRS = OUT32 ? COUT * 4 + 32 : RS;               // row stride of the output staging tile (fp32 rows are 1 KiB)
-  constexpr int SMEM = XROWS * RS > TT * SRS ? XROWS * RS : TT * SRS;
+  constexpr int SRS = OUT32 ? COUT * 4 + 32 : (RS > COUT * 2 + 32 ? RS : COUT * 2 + 32);      // row stride of the output staging tile (fp32 rows are 1 KiB; bf16 rows reuse the window's stride unless the window is narrower than the output: CIN = 96)
+  // (the instances that can emit BatchNorm statistics — the PostNet's: 512 or 96 input channels, fp32 output — keep NH - 1 rows of partial
+  // sums behind the staged output tile)
+  constexpr bool STATS = OUT32 && (CIN == 512 || CIN == 96);
+  constexpr int NH = NT / COUT;                                   // row groups of the tile in that epilogue: 512 threads x 256 channels: two; 320 x 80: four
+  constexpr int STG = TT * SRS + (STATS ? (NH - 1) * 2 * COUT * 4 : 0);
+  constexpr int SMEM = XROWS * RS > STG ? XROWS * RS : STG;
   __shared__ __attribute__((aligned(16))) unsigned char XW[SMEM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, q = lane >> 4;
@@ -223,10 +252,11 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
   const int ldx = a.ldx;
   const bf16_t* __restrict__ xb = a.x + (int64_t)bi * S * ldx + sp * C;
   const bf16_t* __restrict__ wbase = a.w;
-  const int ks_total = ldx / 32, ks_base = sp * (C / 32);
+  const int ks_total = (ldx + 31) / 32, ks_base = sp * (C / 32);
+  const int cin_valid = a.cin_valid > 0 ? a.cin_valid : C;
 
   // weight fragments by buffer loads (tapring.h): one per-lane byte offset for the whole kernel, the step's distance in a scalar register
-  const __amdgpu_buffer_rsrc_t wres = weights_rsrc(wbase, K * ldx * a.Cout * 2);
+  const __amdgpu_buffer_rsrc_t wres = weights_rsrc(wbase, K * ks_total * 32 * a.Cout * 2);
   const int wlane = PACKED ? (cg * (COUT / 16) + wave * CT) * 1024 + lane * 16 : ((cg * COUT + wave * CT * 16 + l15) * K * C + q * 8) * 2;
   const int kstep_bytes = (a.Cout / 16) * 1024;                  // PACKED: bytes per (tap, k-step)
   bf16x8 wa[KH][CT], wb[KH][CT], wc[KH][CT];      // three register sets: a step's weights are requested two steps (>= 1 us) ahead
@@ -259,7 +289,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
       const int row = idx / CH8, ch = idx - row * CH8;
       const int t = t0 - WC_H + row;
       xv[it] = make_uint4(0, 0, 0, 0);
-      if (idx < XROWS * CH8 && t >= 0 && t < S) xv[it] = *(const uint4*)(xb + (int64_t)t * ldx + ch * 8);
+      if (idx < XROWS * CH8 && t >= 0 && t < S && ch * 8 < cin_valid) xv[it] = *(const uint4*)(xb + (int64_t)t * ldx + ch * 8);
     }
 #if WC_XFIRST
     load_w(0, wa);
@@ -342,7 +372,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
   // they arrive during the staging and the stores)
   f32x4 bnb_v[8];
   unsigned bnb_kb[8];
-  if constexpr (!OUT32 && CIN == 512 && !F16 && NWV == 8 && CTV == 2) {
+  if constexpr (!OUT32 && (CIN == 512 || CIN == 96) && !F16 && NWV == 8 && CTV == 2) {
     if (a.bnb_x) {
       const int cq = cg * COUT + (tid & 63) * 4, rg = tid >> 6;
 #pragma unroll
@@ -372,23 +402,24 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
     }
   }
   __syncthreads();
-  if constexpr (OUT32 && CIN == 512) {
-    static_assert(SMEM >= TT * SRS + 2 * COUT * 4, "room for the two half-sums behind the staging tile");
+  if constexpr (STATS) {
+    static_assert(NT % COUT == 0 && TT % NH == 0 && SMEM >= TT * SRS + (NH - 1) * 2 * COUT * 4, "room for the partial sums behind the staging tile");
     if (a.stats) {
-      constexpr int NH = NT / COUT;                                 // 512 threads: two halves of the tile's rows; 256: one
-      const int c = tid & (COUT - 1), half = tid / COUT;
+      const int half = tid / COUT, c = tid - half * COUT;
       const int lim = a.frame_limit ? (a.frame_limit[0] < S ? a.frame_limit[0] : S) : S;
       float sm = 0.f, sq = 0.f;
       for (int r = half * (TT / NH); r < (half + 1) * (TT / NH); ++r) {
         if (t0 + r < lim) { const float v = *(const float*)(XW + r * SRS + c * 4); sm += v; sq += v * v; }
       }
-      float* red = (float*)(XW + TT * SRS);
-      if (NH == 2 && half == 1) { red[c] = sm; red[COUT + c] = sq; }
-      if (NH == 2) __syncthreads();
+      float* red = (float*)(XW + TT * SRS);                       // [NH - 1][2][COUT]
+      if (half > 0) { red[((half - 1) * 2 + 0) * COUT + c] = sm; red[((half - 1) * 2 + 1) * COUT + c] = sq; }
+      if (NH > 1) __syncthreads();
       if (half == 0) {
+#pragma unroll
+        for (int h = 1; h < NH; ++h) { sm += red[((h - 1) * 2 + 0) * COUT + c]; sq += red[((h - 1) * 2 + 1) * COUT + c]; }
         float* P = a.stats + ((int64_t)bi * a.tiles_per_utt + t0 / TT) * 2 * a.Cout + cg * COUT + c;
-        P[0] = NH == 2 ? sm + red[c] : sm;
-        P[a.Cout] = NH == 2 ? sq + red[COUT + c] : sq;
+        P[0] = sm;
+        P[a.Cout] = sq;
       }
     }
   }
@@ -412,6 +443,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
         };
         v.x &= keep(g.x); v.y &= keep(g.y); v.z &= keep(g.z); v.w &= keep(g.w);
       }
+      if (!OUT32 && a.resid32) {          // (the sum is rounded once: the staged bf16 values are exact in fp32)
+        const float* rp = a.resid32 + ((int64_t)bi * S + t) * a.Cout + cg * COUT + ch * 8;
+        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+        v.x = pack_bf2(__uint_as_float(v.x << 16) + r0[0], __uint_as_float(v.x & 0xFFFF0000u) + r0[1]);
+        v.y = pack_bf2(__uint_as_float(v.y << 16) + r0[2], __uint_as_float(v.y & 0xFFFF0000u) + r0[3]);
+        v.z = pack_bf2(__uint_as_float(v.z << 16) + r1[0], __uint_as_float(v.z & 0xFFFF0000u) + r1[1]);
+        v.w = pack_bf2(__uint_as_float(v.w << 16) + r1[2], __uint_as_float(v.w & 0xFFFF0000u) + r1[3]);
+      }
       *(uint4*)(ob + (int64_t)t * a.Cout * ESZ + ch * 16) = v;
       if (!OUT32 && a.delta) {
         const float* op = a.o32 + ((int64_t)bi * S + t) * a.Cout + cg * COUT + ch * 8;
@@ -427,7 +466,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
       if (idx < TT * OCH && t < S && (ch & 15) == 0) a.delta[((int64_t)bi * nh + hd) * S + t] = dacc;
     }
   }
-  if constexpr (!OUT32 && CIN == 512 && !F16 && NWV == 8 && CTV == 2) {
+  if constexpr (!OUT32 && (CIN == 512 || CIN == 96) && !F16 && NWV == 8 && CTV == 2) {
     if (a.bnb_x) {
       // thread = (channel quad of the group's 256 channels, one of 8 row groups); rows rg, rg + 8, ... of the tile
       static_assert(TT == 64 && NT == 512, "eight rows per thread");
@@ -506,6 +545,18 @@ int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int pa
     else hipLaunchKernelGGL((win_conv_kernel<512, 128, false, true, WC_NW, WC_CT, true>), gu, dim3(WC_NT), 0, s, a);
     return 0;
   }
+  if (Cin == 80) {           // the PostNet's first conv (80 -> 512) / its last conv's input gradient: contraction padded to 96 channels
+    a.cin_valid = 80;
+    if (out_f32) hipLaunchKernelGGL((win_conv_kernel<96, 64, true, true>), grid, dim3(WC_NT), 0, s, a);
+    else hipLaunchKernelGGL((win_conv_kernel<96, 64, false, true>), grid, dim3(WC_NT), 0, s, a);
+    return 0;
+  }
+  if (Cin == 512 && a.Cout == 80) {      // the PostNet's last conv (512 -> 80) / its first conv's input gradient: 5 waves x 16 channels
+    const dim3 g5(a.tiles_per_utt * B * a.nsplit);
+    if (out_f32) hipLaunchKernelGGL((win_conv_kernel<512, 64, true, true, 5, 1>), g5, dim3(320), 0, s, a);
+    else hipLaunchKernelGGL((win_conv_kernel<512, 64, false, true, 5, 1>), g5, dim3(320), 0, s, a);
+    return 0;
+  }
   if (short_seq && !a.delta && (int)grid.x <= 128) {     // few workgroups, each bound by its weight stream: 64-channel groups
     dim3 g4(grid.x * 4);
     if (out_f32) hipLaunchKernelGGL((win_conv_kernel<256, 64, true, true, 4, 1>), g4, dim3(256), 0, s, a);
@@ -530,7 +581,9 @@ int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int pa
 }  // namespace
 
 extern "C" int ttsk_win_conv_supported(int Cin, int Cout, int K) {
-  return (Cin == 256 || Cin == 512) && Cout > 0 && Cout % WC_COUT == 0 && K >= 1 && K <= 2 * WC_H + 1 && (K & 1) == 1;
+  if (!(K >= 1 && K <= 2 * WC_H + 1 && (K & 1) == 1)) return 0;
+  if ((Cin == 256 || Cin == 512 || Cin == 80) && Cout > 0 && Cout % WC_COUT == 0) return 1;
+  return Cin == 512 && Cout == 80;          // (the two 80-channel shapes: the PostNet's ends)
 }
 extern "C" int ttsk_ffn_conv_supported(int Cin, int Cout, int K) { return Cin == 256 && ttsk_win_conv_supported(Cin, Cout, K); }
 
@@ -548,7 +601,7 @@ extern "C" int ttsk_win_conv_pack_items(const ttsk_pack_item* items, int n, void
   for (int i = 0; i < 48; ++i) {
     const ttsk_pack_item& it = items[i < n ? i : 0];
     TTSK_REQUIRE(it.src && it.dst && ((((uintptr_t)it.src) | ((uintptr_t)it.dst)) & 15) == 0, "ttsk_win_conv_pack_items: null / unaligned pointer");
-    TTSK_REQUIRE(it.Cs > 0 && it.Cs % 32 == 0 && it.Ds > 0 && it.Ds % 32 == 0 && it.K >= 1, "ttsk_win_conv_pack_items: bad shape (%d, %d, %d)", it.Cs, it.K, it.Ds);
+    TTSK_REQUIRE(it.Cs > 0 && it.Cs % 16 == 0 && it.Ds > 0 && it.Ds % 16 == 0 && it.K >= 1, "ttsk_win_conv_pack_items: bad shape (%d, %d, %d)", it.Cs, it.K, it.Ds);
     c.it[i] = it;
   }
   hipLaunchKernelGGL(win_pack_args_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, c);
@@ -582,6 +635,21 @@ extern "C" int ttsk_win_conv(const void* x_bf16, const void* w_packed, const flo
   TTSK_REQUIRE(!delta_out || (delta_o32 && !out_f32 && Cout % 128 == 0 && (((uintptr_t)delta_o32) & 15) == 0),
                "ttsk_win_conv: delta needs o32 (16-byte aligned), bf16 output and Cout = heads * 128");
   launch_win_conv(a, B, S, Cin, out_f32, 1, (hipStream_t)stream);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+// ttsk_win_conv (bf16 output, no bias / gate) + an fp32 residual added before the rounding: the PostNet's first conv's input gradient
+// (512 -> 80 on the transposed pack) + the mel loss's own gradient (fastspeech2.py:104: postnet(output) + output)
+extern "C" int ttsk_win_conv_resid(const void* x_bf16, const void* w_packed, const float* resid_f32, void* out_bf16, int B, int S, int Cin,
+                                   int Cout, int K, void* stream) {
+  TTSK_REQUIRE(x_bf16 && w_packed && resid_f32 && out_bf16, "ttsk_win_conv_resid: null pointer");
+  TTSK_REQUIRE(B > 0 && S > 0 && B <= 65535, "ttsk_win_conv_resid: bad sizes B=%d S=%d", B, S);
+  TTSK_REQUIRE(ttsk_win_conv_supported(Cin, Cout, K), "ttsk_win_conv_resid: no instance for Cin=%d Cout=%d K=%d", Cin, Cout, K);
+  TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_packed) | ((uintptr_t)resid_f32) | ((uintptr_t)out_bf16)) & 15) == 0, "ttsk_win_conv_resid: 16-byte alignment");
+  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, nullptr, out_bf16, S, K, Cout, 0, 0, 0, nullptr, 1, Cin, 0, nullptr, nullptr};
+  a.resid32 = resid_f32;
+  launch_win_conv(a, B, S, Cin, 0, 1, (hipStream_t)stream);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }
@@ -623,7 +691,7 @@ extern "C" int ttsk_win_conv_stats(const void* x_bf16, const void* w_packed, con
                                    const int32_t* frame_limit, int B, int S, int Cin, int Cout, int K, void* stream) {
   TTSK_REQUIRE(x_bf16 && w_packed && out_f32 && stats, "ttsk_win_conv_stats: null pointer");
   TTSK_REQUIRE(B > 0 && S > 0 && B <= 65535, "ttsk_win_conv_stats: bad sizes B=%d S=%d", B, S);
-  TTSK_REQUIRE(Cin == 512 && ttsk_win_conv_supported(Cin, Cout, K), "ttsk_win_conv_stats: built for Cin = 512 (got Cin=%d Cout=%d K=%d)", Cin, Cout, K);
+  TTSK_REQUIRE((Cin == 512 || Cin == 80) && ttsk_win_conv_supported(Cin, Cout, K), "ttsk_win_conv_stats: built for Cin = 512 or 80 (got Cin=%d Cout=%d K=%d)", Cin, Cout, K);
   TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_packed) | ((uintptr_t)bias) | ((uintptr_t)out_f32)) & 15) == 0, "ttsk_win_conv_stats: 16-byte alignment");
   WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, bias, out_f32, S, K, Cout, 0, 0, 0, nullptr, 1, Cin, 0, nullptr, nullptr, stats, frame_limit};
   launch_win_conv(a, B, S, Cin, 1, 1, (hipStream_t)stream);
@@ -638,7 +706,7 @@ extern "C" int ttsk_win_conv_bnb(const void* x_bf16, const void* w_packed, void*
                                  int use_tanh, const int32_t* frame_limit, int B, int S, int Cin, int Cout, int K, void* stream) {
   TTSK_REQUIRE(x_bf16 && w_packed && out_bf16 && stats && bn_x_f32 && mean && rstd && gamma && beta, "ttsk_win_conv_bnb: null pointer");
   TTSK_REQUIRE(B > 0 && S > 0 && B <= 65535, "ttsk_win_conv_bnb: bad sizes B=%d S=%d", B, S);
-  TTSK_REQUIRE(Cin == 512 && ttsk_win_conv_supported(Cin, Cout, K), "ttsk_win_conv_bnb: built for Cin = 512 (got Cin=%d Cout=%d K=%d)", Cin, Cout, K);
+  TTSK_REQUIRE((Cin == 512 || Cin == 80) && Cout % WC_COUT == 0 && ttsk_win_conv_supported(Cin, Cout, K), "ttsk_win_conv_bnb: built for Cin = 512 or 80, Cout a multiple of 256 (got Cin=%d Cout=%d K=%d)", Cin, Cout, K);
   TTSK_REQUIRE(p >= 0.f && p < 1.f && (p == 0.f || keep), "ttsk_win_conv_bnb: dropout needs the forward's keep bits");
   TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_packed) | ((uintptr_t)out_bf16) | ((uintptr_t)bn_x_f32) | ((uintptr_t)mean) | ((uintptr_t)rstd) |
                  ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0, "ttsk_win_conv_bnb: 16-byte alignment");

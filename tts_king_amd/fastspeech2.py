@@ -151,6 +151,7 @@ class FastSpeech2(nn.Module):
         self.adam_packs = True          # the optimizer's Adam launch writes the window kernels' weight packs itself (ttsk_optim_step_packed)
         self.flash_attention = True     # attention without the S x S tensors when d_k = 128 (csrc/flash_attn.hip); False / other head sizes: scores GEMM + softmax + P V GEMM
         self.fused_ln = True            # fc / w_2 + dropout + residual + LayerNorm + PAD zeroing in one kernel when d = 256
+        self.postnet_ends_win = True        # the PostNet's 80 -> 512 / 512 -> 80 convs and their input gradients on the window kernel too (round 5)
         self.bn_stats_in_conv = True        # PostNet 512 -> 512 convs emit their BatchNorm statistics partials
         self.bn_bwd_stats_in_conv = True    # ... and their input-gradient convs the backward's
         self.fused_qkv_tail = True          # a block's last kernel also projects q|k|v for the next block
@@ -365,6 +366,12 @@ class FastSpeech2(nn.Module):
             self._build_packs()
         if self._pack_table is not None:
             ops.win_conv_pack_run(*self._pack_table)
+        self.refresh_odd_packs()
+
+    def refresh_odd_packs(self):
+        """The packs the optimizer's Adam launch does not write itself (the PostNet's 80-channel ends), from the bf16 shadow: one small launch."""
+        if self.window_ffn and getattr(self, "_odd_pack_table", None) is not None:
+            ops.win_conv_pack_run(*self._odd_pack_table)
 
     def _build_packs(self):
         """Allocate the packs and their item table (host -> device copy: not capturable, so this runs at construction and after
@@ -383,6 +390,10 @@ class FastSpeech2(nn.Module):
                [("qkvT", p + "slf_attn.w_qs.weight", 3 * d, True) for p in dec + enc] + \
                [("pn", "postnet.convolutions.%d.0.conv.weight" % i, None, False) for i in range(1, 4)] + \
                [("pnT", "postnet.convolutions.%d.0.conv.weight" % i, None, True) for i in range(1, 4)]
+        # the PostNet's ends (80 -> 512 and 512 -> 80 channels, round 5): packs Adam's tile walk cannot write (80 is neither a multiple of
+        # 32 storage rows nor of 256 storage columns); one small launch of their own behind the optimizer step (refresh_odd_packs)
+        odd = [(t, "postnet.convolutions.%d.0.conv.weight" % i, None, tr) for t, i, tr in
+               (("pn", 0, False), ("pnT", 0, True), ("pn", 4, False), ("pnT", 4, True))] if self.postnet_ends_win else []
         items = []
         for tag, key, fused_rows, tr in want:
             if key not in self._table:
@@ -406,6 +417,21 @@ class FastSpeech2(nn.Module):
         # the shadow views and the packs keep their addresses until _apply: a device-resident item table, one pack launch per step
         self._pack_table = ops.win_conv_pack_table([(self._pack_source(key, fr), out, tr) for key, fr, out, tr in self._pack_items],
                                                    self._shadow.device) if self._pack_items else None
+        self._odd_pack_table = None
+        odd_items = []
+        for tag, key, _, tr in odd:
+            if key not in self._table:
+                continue
+            W = self._pack_source(key)
+            cs, kk, ds = W.shape
+            cin, cout = (cs, ds) if tr else (ds, cs)
+            if not ops.win_conv_supported(cin, cout, kk):
+                continue
+            pk = torch.empty(ops.win_pack_numel(cs, kk, ds, tr), dtype=bf16, device=self._shadow.device)
+            self._w1_packed[(tag, key)] = pk
+            odd_items.append((W, pk, tr))
+        if odd_items:
+            self._odd_pack_table = ops.win_conv_pack_table(odd_items, self._shadow.device)
         # ... and the tables with which the optimizer's Adam launch writes these packs itself (ttsk_optim_step_packed): per weight its
         # flat offset, storage shape and its plain / transposed packs.  A weight with more than one pack of a kind (w_1's transposed
         # pack exists once) or one that does not tile leaves `_adam_tables` None: the optimizer then calls refresh_packed as before.
@@ -761,7 +787,7 @@ class FastSpeech2(nn.Module):
             stats = None
             if pk is not None and xin.dtype == bf16:
                 cw = self._table[pp + "0.conv.weight"].storage_shape
-                if train and xin.shape[2] == 512 and ops.bn_slab_supported(cw[0]) and self.bn_stats_in_conv:
+                if train and xin.shape[2] in (512, 80) and ops.bn_slab_supported(cw[0]) and self.bn_stats_in_conv:
                     # window kernel; the BatchNorm statistics partials of its output come out of its epilogue
                     yc, stats = ops.win_conv_stats(xin, pk, cw[0], cw[1], bias=self._m(pp + "0.conv.bias"), frame_limit=fl)
                 else:
@@ -1239,7 +1265,7 @@ class FastSpeech2(nn.Module):
             if i > 0 and pkt is not None:
                 cw = self._table[pp + "0.conv.weight"].storage_shape
                 pb, _, ycb, meanb, rstdb, keepb = ctx.pn[i - 1]
-                if (self.bn_bwd_stats_in_conv and C == 512 and cw[2] == 512 and ycb.dtype == torch.float32 and ops.bn_slab_supported(cw[2])
+                if (self.bn_bwd_stats_in_conv and C in (512, 80) and cw[2] == 512 and ycb.dtype == torch.float32 and ops.bn_slab_supported(cw[2])
                         and (keepb is not None or self.p_post == 0.0)):
                     # ... which also sums the BatchNorm-backward statistics of the layer below over its output tile
                     dout, bn_partials = ops.win_conv_bnb(dy.view(Bn, T, C), pkt, cw[2], cw[1], ycb.view(rows, cw[2]), meanb, rstdb,
@@ -1251,7 +1277,11 @@ class FastSpeech2(nn.Module):
             elif i > 0:
                 dout = ops.conv1d_dx(dy.view(Bn, T, C), self._w(pp + "0.conv.weight")).view(rows, -1)
             else:
-                dmel_tot = ops.conv1d_dx(dy.view(Bn, T, C), self._w(pp + "0.conv.weight"), R=dmel_sum.view(Bn, T, nm)).view(rows, nm)
+                if pkt is not None:          # the first conv's input gradient (512 -> 80) + the mel terms' own gradient, on the window kernel
+                    cw = self._table[pp + "0.conv.weight"].storage_shape
+                    dmel_tot = ops.win_conv_resid(dy.view(Bn, T, C), pkt, dmel_sum.view(Bn, T, nm), cw[2], cw[1]).view(rows, nm)
+                else:
+                    dmel_tot = ops.conv1d_dx(dy.view(Bn, T, C), self._w(pp + "0.conv.weight"), R=dmel_sum.view(Bn, T, nm)).view(rows, nm)
                 if ctx.frame_limit is not None:
                     ops.zero_frames_from(dmel_tot, ctx.frame_limit)      # the conv's reach past the batch's own length is not a frame
         notify("postnet")

@@ -652,6 +652,23 @@ def win_conv_bnb(x, packed, Cout, k, bn_x, mean, rstd, gamma, beta, use_tanh, p=
 
 
 @_family("win_conv", _conv_flops)
+def win_conv_resid(x, packed, resid, Cout, k):
+    """bf16 (B,S,Cout) = Conv1d(Cin -> Cout, k)(x) + resid (fp32 (B,S,Cout)) on the window kernel (ttsk_win_conv_resid): the PostNet's
+    first conv's input gradient (512 -> 80 on the transposed pack) + the mel terms' own gradient."""
+    _dev(x, packed, resid)
+    Bsz, S, Cin = x.shape
+    out = torch.empty(Bsz, S, Cout, dtype=bf16, device=x.device)
+    check(L.load().ttsk_win_conv_resid(_ptr(x), _ptr(packed), _ptr(resid), _ptr(out), Bsz, S, Cin, Cout, k, _stream()), "ttsk_win_conv_resid")
+    return out
+
+
+def win_pack_numel(Cs, k, Ds, transpose):
+    """Elements of the fragment-major pack of a (Cs, k, Ds) tap-major weight (win_conv_pack_*): the contraction padded to whole 32-channel k-steps."""
+    cout, cin = (Ds, Cs) if transpose else (Cs, Ds)
+    return k * ((cin + 31) // 32) * 32 * cout
+
+
+@_family("win_conv", _conv_flops)
 def win_conv_split(x, packed, Cout, k):
     """An input-gradient conv with a wide contraction (x (B,S,n*256) bf16) as n window convs over 256-channel slices in one launch:
     fp32 Slabs (n, B*S*Cout) for layernorm_bwd(slabs=...) (ttsk_win_conv_split).  `packed`: the whole transposed pack."""

@@ -60,6 +60,8 @@ class ScheduledOptim:
             ops.optim_step_packed(flat, grad, self.exp_avg, self.exp_avg_sq, shadow, self.state, self._partials, self.grad_clip_thresh,
                                   self.betas[0], self.betas[1], self.eps, self.d_model, self.n_warmup_steps, self.anneal_steps,
                                   self.anneal_rate, tables, zero_grad=not keep_grads, advance_rng=advance_rng)
+            if hasattr(self.model, "refresh_odd_packs"):
+                self.model.refresh_odd_packs()     # the few packs that launch does not write (the PostNet's 80-channel ends)
         else:
             ops.optim_step(flat, grad, self.exp_avg, self.exp_avg_sq, shadow, self.state, self._partials, self.grad_clip_thresh,
                            self.betas[0], self.betas[1], self.eps, self.d_model, self.n_warmup_steps, self.anneal_steps, self.anneal_rate,

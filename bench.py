@@ -634,7 +634,14 @@ def main():
                        "global_batch": B * world, "batch_per_gpu": B, "phonemes": L, "T_max": T, "valid_frames_per_gpu": frames,
                        "padded_frames_per_gpu": B * T, "grad_acc_step": 1, "parallelism": "dp%d" % world,
                        "launch": ("hipGraph replay" + (" incl. RCCL bucketed all-reduce" if world > 1 else "")) if use_graph
-                                 else "eager (+RCCL bucketed all-reduce on a side stream)"},
+                                 else "eager (+RCCL bucketed all-reduce on a side stream)",
+                       # what the collective layer itself saw (a SCALE record can be checked for "RCCL ran with N ranks"): the size of
+                       # the process group, its backend, and the bytes of every bucket's all-reduce in launch order, per step
+                       "collective_world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                       "collective_backend": dist.get_backend() if dist.is_initialized() else None,
+                       "allreduce_bucket_bytes": reducer.bucket_bytes() if reducer is not None else [],
+                       "allreduces_per_step": (len(reducer.history[-1]) if (reducer is not None and reducer.history) else 0),
+                       "collective_timeout_s": (__import__("tts_king_amd.parallel", fromlist=["dist_timeout_s"]).dist_timeout_s() if world > 1 else None)},
             "mel_frames_per_s_per_gpu": value / world,
             "model_tflops": flops * world / (ms * 1e-3) / 1e12,
             "step_mfma_roofline_frac": flops / (ms * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS,

@@ -302,3 +302,70 @@ def test_train_engine_with_reducer_capture_and_fallback(cfg):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_collective_sequence_is_the_same_replayed_refused_or_eager(cfg):
+    """ranks deadlock when they issue different sequences of collectives, and each rank decides by itself, shape by
+    shape, whether it replays a graph, captures one, or — when a capture is refused — launches eagerly.  Here three engines over a REAL
+    RCCL process group (size 1, collectives forced) run the same nine batches: plain launches; replayed graphs; replayed graphs with the
+    first capture refused mid-run (a capture that recorded a whole step and was then thrown away, as RCCL refusing it would leave
+    things).  What the reducer issued (or a replay executed) per update step must be identical across the three — every bucket once, in
+    bucket order — and so must the weights."""
+    from tts_king_amd import graph as G
+    from tts_king_amd.dataset import DeviceFeeder
+    from tts_king_amd.engine import TrainEngine
+    from tts_king_amd.fastspeech2 import FastSpeech2
+    from tts_king_amd.loss import FastSpeech2Loss
+    from tts_king_amd.optimizer import ScheduledOptim
+    from tts_king_amd.parallel import GradReducer
+    from tts_king_amd.synthetic import make_batch
+    import tts_king_amd.engine as E
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29537")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        created = True
+    try:
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        c = copy.deepcopy(cfg)
+        c.train_config["optimizer"]["grad_acc_step"] = 1
+        host = [tuple(x.numpy() if torch.is_tensor(x) else x for x in make_batch(4, 30 + (i % 2) * 4, seed=90 + i % 2, ragged=True)) for i in range(9)]
+        bucket = (8, 32, int(c.model_config["max_seq_len"]))
+        res = {}
+        for mode in ("eager", "graph", "refused_once"):
+            m = FastSpeech2(c.preprocess_config, c.model_config, 65, device=DEV, seed=5).train()      # dropout on: counters tick per step
+            opt = ScheduledOptim(m, c.train_config, c.model_config, 0)
+            red = GradReducer(m.flat_buffers()[1], m.grad_buckets(8), m.group_offsets(), force_collectives=True)
+            eng = TrainEngine(m, opt, c, FastSpeech2Loss(c.preprocess_config, c.model_config), reducer=red, hip_graph=mode != "eager")
+            keep = G.GraphedTrainStep
+            refused = [0]
+            if mode == "refused_once":
+                class RefuseFirst(keep):
+                    def __init__(self, enqueue, example_batch, warmup=2, pool=None, **kw):
+                        if refused[0] == 0:
+                            refused[0] += 1
+                            g = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                                enqueue(list(example_batch))             # a whole step recorded, collectives included, nothing executed
+                            raise RuntimeError("capture refused (test)")
+                        keep.__init__(self, enqueue, example_batch, warmup=warmup, pool=pool, **kw)
+                E.GraphedTrainStep = RefuseFirst
+            try:
+                step = 0
+                for b in DeviceFeeder(host, DEV, bucket=bucket):
+                    step += 1
+                    eng.step(b, step)
+                torch.cuda.synchronize()
+            finally:
+                E.GraphedTrainStep = keep
+            res[mode] = (list(red.history), m.flat_buffers()[0].cpu().clone(), dict(eng.stats), opt.current_step, opt._host_step)
+        every = tuple(red.buckets)
+        for mode, (hist, _, stats, cur, host_step) in res.items():
+            assert len(hist) == 9 and all(h == every for h in hist), (mode, [len(h) for h in hist])
+            assert cur == 9 and host_step == 9, (mode, cur, host_step)
+        assert res["graph"][2]["replayed"] >= 4 and res["refused_once"][2].get("capture_failed", 0) == 1 and res["refused_once"][2]["replayed"] >= 2
+        assert torch.equal(res["eager"][1], res["graph"][1]) and torch.equal(res["eager"][1], res["refused_once"][1])
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -9,6 +9,7 @@ energy values the HIP path produced (stated tolerance for this single random-wei
 the golden-vector tests in tests/test_fs2_gpu.py hold the 1 % bar), the waveform with the oracle vocoder on the
 HIP path's own mel (rel-RMS <= 0.5 %).  Graph replay must reproduce the eager result bit for bit."""
 import copy
+import math
 import os
 
 import numpy as np
@@ -107,3 +108,96 @@ def test_graphed_outputs_are_not_aliased(tmp_path):
         assert not torch.equal(again, held) or torch.equal(again, snapshot)
     assert torch.equal(held, snapshot), "a previously returned mel was overwritten by a later call"
     assert held.data_ptr() != again.data_ptr()
+
+
+def test_free_running_second_control_setting_through_to_the_waveform(tmp_path):
+    """one FREE-RUNNING case (nothing teacher-forced on the HIP path's own values) on the controls of the reference's
+    notebook (examples.ipynb cell 3: duration 0.9, pitch 1.5, energy 1.2), followed through to the int16 waveform.  The oracle runs
+    free as well, on the same weights.  Durations: the HIP log-durations within the stated 0.06 of the oracle's, the HIP durations
+    exactly the reference's rounding rule (modules.py:199-204) applied to them, and EVERY position where the two disagree has a
+    rounding boundary between the two pre-rounding values.  Then the frames: where no duration differs the two runs share every frame
+    position and the mel / waveform are compared directly (mel rel-RMS <= 3 %: a pitch or energy prediction next to a bin edge may pick
+    the neighbouring embedding row, as in tests/test_fs2_gpu.py::test_eval_free_running; waveform vs the oracle vocoder on the HIP mel
+    <= 0.5 % + int16 quantisation); where some differ, the oracle is re-run with the HIP durations only (pitch and energy still its
+    own predictions) and the same bars apply."""
+    tts = make_tts(tmp_path, False)
+    g = torch.Generator().manual_seed(11)
+    L = 56
+    phon = torch.randint(1, 207, (1, L), generator=g).numpy()
+    dc, pc, ec = 0.9, 1.5, 1.2
+    mel = tts.generate_mel(phon, duration_control=dc, pitch_control=pc, energy_control=ec, speaker=9)
+    wav = tts.mel_to_wav(mel)
+    T = mel.shape[1]
+    assert wav.dtype == np.int16 and wav.shape == (1, 1, 256 * T)
+    m = tts.tts.model
+    out = m(torch.tensor([9]), torch.from_numpy(phon), torch.tensor([L]), L, d_control=dc, p_control=pc, e_control=ec)
+    assert torch.equal(out[9].detach().float().cpu(), mel.cpu())                   # the facade returned the model's postnet mel
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    cfg = tts.cfg
+    with torch.no_grad():
+        ref = ofs2.fs2_forward(sd, cfg.model_config, torch.tensor([9]), torch.from_numpy(phon).long(), torch.tensor([L]), L,
+                               p_control=pc, e_control=ec, d_control=dc)
+    logd_h, logd_r = out[3].detach().float().cpu(), ref[3].float()
+    assert float((logd_h - logd_r).abs().max()) <= 0.06
+    d_h, d_r = out[4].detach().float().cpu(), ref[4].float()
+    v_h, v_r = torch.exp(logd_h) - 1.0, torch.exp(logd_r) - 1.0
+    rule = torch.clamp(torch.round(v_h) * dc, min=0.0)
+    assert bool((((v_h - torch.floor(v_h) - 0.5).abs() < 1e-5) | (rule == d_h)).all())
+    mism = (d_h != d_r)
+    for bi, li in mism.nonzero().tolist():
+        vr, vh = float(v_r[bi, li]), float(v_h[bi, li])
+        bnd = math.floor(vr) + 0.5
+        if abs(vr - bnd) > 0.5:
+            bnd += 1.0
+        assert min(vr, vh) - 1e-5 <= bnd <= max(vr, vh) + 1e-5, (bi, li, vh, vr)
+    print("free-running facade: %d of %d durations differ from the oracle's (each across a rounding boundary); T = %d" % (int(mism.sum()), L, T))
+    assert int(d_h.clamp(min=0).trunc().sum()) == T
+    if bool(mism.any()):
+        with torch.no_grad():          # the oracle on the HIP durations; pitch / energy still its own free-running predictions
+            ref = ofs2.fs2_forward(sd, cfg.model_config, torch.tensor([9]), torch.from_numpy(phon).long(), torch.tensor([L]), L,
+                                   d_targets=d_h, max_mel_len=T, mel_lens=torch.tensor([T]), p_control=pc, e_control=ec)
+    assert ref[9].shape == mel.shape
+    r_free = rel_rms(mel.cpu(), ref[9])
+    # Pitch and energy pick an embedding row by bucketize(prediction * control, 255 edges) (modules.py:92-101,131-140): a bf16-level
+    # difference in a prediction that sits next to an edge selects the neighbouring row — one row of a random-weight table is a large
+    # step for a 33-frame utterance.  Same argument as for the durations, position by position: wherever the HIP path and the oracle
+    # chose different rows, a bin edge lies between their two predictions; with the HIP path's choices handed over (its predictions as
+    # the oracle's `targets`, which only pick rows) the mel must agree to the teacher-forced bar.
+    va = "variance_adaptor."
+
+    def edge_between(name, h, r_, bins):
+        bh, br = torch.bucketize(h, bins), torch.bucketize(r_, bins)
+        n = 0
+        for bi, li in (bh != br).nonzero().tolist():
+            lo, hi = min(float(h[bi, li]), float(r_[bi, li])), max(float(h[bi, li]), float(r_[bi, li]))
+            assert bool(((bins >= lo - 1e-6) & (bins <= hi + 1e-6)).any()), (name, bi, li, lo, hi)
+            assert hi - lo <= 0.1 * max(1.0, abs(hi)), (name, bi, li, lo, hi)
+            n += 1
+        return n
+    pitch_h, energy_h = out[1].detach().float().cpu(), out[2].detach().float().cpu()
+    n_p = edge_between("pitch", pitch_h, ref[1].float(), sd[va + "pitch_bins"])
+    with torch.no_grad():          # the oracle with the HIP path's pitch rows: its energy predictor now sees the same pitch embedding
+        ref = ofs2.fs2_forward(sd, cfg.model_config, torch.tensor([9]), torch.from_numpy(phon).long(), torch.tensor([L]), L,
+                               d_targets=d_h, max_mel_len=T, mel_lens=torch.tensor([T]), pitches_raw=pitch_h, e_control=ec)
+    n_e = edge_between("energy", energy_h, ref[2].float(), sd[va + "energy_bins"])
+    with torch.no_grad():
+        ref = ofs2.fs2_forward(sd, cfg.model_config, torch.tensor([9]), torch.from_numpy(phon).long(), torch.tensor([L]), L,
+                               d_targets=d_h, max_mel_len=T, mel_lens=torch.tensor([T]), pitches_raw=pitch_h, e_targets=energy_h)
+    r = rel_rms(mel.cpu(), ref[9])
+    print("free-running facade mel vs the free-running oracle: rel-RMS %.3f%%; %d pitch / %d energy rows differ (each across a bin edge); "
+          "with those rows handed over: %.3f%%" % (100 * r_free, n_p, n_e, 100 * r))
+    assert r <= 0.015
+    assert r_free <= 0.03 or (n_p + n_e) > 0          # without a differing row the free runs themselves must agree
+    gsd = {k: v.detach().float().cpu() for k, v in tts.vocoder.model.state_dict().items()}
+    with torch.no_grad():
+        wref = ohifi.generator(gsd, cfg.hifi, mel.cpu().transpose(1, 2))
+        wfree = ohifi.generator(gsd, cfg.hifi, ref[9].transpose(1, 2))
+    got = torch.from_numpy(wav.astype(np.float32) / 32768.0)
+    r = rel_rms(got, wref)
+    print("free-running facade waveform vs the oracle vocoder on the HIP mel: rel-RMS %.3f%%; vs the oracle end to end: %.1f%%"
+          % (100 * rel_rms(got, wref), 100 * rel_rms(got, wfree)))
+    r = rel_rms(got, wref)
+    assert r <= 0.005 + 2e-5 / float(wref.pow(2).mean().sqrt())
+    # int16 conversion: C truncation toward zero of audio * 32768 (hifiapi.py:50-51), checked against the float output of the HIP generator
+    f = tts.vocoder(mel.transpose(1, 2)).detach().float().cpu().numpy()
+    assert np.array_equal((f * 32768.0).astype("int16"), wav)

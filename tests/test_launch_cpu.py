@@ -60,3 +60,35 @@ def test_bench_gpus_n_without_devices_exits_nonzero():
     assert p.returncode != 0
     assert b"n_gpus" not in p.stdout
     assert b"HIP device" in p.stderr
+
+
+HANG = r"""
+import os, sys, time
+sys.path.insert(0, os.environ["TTSK_ROOT"])
+import torch, torch.distributed as dist
+from tts_king_amd.parallel import init_distributed
+rank, world, _ = init_distributed(backend="gloo", timeout_s=4)
+t = torch.ones(4)
+dist.all_reduce(t)
+if rank == 1:
+    time.sleep(120)              # this rank issues one collective fewer than its peer: the deadlock of a divergent schedule
+    sys.exit(0)
+dist.all_reduce(t)               # must fail within the bound, not hang
+print("unreachable")
+"""
+
+
+def test_a_hung_collective_fails_the_job_within_the_bound():
+    """every collective is bounded (parallel.init_distributed(timeout_s)); a rank left waiting by a peer that
+    issued a different sequence of collectives raises, exits non-zero, and the launcher ends the other rank — no hang, no re-exec."""
+    import time
+    from tts_king_amd import launch
+    env = dict(os.environ, TTSK_ROOT=ROOT)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    t0 = time.time()
+    buf = io.BytesIO()
+    rc = launch.spawn_ranks(2, [sys.executable, "-c", HANG], env=env, n_devices=2, stdout=buf, timeout=90)
+    dt = time.time() - t0
+    assert rc not in (0, 124), rc           # a rank failed (not: the launcher's own deadline)
+    assert dt < 60, dt
+    assert b"unreachable" not in buf.getvalue()

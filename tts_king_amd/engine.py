@@ -150,6 +150,7 @@ class TrainEngine:
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()
             host_step = self.optimizer._host_step
+            n_hist = len(self.reducer.history) if self.reducer is not None else 0
             torch.cuda.synchronize()
             try:
                 g = GraphedTrainStep(self._enqueue(is_update, static_fl, static_pl, accumulate=acc), static, warmup=0, pool=self._pool,
@@ -159,6 +160,7 @@ class TrainEngine:
                 self.optimizer._host_step = host_step
                 if self.reducer is not None:
                     self.reducer.reset()
+                    del self.reducer.history[n_hist:]       # (the aborted capture's Python may have closed a step that never ran)
                 self.model._ctx = None
                 self.model._dw_side_pending = False
                 self.model._pred_fwd_pending = False
@@ -170,6 +172,11 @@ class TrainEngine:
                 self.stats["eager"] += 1
                 return self._enqueue(is_update, fl, pl)(batch)
             self.optimizer._host_step = host_step     # capture ran the Python of one step without executing it
+            # ... including the reducer's: the collectives it recorded are what every replay of this graph will execute
+            g.collectives = ()
+            if self.reducer is not None:
+                g.collectives = self.reducer.history[n_hist] if len(self.reducer.history) > n_hist else ()
+                del self.reducer.history[n_hist:]
             g.frame_limit, g.phoneme_limit = static_fl, static_pl
             self._graphs[key] = g
             self.stats["captured"] += 1
@@ -182,6 +189,8 @@ class TrainEngine:
             if g.phoneme_limit is not None:
                 g.phoneme_limit.copy_(pl, non_blocking=True)
         losses, out = g.run(batch)
+        if self.reducer is not None and is_update:
+            self.reducer.history.append(g.collectives)
         self.model.grads_partial = not is_update      # what the replayed step's Python would have left
         if is_update:
             self.optimizer._host_step += 1

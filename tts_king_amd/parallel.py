@@ -14,8 +14,22 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend=None):
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run contract).  backend 'nccl' is RCCL."""
+def dist_timeout_s(timeout_s=None):
+    """The bound on every collective of the job, in seconds: the argument, else TTSK_DIST_TIMEOUT_S, else 300."""
+    import os
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("TTSK_DIST_TIMEOUT_S", "300"))
+    return max(1.0, float(timeout_s))
+
+
+def init_distributed(backend=None, timeout_s=None):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run contract).  backend 'nccl' is RCCL.
+    Every collective of the group is BOUNDED (`timeout_s`, default 300 s, TTSK_DIST_TIMEOUT_S): a rank that waits longer for its peers
+    — one of them died, or issued a different sequence of collectives — fails instead of hanging, and the job ends with a non-zero
+    status (launch.spawn_ranks / torch.distributed.run then end the other ranks).  With RCCL the watchdog thread enforces it
+    (TORCH_NCCL_ASYNC_ERROR_HANDLING=1: abort the communicator and the process); with gloo the collective raises.  A rank is never
+    re-executed."""
+    import datetime
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -25,7 +39,8 @@ def init_distributed(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=dist_timeout_s(timeout_s)))
     return rank, world, local
 
 
@@ -55,6 +70,11 @@ class GradReducer:
         self._next = 0
         self._handles = []
         self.launched = []          # (start, end) in launch order, for tests / tracing
+        # One entry per finished step: the buckets whose all-reduce that step issued, in order.  Ranks must agree on this sequence step
+        # by step — a rank that issues a different one leaves its peers waiting in a collective (bounded: init_distributed) — whatever
+        # mix of replayed graphs and plain launches each of them runs (TrainEngine keeps it for replays too).
+        self.history = []
+        self._step_start = 0
 
     def _launch_down_to(self, watermark):
         while self._next < len(self.buckets) and self.buckets[self._next][0] >= watermark:
@@ -100,12 +120,19 @@ class GradReducer:
             h.wait()
         self._handles = []
         self._next = 0
+        self.history.append(tuple(self.launched[self._step_start:]) if (self.world > 1 or self.force) else ())
+        self._step_start = len(self.launched)
 
     def reset(self):
         """Forget a half-issued step (a hipGraph capture of it was aborted): no handles, first bucket next."""
         self._handles = []
         self._staged = []
         self._next = 0
+        del self.launched[self._step_start:]
+
+    def bucket_bytes(self):
+        """Bytes of each bucket's all-reduce, in launch order."""
+        return [int((e - s) * self.flat_grad.element_size()) for s, e in self.buckets]
 
     def grad_scale(self, grad_acc_step=1):
         return 1.0 / (grad_acc_step * self.world)

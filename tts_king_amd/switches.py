@@ -14,6 +14,8 @@ TABLE = {
     "TTSK_PRED_SIDE": ("1", "FS2: the predictors' forward / backward on a stream of their own: 1 both, f forward only, b backward only, 0 neither"),
     "TTSK_DP_SCHEDULE": ("side", "data parallel: side = buckets announced from the second stream behind the decoder-side weight gradients; "
                                  "late = every all-reduce after the last weight-gradient launch"),
+    "TTSK_DIST_TIMEOUT_S": ("300", "data parallel: bound on every collective of the job in seconds (parallel.init_distributed): a rank that waits "
+                                   "longer fails, the job exits non-zero"),
     "TTSK_DP_GRAPH": ("1", "bench.py --gpus N: capture the data-parallel step (RCCL all-reduces included) in a hipGraph; 0 = eager launches"),
     "TTSK_HIFI_UPS8": ("1", "HiFi-GAN: stride-8 upsamplers and 128 -> 64 on the window-conv kernel; 0 = polyphase GEMMs / streaming kernel"),
     "TTSK_CPU_THREADS": ("16", "bench.py: threads of the CPU baseline leg (capped at the host's cores)"),

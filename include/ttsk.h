@@ -196,6 +196,11 @@ int ttsk_win_conv_stats_rows(int B, int S);
  * sum rounded once more — conv 0's input gradient + the mel terms' own gradient (fastspeech2.py:104, postnet(output) + output). */
 int ttsk_win_conv_resid(const void* x_bf16, const void* w_packed, const float* resid_f32, void* out_bf16, int B, int S, int Cin, int Cout,
                         int K, void* stream);
+/* ttsk_win_conv with fp32 output and a bf16 copy of the same rows (round 5: mel_linear, fastspeech2.py:102, Linear(256 -> 80) as a k = 1
+ * conv on the five-wave instance: the fp32 mel is what the loss reads and what the PostNet's output is added to, the copy is the PostNet's
+ * input).  Shapes as ttsk_win_conv plus (Cin 256, Cout 80). */
+int ttsk_win_conv_dual(const void* x_bf16, const void* w_packed, const float* bias, float* out_f32, void* out_bf16, int B, int S, int Cin,
+                       int Cout, int K, void* stream);
 int ttsk_win_conv_stats(const void* x_bf16, const void* w_packed, const float* bias, float* out_f32, float* stats,
                         const int32_t* frame_limit, int B, int S, int Cin, int Cout, int K, void* stream);
 /* ttsk_win_conv (Cin = 512, bf16 output: the input gradient of a PostNet 512 -> 512 conv, run on the transposed pack) that also emits

@@ -156,3 +156,28 @@ def test_step_with_the_ends_on_the_window_kernel_matches_the_gemm_path(cfg):
         hi = min([o for o in ma.group_offsets().values() if o > lo] + [ga.numel()])
         na = float(ga[lo:hi].norm())
         assert float((gb[lo:hi] - ga[lo:hi]).norm()) <= 2e-2 * na + 1e-6, name
+
+
+@pytest.mark.parametrize("B,S", [(16, 423), (3, 65), (1, 7)])
+def test_mel_linear_on_the_window_kernel(B, S):
+    """mel_linear (fastspeech2.py:102, Linear(256 -> 80)) as a k = 1 conv on the five-wave instance with an fp32 output and its bf16 copy
+    (ttsk_win_conv_dual), and its input gradient (80 -> 256 on the padded transposed pack), against fp64 and the GEMM path."""
+    from tts_king_amd import ops
+    g = torch.Generator().manual_seed(S)
+    x = bf(torch.randn(B, S, 256, generator=g)).to(DEV)
+    W = bf(torch.randn(80, 1, 256, generator=g) / 16).to(DEV)
+    bias = (0.1 * torch.randn(80, generator=g)).to(DEV)
+    pk, pkt = _packs(W)
+    ref = x.double().cpu().view(-1, 256) @ W.double().cpu().view(80, 256).t() + bias.double().cpu()
+    out, out16 = ops.win_conv_dual(x, pk, 80, 1, bias=bias)
+    assert out.dtype == torch.float32 and out16.dtype == torch.bfloat16
+    assert float((out.double().cpu().view(-1, 80) - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-5
+    assert torch.equal(out16, out.to(torch.bfloat16))
+    old = ops.linear(x.view(-1, 256), W.view(80, 256), bias, out_dtype=torch.float32)
+    assert float((out.view(-1, 80) - old).abs().max()) <= 1e-4 * float(ref.abs().max())
+    dy = bf(torch.randn(B, S, 80, generator=g)).to(DEV)
+    dref = dy.double().cpu().view(-1, 80) @ W.double().cpu().view(80, 256)
+    dx = ops.win_conv(dy, pkt, 256, 1)
+    assert float((dx.double().cpu().view(-1, 256) - dref).abs().max()) <= 2 ** -8 * float(dref.abs().max()) + 1e-3
+    dold = ops.linear_dx(dy.view(-1, 80), W.view(80, 256))
+    assert float((dx.view(-1, 256).float() - dold.float()).abs().max()) <= 2 ** -7 * float(dref.abs().max())

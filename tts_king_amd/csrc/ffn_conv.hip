@@ -81,6 +81,7 @@ struct WcArgs {
   // conv's input gradient + the mel loss's own gradient, fastspeech2.py:104).
   int cin_valid;
   const float* resid32;
+  bf16_t* out16;        // fp32 output only: a bf16 copy of the rows as well, or null (mel_linear: the mel for the loss + the PostNet's input)
 #ifdef TTSK_STAMPS
   unsigned long long* stamps;   // diagnostic build only (make stamps; ttsk_win_conv_set_stamps): 24 slots per workgroup
 #endif
@@ -452,6 +453,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
         v.w = pack_bf2(__uint_as_float(v.w << 16) + r1[2], __uint_as_float(v.w & 0xFFFF0000u) + r1[3]);
       }
       *(uint4*)(ob + (int64_t)t * a.Cout * ESZ + ch * 16) = v;
+      if (OUT32 && a.out16)
+        *(uint2*)(a.out16 + ((int64_t)bi * S + t) * a.Cout + cg * COUT + ch * 4) =
+            make_uint2(pack_bf2(__uint_as_float(v.x), __uint_as_float(v.y)), pack_bf2(__uint_as_float(v.z), __uint_as_float(v.w)));
       if (!OUT32 && a.delta) {
         const float* op = a.o32 + ((int64_t)bi * S + t) * a.Cout + cg * COUT + ch * 8;
         const f32x4 y0 = *(const f32x4*)op, y1 = *(const f32x4*)(op + 4);
@@ -545,6 +549,13 @@ int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int pa
     else hipLaunchKernelGGL((win_conv_kernel<512, 128, false, true, WC_NW, WC_CT, true>), gu, dim3(WC_NT), 0, s, a);
     return 0;
   }
+  if (Cin == 256 && a.Cout == 80) {      // mel_linear (256 -> 80, k = 1): five waves of 16 channels over 64-frame tiles
+    a.tiles_per_utt = (S + 63) / 64;
+    const dim3 g5(a.tiles_per_utt * B * a.nsplit);
+    if (out_f32) hipLaunchKernelGGL((win_conv_kernel<256, 64, true, true, 5, 1>), g5, dim3(320), 0, s, a);
+    else hipLaunchKernelGGL((win_conv_kernel<256, 64, false, true, 5, 1>), g5, dim3(320), 0, s, a);
+    return 0;
+  }
   if (Cin == 80) {           // the PostNet's first conv (80 -> 512) / its last conv's input gradient: contraction padded to 96 channels
     a.cin_valid = 80;
     if (out_f32) hipLaunchKernelGGL((win_conv_kernel<96, 64, true, true>), grid, dim3(WC_NT), 0, s, a);
@@ -583,7 +594,7 @@ int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int pa
 extern "C" int ttsk_win_conv_supported(int Cin, int Cout, int K) {
   if (!(K >= 1 && K <= 2 * WC_H + 1 && (K & 1) == 1)) return 0;
   if ((Cin == 256 || Cin == 512 || Cin == 80) && Cout > 0 && Cout % WC_COUT == 0) return 1;
-  return Cin == 512 && Cout == 80;          // (the two 80-channel shapes: the PostNet's ends)
+  return (Cin == 512 || Cin == 256) && Cout == 80;          // (80 output channels: the PostNet's last conv / first conv's input gradient; mel_linear)
 }
 extern "C" int ttsk_ffn_conv_supported(int Cin, int Cout, int K) { return Cin == 256 && ttsk_win_conv_supported(Cin, Cout, K); }
 
@@ -650,6 +661,23 @@ extern "C" int ttsk_win_conv_resid(const void* x_bf16, const void* w_packed, con
   WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, nullptr, out_bf16, S, K, Cout, 0, 0, 0, nullptr, 1, Cin, 0, nullptr, nullptr};
   a.resid32 = resid_f32;
   launch_win_conv(a, B, S, Cin, 0, 1, (hipStream_t)stream);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
+// ttsk_win_conv with fp32 output AND a bf16 copy of it (mel_linear: fastspeech2.py:102 — the fp32 mel goes to the loss and is added back
+// behind the PostNet, the bf16 copy is the PostNet's input)
+extern "C" int ttsk_win_conv_dual(const void* x_bf16, const void* w_packed, const float* bias, float* out_f32, void* out_bf16, int B, int S,
+                                  int Cin, int Cout, int K, void* stream) {
+  TTSK_REQUIRE(x_bf16 && w_packed && out_f32 && out_bf16, "ttsk_win_conv_dual: null pointer");
+  TTSK_REQUIRE(B > 0 && S > 0 && B <= 65535, "ttsk_win_conv_dual: bad sizes B=%d S=%d", B, S);
+  TTSK_REQUIRE(ttsk_win_conv_supported(Cin, Cout, K), "ttsk_win_conv_dual: no instance for Cin=%d Cout=%d K=%d", Cin, Cout, K);
+  TTSK_REQUIRE(((((uintptr_t)x_bf16) | ((uintptr_t)w_packed) | ((uintptr_t)bias) | ((uintptr_t)out_f32)) & 15) == 0 && (((uintptr_t)out_bf16) & 7) == 0,
+               "ttsk_win_conv_dual: 16-byte alignment (bf16 copy: 8)");
+  TTSK_REQUIRE((Cout & 3) == 0, "ttsk_win_conv_dual: Cout must be a multiple of 4");
+  WcArgs a{(const bf16_t*)x_bf16, (const bf16_t*)w_packed, bias, out_f32, S, K, Cout, 0, 0, 0, nullptr, 1, Cin, 0, nullptr, nullptr};
+  a.out16 = (bf16_t*)out_bf16;
+  launch_win_conv(a, B, S, Cin, 1, 1, (hipStream_t)stream);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

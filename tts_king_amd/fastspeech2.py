@@ -394,6 +394,8 @@ class FastSpeech2(nn.Module):
         # 32 storage rows nor of 256 storage columns); one small launch of their own behind the optimizer step (refresh_odd_packs)
         odd = [(t, "postnet.convolutions.%d.0.conv.weight" % i, None, tr) for t, i, tr in
                (("pn", 0, False), ("pnT", 0, True), ("pn", 4, False), ("pnT", 4, True))] if self.postnet_ends_win else []
+        if self.postnet_ends_win:            # ... and mel_linear (256 -> 80) both ways
+            odd += [("lin", "mel_linear.weight", None, False), ("linT", "mel_linear.weight", None, True)]
         items = []
         for tag, key, fused_rows, tr in want:
             if key not in self._table:
@@ -772,8 +774,13 @@ class FastSpeech2(nn.Module):
             y, qkv = y if nxt else (y, None)
         # ---- mel_linear (fp32 output + bf16 copy for the PostNet): fastspeech2.py:102
         rows = Bn * T
-        mel16 = torch.empty(rows, self.n_mel, dtype=bf16, device=dev)
-        mel = ops.linear(y, self._w("mel_linear.weight"), self._m("mel_linear.bias"), out_dtype=torch.float32, C2=mel16)
+        pkm = self._w1_packed.get(("lin", "mel_linear.weight")) if (self.window_ffn and self._w1_packed) else None
+        if pkm is not None and y.dtype == bf16:
+            mel, mel16 = ops.win_conv_dual(y.view(Bn, T, d), pkm, self.n_mel, 1, bias=self._m("mel_linear.bias"))      # window kernel, k = 1
+            mel, mel16 = mel.view(rows, self.n_mel), mel16.view(rows, self.n_mel)
+        else:
+            mel16 = torch.empty(rows, self.n_mel, dtype=bf16, device=dev)
+            mel = ops.linear(y, self._w("mel_linear.weight"), self._m("mel_linear.bias"), out_dtype=torch.float32, C2=mel16)
         fl = (frame_limit, T) if (frame_limit is not None and train) else None
         if fl is not None:
             ops.zero_frames_from(mel16, fl)          # the PostNet's first conv sees zero padding past the batch's own length
@@ -1290,7 +1297,11 @@ class FastSpeech2(nn.Module):
         with self._side_work(dmel_tot, ctx.dec_out):
             ops.colsum_into(dmel_tot, self._g("mel_linear.bias"), defer=self._deferred_fin, accumulate=self._acc)
             ops.linear_dw(dmel_tot, ctx.dec_out, self._g("mel_linear.weight"), defer=self._deferred, accumulate=self._acc)
-        dx = ops.linear_dx(dmel_tot, self._w("mel_linear.weight"))
+        pkm = self._w1_packed.get(("linT", "mel_linear.weight")) if (self.window_ffn and self._w1_packed) else None
+        if pkm is not None and dmel_tot.dtype == bf16:
+            dx = ops.win_conv(dmel_tot.view(Bn, T, nm), pkm, d, 1).view(rows, d)      # mel_linear's input gradient: a k = 1 conv on the transposed pack
+        else:
+            dx = ops.linear_dx(dmel_tot, self._w("mel_linear.weight"))
         notify("mel_linear")
         # ---- decoder
         for i in range(self.n_dec - 1, -1, -1):

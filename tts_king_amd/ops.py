@@ -662,6 +662,17 @@ def win_conv_resid(x, packed, resid, Cout, k):
     return out
 
 
+@_family("win_conv", _conv_flops)
+def win_conv_dual(x, packed, Cout, k, bias=None):
+    """fp32 (B,S,Cout) = Conv1d(Cin -> Cout, k)(x) + bias on the window kernel, and its bf16 copy (ttsk_win_conv_dual: mel_linear)."""
+    _dev(x, packed, bias)
+    Bsz, S, Cin = x.shape
+    out = torch.empty(Bsz, S, Cout, dtype=torch.float32, device=x.device)
+    out16 = torch.empty(Bsz, S, Cout, dtype=bf16, device=x.device)
+    check(L.load().ttsk_win_conv_dual(_ptr(x), _ptr(packed), _ptr(bias), _ptr(out), _ptr(out16), Bsz, S, Cin, Cout, k, _stream()), "ttsk_win_conv_dual")
+    return out, out16
+
+
 def win_pack_numel(Cs, k, Ds, transpose):
     """Elements of the fragment-major pack of a (Cs, k, Ds) tap-major weight (win_conv_pack_*): the contraction padded to whole 32-channel k-steps."""
     cout, cin = (Ds, Cs) if transpose else (Cs, Ds)

@@ -181,3 +181,32 @@ def test_mel_linear_on_the_window_kernel(B, S):
     assert float((dx.double().cpu().view(-1, 256) - dref).abs().max()) <= 2 ** -8 * float(dref.abs().max()) + 1e-3
     dold = ops.linear_dx(dy.view(-1, 80), W.view(80, 256))
     assert float((dx.view(-1, 256).float() - dold.float()).abs().max()) <= 2 ** -7 * float(dref.abs().max())
+
+
+def test_traced_step_accounts_every_family(cfg):
+    """bench.py's roofline leg runs a step with ops.GEMM_TRACE set: every launch wrapper's FLOP formula is then evaluated on the
+    wrapper's own arguments.  (Round 5: a wrapper with a new signature behind the shared formula failed there, and only there.)"""
+    from tts_king_amd import ops
+    from tts_king_amd.fastspeech2 import FastSpeech2
+    from tts_king_amd.graph import make_enqueue
+    from tts_king_amd.loss import FastSpeech2Loss
+    from tts_king_amd.optimizer import ScheduledOptim
+    from tts_king_amd.synthetic import make_batch
+    from tts_king_amd.train_step import to_device
+    c = copy.deepcopy(cfg)
+    c.train_config["optimizer"]["grad_acc_step"] = 1
+    batch = to_device(make_batch(3, 40, seed=5, ragged=True), DEV)
+    m = FastSpeech2(c.preprocess_config, c.model_config, 65, device=DEV, seed=3).train()
+    opt = ScheduledOptim(m, c.train_config, c.model_config, 0)
+    enq = make_enqueue(m, opt, c, FastSpeech2Loss(c.preprocess_config, c.model_config))
+    enq(batch)
+    ops.GEMM_TRACE = []
+    try:
+        enq(batch)
+        torch.cuda.synchronize()
+        trace = ops.GEMM_TRACE
+    finally:
+        ops.GEMM_TRACE = None
+    kinds = {t[3] for t in trace}
+    assert "win_conv" in kinds and len(trace) > 50
+    assert all(t[2] >= 0.0 for t in trace)

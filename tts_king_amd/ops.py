@@ -651,7 +651,7 @@ def win_conv_bnb(x, packed, Cout, k, bn_x, mean, rstd, gamma, beta, use_tanh, p=
     return out, stats
 
 
-@_family("win_conv", _conv_flops)
+@_family("win_conv", lambda x, packed, resid, Cout, k: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * Cout * k)
 def win_conv_resid(x, packed, resid, Cout, k):
     """bf16 (B,S,Cout) = Conv1d(Cin -> Cout, k)(x) + resid (fp32 (B,S,Cout)) on the window kernel (ttsk_win_conv_resid): the PostNet's
     first conv's input gradient (512 -> 80 on the transposed pack) + the mel terms' own gradient."""

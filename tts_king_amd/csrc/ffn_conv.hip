@@ -207,8 +207,10 @@ __global__ __launch_bounds__(256) void win_pack_args_kernel(const ItemChunk c) {
 // NWV waves x CTV cout tiles of 16: the workgroup's channel group.  8 x 2 = 256 channels everywhere but on the phoneme side, where a
 // 1,024-row problem is 16 tiles x Cout / 256 = 48-64 workgroups that each stream 1.2 MB of weights through one CU's L2 port (22 us
 // for w_1's 4.8 GFLOP): 4 x 1 = 64 channels there — 192-256 workgroups, 0.3 MB each.
+// (HiFi-GAN's 128 -> 64 upsampler — four waves, 67 KiB of LDS — is held to 256 registers so that TWO workgroups share a CU and one's window
+// load / stores run under the other's taps: with the default bound the compiler took 316 and a CU held one: 46 us per launch.)
 template <int CIN, int TT, bool OUT32, bool PACKED, int NWV = WC_NW, int CTV = WC_CT, bool F16 = false>
-__global__ __launch_bounds__(NWV * 64, 1) void win_conv_kernel(const WcArgs a) {
+__global__ __launch_bounds__(NWV * 64, (F16 && NWV == 4 && CIN == 128) ? 2 : 1) void win_conv_kernel(const WcArgs a) {
   constexpr int COUT = NWV * CTV * 16;
   // a step = one tap x KH k-steps of 32 input channels: 128-channel parts, or the whole (padded) contraction when it is shorter
   constexpr int C = CIN, RS = CIN * 2 + 32, NT = NWV * 64, CH8 = C / 8, KH = CIN % 128 == 0 ? WC_KH : CIN / 32, CT = CTV, NF = TT / 16,

@@ -226,6 +226,13 @@ int ttsk_hifi_upsample8(const void* x16, const void* w_packed, const float* bias
 int ttsk_hifi_upsample_win_supported(int Cin, int Cout, int stride);
 int ttsk_hifi_upsample_win(const void* x16, const void* w_packed, const float* bias_rep, void* out16, int f16, int B, int T, int Cin, int Cout,
                            int stride, void* stream);
+/* The same operator, operands and pack (ttsk_hifi_upsample_win's) for Cin = 256, stride 8 on a kernel that loads a 96-frame window once and
+ * loops over the 8 * Cout / 256 channel groups inside the workgroup, each group's stores in flight under the next group's MFMAs
+ * (hifi/models.py: ups[1], 256 -> 128: one round of 256 workgroups instead of two rounds of 448 window loads).  The bias is the
+ * accumulators' initial value here: results equal ttsk_hifi_upsample_win's to the last fp32 bit before the fp16 rounding. */
+int ttsk_hifi_upsample_loop_supported(int Cin, int Cout, int stride);
+int ttsk_hifi_upsample_loop(const void* x16, const void* w_packed, const float* bias_rep, void* out16, int f16, int B, int T, int Cin, int Cout,
+                            int stride, void* stream);
 
 /* Fused sub-layer tail of an FFT block (reference: fs_two/transformer/SubLayers.py:62-63 and :96-99 + Layers.py:29,32):
  *   out = zero_PAD_rows( LayerNorm( dropout_{p_pre, site_pre}( A[M,K] @ W[D,K]^T + bias ) + res ) ),  D = 256 only.

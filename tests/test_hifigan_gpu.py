@@ -337,6 +337,50 @@ def test_window_upsample8_vs_fp64(Cin, Cout, B, T):
     assert float((gen.float() - out.float()).abs().max()) <= 2e-3 * float(ref.abs().max())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cout,B,T", [(128, 2, 300), (128, 1, 1), (128, 3, 96), (128, 2, 97), (128, 8, 3072), (32, 2, 200), (256, 1, 130)])
+def test_loop_upsample8_vs_fp64_and_window_kernel(Cout, B, T):
+    """ttsk_hifi_upsample_loop (Cin = 256, stride 8: a 96-frame window loaded once, the 8 * Cout / 256 channel groups looped inside the
+    workgroup) vs float64 ConvTranspose1d (hifi/models.py:166-176) — ragged last tiles, T = 1, tile-sized and bench-sized inputs, one to
+    eight channel groups — and vs ttsk_hifi_upsample_win on the same pack: the same products in the same order with the bias added first
+    instead of last, so the fp16 results may differ in the last place only."""
+    from tts_king_amd import ops
+    Cin = 256
+    g = torch.Generator().manual_seed(Cout + T)
+    x = torch.randn(B, T, Cin, generator=g).half()
+    w = (torch.randn(Cin, Cout, 16, generator=g) * (2 * Cin) ** -0.5).half()
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv_transpose1d(x.double().transpose(1, 2), w.double(), bias.double(), stride=8, padding=4).transpose(1, 2)
+    assert ops.hifi_upsample_loop_supported(Cin, Cout, 8, 16) and not ops.hifi_upsample_loop_supported(512, Cout, 8, 16)
+    assert not ops.hifi_upsample_loop_supported(Cin, Cout, 2, 4)
+    wp = ops.pack_conv_weight(w.float().to(DEV), transposed=True, dtype=torch.float16)
+    pack, b8 = ops.hifi_upsample_win_pack(wp, bias.to(DEV), 8)
+    out = ops.hifi_upsample_loop(x.to(DEV), pack, b8, Cout, 8)
+    assert out.shape == (B, 8 * T, Cout) and out.dtype == torch.float16
+    r = rel_rms(out.float().cpu(), ref.float())
+    worst = float((out.float().cpu() - ref.float()).abs().max()) / float(ref.abs().max())
+    print("upsample_loop 256->%d B=%d T=%d: rel-RMS %.4f%%, max %.2e of max |y|" % (Cout, B, T, 100 * r, worst))
+    assert r <= 1e-3 and worst <= 2e-3
+    if ops.hifi_upsample_win_supported(Cin, Cout, 8, 16):
+        win = ops.hifi_upsample_win(x.to(DEV), pack, b8, Cout, 8)
+        d = (win.float() - out.float()).abs()
+        assert float(d.max()) <= 2.0 ** -10 * float(ref.abs().max()) and float((d > 0).float().mean()) <= 0.05      # an fp16 ulp, on few elements
+
+
+@pytest.mark.gpu
+def test_loop_upsample_generator_agrees(cfg):
+    from tts_king_amd.hifi_bench import build_generator
+    gen = build_generator(cfg, DEV)
+    mel = make_mel(2, 40, seed=5).to(DEV)
+    assert gen.loop_upsample
+    a = gen(mel)
+    gen.loop_upsample = False
+    b = gen(mel)
+    r = rel_rms(a.cpu(), b.cpu())
+    print("looped vs one-group-per-workgroup 256 -> 128 upsampler, waveform: rel-RMS %.4f%%" % (100 * r))
+    assert r <= 1e-3
+
+
 def test_window_upsample8_generator_agrees(cfg):
     from tts_king_amd.hifi_bench import build_generator
     gen = build_generator(cfg, DEV)

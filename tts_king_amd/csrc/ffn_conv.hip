@@ -516,6 +516,100 @@ __global__ __launch_bounds__(NWV * 64, (F16 && NWV == 4 && CIN == 128) ? 2 : 1) 
   WC_STAMP(5);
 }
 
+// ---- HiFi-GAN's 256 -> 128 stride-8 upsampler (WcArgs::ups_cout's transposed-conv mode, fp16 rows) with the window loaded ONCE per frame
+// tile and the channel groups looped inside the workgroup.  On win_conv_kernel<256, 224, ..> the launch is 448 workgroups (14 tiles x 8
+// utterances x 4 groups of 256 phase-major channels), one per CU in two rounds, each 4.4 us of window load + 1.5 us barrier + 10.8 us of
+// taps + 3.6 us of staging and stores with nothing beside it (tools/debug/ups_stamps.py): 49 us for 11.7 us of MFMAs.  Here a workgroup
+// owns 96 frames (32 tiles x 8 utterances = 256 workgroups: one round), keeps their 98-row window (53 KiB) for all NG groups, stages
+// each group's 96 x 256 outputs in a tile of its own (52 KiB) and leaves its stores in flight under the next group's taps; the weights
+// (all 1 MiB per workgroup, L2 -> registers) go through four register sets, one per step (2 pseudo-taps x 2 halves of the channels),
+// each refilled with the next group's same step right behind its MFMAs.
+template <int CIN, int TT>
+__global__ __launch_bounds__(WC_NT, 1) void ups_loop_kernel(const WcArgs a) {
+  constexpr int RS = CIN * 2 + 32, NT = WC_NT, CH8 = CIN / 8, KH = WC_KH, CT = WC_CT, NF = TT / 16, NP = CIN / (KH * 32), COUT = WC_COUT, NS = 2 * NP;
+  static_assert(NS == 4 && NF <= 8 && TT % 16 == 0, "four steps = four register sets; the activation ring holds NF fragments");
+  constexpr int XROWS = TT + 2, SRS = COUT * 2 + 32;
+  __shared__ __attribute__((aligned(16))) unsigned char XW[XROWS * RS];
+  __shared__ __attribute__((aligned(16))) unsigned char ST[TT * SRS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int S = a.S, NG = a.Cout / COUT;
+  const int bi = blockIdx.x / a.tiles_per_utt, t0 = (blockIdx.x - bi * a.tiles_per_utt) * TT;
+  const bf16_t* __restrict__ xb = a.x + (int64_t)bi * S * CIN;
+  const __amdgpu_buffer_rsrc_t wres = weights_rsrc(a.w, 2 * (CIN / 32) * 32 * a.Cout * 2);
+  const int kstep_bytes = (a.Cout / 16) * 1024;
+  bf16x8 w0[KH][CT], w1[KH][CT], w2[KH][CT], w3[KH][CT];
+  auto load_w = [&](int cg, int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {      // step g = pseudo-tap g / NP, channels (g % NP) * 128 ..
+    const int tap = g / NP, part = g - tap * NP;
+    frags_load<KH, CT>(w, wres, (cg * (COUT / 16) + wave * CT) * 1024 + lane * 16, (tap * (CIN / 32) + part * KH) * kstep_bytes, kstep_bytes);
+  };
+  {  // window rows t0 - 1 .. t0 + TT (zeros outside the utterance), then the first group's four steps of weights behind them
+    constexpr int NCH = (XROWS * CH8 + NT - 1) / NT;
+    uint4 xv[NCH];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int idx = it * NT + tid;
+      const int row = idx / CH8, ch = idx - row * CH8;
+      const int t = t0 - 1 + row;
+      xv[it] = make_uint4(0, 0, 0, 0);
+      if (idx < XROWS * CH8 && t >= 0 && t < S) xv[it] = *(const uint4*)(xb + (int64_t)t * CIN + ch * 8);
+    }
+    load_w(0, 0, w0); load_w(0, 1, w1); load_w(0, 2, w2); load_w(0, 3, w3);
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int idx = it * NT + tid;
+      const int row = idx / CH8, ch = idx - row * CH8;
+      if (idx < XROWS * CH8) *(uint4*)(XW + row * RS + ch * 16) = xv[it];
+    }
+  }
+  __syncthreads();
+  const int inl = (l15 + 1) * RS + q * 16;                  // this lane's window position at row shift 0
+  bf16x8 ring[NF];
+  ring_prime<NF, RS>(ring, XW, inl);
+#pragma unroll 1
+  for (int cg = 0; cg < NG; ++cg) {
+    const int shift = (cg * COUT + wave * CT * 16) / a.ups_cout < a.ups_half ? -1 : 1;      // a wave's 32 channels lie in one phase
+    const int nx = cg + 1 < NG ? cg + 1 : cg;                 // (past the last group: its own fragments again, into registers nobody reads — exact wait counts)
+    f32x4 acc[CT][NF];                                        // starts at the bias (fp32 sums: bias + products in any order round the same way only
+#pragma unroll                                                // to the last bit — the stored value is fp16)
+    for (int cc = 0; cc < CT; ++cc) {
+      const f32x4 bv = *(const f32x4*)(a.bias + cg * COUT + (wave * CT + cc) * 16 + q * 4);
+#pragma unroll
+      for (int i = 0; i < NF; ++i) acc[cc][i] = bv;
+    }
+    auto inp_of = [&](int g) __attribute__((always_inline)) {
+      const int tap = g / NP, part = g - tap * NP;
+      return inl + tap * shift * RS + part * (KH * 64);
+    };
+    tap_ring<true, KH, CT, NF, RS>(acc, ring, w0, XW, inp_of(0), inp_of(1));
+    load_w(nx, 0, w0);
+    tap_ring<true, KH, CT, NF, RS>(acc, ring, w1, XW, inp_of(1), inp_of(2));
+    load_w(nx, 1, w1);
+    tap_ring<true, KH, CT, NF, RS>(acc, ring, w2, XW, inp_of(2), inp_of(3));
+    load_w(nx, 2, w2);
+    tap_ring<true, KH, CT, NF, RS>(acc, ring, w3, XW, inp_of(3), inl);      // (every group starts at row shift 0, channels 0 ..)
+    load_w(nx, 3, w3);
+    __syncthreads();          // every thread is past its reads of the previous group's staged tile
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc) {
+        const f32x4 v = acc[cc][i];
+        *(uint2*)(ST + (i * 16 + l15) * SRS + ((wave * CT + cc) * 16 + q * 4) * 2) = make_uint2(pack2<true>(v[0], v[1]), pack2<true>(v[2], v[3]));
+      }
+    __syncthreads();
+    constexpr int OCH = COUT * 2 / 16, NCO = TT * OCH / NT;
+    static_assert(TT * OCH % NT == 0, "whole passes of the store loop");
+    unsigned char* __restrict__ ob = (unsigned char*)a.out + ((int64_t)bi * S * a.Cout + cg * COUT) * 2;
+#pragma unroll
+    for (int it = 0; it < NCO; ++it) {
+      const int idx = it * NT + tid;
+      const int rr = idx / OCH, ch = idx - rr * OCH;
+      if (t0 + rr < S) *(uint4*)(ob + (int64_t)(t0 + rr) * a.Cout * 2 + ch * 16) = *(const uint4*)(ST + rr * SRS + ch * 16);
+    }
+  }
+}
+
 #ifdef TTSK_STAMPS
 static unsigned long long* g_wc_stamps = nullptr;
 // diagnostic build only (`make stamps`, tools/debug/wc_stamps.py; not declared in ttsk.h, not in the product library)
@@ -706,6 +800,27 @@ extern "C" int ttsk_hifi_upsample_win(const void* x16, const void* w_packed, con
   WcArgs a{(const bf16_t*)x16, (const bf16_t*)w_packed, bias_rep, out16, T, 2, stride * Cout, 0, 0, 0, nullptr, 1, Cin, 0, nullptr, nullptr, nullptr, nullptr,
            Cout, stride / 2};
   launch_win_conv(a, B, T, Cin, 0, 1, (hipStream_t)stream, 1);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+// The same operator, operands and pack for Cin = 256 on ups_loop_kernel: a workgroup per 96-frame tile loops over the stride * Cout / 256
+// channel groups (HiFi-GAN's 256 -> 128 stride-8 upsampler: 49 -> see DESIGN.md 7.1).
+extern "C" int ttsk_hifi_upsample_loop_supported(int Cin, int Cout, int stride) {
+  return Cin == 256 && stride == 8 && Cout > 0 && Cout % 32 == 0;      // (8 * Cout is then a multiple of the 256-channel group; a wave's 32 channels lie in one phase)
+}
+extern "C" int ttsk_hifi_upsample_loop(const void* x16, const void* w_packed, const float* bias_rep, void* out16, int f16, int B, int T, int Cin,
+                                       int Cout, int stride, void* stream) {
+  TTSK_REQUIRE(x16 && w_packed && bias_rep && out16, "ttsk_hifi_upsample_loop: null pointer");
+  TTSK_REQUIRE(B > 0 && T > 0 && (int64_t)B * ((T + 95) / 96) < ((int64_t)1 << 31), "ttsk_hifi_upsample_loop: bad sizes B=%d T=%d", B, T);
+  TTSK_REQUIRE(ttsk_hifi_upsample_loop_supported(Cin, Cout, stride), "ttsk_hifi_upsample_loop: no instance for Cin=%d Cout=%d stride=%d", Cin, Cout, stride);
+  TTSK_REQUIRE(f16 == 1, "ttsk_hifi_upsample_loop: built for fp16 rows (HiFi-GAN inference)");
+  TTSK_REQUIRE(((((uintptr_t)x16) | ((uintptr_t)w_packed) | ((uintptr_t)bias_rep) | ((uintptr_t)out16)) & 15) == 0, "ttsk_hifi_upsample_loop: 16-byte alignment");
+  TTSK_REQUIRE((int64_t)B * T * stride * Cout * 2 < ((int64_t)1 << 40), "ttsk_hifi_upsample_loop: sizes out of range");
+  WcArgs a{(const bf16_t*)x16, (const bf16_t*)w_packed, bias_rep, out16, T, 2, stride * Cout, 0, 0, 0, nullptr, 1, Cin, 0, nullptr, nullptr, nullptr, nullptr,
+           Cout, stride / 2};
+  a.B = B;
+  a.tiles_per_utt = (T + 95) / 96;
+  hipLaunchKernelGGL((ups_loop_kernel<256, 96>), dim3(a.tiles_per_utt * B), dim3(WC_NT), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -103,6 +103,7 @@ class Generator(nn.Module):
         self.fused = True            # fused ResBlock1 kernel where an instance exists (C in {32,64}); False = conv-by-conv
         self.stream_upsample = True  # stride-2 upsamplers (128->64, 64->32) on the streaming kernel; False = polyphase implicit GEMMs
         self.window_upsample = switches.get("TTSK_HIFI_UPS8") != "0"   # stride-8 upsamplers and 128 -> 64 on the window-conv kernel (fp16); 0 = polyphase GEMMs / streaming kernel
+        self.loop_upsample = True         # the 256 -> 128 upsampler on ups_loop_kernel (False: win_conv_kernel, one channel group per workgroup)
         self.group_resblocks = True  # conv m of the three MRF ResBlocks as one grouped launch where they run conv by conv (C = 256)
         self.mrf_fused = True        # the last stage (C = 32: three ResBlock1s + average + LeakyReLU + conv_post + tanh) as ONE launch (csrc/mrf32.hip)
 
@@ -290,7 +291,10 @@ class Generator(nn.Module):
                 ppacks = self._pair_packs(pk, i, nk, rbs, C_out) if want_pair else None
                 if ppacks is not None:
                     if pk["ups8"][i] is not None and al.is_contiguous():
-                        a = ops.hifi_upsample_win(al, pk["ups8"][i][0], pk["ups8"][i][1], C_out, u)
+                        if self.loop_upsample and ops.hifi_upsample_loop_supported(al.shape[2], C_out, u, k):
+                            a = ops.hifi_upsample_loop(al, pk["ups8"][i][0], pk["ups8"][i][1], C_out, u)      # 256 -> 128: channel groups looped per frame tile
+                        else:
+                            a = ops.hifi_upsample_win(al, pk["ups8"][i][0], pk["ups8"][i][1], C_out, u)
                     elif self.stream_upsample and ops.hifi_upsample2_supported(wu.shape[2], wu.shape[1], u, k) and al.is_contiguous():
                         a = ops.hifi_upsample2(al, wu, bu)
                     else:

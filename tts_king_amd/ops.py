@@ -1581,6 +1581,20 @@ def hifi_upsample_win(x, pack, bias_rep, Cout, stride):
     return out
 
 
+def hifi_upsample_loop_supported(Cin, Cout, stride, k):
+    return k == 2 * stride and bool(L.load().ttsk_hifi_upsample_loop_supported(Cin, Cout, stride))
+
+
+def hifi_upsample_loop(x, pack, bias_rep, Cout, stride):
+    """hifi_upsample_win's operator and operands on the kernel that loops over the channel groups per frame tile (Cin = 256, stride 8)."""
+    _dev(x, pack, bias_rep)
+    Bsz, T, Cin = x.shape
+    out = torch.empty(Bsz, stride * T, Cout, dtype=x.dtype, device=x.device)
+    check(L.load().ttsk_hifi_upsample_loop(_ptr(x), _ptr(pack), _ptr(bias_rep), _ptr(out), int(x.dtype == f16), Bsz, T, Cin, Cout, stride,
+                                           _stream()), "ttsk_hifi_upsample_loop")
+    return out
+
+
 def hifi_upsample8(x, pack, bias8, Cout):
     return hifi_upsample_win(x, pack, bias8, Cout, 8)
 

@@ -388,7 +388,11 @@ struct BnTrain {
 
 // mean / rstd of the slab from the partial rows (the row-chunk-0 workgroups also publish them and update the running statistics),
 // then y = tanh?(gamma * xhat + beta) -> dropout -> (+ residual) -> out for the workgroup's rows
-__global__ __launch_bounds__(256) void bn_apply2_kernel(const BnCommon a, const BnTrain t, const float* __restrict__ resid,
+// (Held to 128 registers: the training shape's 848 workgroups then fit the chip's 1,024 slots in ONE round — at the 130-136 the compiler took
+// unbounded, 768 slots left 80 workgroups for a second round of the same length.  RESID: the residual rows' 16 registers only where there
+// is a residual, the PostNet's last layer.)
+template <bool RESID>
+__global__ __launch_bounds__(256, RESID ? 3 : 4) void bn_apply2_kernel(const BnCommon a, const BnTrain t, const float* __restrict__ resid,
                                                         bf16_t* __restrict__ out16, float* __restrict__ out32) {
   __shared__ double tot[BN_TOT];
   __shared__ float ms[128], rs[128];
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const BnCommon a, const 
   const int cl = g.cq * 4, c4 = g.c0 + cl, tprC = a.C >> 2;
   const bool act = g.r_in < g.rpi;
   // the workgroup's (at most four) rows are fetched before the partial rows are summed: one memory latency, not two
-  float v[4][4], rr[4][4];
+  float v[4][4], rr[RESID ? 4 : 1][4];
   bool live[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const BnCommon a, const 
     live[u] = act && r < g.re && bn_live(a.frame_limit, a.seg_len, r);
     if (act) {
       ldx4(a.x, a.x_f32, (int64_t)rc * a.C + c4, v[u]);
-      if (resid) { const f32x4 q = *(const f32x4*)(resid + (int64_t)rc * a.C + c4); rr[u][0] = q[0]; rr[u][1] = q[1]; rr[u][2] = q[2]; rr[u][3] = q[3]; }
+      if constexpr (RESID) { const f32x4 q = *(const f32x4*)(resid + (int64_t)rc * a.C + c4); rr[u][0] = q[0]; rr[u][1] = q[1]; rr[u][2] = q[2]; rr[u][3] = q[3]; }
     }
   }
   f32x4 gm = f32x4{0.f, 0.f, 0.f, 0.f}, bt = gm;
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const BnCommon a, const 
       v[u][2] = k2 ? v[u][2] * scale : 0.f; v[u][3] = k3 ? v[u][3] * scale : 0.f;
       if (a.keep) a.keep[i] = (uint8_t)((int)k0 | ((int)k1 << 1) | ((int)k2 << 2) | ((int)k3 << 3));
     }
-    if (resid) {
+    if constexpr (RESID) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[u][e] += rr[u][e];
     }
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats2_kernel(const BnCommon a, co
 
 // dx = gamma * rstd * (dy − mean(dy) − xhat * mean(dy·xhat)) with the two sums taken from the partial rows; the row-chunk-0
 // workgroups add them to dbeta / dgamma
-__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const BnCommon a, const void* __restrict__ dout, int dout_f32,
+__global__ __launch_bounds__(256, 4) void bn_bwd_apply2_kernel(const BnCommon a, const void* __restrict__ dout, int dout_f32,
                                                             const float* __restrict__ partials, int nblk, bf16_t* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
   __shared__ double tot[BN_TOT];
@@ -669,8 +673,9 @@ extern "C" int ttsk_bn_train_apply(const void* x, int x_is_f32, const float* par
   if (int rc = bn2_check(rows, C)) return rc;
   BnCommon a{x, nullptr, nullptr, gamma, beta, rng, rows, C, use_tanh, p, site, x_is_f32, frame_limit, seg_len > 0 ? seg_len : 1, keep_out};
   BnTrain t{partials, nblk, eps, momentum, mean, rstd, running_mean, running_var, (long long*)num_batches_tracked};
-  hipLaunchKernelGGL(bn_apply2_kernel, dim3(C / bn_slab(C), bn_apply_chunks(rows, C)), dim3(256), 0, (hipStream_t)stream, a, t, resid_f32,
-                     (bf16_t*)out_bf16, out_f32);
+  const dim3 grid(C / bn_slab(C), bn_apply_chunks(rows, C));
+  if (resid_f32) hipLaunchKernelGGL(bn_apply2_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a, t, resid_f32, (bf16_t*)out_bf16, out_f32);
+  else hipLaunchKernelGGL(bn_apply2_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a, t, resid_f32, (bf16_t*)out_bf16, out_f32);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

@@ -148,18 +148,22 @@ struct LnBwdArgs {
 
 // 8 waves per workgroup, one row per wave at a time: the per-row chain (loads -> two wave reductions -> stores) is pure
 // latency, so the rows in flight per CU set the rate (4 waves: 11 us for 6768 x 256; the partial count stays 256 blocks)
+// MJ = D / 256 rounded up to the instance (1: the predictors' 256-channel LayerNorms — 80 registers instead of the 231 the D <= 1024
+// instance carries in per-lane column sums, so that three of these 8-wave workgroups share a CU with whatever runs beside the predictors'
+// backward on the other stream).
 constexpr int LNB_WAVES = 8;
+template <int MJ>
 __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs a) {
-  __shared__ float red[LNB_WAVES][MAXJ * 256];
+  __shared__ float red[LNB_WAVES][MJ * 256];
   __shared__ float redb[LNB_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D = a.D, nj = D >> 8;
   const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
   const bool head = a.dhead != nullptr;
-  float dg[MAXJ][4], db[MAXJ][4], dbias[MAXJ][4], dhw[MAXJ][4];
+  float dg[MJ][4], db[MJ][4], dbias[MJ][4], dhw[MJ][4];
   float dhb = 0.f;
 #pragma unroll
-  for (int j = 0; j < MAXJ; ++j)
+  for (int j = 0; j < MJ; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) dg[j][e] = db[j][e] = dbias[j][e] = dhw[j][e] = 0.f;
 
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs 
   const unsigned site_pre = a.site_pre + grp * a.site_stride, site_post = a.site_post + grp * a.site_stride;
   // the loads of a wave's NEXT row are issued before the two wave reductions of the current one (the per-row chain
   // loads -> reductions -> stores is latency; one row at a time took 12.5 us for 6768 x 256)
-  struct RowIn { uint2 z[MAXJ]; f32x4 d[MAXJ]; float mean, rstd, dh; bool masked; };
+  struct RowIn { uint2 z[MJ]; f32x4 d[MJ]; float mean, rstd, dh; bool masked; };
   auto fetch = [&](int lr, RowIn& r) __attribute__((always_inline)) {
     const int rw = grp * grows + lr;
     r.masked = false;
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs 
     r.mean = a.mean[rw]; r.rstd = a.rstd[rw];
     r.dh = head ? (r.masked ? 0.f : a.dhead[rw]) : 0.f;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j)
+    for (int j = 0; j < MJ; ++j)
       if (j < nj) {
         const int c = j * 256 + lane * 4;
         r.z[j] = *(const uint2*)(a.z + (int64_t)rw * D + c);
@@ -211,11 +215,11 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs 
     if (more) fetch(lrow + rstride, nxt);
     const bool masked = cur.masked;
     const float mean = cur.mean, rstd = cur.rstd, dh = cur.dh;
-    float xh[MAXJ][4], g[MAXJ][4];
+    float xh[MJ][4], g[MJ][4];
     float c1 = 0.f, c2 = 0.f;
     unsigned closed = 0;  // bit j*4+e set: the ReLU that produced z was inactive (relu_in mode)
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
+    for (int j = 0; j < MJ; ++j) {
       if (j < nj) {
         const int c = j * 256 + lane * 4;
         const float zz[4] = {__uint_as_float(cur.z[j].x << 16), __uint_as_float(cur.z[j].x & 0xFFFF0000u),
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs 
     c1 = wave_sum(c1) / D;
     c2 = wave_sum(c2) / D;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
+    for (int j = 0; j < MJ; ++j) {
       if (j < nj) {
         const int c = j * 256 + lane * 4;
         float dzv[4];
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const LnBwdArgs 
   float* P = a.partials + (int64_t)blockIdx.x * (nq * D + (head ? 1 : 0));
   for (int qn = 0; qn < nq; ++qn) {
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j)
+    for (int j = 0; j < MJ; ++j)
       if (j < nj)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -916,8 +920,10 @@ extern "C" int ttsk_layernorm_bwd(const void* dout, const float* dhead, const fl
               (bf16_t*)dz, (bf16_t*)dy, partials, rows, D, seg_len, relu_in, p_pre, p_post, site_pre, site_post, 0, nblk, 0, 0, nullptr, nullptr, 0, 0};
   if (D == 256 && !dhead && !relu_in && p_post == 0.f && dout)
     hipLaunchKernelGGL(ln_bwd256_kernel, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
+  else if (a.D <= 256)
+    hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ln_bwd_kernel<MAXJ>, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }
@@ -938,7 +944,8 @@ extern "C" int ttsk_layernorm_bwd_grouped(const void* dout, const float* dhead, 
   LnBwdArgs a{(const bf16_t*)dout, dhead, head_w, (const bf16_t*)z, mean, rstd, gamma, beta, (const long long*)lens, rng,
               (bf16_t*)dz, (bf16_t*)dy, partials, groups * group_rows, D, seg_len, relu_in, p_pre, p_post, site_pre, site_post,
               group_rows, nblk, (long long)param_stride, site_stride, nullptr, nullptr, 0, 0};
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(groups * nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
+  if (a.D <= 256) hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(groups * nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(ln_bwd_kernel<MAXJ>, dim3(groups * nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }
@@ -959,8 +966,10 @@ extern "C" int ttsk_layernorm_bwd_slabs(const float* slabs, int nsplit, int64_t 
               slabs, (const bf16_t*)R, (long long)slab_stride, nsplit};
   if (D == 256 && !relu_in && p_post == 0.f)
     hipLaunchKernelGGL(ln_bwd256_kernel, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
+  else if (a.D <= 256)
+    hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ln_bwd_kernel<MAXJ>, dim3(nblk), dim3(LNB_WAVES * 64), 0, (hipStream_t)stream, a);
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }

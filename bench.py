@@ -591,8 +591,7 @@ def main():
             if reducer is not None:
                 reducer.reset()
             model.grads_partial = False
-            model._dw_side_pending = False
-            model._pred_fwd_pending = False
+            model.abort_step()
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):

@@ -579,6 +579,17 @@ int ttsk_fs2_loss(const float* mel, const float* post, const float* mel_target, 
                   const int64_t* dur_target, const int64_t* src_lens, int B, int T, int T_target, int n_mel, int L,
                   float grad_scale, float* dmel_sum, float* dpost, float* dpitch, float* denergy, float* dlogd,
                   float* partials, float* losses, const int32_t* frame_limit, void* stream);
+/* The same loss as three launches (a `partials` buffer per half: each stream writes memory of its own; they may be one buffer), for a step whose variance predictors run on a stream of their own: the
+ * frame-level terms (loss.py:57-77: mel MSE + L1, postnet L1) and dmel_sum / dpost read nothing of the predictors; the phoneme-level terms
+ * (loss.py:79-99) and dpitch / denergy / dlogd nothing of the decoder; ttsk_fs2_loss_finalize turns both sets of partial rows into
+ * losses[8] wherever both are visible.  Same grid and per-thread order as ttsk_fs2_loss: bit-identical losses and gradients. */
+int ttsk_fs2_loss_mel(const float* mel, const float* post, const float* mel_target, const int64_t* mel_lens, int B, int T, int T_target,
+                      int n_mel, float grad_scale, float* dmel_sum, float* dpost, float* partials, const int32_t* frame_limit, void* stream);
+int ttsk_fs2_loss_var(const float* pitch, const float* energy, const float* logd, const float* pitch_target, const float* energy_target,
+                      const int64_t* dur_target, const int64_t* src_lens, int B, int L, float grad_scale, float* dpitch, float* denergy,
+                      float* dlogd, float* partials, void* stream);
+int ttsk_fs2_loss_finalize(const float* partials_mel, const float* partials_var, const int64_t* src_lens, int B, int T, int n_mel,
+                           const int32_t* frame_limit, float* losses, void* stream);
 
 /* ------------------------------------------------------------------------------------------- optimiser
  * reference: train.py:47-54, fs_two/model/optimizer.py:5-53, torch.optim.Adam.

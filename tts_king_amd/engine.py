@@ -161,9 +161,7 @@ class TrainEngine:
                 if self.reducer is not None:
                     self.reducer.reset()
                     del self.reducer.history[n_hist:]       # (the aborted capture's Python may have closed a step that never ran)
-                self.model._ctx = None
-                self.model._dw_side_pending = False
-                self.model._pred_fwd_pending = False
+                self.model.abort_step()
                 self.model.grads_partial = acc
                 torch.cuda.synchronize()
                 self._eager_only.add(key)

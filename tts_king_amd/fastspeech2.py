@@ -194,6 +194,9 @@ class FastSpeech2(nn.Module):
         self.pred_side = switches.get("TTSK_PRED_SIDE")     # "1" both, "f" forward only, "b" backward only, "0" neither
         self._pred_stream = None
         self._pred_fwd_pending = False
+        self._var_on_pred = False           # the loss was taken in two halves (graph.make_enqueue): the variance gradients live on the predictors' stream
+        self._loss_finalize = None          # ... and this makes the loss values, on a stream that has waited for both halves (backward_native)
+        self.split_loss = True              # training steps built by graph.make_enqueue take the loss that way when the predictors have their stream
         # Does the flat gradient buffer hold an unfinished accumulation (micro-steps of a grad_acc_step cycle)?  False after an optimizer
         # update or zero_grad(): the next backward then overwrites instead of accumulating (see backward_native).
         self.grads_partial = False
@@ -671,8 +674,10 @@ class FastSpeech2(nn.Module):
         return dxin
 
     def _forward(self, train, speakers, texts, src_lens, Lp, mel_lens, max_mel_len, e_targets, d_targets, pitches_raw,
-                 p_control, e_control, d_control, frame_limit=None, phoneme_limit=None):
-        """`phoneme_limit` (device int64[B], every entry = the batch's own longest text, training only): phoneme positions beyond it
+                 p_control, e_control, d_control, frame_limit=None, phoneme_limit=None, defer_pred_join=False):
+        """`defer_pred_join` (training): leave the predictors' stream un-joined (`_pred_fwd_pending` stays set) — for a caller that takes the
+        loss in two halves (ops.fs2_loss_split: the frame-level half needs nothing of the predictors) and joins that stream itself.
+        `phoneme_limit` (device int64[B], every entry = the batch's own longest text, training only): phoneme positions beyond it
         exist only because the batch was padded to a shape bucket; the predictors treat them as the zero padding the reference's
         batch has there.  `frame_limit` (device int32[1], training only): the batch was padded to a shape bucket (tts_king_amd/engine.py);
         frames t >= frame_limit[0] of every utterance do not exist in the reference's batch — the PostNet's BatchNorm statistics,
@@ -822,7 +827,7 @@ class FastSpeech2(nn.Module):
             pn.append((pp, xin, yc, mean, rstd, keep))
             xin = nxt.view(Bn, T, C) if not last else nxt
         post = xin
-        if self._pred_fwd_pending:
+        if self._pred_fwd_pending and not defer_pred_join:
             torch.cuda.current_stream().wait_stream(self._pred_stream)
             self._pred_fwd_pending = False
         if train:
@@ -1107,6 +1112,18 @@ class FastSpeech2(nn.Module):
             ops.conv1d_dw(dh1.view(Bn, Lp, Fh), x.view(Bn, Lp, d), self._g(c + "conv1d_1.conv.weight"), k=self.k_var, defer=self._deferred, accumulate=self._acc)
         return ops.conv1d_dx(dh1.view(Bn, Lp, Fh), self._w(c + "conv1d_1.conv.weight"), R=R)
 
+    def _finalize_loss(self):
+        if self._loss_finalize is not None:
+            fin, self._loss_finalize = self._loss_finalize, None
+            fin()
+
+    def abort_step(self):
+        """Forget the stream bookkeeping of a step whose Python ran only in part (a hipGraph capture of it was aborted)."""
+        self._ctx = None
+        self._dw_side_pending = False
+        self._pred_fwd_pending = False
+        self._var_on_pred, self._loss_finalize = False, None
+
     def backward_group_order(self):
         """The parameter groups in the order backward_native completes their gradients (= reverse forward order; the flat
         gradient buffer is laid out in forward order, so everything at or above a finished group's offset is final)."""
@@ -1187,6 +1204,7 @@ class FastSpeech2(nn.Module):
                 ops.stamp("fin.dwgemm")
             ops.flush_finalize(self._deferred_fin)
             ops.stamp("fin.colsum")
+            self._finalize_loss()       # the two-stream loss's values: behind the column sums, on the branch of the final phase that ends first
             cur.wait_stream(self._dw_side)
             if getattr(self, "_fin_pending", False):
                 cur.wait_stream(self._fin_side)
@@ -1250,9 +1268,14 @@ class FastSpeech2(nn.Module):
                 and self.group_param_grads):
             if self._pred_stream is None:
                 self._pred_stream = torch.cuda.Stream(device=self.device)
-            self._pred_stream.wait_stream(torch.cuda.current_stream())
+            if not self._var_on_pred:             # (the two-stream loss left dlogd / dpitch / denergy ON that stream: nothing of this one is needed)
+                self._pred_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._pred_stream):
                 pred_dxin = self._predictors_bwd_inputs(ctx.preds["grouped"], self._stack3(dlogd, dpitch, denergy), rng)
+        elif self._var_on_pred:                   # the predictors' backward runs on this stream: it needs the two-stream loss's other half
+            torch.cuda.current_stream().wait_stream(self._pred_stream)
+            self._finalize_loss()
+        self._var_on_pred = False
         # ---- PostNet (last layer first)
         dout = dpost.view(rows, nm)
         bn_partials = None          # BatchNorm-backward statistics of layer i, when conv i+1's input-gradient kernel emitted them
@@ -1350,4 +1373,5 @@ class FastSpeech2(nn.Module):
             for name, _, _, _ in self._dp_marks:    # everything is in the buffer now: the remaining buckets, in completion order
                 on_bucket(name)
             self._dp_marks = []
+        self._finalize_loss()       # (a schedule without the second stream: here, where this stream has seen both halves of the loss)
         self._ctx = None

@@ -78,12 +78,27 @@ def make_enqueue(model, optimizer, cfg, Loss, step_is_update=True, reducer=None,
         with torch.no_grad():
             ops.stamp("step.start")
             out, ctx = model._forward(True, batch[2], batch[3], batch[4], int(batch[5]), batch[7], batch[8], batch[9],
-                                      batch[10], batch[11], 1.0, 1.0, 1.0, frame_limit=frame_limit, phoneme_limit=phoneme_limit)
+                                      batch[10], batch[11], 1.0, 1.0, 1.0, frame_limit=frame_limit, phoneme_limit=phoneme_limit,
+                                      defer_pred_join=bool(getattr(model, "split_loss", False)))
             ops.stamp("fwd.done")
             mel, pitch, energy, logd = out[0], out[1], out[2], out[3]
             post = out[8]
-            losses, dmel_sum, dpost, dp, de, dd = ops.fs2_loss(mel, post, batch[6], batch[7], pitch, energy, logd, batch[11],
-                                                               batch[9], batch[10], batch[4], grad_scale=gs, frame_limit=None if frame_limit is None else (frame_limit, 0))
+            lim = None if frame_limit is None else (frame_limit, 0)
+            if model._pred_fwd_pending:
+                # The predictors ran on a stream of their own and nobody has waited for it yet.  The frame-level half of the loss — all the
+                # PostNet's backward needs — goes out on this stream without that wait; the phoneme-level half and the predictors' backward
+                # follow the predictors on THEIR stream at once (backward_native joins it where the variance adaptor's gradients meet);
+                # the loss values are made behind that join, off the chain.  One launch for everything put the loss behind a cross-queue
+                # wait and the PostNet's backward behind another (~10 us each on a replayed graph) plus the finalize kernel.
+                side = model._pred_stream
+                losses, dmel_sum, dpost, dp, de, dd, pending = ops.fs2_loss_split(mel, post, batch[6], batch[7], pitch, energy, logd, batch[11], batch[9],
+                                                                                  batch[10], batch[4], side, grad_scale=gs, frame_limit=lim)
+                model._pred_fwd_pending = False
+                model._var_on_pred = True
+                model._loss_finalize = lambda: ops.fs2_loss_finalize(losses, pending, batch[4])
+            else:
+                losses, dmel_sum, dpost, dp, de, dd = ops.fs2_loss(mel, post, batch[6], batch[7], pitch, energy, logd, batch[11],
+                                                                   batch[9], batch[10], batch[4], grad_scale=gs, frame_limit=lim)
             if reducer is not None and step_is_update:
                 model.backward_native(ctx, dmel_sum, dpost, dp, de, dd, on_bucket=reducer.on_group_done, accumulate=accumulate)
                 reducer.finish()

@@ -1352,6 +1352,41 @@ def fs2_loss(mel, post, mel_t, mel_lens, pitch, energy, logd, pitch_t, energy_t,
     return losses, dmel, dpost, dp, de, dd
 
 
+def fs2_loss_split(mel, post, mel_t, mel_lens, pitch, energy, logd, pitch_t, energy_t, dur_t, src_lens, side, grad_scale=1.0, frame_limit=None):
+    """fs2_loss for a step whose variance predictors ran on stream `side` and nobody has waited for it: the frame-level terms and dmel_sum /
+    dpost on the current stream (which does NOT wait for `side`), the phoneme-level terms and dpitch / denergy / dlogd on `side`, right
+    behind the predictors (they need nothing of this stream).  The eight loss values come from fs2_loss_finalize, on any stream that has
+    waited for both.  Same values, bit for bit, as fs2_loss (include/ttsk.h: ttsk_fs2_loss_mel / _var / _finalize)."""
+    _dev(mel, post, mel_t, mel_lens, pitch, energy, logd, pitch_t, energy_t, dur_t, src_lens)
+    B, T, nm = mel.shape
+    Tt = mel_t.shape[1]
+    Lp = pitch.shape[1]
+    dev = mel.device
+    lib = L.load()
+    dmel, dpost = _f32(B, T, nm, device=dev), _f32(B, T, nm, device=dev)
+    partials = _f32(lib.ttsk_fs2_loss_nblocks(), 6, device=dev)
+    losses = _f32(8, device=dev)
+    lim = _lim(frame_limit)[0]
+    check(lib.ttsk_fs2_loss_mel(_ptr(mel), _ptr(post), _ptr(mel_t), _ptr(mel_lens), B, T, Tt, nm, grad_scale, _ptr(dmel), _ptr(dpost), _ptr(partials),
+                                lim, _stream()), "ttsk_fs2_loss_mel")
+    with torch.cuda.stream(side):
+        # what `side` writes is allocated under `side`: the allocator hands a stream memory whose earlier users ran on that stream (a buffer of
+        # the current stream's pool may still hold a live activation when `side` — far ahead of it — gets here; so it is in a captured step)
+        dstack = _f32(3, B, Lp, device=dev)
+        dd, dp, de = dstack[0], dstack[1], dstack[2]
+        partials_var = _f32(lib.ttsk_fs2_loss_nblocks(), 6, device=dev)
+        check(lib.ttsk_fs2_loss_var(_ptr(pitch), _ptr(energy), _ptr(logd), _ptr(pitch_t), _ptr(energy_t), _ptr(dur_t), _ptr(src_lens), B, Lp,
+                                    grad_scale, _ptr(dp), _ptr(de), _ptr(dd), _ptr(partials_var), _stream()), "ttsk_fs2_loss_var")
+    return losses, dmel, dpost, dp, de, dd, (partials, partials_var, lim, (B, T, nm))
+
+
+def fs2_loss_finalize(losses, pending, src_lens):
+    """The eight loss values of fs2_loss_split, on the current stream — which must have waited for both halves."""
+    partials, partials_var, lim, (B, T, nm) = pending
+    check(L.load().ttsk_fs2_loss_finalize(_ptr(partials), _ptr(partials_var), _ptr(src_lens), B, T, nm, lim, _ptr(losses), _stream()),
+          "ttsk_fs2_loss_finalize")
+
+
 def optim_state(device, seed=1234, sched_step=0):
     """Device state block (see include/ttsk.h): int64[8] view; fields set here, advanced by kernels."""
     n = L.load().ttsk_optim_state_bytes() // 8

@@ -226,6 +226,12 @@ int ttsk_hifi_upsample8(const void* x16, const void* w_packed, const float* bias
 int ttsk_hifi_upsample_win_supported(int Cin, int Cout, int stride);
 int ttsk_hifi_upsample_win(const void* x16, const void* w_packed, const float* bias_rep, void* out16, int f16, int B, int T, int Cin, int Cout,
                            int stride, void* stream);
+/* HiFi-GAN's conv_pre + the LeakyReLU its only reader applies (hifi/models.py:152,186,188), Conv1d(80 -> Cout, k) on fp16 rows, on the
+ * window-conv kernel (96-channel instance, contraction zero-padded): out16 (B, T, Cout) = lrelu(conv(x16 (B, T, 80)) + bias, slope).
+ * w_packed: ttsk_win_conv_pack_items of the (Cout, k, 80) tap-major weight.  Replaces ttsk_conv1d's implicit GEMM for this layer. */
+int ttsk_hifi_conv_pre_win_supported(int Cin, int Cout, int K);
+int ttsk_hifi_conv_pre_win(const void* x16, const void* w_packed, const float* bias, void* out16, int f16, int B, int T, int Cin, int Cout, int K,
+                           float slope, void* stream);
 /* The same operator, operands and pack (ttsk_hifi_upsample_win's) for Cin = 256, stride 8 on a kernel that loads a 96-frame window once and
  * loops over the 8 * Cout / 256 channel groups inside the workgroup, each group's stores in flight under the next group's MFMAs
  * (hifi/models.py: ups[1], 256 -> 128: one round of 256 workgroups instead of two rounds of 448 window loads).  The bias is the

@@ -338,6 +338,31 @@ def test_window_upsample8_vs_fp64(Cin, Cout, B, T):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,T,k", [(8, 384, 7), (1, 1, 7), (3, 65, 7), (2, 130, 3)])
+def test_conv_pre_on_the_window_kernel_vs_fp64(B, T, k):
+    """ttsk_hifi_conv_pre_win (hifi/models.py:152,186 + the LeakyReLU of :188): Conv1d(80 -> 512, k) with zero padding at both ends of every
+    utterance, the contraction zero-padded to 96 channels, LeakyReLU(0.1) on the way out — vs float64, and vs the implicit GEMM it replaces."""
+    from tts_king_amd import ops
+    g = torch.Generator().manual_seed(T + k)
+    Cin, Cout = 80, 512
+    x = torch.randn(B, T, Cin, generator=g).half()
+    w = (torch.randn(Cout, Cin, k, generator=g) * (k * Cin) ** -0.5)
+    bias = torch.randn(Cout, generator=g)
+    w16 = ops.pack_conv_weight(w.to(DEV), dtype=torch.float16)                                  # (Cout, k, Cin)
+    ref = F.leaky_relu(F.conv1d(x.double().transpose(1, 2), w16.double().cpu().permute(0, 2, 1), bias.double(), padding=k // 2), 0.1).transpose(1, 2)
+    assert ops.hifi_conv_pre_win_supported(Cin, Cout, k) and not ops.hifi_conv_pre_win_supported(Cin, Cout, 11)
+    pack = ops.hifi_conv_pre_win_pack(w16)
+    out = ops.hifi_conv_pre_win(x.to(DEV), pack, bias.to(DEV), Cout, k, 0.1)
+    assert out.shape == (B, T, Cout) and out.dtype == torch.float16
+    r = rel_rms(out.float().cpu(), ref.float())
+    worst = float((out.float().cpu() - ref.float()).abs().max()) / float(ref.abs().max())
+    print("conv_pre window B=%d T=%d k=%d: rel-RMS %.4f%%, max %.2e of max |y|" % (B, T, k, 100 * r, worst))
+    assert r <= 1e-3 and worst <= 2e-3
+    gen = ops.conv1d(x.to(DEV), w16, bias.to(DEV), flags=ops.LRELU_OUT, out_slope=0.1)
+    assert float((gen.float() - out.float()).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("Cout,B,T", [(128, 2, 300), (128, 1, 1), (128, 3, 96), (128, 2, 97), (128, 8, 3072), (32, 2, 200), (256, 1, 130)])
 def test_loop_upsample8_vs_fp64_and_window_kernel(Cout, B, T):
     """ttsk_hifi_upsample_loop (Cin = 256, stride 8: a 96-frame window loaded once, the 8 * Cout / 256 channel groups looped inside the

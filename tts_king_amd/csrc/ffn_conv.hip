@@ -82,6 +82,7 @@ struct WcArgs {
   int cin_valid;
   const float* resid32;
   bf16_t* out16;        // fp32 output only: a bf16 copy of the rows as well, or null (mel_linear: the mel for the loss + the PostNet's input)
+  float lrelu_slope;    // > 0 (and relu == 0): out = max(v, slope * v) — HiFi-GAN's conv_pre, whose only reader is the first upsampler's LeakyReLU
 #ifdef TTSK_STAMPS
   unsigned long long* stamps;   // diagnostic build only (make stamps; ttsk_win_conv_set_stamps): 24 slots per workgroup
 #endif
@@ -398,6 +399,9 @@ __global__ __launch_bounds__(NWV * 64, (F16 && NWV == 4 && CIN == 128) ? 2 : 1) 
       if (a.relu) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (F16 && a.lrelu_slope > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * a.lrelu_slope);
       }
       const int col = (wave * CT + cc) * 16 + q * 4;
       if (OUT32) *(f32x4*)(XW + (i * 16 + l15) * SRS + col * 4) = v;
@@ -633,6 +637,11 @@ int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int pa
     // HiFi-GAN's operand type: the two shapes its stride-8 upsamplers need.  Their contraction is short (2 pseudo-taps x Cin), so a
     // workgroup's time is its prologue, its weight stream (0.26 / 0.52 MB) and its stores: frame tiles twice as tall as the training
     // shapes' (224 / 128 frames) halve the number of times each is paid (stage times at B = 8, T = 384: ups1 82 us on the polyphase GEMMs, 53 at 112 frames, 50 at 224; ups0 70 / 46 / 41).
+    if (Cin == 80) {         // conv_pre (80 -> 512, k = 7): the PostNet's first conv's instance on fp16 rows
+      a.cin_valid = 80;
+      hipLaunchKernelGGL((win_conv_kernel<96, 64, false, true, WC_NW, WC_CT, true>), grid, dim3(WC_NT), 0, s, a);
+      return 0;
+    }
     const int TTU = Cin == 512 ? 128 : 224;
     a.tiles_per_utt = (S + TTU - 1) / TTU;
     if (Cin == 128) {          // the stride-2 upsampler 128 -> 64: 128 phase-major channels = one group of 4 waves x 32
@@ -803,6 +812,27 @@ extern "C" int ttsk_hifi_upsample_win(const void* x16, const void* w_packed, con
   TTSK_CHECK_LAUNCH();
   return TTSK_OK;
 }
+// HiFi-GAN's conv_pre, Conv1d(80 -> Cout, k) + LeakyReLU (hifi/models.py:152,186 and the first F.leaky_relu of :188) on fp16 rows, on the
+// window-conv kernel's 96-channel instance (the contraction zero-padded from 80): x16 (B, T, 80) -> out16 (B, T, Cout) = lrelu(conv + bias).
+// w_packed: ttsk_win_conv_pack_items of the (Cout, k, 80) tap-major weight.  Replaces a 3,072-row implicit GEMM (21 us of launch-bound work).
+extern "C" int ttsk_hifi_conv_pre_win_supported(int Cin, int Cout, int K) {
+  return Cin == 80 && Cout > 0 && Cout % WC_COUT == 0 && K >= 1 && K <= 2 * WC_H + 1 && (K & 1) == 1;
+}
+extern "C" int ttsk_hifi_conv_pre_win(const void* x16, const void* w_packed, const float* bias, void* out16, int f16, int B, int T, int Cin, int Cout,
+                                      int K, float slope, void* stream) {
+  TTSK_REQUIRE(x16 && w_packed && bias && out16, "ttsk_hifi_conv_pre_win: null pointer");
+  TTSK_REQUIRE(B > 0 && T > 0 && B <= 65535, "ttsk_hifi_conv_pre_win: bad sizes B=%d T=%d", B, T);
+  TTSK_REQUIRE(ttsk_hifi_conv_pre_win_supported(Cin, Cout, K), "ttsk_hifi_conv_pre_win: no instance for Cin=%d Cout=%d K=%d", Cin, Cout, K);
+  TTSK_REQUIRE(f16 == 1, "ttsk_hifi_conv_pre_win: built for fp16 rows (HiFi-GAN inference)");
+  TTSK_REQUIRE(slope >= 0.f && slope <= 1.f, "ttsk_hifi_conv_pre_win: slope in [0, 1] (0: no activation)");
+  TTSK_REQUIRE(((((uintptr_t)x16) | ((uintptr_t)w_packed) | ((uintptr_t)bias) | ((uintptr_t)out16)) & 15) == 0, "ttsk_hifi_conv_pre_win: 16-byte alignment");
+  WcArgs a{(const bf16_t*)x16, (const bf16_t*)w_packed, bias, out16, T, K, Cout, 0, 0, 0, nullptr, 1, Cin, 0, nullptr, nullptr};
+  a.lrelu_slope = slope;
+  launch_win_conv(a, B, T, Cin, 0, 1, (hipStream_t)stream, 1);
+  TTSK_CHECK_LAUNCH();
+  return TTSK_OK;
+}
+
 // The same operator, operands and pack for Cin = 256 on ups_loop_kernel: a workgroup per 96-frame tile loops over the stride * Cout / 256
 // channel groups (HiFi-GAN's 256 -> 128 stride-8 upsampler: 49 -> see DESIGN.md 7.1).
 extern "C" int ttsk_hifi_upsample_loop_supported(int Cin, int Cout, int stride) {

@@ -103,6 +103,7 @@ class Generator(nn.Module):
         self.fused = True            # fused ResBlock1 kernel where an instance exists (C in {32,64}); False = conv-by-conv
         self.stream_upsample = True  # stride-2 upsamplers (128->64, 64->32) on the streaming kernel; False = polyphase implicit GEMMs
         self.window_upsample = switches.get("TTSK_HIFI_UPS8") != "0"   # stride-8 upsamplers and 128 -> 64 on the window-conv kernel (fp16); 0 = polyphase GEMMs / streaming kernel
+        self.window_conv_pre = True       # conv_pre on the window-conv kernel (False: the implicit GEMM)
         self.loop_upsample = True         # the 256 -> 128 upsampler on ups_loop_kernel (False: win_conv_kernel, one channel group per workgroup)
         self.group_resblocks = True  # conv m of the three MRF ResBlocks as one grouped launch where they run conv by conv (C = 256)
         self.mrf_fused = True        # the last stage (C = 32: three ResBlock1s + average + LeakyReLU + conv_post + tanh) as ONE launch (csrc/mrf32.hip)
@@ -147,6 +148,9 @@ class Generator(nn.Module):
             return self._packed
         pk = {}
         pk["pre"] = (ops.pack_conv_weight(self.conv_pre.folded_weight(), dtype=dt), self.conv_pre.bias.data)
+        cpre, kpre = pk["pre"][0].shape[0], pk["pre"][0].shape[1]
+        pk["pre_win"] = (ops.hifi_conv_pre_win_pack(pk["pre"][0]) if (self.window_upsample and self.window_conv_pre and dt == torch.float16 and
+                                                                      ops.hifi_conv_pre_win_supported(80, cpre, kpre)) else None)
         pk["ups"] = [(ops.pack_conv_weight(u.folded_weight(), transposed=True, dtype=dt), u.bias.data) for u in self.ups]
         # the stride-8 upsamplers and the 128 -> 64 stride-2 one on the window-conv kernel (fp16 rows): a two-tap conv over the input frames
         # with stride * Cout phase-major channels
@@ -277,7 +281,10 @@ class Generator(nn.Module):
         with torch.no_grad():
             self._mark("start")
             a0 = ops.nct_to_ntc(x.float(), self.act_dtype)                                 # (B, T, 80) 16-bit
-            al = ops.conv1d(a0, pk["pre"][0], pk["pre"][1], flags=ops.LRELU_OUT, out_slope=LRELU_SLOPE)   # lrelu(conv_pre(x))
+            if pk["pre_win"] is not None:
+                al = ops.hifi_conv_pre_win(a0, pk["pre_win"], pk["pre"][1], pk["pre"][0].shape[0], pk["pre"][0].shape[1], LRELU_SLOPE)   # window kernel
+            else:
+                al = ops.conv1d(a0, pk["pre"][0], pk["pre"][1], flags=ops.LRELU_OUT, out_slope=LRELU_SLOPE)   # lrelu(conv_pre(x))
             for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
                 self._mark("conv_pre" if i == 0 else "mrf%d" % (i - 1))
                 wu, bu = pk["ups"][i]

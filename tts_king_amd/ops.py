@@ -1616,6 +1616,29 @@ def hifi_upsample_win(x, pack, bias_rep, Cout, stride):
     return out
 
 
+def hifi_conv_pre_win_supported(Cin, Cout, k):
+    return bool(L.load().ttsk_hifi_conv_pre_win_supported(Cin, Cout, k))
+
+
+def hifi_conv_pre_win_pack(w16):
+    """(Cout, k, 80) fp16 tap-major weight (pack_conv_weight) -> the window kernel's fragment-major pack (contraction padded to 96)."""
+    _dev(w16)
+    Cout, k, Cin = w16.shape
+    pack = torch.empty(win_pack_numel(Cout, k, Cin, False), dtype=w16.dtype, device=w16.device)
+    win_conv_pack_items([(w16.contiguous(), pack, False)])
+    return pack
+
+
+def hifi_conv_pre_win(x, pack, bias, Cout, k, slope):
+    """lrelu(Conv1d(80 -> Cout, k)(x) + bias, slope) on the window-conv kernel: x (B, T, 80) fp16 -> (B, T, Cout) fp16."""
+    _dev(x, pack, bias)
+    Bsz, T, Cin = x.shape
+    out = torch.empty(Bsz, T, Cout, dtype=x.dtype, device=x.device)
+    check(L.load().ttsk_hifi_conv_pre_win(_ptr(x), _ptr(pack), _ptr(bias), _ptr(out), int(x.dtype == f16), Bsz, T, Cin, Cout, k, slope, _stream()),
+          "ttsk_hifi_conv_pre_win")
+    return out
+
+
 def hifi_upsample_loop_supported(Cin, Cout, stride, k):
     return k == 2 * stride and bool(L.load().ttsk_hifi_upsample_loop_supported(Cin, Cout, stride))
 

@@ -1,5 +1,5 @@
-"""Model attributes A/B'd on the replayed FS2 step, alternated on one box: python tools/debug/attr_ab.py name=value[,name=value] ...
-(each argument one variant beside the default), e.g.  keep_prefill=False   p_enc=0,p_dec=0"""
+"""Model attributes A/B'd on the replayed FS2 step, alternated on one box: python tools/debug/attr_ab.py name=value[;name=value] ...
+(each argument one variant beside the default), e.g.  split_loss=False   'p_enc=0;p_dec=0'   'ops.DWG_TARGET_STEPS=[112]*2'"""
 import copy, os, sys, time
 import torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.getcwd()))
@@ -21,7 +21,11 @@ def build(attrs):
     m = FastSpeech2(cfg.preprocess_config, cfg.model_config, 65, device=dev, seed=1234).train()
     for kv in attrs:
         k, v = kv.split("=")
-        setattr(m, k, eval(v))
+        if k.startswith("ops."):          # a module-level knob of tts_king_amd.ops, in force while THIS variant's graph is captured
+            from tts_king_amd import ops as _ops
+            setattr(_ops, k[4:], eval(v))
+        else:
+            setattr(m, k, eval(v))
     if attrs:
         m._build_packs()                 # (attributes that decide which weight packs exist)
         m.sync_shadow(force=True)
@@ -29,6 +33,10 @@ def build(attrs):
     enq = make_enqueue(m, o, cfg, FastSpeech2Loss(cfg.preprocess_config, cfg.model_config))
     g = GraphedTrainStep(enq, batch, warmup=2)
     g.keepalive = (m, o, enq)          # the graph's kernels point into the model's and the optimizer's buffers
+    for kv in attrs:                   # module-level knobs back to their defaults for the next variant
+        if kv.startswith("ops."):
+            from tts_king_amd import ops as _ops
+            setattr(_ops, kv.split("=")[0][4:], DEFAULTS[kv.split("=")[0][4:]])
     return g
 
 
@@ -43,9 +51,18 @@ def t(g, n=200):
     return 1e3 * (time.perf_counter() - t0) / n
 
 
+from tts_king_amd import ops as _ops0
+DEFAULTS = {k: getattr(_ops0, k) for k in dir(_ops0) if k.isupper()}
 variants = {"default": ()}
 for arg in sys.argv[1:]:
-    variants[arg] = tuple(arg.split(","))
-graphs = {k: build(v) for k, v in variants.items()}
+    variants[arg] = tuple(arg.split(";"))          # (";" between the settings of one variant: values may hold commas)
+# INSTANCES > 1: that many captured graphs per variant (each capture lands its buffers and its queues differently: +-15 us between two
+# instances of the SAME variant), their mean and spread reported
+N = int(os.environ.get("INSTANCES", "1"))
+graphs = {k: [build(v) for _ in range(N)] for k, v in variants.items()}
 for r in range(3):
-    print(" | ".join("%s %.4f ms" % (k, t(g)) for k, g in graphs.items()), flush=True)
+    out = []
+    for k, gs in graphs.items():
+        ts = [t(g) for g in gs]
+        out.append("%s %.4f ms" % (k, sum(ts) / len(ts)) + ("" if N == 1 else " (%s)" % " ".join("%.4f" % x for x in ts)))
+    print(" | ".join(out), flush=True)

@@ -10,7 +10,7 @@ g = torch.Generator().manual_seed(0)
 lib = L.load()
 lib.ttsk_win_conv_set_stamps.argtypes = [C.c_void_p]
 B = 8
-for name, T, Cin, Cout, s, TT, cgw in (("ups0 512->256 s8", 384, 512, 256, 8, 128, 256), ("ups1 256->128 s8", 3072, 256, 128, 8, 224, 256),
+for name, T, Cin, Cout, s, TT, cgw in (("ups0 512->256 s8", 384, 512, 256, 8, 96, 256), ("ups1 256->128 s8", 3072, 256, 128, 8, 224, 256),
                                        ("ups2 128->64 s2", 24576, 128, 64, 2, 224, 128)):
     x = torch.randn(B, T, Cin, generator=g).half().to(DEV)
     Wp = (torch.randn(2 * s, Cout, Cin, generator=g) * 0.02).half().to(DEV)

@@ -642,7 +642,7 @@ int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int pa
       hipLaunchKernelGGL((win_conv_kernel<96, 64, false, true, WC_NW, WC_CT, true>), grid, dim3(WC_NT), 0, s, a);
       return 0;
     }
-    const int TTU = Cin == 512 ? 128 : 224;
+    const int TTU = Cin == 512 ? 96 : 224;      // (512 -> 256: 96-frame tiles are 4 x 8 x 8 = 256 workgroups at 384 frames per utterance — one per CU; 128-frame tiles 192)
     a.tiles_per_utt = (S + TTU - 1) / TTU;
     if (Cin == 128) {          // the stride-2 upsampler 128 -> 64: 128 phase-major channels = one group of 4 waves x 32
       const dim3 g1(a.tiles_per_utt * B * (a.Cout / 128) * a.nsplit);
@@ -651,7 +651,7 @@ int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int pa
     }
     const dim3 gu(a.tiles_per_utt * B * (a.Cout / WC_COUT) * a.nsplit);
     if (Cin == 256) hipLaunchKernelGGL((win_conv_kernel<256, 224, false, true, WC_NW, WC_CT, true>), gu, dim3(WC_NT), 0, s, a);
-    else hipLaunchKernelGGL((win_conv_kernel<512, 128, false, true, WC_NW, WC_CT, true>), gu, dim3(WC_NT), 0, s, a);
+    else hipLaunchKernelGGL((win_conv_kernel<512, 96, false, true, WC_NW, WC_CT, true>), gu, dim3(WC_NT), 0, s, a);
     return 0;
   }
   if (Cin == 256 && a.Cout == 80) {      // mel_linear (256 -> 80, k = 1): five waves of 16 channels over 64-frame tiles

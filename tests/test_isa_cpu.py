@@ -30,3 +30,30 @@ def test_mfma_operands_are_read_ahead(fname):
             assert n >= at_least, (k, n)
             assert behind_lds <= most, "%s: %d of %d MFMAs wait for an LDS read issued just before them (allowed: %d)" % (k, behind_lds, n, most)
             assert behind_vm <= 4, "%s: %d MFMAs behind s_waitcnt vmcnt(0|1): the weight prefetch is gone" % (k, behind_vm)
+
+
+# ---- registers decide the workgroups per CU, and those the ROUNDS of a launch: the kernels whose design rests on a count
+# file -> (substring of the mangled kernel name, most VGPRs, most spilled VGPRs)
+from tools.debug import occupancy      # noqa: E402
+
+REGISTER_BOUNDS = {
+    # 848 workgroups at the training shape need four per CU to run in one round (130-136 registers gave three: a second round for 80)
+    "batchnorm.hip": [("bn_apply2_kernelILb0", 128, 0), ("bn_bwd_apply2_kernel", 128, 4)],
+    # two 4-wave workgroups per CU (the compiler took 316 when left alone); the looped upsampler holds four weight sets without spilling
+    "ffn_conv.hip": [("win_conv_kernelILi128ELi224ELb0ELb1ELi4ELi2ELb1", 256, 0), ("ups_loop_kernelILi256ELi96", 256, 0)],
+    # the predictors' LayerNorm backward beside the PostNet's kernels: two 8-wave workgroups per CU
+    "layernorm.hip": [("ln_bwd_kernelILi1", 128, 0)],
+    # two pair workgroups per CU (convwin.hip: one's window load under the other's taps)
+    "convwin.hip": [("conv_pair_kernelILb1", 256, 0), ("conv_pair_fs_kernelILi64ELi4ELb1", 256, 0)],
+}
+
+
+@pytest.mark.parametrize("fname", sorted(REGISTER_BOUNDS))
+def test_register_counts_keep_the_designed_workgroups_per_cu(fname):
+    rows = {name: (vg, sp) for name, lds, wg, vg, sp, by_v, by_l in occupancy.scan(os.path.join(CSRC, fname))}
+    for sub, most, most_spilled in REGISTER_BOUNDS[fname]:
+        hit = [(k, v) for k, v in rows.items() if sub in k]
+        assert hit, "%s: no kernel matching %s among %s" % (fname, sub, sorted(rows))
+        for k, (vg, sp) in hit:
+            assert vg <= most, "%s: %d registers (the design needs <= %d)" % (k, vg, most)
+            assert sp <= most_spilled, "%s: %d spilled registers (allowed: %d)" % (k, sp, most_spilled)

@@ -38,6 +38,11 @@ def t(g, n=50):
 variants = {"default": ()}
 for arg in sys.argv[1:]:
     variants[arg] = tuple(arg.split(","))
-graphs = {k: build(v) for k, v in variants.items()}
+N = int(os.environ.get("INSTANCES", "1"))          # captured graphs per variant (two instances of one variant differ by several us)
+graphs = {k: [build(v) for _ in range(N)] for k, v in variants.items()}
 for r in range(4):
-    print(" | ".join("%s %.4f ms" % (k, t(g[0])) for k, g in graphs.items()), flush=True)
+    out = []
+    for k, gs in graphs.items():
+        ts = [t(g[0]) for g in gs]
+        out.append("%s %.4f ms" % (k, sum(ts) / len(ts)) + ("" if N == 1 else " (%s)" % " ".join("%.4f" % x for x in ts)))
+    print(" | ".join(out), flush=True)

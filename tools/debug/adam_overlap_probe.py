@@ -15,7 +15,11 @@ from tts_king_amd.optimizer import ScheduledOptim
 from tts_king_amd.synthetic import make_batch
 from tts_king_amd.train_step import to_device
 
-lib = ctypes.CDLL(os.path.join(root, "tools/debug/stream_probe.so"))
+so = os.path.join(root, "tools/debug/stream_probe.so")
+if not os.path.exists(so):          # (built artefacts are not in the history: build it where hipcc is — the container, before gpurun ships the tree)
+    import subprocess
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, os.path.join(root, "tools/debug/stream_probe.hip")], check=True)
+lib = ctypes.CDLL(so)
 lib.probe_launch.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
 dev = "cuda:0"
 cfg = default_config()

@@ -77,3 +77,33 @@ def test_training_with_the_two_stream_loss_ends_where_the_one_launch_loss_ends(c
         assert torch.equal(a, b)
     assert torch.equal(pa, pb)
     assert float(la[0][0]) != float(la[2][0])          # (the steps did train)
+
+
+@pytest.mark.parametrize("pred_side", ["f", "b", "0"])
+def test_every_predictor_stream_setting_takes_the_same_steps(cfg, pred_side):
+    """TTSK_PRED_SIDE = f (the predictors' forward alone on their stream: the two-stream loss is taken and the predictors' backward, on the
+    step's stream, has to wait for its other half), b (no pending stream at the loss: one launch), 0: the same two steps, bit for bit, as
+    the default."""
+    from tts_king_amd.fastspeech2 import FastSpeech2
+    from tts_king_amd.graph import make_enqueue
+    from tts_king_amd.loss import FastSpeech2Loss
+    from tts_king_amd.optimizer import ScheduledOptim
+    from tts_king_amd.synthetic import make_batch
+    from tts_king_amd.train_step import to_device
+    c = copy.deepcopy(cfg)
+    c.train_config["optimizer"]["grad_acc_step"] = 1
+    batch = to_device(make_batch(4, 36, seed=13, ragged=True), DEV)
+    res = []
+    for ps in ("1", pred_side):
+        m = FastSpeech2(c.preprocess_config, c.model_config, 65, device=DEV, seed=9).train()
+        m.pred_side = ps
+        opt = ScheduledOptim(m, c.train_config, c.model_config, 0)
+        enq = make_enqueue(m, opt, c, FastSpeech2Loss(c.preprocess_config, c.model_config))
+        ls = [enq(batch)[0].cpu().clone() for _ in range(2)]
+        torch.cuda.synchronize()
+        assert m._var_on_pred is False and m._loss_finalize is None and not m._pred_fwd_pending
+        res.append((ls, m.flat_buffers()[0].cpu().clone()))
+    (la, pa), (lb, pb) = res
+    for a, b in zip(la, lb):
+        assert torch.equal(a, b)
+    assert torch.equal(pa, pb)

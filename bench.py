@@ -303,6 +303,17 @@ def step_roofline(enqueue, batch, steps=3):
                      "pmc_source": (tr or mb or {}).get("source")})
     rows.sort(key=lambda r: -r["ms_per_step"])
     top = rows[0]
+    # the dominant family launch by launch: its instances by (wrapper, algorithmic GFLOP) — the family figure averages w_1's 32 GFLOP
+    # launches with the 80-channel and phoneme-side ones
+    inst = {}
+    for e0, e1, fl, kind, shape in trace:
+        if _family_of(kind) == top["family"]:
+            d = inst.setdefault((shape[6] if len(shape) > 6 else kind, round(fl / 1e9, 2)), [0.0, 0])
+            d[0] += e0.elapsed_time(e1); d[1] += 1
+    inst_rows = [{"op": k[0], "gflop_per_launch": k[1], "launches": n // steps, "us_per_launch": 1e3 * ms / n,
+                  "tflops": k[1] / (ms / n) if ms > 0 else 0.0,
+                  "frac_of_peak": (k[1] / (ms / n)) / PEAK_MFMA_BF16_TFLOPS if ms > 0 else 0.0} for k, (ms, n) in inst.items()]
+    inst_rows.sort(key=lambda r: -r["us_per_launch"] * r["launches"])
     byfl = max(rows, key=lambda r: r["gflop"])
     tot_ms = sum(r["ms_per_step"] for r in rows)
     tot_gf = sum(r["gflop"] for r in rows)
@@ -318,7 +329,7 @@ def step_roofline(enqueue, batch, steps=3):
            "mfma_busy_frac": top["mfma_busy_frac"],
            "dominant_by_time": {k: top[k] for k in ("family", "launches", "ms_per_step", "gflop", "tflops", "frac_of_peak")},
            "dominant_by_flops": {k: byfl[k] for k in ("family", "launches", "ms_per_step", "gflop", "tflops", "frac_of_peak", "mfma_busy_frac")},
-           "families": rows[:6],
+           "families": rows[:6], "instances": inst_rows[:8],
            "traced": {"launches_per_step": len(trace) // steps, "ms_per_step": tot_ms, "gflop_per_step": tot_gf,
                       "tflops": tot_gf / tot_ms if tot_ms > 0 else 0.0},
            "profile_stale": stale}

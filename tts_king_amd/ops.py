@@ -54,7 +54,7 @@ def _family(kind, flops):
             e0.record()
             out = fn(*a, **kw)
             e1.record()
-            GEMM_TRACE.append((e0, e1, float(flops(*a, **kw)), kind, (0, 0, 0, 1, 1, 0)))
+            GEMM_TRACE.append((e0, e1, float(flops(*a, **kw)), kind, (0, 0, 0, 1, 1, 0, fn.__name__)))      # (last: the wrapper, for bench.py's per-instance rows)
             return out
         return wrapped
     return deco

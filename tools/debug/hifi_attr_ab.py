@@ -7,7 +7,7 @@ from tts_king_amd.config import default_config
 from tts_king_amd.hifi_bench import build_generator
 DEV = "cuda:0"
 cfg = default_config()
-mel = torch.randn(8, 80, 384, device=DEV)
+mel = (torch.randn(8, 80, 384, device=DEV) * 2.0 - 5.0) if os.environ.get("MEL_RANGE", "1") == "1" else torch.randn(8, 80, 384, device=DEV)      # bench.py's input statistics (synthetic.make_mel) by default
 
 
 def build(attrs):

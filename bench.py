@@ -157,7 +157,7 @@ def e2e_synth_leg(cfg, dev, L=64, iters=20, with_cpu=True):
     def graphed():
         post, lens = synth.mel(spk, texts)
         wav = synth.wav(post.transpose(1, 2))
-        return ops.to_int16(wav, scale).cpu(), int(lens[0])
+        return ops.to_host(ops.to_int16(wav, scale)), int(lens[0])      # (as hifiapi.HIFIapi.generate hands the samples over)
 
     def eager():
         with torch.no_grad():
@@ -166,7 +166,7 @@ def e2e_synth_leg(cfg, dev, L=64, iters=20, with_cpu=True):
             T = max(int(total.max().item()), 1)
             _, post, lens, _ = model.eval_back(x3, dur, L, T)
             wav = gen(post.transpose(1, 2).contiguous())
-            return ops.to_int16(wav, scale).cpu(), int(lens[0])
+            return ops.to_host(ops.to_int16(wav, scale)), int(lens[0])
 
     out = {}
     for name, fn in (("hipgraph", graphed), ("eager", eager)):

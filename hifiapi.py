@@ -67,5 +67,5 @@ class HIFIapi:
             mel_specs = mel_specs.to(self.device)
             audio = self._synth.wav(mel_specs.float()) if self._synth is not None else self.model(mel_specs)
             audio = ops.to_int16(audio, float(self.cfg.hifi.MAX_WAV_VALUE))     # scale + truncate toward zero on device
-            audio = audio.cpu().numpy()
+            audio = ops.to_host(audio).numpy()                                     # D2H through a pinned staging buffer
         return audio

@@ -1219,6 +1219,25 @@ def to_int16(x, scale):
     return out
 
 
+_PINNED = {}
+
+
+def to_host(t):
+    """A device tensor on the host, through a pinned staging buffer kept per (shape, dtype) — at most eight of them: the pageable `.cpu()` of
+    a waveform (0.2 MB for one utterance, 1.5 MB for a batch of eight) goes through the driver's own staging and takes 0.1-0.3 ms, a third
+    to a seventh of that from pinned memory.  The caller gets its own copy (the staging buffer is reused by the next call)."""
+    _dev(t)
+    key = (tuple(t.shape), t.dtype)
+    buf = _PINNED.get(key)
+    if buf is None:
+        if len(_PINNED) >= 8:
+            _PINNED.pop(next(iter(_PINNED)))
+        buf = _PINNED[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+    buf.copy_(t, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return buf.clone()
+
+
 # ---------------------------------------------------------------------------------------------------- batch norm
 
 def _lim(frame_limit):

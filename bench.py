@@ -244,6 +244,41 @@ def pmc_mfma_busy(symbol, section="fs2_train_step"):
     return None
 
 
+def profile_family_time(symbol):
+    """Device time per step of the kernels whose symbol contains `symbol`, from the newest committed
+    profiles/r*_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this same bench command, tools/round_profiles.sh).
+    Steps traced = the calls of the once-per-step Adam launch (or the sidecar's `steps`).  The CSV carries no fingerprint of its own:
+    the sidecar profiles/<tag>_bench_kernel_stats.meta.json (tools/install_profiles.py) or, for summaries installed before it existed,
+    the PMC summary of the same round_profiles.sh run (profiles/<tag>_pmc_traffic.json) says which sources it was measured on.
+    None when there is no summary with such kernels."""
+    import csv
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_bench_kernel_stats.csv")), reverse=True):
+        try:
+            rows = list(csv.DictReader(open(f)))
+        except (OSError, ValueError):
+            continue
+        tag = os.path.basename(f)[:-len("_bench_kernel_stats.csv")]
+        meta = {}
+        for side in ("%s_bench_kernel_stats.meta.json" % tag, "%s_pmc_traffic.json" % tag):
+            try:
+                meta = json.load(open(os.path.join(here, "profiles", side)))
+                break
+            except (OSError, ValueError):
+                continue
+        steps = meta.get("steps") or sum(int(r["Calls"]) for r in rows if "adam_pack_kernel" in r["Name"] or "adam_clip_kernel" in r["Name"])
+        hit = [r for r in rows if symbol in r["Name"]]
+        if not hit or not steps:
+            continue
+        calls = sum(int(r["Calls"]) for r in hit)
+        ns = sum(float(r["TotalDurationNs"]) for r in hit)
+        from tts_king_amd.lib import source_fingerprint
+        return {"ms_per_step": ns / steps * 1e-6, "launches_per_step": calls / steps, "avg_launch_us": ns / calls * 1e-3, "steps_traced": steps,
+                "symbols": len(hit), "source": os.path.relpath(f, here), "stale": meta.get("csrc_fingerprint") != source_fingerprint()}
+    return None
+
+
 # kernel families of the train step: trace kind (tts_king_amd/ops.py: GEMM_TRACE entries) -> (family, rocprofv3 symbol substring, source)
 FAMILIES = {"win_conv": ("win_conv_kernel", "tts_king_amd/csrc/ffn_conv.hip"), "win_ln": ("win_ln_kernel", "tts_king_amd/csrc/gemm_ln.hip"),
             "ln_bwd_proj": ("ln_bwd256_proj_kernel", "tts_king_amd/csrc/layernorm.hip"), "flash_attention": ("flash_", "tts_king_amd/csrc/flash_attn.hip"),
@@ -333,8 +368,110 @@ def step_roofline(enqueue, batch, steps=3):
            "traced": {"launches_per_step": len(trace) // steps, "ms_per_step": tot_ms, "gflop_per_step": tot_gf,
                       "tflops": tot_gf / tot_ms if tot_ms > 0 else 0.0},
            "profile_stale": stale}
+    # `achieved` / `frac`: the family's algorithmic FLOPs per step (counted live, above) over its device time per step in the committed
+    # rocprofv3 --stats summary of this bench command, when that summary was measured on these kernel sources; the live HIP-event
+    # brackets (eager launches behind a spin kernel: 3-4 us of event and launch-boundary time per bracket) are reported beside it and
+    # stand in when there is no current summary.
+    rec["achieved_event_brackets"] = rec["achieved"]
+    rec["frac_event_brackets"] = rec["achieved"] / rec["peak"]
+    rec["frac_source"] = "live HIP-event brackets"
+    prof = profile_family_time(FAMILIES[top["family"]][0]) if mfma else None
+    if prof is not None:
+        rec["profile"] = prof
+        rec["profile_stale"] = rec["profile_stale"] or prof["stale"]
+        if not prof["stale"]:
+            rec["achieved"] = top["gflop"] / prof["ms_per_step"]
+            rec["avg_launch_us"] = prof["avg_launch_us"]
+            rec["kernel_ms_per_step"] = prof["ms_per_step"]
+            rec["frac_source"] = "%s: %d symbols, %.1f launches and %.3f ms per step over %d traced steps" % (
+                prof["source"], prof["symbols"], prof["launches_per_step"], prof["ms_per_step"], prof["steps_traced"])
     rec["frac"] = rec["achieved"] / rec["peak"]
     return rec
+
+
+LINE_LIMIT = 6144          # the driver keeps the last 8 KB of stdout: the whole line must fit with room to spare
+
+
+def _sig(x, n=6):
+    """Floats at n significant digits (the line is read by people and a tail-limited parser; the full precision is in the side file)."""
+    if isinstance(x, float):
+        return float("%.*g" % (n, x))
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+def compact_record(rec, full_path=None):
+    """The ONE line bench.py prints: the contract's keys, `config`, `roofline` (dominant family only), `cpu_baseline` and a compact
+    `hifi_gan` (the metric's second half), plus one scalar per auxiliary leg.  Everything else (`roofline.families` / `instances`, the
+    HiFi-GAN stages' byte counts, the auxiliary legs' records) goes to the side file and to stderr.  Sections are dropped from the
+    end of `optional` until the line fits LINE_LIMIT; the headline halves are never dropped."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "mel_frames_per_s_per_gpu", "model_tflops", "step_mfma_roofline_frac", "final_losses", "unknown_switches")
+    out = {k: rec[k] for k in keep if k in rec}
+    h = rec.get("hifi_gan")
+    if h:
+        hk = ("rtf", "ms_per_batch", "device_ms_per_batch", "tflops", "mfma_roofline_frac", "warm_replays", "iters", "int16_d2h_ms",
+              "samples_per_s", "launch", "dtype", "workload", "cpu_baseline")
+        out["hifi_gan"] = {k: h[k] for k in hk if k in h}
+        if h.get("stages"):
+            out["hifi_gan"]["stages"] = {n: {"ms": s["ms"], "mfma_roofline_frac": s["mfma_roofline_frac"],
+                                             **({"hbm_bytes_pmc": s["hbm_bytes_pmc"]} if "hbm_bytes_pmc" in s else {})}
+                                         for n, s in h["stages"].items() if n.startswith("mrf")}
+    r = rec.get("roofline")
+    if r:
+        rk = ("bound", "achieved", "peak", "unit", "frac", "frac_source", "achieved_event_brackets", "frac_event_brackets", "traffic",
+              "traffic_source", "kernel", "family", "launches_per_step", "avg_launch_us", "avg_launch_gflop", "kernel_ms_per_step",
+              "mfma_busy_frac", "profile_stale")
+        out["roofline"] = {k: r[k] for k in rk if k in r}
+        out["roofline"]["families_ms_per_step"] = {f["family"]: f["ms_per_step"] for f in r.get("families", [])}
+    if "cpu_baseline" in rec:
+        out["cpu_baseline"] = rec["cpu_baseline"]
+    aux = {k: rec[k] for k in ("ms_per_step_eager", "ms_per_step_grad_acc4", "ms_per_step_train_loop") if k in rec}
+    dp = rec.get("dp_schedule_1gpu") or {}
+    if dp.get("by_schedule"):
+        aux["dp1_ms_per_step"] = {k: v.get("dp1_reducer_ms_per_step") for k, v in dp["by_schedule"].items()}
+    if rec.get("e2e_synth"):
+        aux["e2e_synth_latency_ms"] = rec["e2e_synth"].get("latency_ms")
+        aux["e2e_synth_cpu_ms"] = (rec["e2e_synth"].get("cpu_baseline") or {}).get("value")
+    if rec.get("mel_extraction"):
+        aux["mel_extraction_ms_per_batch"] = rec["mel_extraction"].get("ms_per_batch")      # (NOT the HiFi-GAN figure: that is hifi_gan.ms_per_batch)
+    if aux:
+        out["aux"] = aux
+    if full_path:
+        out["full_record"] = full_path
+    out = _sig(out)
+    optional = [("aux",), ("hifi_gan", "stages"), ("roofline", "families_ms_per_step"), ("final_losses",), ("roofline", "traffic_source"),
+                ("hifi_gan", "workload")]
+    line = json.dumps(out)
+    while len(line) > LINE_LIMIT and optional:
+        path = optional.pop(0)
+        d = out
+        for k in path[:-1]:
+            d = d.get(k, {})
+        d.pop(path[-1], None)
+        line = json.dumps(out)
+    if len(line) > LINE_LIMIT:
+        raise RuntimeError("bench line is %d bytes (limit %d) after dropping every optional section" % (len(line), LINE_LIMIT))
+    return line
+
+
+def write_full_record(rec):
+    """The long form next to the line: gpurun_out/bench_full.json under the repo (merged back by gpurun), else the temp directory.
+    Returns the path written (relative to the repo when inside it), or None."""
+    import tempfile
+    for d in (os.path.join(ROOT, "gpurun_out"), tempfile.gettempdir()):
+        try:
+            os.makedirs(d, exist_ok=True)
+            f = os.path.join(d, "bench_full.json")
+            with open(f, "w") as fh:
+                json.dump(rec, fh, indent=1)
+            return os.path.relpath(f, ROOT) if f.startswith(ROOT) else f
+        except OSError:
+            continue
+    return None
 
 
 def _time_loop(fn, n, sync=True):
@@ -651,6 +788,7 @@ def main():
                                    "256-d FFT blocks (BASELINE.json configs[1]); full step = fwd+loss+bwd+clip+Adam, dropout on",
                        "global_batch": B * world, "batch_per_gpu": B, "phonemes": L, "T_max": T, "valid_frames_per_gpu": frames,
                        "padded_frames_per_gpu": B * T, "grad_acc_step": 1, "parallelism": "dp%d" % world, "settle_replays": settle,
+                       "untimed_replays_before_timing": {"fs2": settle + args.warmup, "hifi_gan": 20},
                        "launch": ("hipGraph replay" + (" incl. RCCL bucketed all-reduce" if world > 1 else "")) if use_graph
                                  else "eager (+RCCL bucketed all-reduce on a side stream)",
                        # what the collective layer itself saw (a SCALE record can be checked for "RCCL ran with N ranks"): the size of
@@ -697,7 +835,10 @@ def main():
             if rec.get("hifi_gan"):
                 rec["hifi_gan"]["cpu_baseline"] = hifi_cpu_baseline(cfg)
         sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(rec) + "\n").encode())
+        full = write_full_record(rec)
+        sys.stderr.write("bench.py full record (%s):\n%s\n" % (full, json.dumps(rec)))
+        sys.stderr.flush()
+        os.write(real_stdout, (compact_record(rec, full) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

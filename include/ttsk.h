@@ -193,7 +193,8 @@ int ttsk_win_conv_stats_rows(int B, int S);
  * Conv1d(512 -> 80, k 5); their input gradients are the mirrored shapes on transposed packs).  Cin = 80: rows of 80 channels, the
  * window and the pack zero-padded to three 32-channel k-steps (ttsk_win_conv_pack_* pads such a pack itself); Cout = 80: five waves
  * of 16 channels.  ttsk_win_conv / _stats / _bnb accept both.  ttsk_win_conv_resid: bf16 output = conv + resid_f32 [B*S][Cout], the
- * sum rounded once more — conv 0's input gradient + the mel terms' own gradient (fastspeech2.py:104, postnet(output) + output). */
+ * fp32 sum of the accumulators and the residual rounded ONCE (round 6: the residual joins the accumulators before the staging tile is
+ * packed; round 5 added it to the tile's bf16 values and rounded twice) — conv 0's input gradient + the mel terms' own gradient (fastspeech2.py:104, postnet(output) + output). */
 int ttsk_win_conv_resid(const void* x_bf16, const void* w_packed, const float* resid_f32, void* out_bf16, int B, int S, int Cin, int Cout,
                         int K, void* stream);
 /* ttsk_win_conv with fp32 output and a bf16 copy of the same rows (round 5: mel_linear, fastspeech2.py:102, Linear(256 -> 80) as a k = 1

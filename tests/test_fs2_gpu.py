@@ -163,8 +163,10 @@ def test_train_mode_losses_and_gradients(cfg):
     assert r_own <= 0.05, r_own
     assert float(ch_err.max()) <= 0.08, (wc, float(ch_err[wc]))
     # ... the end-to-end figure against the recorded output (printed above: 8-12 % by build) measures the reference PostNet's own
-    # amplification of the 0.78 % mel error, not this implementation; kept only as a sanity bound on gross breakage
-    assert r <= 0.25
+    # amplification of the 0.78 % mel error (15 % on the CPU for a random perturbation of that size), not this implementation.  Its bar is
+    # the measured range plus a margin (0.25 would have let an error of twice the size through); the PostNet's INPUT — the
+    # mel_linear path on the window kernel — has its own direct bar against the golden above (check_mel: rel-RMS <= 1 %, max-abs <= 0.06).
+    assert r <= 0.14, r
     named = dict(m.named_parameters())
     gn = {str(k): float(v) for k, v in zip(g["grad_keys"], g["grad_norms"])}
     med = float(np.median(list(gn.values())))

@@ -25,3 +25,12 @@ for pat, dst in copies.items():
         j["git_head"] = head
         json.dump(j, open(d, "w"), indent=1)
     print("installed", d)
+# the kernel-stats CSV carries no fingerprint of its own: a sidecar says which sources it was measured on (the PMC summary of the same
+# round_profiles.sh run has been checked against the tree above) and how many steps the trace holds (bench.py: profile_family_time)
+import csv
+stats = os.path.join("profiles", "%s_bench_kernel_stats.csv" % tag)
+steps = sum(int(r["Calls"]) for r in csv.DictReader(open(stats)) if "adam_pack_kernel" in r["Name"] or "adam_clip_kernel" in r["Name"])
+json.dump({"csrc_fingerprint": fp, "git_head": head, "steps": steps, "command": "rocprofv3 --kernel-trace --stats -- /usr/bin/python3 bench.py "
+           "--steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-mel --no-e2e --no-hifi --no-extra (tools/round_profiles.sh)"},
+          open(os.path.join("profiles", "%s_bench_kernel_stats.meta.json" % tag), "w"), indent=1)
+print("installed profiles/%s_bench_kernel_stats.meta.json (%d steps)" % (tag, steps))

@@ -404,6 +404,10 @@ __global__ __launch_bounds__(NWV * 64, (F16 && NWV == 4 && CIN == 128) ? 2 : 1) 
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * a.lrelu_slope);
       }
       const int col = (wave * CT + cc) * 16 + q * 4;
+      if (!OUT32 && a.resid32) {        // the fp32 residual joins the accumulators: the sum is rounded ONCE, when it is packed below
+        const int t = t0 + i * 16 + l15;
+        if (t < S) v += *(const f32x4*)(a.resid32 + ((int64_t)bi * S + t) * a.Cout + cg * COUT + col);
+      }
       if (OUT32) *(f32x4*)(XW + (i * 16 + l15) * SRS + col * 4) = v;
       else *(uint2*)(XW + (i * 16 + l15) * SRS + col * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
     }
@@ -449,14 +453,6 @@ __global__ __launch_bounds__(NWV * 64, (F16 && NWV == 4 && CIN == 128) ? 2 : 1) 
           return ((lo - 1u) < 0x7FFFu ? 0xFFFFu : 0u) | ((hi - 1u) < 0x7FFFu ? 0xFFFF0000u : 0u);
         };
         v.x &= keep(g.x); v.y &= keep(g.y); v.z &= keep(g.z); v.w &= keep(g.w);
-      }
-      if (!OUT32 && a.resid32) {          // (the sum is rounded once: the staged bf16 values are exact in fp32)
-        const float* rp = a.resid32 + ((int64_t)bi * S + t) * a.Cout + cg * COUT + ch * 8;
-        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
-        v.x = pack_bf2(__uint_as_float(v.x << 16) + r0[0], __uint_as_float(v.x & 0xFFFF0000u) + r0[1]);
-        v.y = pack_bf2(__uint_as_float(v.y << 16) + r0[2], __uint_as_float(v.y & 0xFFFF0000u) + r0[3]);
-        v.z = pack_bf2(__uint_as_float(v.z << 16) + r1[0], __uint_as_float(v.z & 0xFFFF0000u) + r1[1]);
-        v.w = pack_bf2(__uint_as_float(v.w << 16) + r1[2], __uint_as_float(v.w & 0xFFFF0000u) + r1[3]);
       }
       *(uint4*)(ob + (int64_t)t * a.Cout * ESZ + ch * 16) = v;
       if (OUT32 && a.out16)

@@ -94,6 +94,11 @@ class TrainEngine:
         self._seen = set()
         self._eager_only = set()          # shapes whose capture failed: plain launches from then on
         self._pool = None
+        # collectives inside a replayed graph are invisible to the process group's timeout and to RCCL's watchdog: the host bounds them
+        self.guard = None
+        if reducer is not None and (getattr(reducer, "world", 1) > 1 or getattr(reducer, "force", False)):
+            from .parallel import ReplayGuard
+            self.guard = ReplayGuard()
         self.stats = {"eager": 0, "captured": 0, "replayed": 0}
         from .hostcpu import fit_torch_threads
         fit_torch_threads()       # host-side staging copies on the cores this process is granted, not on every core the host shows
@@ -150,6 +155,8 @@ class TrainEngine:
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()
             host_step = self.optimizer._host_step
+            if self.reducer is not None:
+                self.reducer.trim()        # (no trim inside the capture's finish(): n_hist stays a valid index)
             n_hist = len(self.reducer.history) if self.reducer is not None else 0
             torch.cuda.synchronize()
             try:
@@ -186,10 +193,24 @@ class TrainEngine:
                 g.frame_limit.copy_(fl, non_blocking=True)
             if g.phoneme_limit is not None:
                 g.phoneme_limit.copy_(pl, non_blocking=True)
+        guarded = self.guard is not None and is_update and len(g.collectives) > 0
+        if guarded:
+            self.guard.before_step()       # the replay two back must be done: bounds a captured all-reduce whose peer is gone
         losses, out = g.run(batch)
+        if guarded:
+            self.guard.after_step()
         if self.reducer is not None and is_update:
             self.reducer.history.append(g.collectives)
+            if len(self.reducer.history) > 2 * self.reducer.KEEP:
+                self.reducer.trim()
         self.model.grads_partial = not is_update      # what the replayed step's Python would have left
         if is_update:
             self.optimizer._host_step += 1
         return losses.clone(), out
+
+    def wait(self):
+        """Everything enqueued so far has finished — within the data-path bound when replayed steps with collectives are outstanding
+        (parallel.ReplayGuard; raises CollectiveTimeout), then a plain synchronize.  The trainer calls this before every host read."""
+        if self.guard is not None:
+            self.guard.wait_all()
+        torch.cuda.synchronize()

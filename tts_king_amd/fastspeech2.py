@@ -151,7 +151,7 @@ class FastSpeech2(nn.Module):
         self.adam_packs = True          # the optimizer's Adam launch writes the window kernels' weight packs itself (ttsk_optim_step_packed)
         self.flash_attention = True     # attention without the S x S tensors when d_k = 128 (csrc/flash_attn.hip); False / other head sizes: scores GEMM + softmax + P V GEMM
         self.fused_ln = True            # fc / w_2 + dropout + residual + LayerNorm + PAD zeroing in one kernel when d = 256
-        self.postnet_ends_win = True        # the PostNet's 80 -> 512 / 512 -> 80 convs and their input gradients on the window kernel too (round 5)
+        self._postnet_ends_win = True       # the PostNet's 80 -> 512 / 512 -> 80 convs and their input gradients on the window kernel too (round 5; property below)
         self.bn_stats_in_conv = True        # PostNet 512 -> 512 convs emit their BatchNorm statistics partials
         self.bn_bwd_stats_in_conv = True    # ... and their input-gradient convs the backward's
         self.fused_qkv_tail = True          # a block's last kernel also projects q|k|v for the next block
@@ -358,6 +358,21 @@ class FastSpeech2(nn.Module):
             ops.cast_bf16(self._flat, self._shadow)
             self._shadow_version = self._flat._version
             self.refresh_packed()
+
+    @property
+    def postnet_ends_win(self):
+        return self._postnet_ends_win
+
+    @postnet_ends_win.setter
+    def postnet_ends_win(self, on):
+        """The attribute decides which packs exist, so a change after construction rebuilds them (it was only read in `_build_packs`)."""
+        on = bool(on)
+        if on != self._postnet_ends_win:
+            self._postnet_ends_win = on
+            self._w1_packed = None
+            self._adam_tables = None
+            if self.window_ffn and self._shadow.is_cuda:
+                self._build_packs()
 
     def refresh_packed(self):
         """Rewrite the fragment-major weight copies the window conv kernel reads (csrc/ffn_conv.hip) from the bf16 shadow — one launch

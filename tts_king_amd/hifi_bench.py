@@ -134,4 +134,4 @@ def hifi_rtf(cfg, dev, B=8, T=384, iters=20, warmup=3, use_graph=True, warm_repl
             "rtf": wall / audio_s, "ms_per_batch": 1e3 * wall, "device_ms_per_batch": 1e3 * dev_s, "samples_per_s": samples / wall,
             "audio_seconds_per_batch": audio_s, "tflops": flops / wall / 1e12, "mfma_roofline_frac": flops / wall / 2.5e15,
             "int16_d2h_ms": 1e3 * d2h, "launch": "hipGraph replay" if use_graph else "eager", "dtype": "f16 (fp32 accumulate)",
-            "iters": iters, "stages": stage_rooflines(gen, mel, B, T)}
+            "iters": iters, "warm_replays": max(1, warm_replays) if use_graph else 0, "stages": stage_rooflines(gen, mel, B, T)}

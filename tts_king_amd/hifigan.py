@@ -150,7 +150,7 @@ class Generator(nn.Module):
         pk["pre"] = (ops.pack_conv_weight(self.conv_pre.folded_weight(), dtype=dt), self.conv_pre.bias.data)
         cpre, kpre = pk["pre"][0].shape[0], pk["pre"][0].shape[1]
         pk["pre_win"] = (ops.hifi_conv_pre_win_pack(pk["pre"][0]) if (self.window_upsample and self.window_conv_pre and dt == torch.float16 and
-                                                                      ops.hifi_conv_pre_win_supported(80, cpre, kpre)) else None)
+                                                                      ops.hifi_conv_pre_win_supported(int(pk["pre"][0].shape[2]), cpre, kpre)) else None)
         pk["ups"] = [(ops.pack_conv_weight(u.folded_weight(), transposed=True, dtype=dt), u.bias.data) for u in self.ups]
         # the stride-8 upsamplers and the 128 -> 64 stride-2 one on the window-conv kernel (fp16 rows): a two-tap conv over the input frames
         # with stride * Cout phase-major channels

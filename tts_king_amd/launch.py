@@ -19,7 +19,7 @@ import time
 
 def free_port():
     """A port nobody listens on right now.  (Bind-and-close leaves a window in which another process may take it; spawn_ranks
-    retries the whole job once on another port when rank 0 dies of EADDRINUSE before any rank has produced output.)"""
+    retries the whole job once on another port when rank 0 reports EADDRINUSE before it has produced any output.)"""
     s = socket.socket()
     s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     s.bind(("127.0.0.1", 0))
@@ -77,7 +77,9 @@ def spawn_ranks(n, argv, env=None, timeout=None, n_devices=None, stdout=None):
     """Start `argv` n times (rank r gets RANK=LOCAL_RANK=r), wait for all, write rank 0's stdout to `stdout` (default
     sys.stdout) and return the exit status: 0 only if every rank returned 0.  Ranks other than 0 have their stdout sent to
     stderr (the bench contract is ONE JSON line from rank 0).  If a rank fails the others are terminated (a missing rank would
-    leave them waiting in the rendezvous or in a collective)."""
+    leave them waiting in the rendezvous or in a collective).  The rendezvous port is found by bind-and-close (`free_port`), which
+    leaves a window for another process to take it: when the job fails with rank 0 reporting EADDRINUSE ("Address already in use")
+    on its standard error before it has written anything to standard output, the whole job is started ONCE more on another port."""
     n = int(n)
     have = visible_devices() if n_devices is None else int(n_devices)
     if have < n:
@@ -87,6 +89,43 @@ def spawn_ranks(n, argv, env=None, timeout=None, n_devices=None, stdout=None):
         sys.stderr.write("running under rocprofv3 (GPU already initialised in this process): rank processes cannot be started "
                          "from here; profile with `rocprofv3 ... -- python3 -m torch.distributed.run ...` instead\n")
         return 4
+    t_end = None if timeout is None else time.time() + timeout
+    rc, out0 = 1, b""
+    for attempt in range(2):
+        rc, out0, port_taken = _run_ranks_once(n, argv, env, t_end)
+        if rc == 0 or not port_taken or out0.strip() or rc >= 128 or rc == 124:
+            break
+        if attempt == 0:
+            sys.stderr.write("rendezvous port was taken between its selection and rank 0's bind (EADDRINUSE): starting the job again on another port\n")
+    (stdout or sys.stdout.buffer).write(out0)
+    (stdout or sys.stdout.buffer).flush()
+    return rc
+
+
+_PORT_TAKEN = (b"EADDRINUSE", b"Address already in use", b"address already in use")
+
+
+def _relay_stderr(pipe, seen):
+    """Copy rank 0's standard error through to ours, remembering whether it ever named a taken rendezvous port."""
+    out = getattr(sys.stderr, "buffer", None)
+    tail = b""
+    for chunk in iter(lambda: pipe.read1(65536) if hasattr(pipe, "read1") else pipe.read(65536), b""):
+        if any(m in tail + chunk for m in _PORT_TAKEN):
+            seen.append(True)
+        tail = chunk[-32:]
+        try:
+            if out is not None:
+                out.write(chunk); out.flush()
+            else:
+                sys.stderr.write(chunk.decode(errors="replace")); sys.stderr.flush()
+        except (OSError, ValueError):
+            pass
+    pipe.close()
+
+
+def _run_ranks_once(n, argv, env, t_end):
+    """One attempt of the job on a fresh port: (exit status, rank 0's stdout, did rank 0 report a taken port)."""
+    import threading
     base = dict(os.environ if env is None else env)
     base.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
                  "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
@@ -98,25 +137,27 @@ def spawn_ranks(n, argv, env=None, timeout=None, n_devices=None, stdout=None):
     if threading_main():
         for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
             old[sig] = signal.signal(sig, _raise_terminated)
-    t_end = None if timeout is None else time.time() + timeout
     rc, out0 = 0, b""
+    port_taken, relay = [], None
     try:
         for r in range(n):
             e = dict(base)
             e.update({"RANK": str(r), "LOCAL_RANK": str(r)})
-            procs.append(subprocess.Popen(list(argv), env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None,
-                                          start_new_session=True))
+            procs.append(subprocess.Popen(list(argv), env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                          stderr=subprocess.PIPE if r == 0 else None, start_new_session=True))
+        relay = threading.Thread(target=_relay_stderr, args=(procs[0].stderr, port_taken), daemon=True)
+        relay.start()
         pending = set(range(n))
         while pending:
             for r in sorted(pending):
                 p = procs[r]
                 if r == 0:
-                    # drain rank 0's pipe while waiting so that a large record cannot block it
-                    try:
-                        o, _ = p.communicate(timeout=0.2)
-                        out0 += o or b""
-                    except subprocess.TimeoutExpired:
+                    # drain rank 0's pipe while waiting so that a large record cannot block it (its stderr is drained by the relay)
+                    chunk = _read_available(p.stdout, 0.2)
+                    out0 += chunk
+                    if chunk or p.poll() is None:
                         continue
+                    out0 += p.stdout.read() or b""
                 elif p.poll() is None:
                     continue
                 pending.discard(r)
@@ -143,6 +184,18 @@ def spawn_ranks(n, argv, env=None, timeout=None, n_devices=None, stdout=None):
             except subprocess.TimeoutExpired:
                 _signal_group(p, signal.SIGKILL)
                 p.wait()
-    (stdout or sys.stdout.buffer).write(out0)
-    (stdout or sys.stdout.buffer).flush()
-    return rc
+        if relay is not None:
+            relay.join(timeout=5)
+    return rc, out0, bool(port_taken)
+
+
+def _read_available(pipe, wait_s):
+    """Up to 64 KiB of what `pipe` holds, waiting at most `wait_s` for the first byte; b"" when nothing came (or at end of file)."""
+    import select
+    try:
+        ready, _, _ = select.select([pipe], [], [], wait_s)
+    except (OSError, ValueError):
+        return b""
+    if not ready:
+        return b""
+    return os.read(pipe.fileno(), 65536)

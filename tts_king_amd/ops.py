@@ -6,6 +6,8 @@ PyTorch-ROCm naming) — CPU tensors are rejected, there is no fallback.
 """
 import ctypes as C
 
+import threading
+
 import torch
 
 from . import lib as L
@@ -1220,22 +1222,27 @@ def to_int16(x, scale):
 
 
 _PINNED = {}
+_PINNED_LOCK = threading.Lock()
 
 
 def to_host(t):
-    """A device tensor on the host, through a pinned staging buffer kept per (shape, dtype) — at most eight of them: the pageable `.cpu()` of
-    a waveform (0.2 MB for one utterance, 1.5 MB for a batch of eight) goes through the driver's own staging and takes 0.1-0.3 ms, a third
-    to a seventh of that from pinned memory.  The caller gets its own copy (the staging buffer is reused by the next call)."""
+    """A device tensor on the host, through a pinned staging buffer kept per (device, shape, dtype) — at most eight of them: the pageable
+    `.cpu()` of a waveform (0.2 MB for one utterance, 1.5 MB for a batch of eight) goes through the driver's own staging and takes 0.1-0.3 ms,
+    a third to a seventh of that from pinned memory.  The caller gets its own copy (the staging buffer is reused by the next call).  The copy
+    runs on the current stream of the TENSOR's device and that stream is the one waited for (not the current device's: `HIFIapi(device=
+    "cuda:1")`); lookup, copy and clone happen under one lock, so two threads with same-shaped outputs cannot read each other's samples."""
     _dev(t)
-    key = (tuple(t.shape), t.dtype)
-    buf = _PINNED.get(key)
-    if buf is None:
-        if len(_PINNED) >= 8:
-            _PINNED.pop(next(iter(_PINNED)))
-        buf = _PINNED[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
-    buf.copy_(t, non_blocking=True)
-    torch.cuda.current_stream().synchronize()
-    return buf.clone()
+    key = (t.device.index, tuple(t.shape), t.dtype)
+    with _PINNED_LOCK:
+        buf = _PINNED.get(key)
+        if buf is None:
+            if len(_PINNED) >= 8:
+                _PINNED.pop(next(iter(_PINNED)))
+            buf = _PINNED[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+        with torch.cuda.device(t.device):
+            buf.copy_(t, non_blocking=True)
+            torch.cuda.current_stream(t.device).synchronize()
+        return buf.clone()
 
 
 # ---------------------------------------------------------------------------------------------------- batch norm

@@ -8,6 +8,8 @@ import pytest
 import torch
 import torch.distributed as dist
 
+from tests.conftest import isolated
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -118,6 +120,7 @@ def test_buckets_are_final_when_announced_full_size(cfg, schedule):
         assert bad == 0, "bucket [%d, %d) announced with group %r held %d elements that changed afterwards" % (s, e, name, bad)
 
 
+@isolated
 def test_reducer_step_is_graph_capturable(cfg):
     """The RCCL all-reduces are captured into the step's hipGraph (bench.py replays the data-parallel step too): three
     replays leave exactly the weights of three eager steps."""
@@ -240,6 +243,7 @@ def test_two_virtual_ranks_equal_reference_grad_accumulation(cfg):
     assert worst[0] <= 0.06, worst
 
 
+@isolated
 def test_train_engine_with_reducer_capture_and_fallback(cfg):
     """the trainer's engine (shape buckets, one captured graph per shape) WITH a reducer whose collectives are really
     issued (RCCL communicator of size 1, `force_collectives`): weights after 8 varying-shape steps equal the eager loop's; and a
@@ -304,6 +308,7 @@ def test_train_engine_with_reducer_capture_and_fallback(cfg):
             dist.destroy_process_group()
 
 
+@isolated
 def test_collective_sequence_is_the_same_replayed_refused_or_eager(cfg):
     """ranks deadlock when they issue different sequences of collectives, and each rank decides by itself, shape by
     shape, whether it replays a graph, captures one, or — when a capture is refused — launches eagerly.  Here three engines over a REAL

@@ -508,3 +508,53 @@ def test_fused_last_stage_full_size_and_generator(cfg):
     gen.mrf_fused = False
     b = gen(mel)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("K,dil,B,ln,dt", [(3, 1, 2, 700, torch.float16), (3, 3, 1, 192, torch.float16), (3, 5, 3, 193, torch.bfloat16), (7, 1, 1, 191, torch.float16),
+                                           (7, 3, 2, 1000, torch.float16), (7, 5, 2, 385, torch.bfloat16), (11, 1, 1, 5, torch.float16), (11, 3, 3, 383, torch.float16),
+                                           (11, 5, 2, 1000, torch.float16), (11, 5, 1, 1, torch.bfloat16), (7, 3, 8, 4099, torch.float16), (11, 5, 4, 12288, torch.float16)])
+def test_weights_stationary_pair_is_bit_identical_to_the_pair_kernel(K, dil, B, ln, dt):
+    """ttsk_hifi_conv_pair_ws (round 6, csrc/pairws.hip: persistent workgroups, both convs' weights in registers, c1 of tile s beside c2 of
+    tile s - 1; hifi/models.py:88-95) against ttsk_hifi_conv_pair at C = 64: same roundings and accumulation order, so bit-identical — in all three
+    MRF modes (:190-197), at one tile, ragged tiles, more tiles than workgroups (every workgroup walks several, runs crossing utterances) and with the
+    grid capped to 1, 3 and 7 workgroups (uneven runs); and against fp64 on the same 16-bit operands."""
+    from tts_king_amd import ops
+    C = 64
+    g = torch.Generator().manual_seed(K * 1000 + ln + dil)
+    x = torch.randn(B, ln, C, generator=g).to(dt).to(DEV)
+    w1 = torch.randn(C, C, K, generator=g) * (C * K) ** -0.5
+    w2 = torch.randn(C, C, K, generator=g) * (C * K) ** -0.5
+    b1, b2 = (0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    p1, p2 = ops.pack_resblock_weight(w1.to(DEV), dtype=dt), ops.pack_resblock_weight(w2.to(DEV), dtype=dt)
+    assert ops.hifi_conv_pair_ws_supported(C, K, dil, ln) and not ops.hifi_conv_pair_ws_supported(128, K, dil) and not ops.hifi_conv_pair_ws_supported(C, 5, 1)
+    want = ops.hifi_conv_pair(x, p1, b1, p2, b2, K, dil)
+    for cap in (0, 1, 3, 7):
+        got = ops.hifi_conv_pair(x, p1, b1, p2, b2, K, dil, ws=True, max_wgs=cap)
+        assert torch.equal(got, want), (cap, float((got.float() - want.float()).abs().max()))
+    prev = torch.randn(B, ln, C, generator=g).to(dt).to(DEV)
+    for mode, kw in ((1, {}), (2, dict(scale=1.0 / 3.0, final_slope=0.01))):
+        a, b = prev.clone(), prev.clone()
+        ops.hifi_conv_pair(x, p1, b1, p2, b2, K, dil, out=a, mode=mode, **kw)
+        ops.hifi_conv_pair(x, p1, b1, p2, b2, K, dil, out=b, mode=mode, ws=True, **kw)
+        assert torch.equal(a, b), (mode, float((a.float() - b.float()).abs().max()))
+    if B * ln <= 4000:
+        xl = torch.where(x.float() > 0, x.float(), 0.1 * x.float()).to(dt)
+        xd = xl.double().cpu().transpose(1, 2)
+        t = F.conv1d(xd, w1.to(dt).double(), b1.double().cpu(), dilation=dil, padding=dil * (K - 1) // 2)
+        t = torch.where(t > 0, t, 0.1 * t).to(dt).double()
+        ref = (F.conv1d(t, w2.to(dt).double(), b2.double().cpu(), padding=(K - 1) // 2) + x.double().cpu().transpose(1, 2)).transpose(1, 2)
+        eps = 2.0 ** (-10 if dt == torch.float16 else -7)
+        assert float((want.double().cpu() - ref).abs().max()) <= 4 * eps * float(ref.abs().max())
+
+
+def test_generator_with_and_without_the_weights_stationary_pairs_agrees_bit_for_bit(cfg):
+    """The whole generator with the C = 64 stage's k = 7 / 11 pairs on either kernel: bit-identical waveform (k = 3 moves from the six-conv fused kernel
+    to three pair launches, which round the block's intermediate tensors to 16 bits: that stage is compared within the fused-vs-pairs bar)."""
+    gen = build(cfg, 5)
+    mel = make_mel(2, 40, seed=9).to(DEV)
+    gen.pair_ws = True
+    a = gen(mel)
+    gen.pair_ws = False
+    b = gen(mel)
+    torch.cuda.synchronize()
+    assert rel_rms(a.float().cpu(), b.float().cpu()) <= 2e-3

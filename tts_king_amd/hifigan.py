@@ -100,6 +100,7 @@ class Generator(nn.Module):
         self.window_conv = True      # window-conv kernel at the C = 128 stage; False = implicit-GEMM convs
         self.conv_pair = True        # each (c1, c2) pair of a ResBlock1 as one launch (ttsk_hifi_conv_pair) at C = 128 ...
         self.conv_pair_small = True  # ... and at C = 64 / 32, instead of the six-conv fused kernel
+        self.pair_ws = True          # C = 64: the pairs on the weights-stationary persistent kernel (csrc/pairws.hip, round 6), every kernel size
         self.fused = True            # fused ResBlock1 kernel where an instance exists (C in {32,64}); False = conv-by-conv
         self.stream_upsample = True  # stride-2 upsamplers (128->64, 64->32) on the streaming kernel; False = polyphase implicit GEMMs
         self.window_upsample = switches.get("TTSK_HIFI_UPS8") != "0"   # stride-8 upsamplers and 128 -> 64 on the window-conv kernel (fp16); 0 = polyphase GEMMs / streaming kernel
@@ -212,13 +213,14 @@ class Generator(nn.Module):
             ws, bs = packs[j]
             mode = 0 if j == 0 else (2 if j == nk - 1 else 1)
             fs = nxt_slope if j == nk - 1 else 1.0
-            if rb.k in fused_for:
+            ws_kernel = self.pair_ws and a.is_contiguous() and all(ops.hifi_conv_pair_ws_supported(a.shape[2], rb.k, d, a.shape[1]) for d in rb.dilation)
+            if rb.k in fused_for and not ws_kernel:
                 ops.hifi_resblock1(a, ws, bs, rb.dilation, out, rb.k, mode=mode, scale=1.0 / nk, slope=LRELU_SLOPE, final_slope=fs)
                 continue
             x, nd = a, len(rb.dilation)
             for m, d in enumerate(rb.dilation):
                 kw = dict(out=out, mode=mode, scale=1.0 / nk, final_slope=fs) if m == nd - 1 else {}
-                x = ops.hifi_conv_pair(x, ws[2 * m], bs[2 * m], ws[2 * m + 1], bs[2 * m + 1], rb.k, d, slope=LRELU_SLOPE, **kw)
+                x = ops.hifi_conv_pair(x, ws[2 * m], bs[2 * m], ws[2 * m + 1], bs[2 * m + 1], rb.k, d, slope=LRELU_SLOPE, ws=ws_kernel, **kw)
         return out
 
     def _pair_packs(self, pk, i, nk, rbs, C):

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
     for (int it = 0; it < NCH; ++it) {
       const int idx = it * NT + tid;
       const int row = idx / CH8, ch = idx - row * CH8;
-      if (idx < CP_XROWS * CH8) *(uint4*)(XW + row * RS + ch * 16) = lrelu8<F16>(xv[it], a.slope);
+      if (idx < CP_XROWS * CH8) *(uint4*)(XW + row * RS + ch * 16) = lrelu8_fast<F16>(xv[it], a.slope);
     }
   }
   f32x4 bv1[CT], bv2[CT];
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
     for (int it = 0; it < NCH; ++it) {
       const int idx = it * NT + tid;
       const int row = idx / CH8, ch = idx - row * CH8;
-      if (idx < CP_XROWS * CH8) *(uint4*)(XW + row * RS + ch * 16) = lrelu8<F16>(xv[it], a.slope);
+      if (idx < CP_XROWS * CH8) *(uint4*)(XW + row * RS + ch * 16) = lrelu8_fast<F16>(xv[it], a.slope);
     }
   }
   f32x4 bv1[CT], bv2[CT];
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(NW * 64, (FsGeom<C, NW>::OCC * NW) / 4) void conv_p
     for (int it = 0; it < NCH; ++it) {
       const int idx = it * NT + tid;
       const int row = idx / CH8, ch = idx - row * CH8;
-      if (idx < XROWS * CH8) *(uint4*)(XW + row * RS + ch * 16) = lrelu8<F16>(xv[it], a.slope);
+      if (idx < XROWS * CH8) *(uint4*)(XW + row * RS + ch * 16) = lrelu8_fast<F16>(xv[it], a.slope);
     }
   }
   f32x4 bv1[CT], bv2[CT];
@@ -832,6 +832,7 @@ extern "C" int ttsk_hifi_conv_pair(const void* x16, const void* w1_pack, const f
   TTSK_REQUIRE(B > 0 && len > 0 && B <= 65535 && x16 != out16, "ttsk_hifi_conv_pair: bad sizes / in-place output");
   TTSK_REQUIRE(ttsk_hifi_conv_pair_supported(C, K, dil), "ttsk_hifi_conv_pair: no instance for C=%d K=%d dil=%d", C, K, dil);
   TTSK_REQUIRE(mode >= 0 && mode <= 2 && (final_slope > 0.f || mode != 2), "ttsk_hifi_conv_pair: bad mode / final_slope");
+  TTSK_REQUIRE(slope > 0.f && slope < 1.f, "ttsk_hifi_conv_pair: LeakyReLU slope %g outside (0, 1)", slope);
   TTSK_REQUIRE(((((uintptr_t)x16) | ((uintptr_t)w1_pack) | ((uintptr_t)w2_pack) | ((uintptr_t)bias1) | ((uintptr_t)bias2) | ((uintptr_t)out16)) & 15) == 0,
                "ttsk_hifi_conv_pair: 16-byte alignment");
   PairArgs a{(const bf16_t*)x16, (const bf16_t*)w1_pack, (const bf16_t*)w2_pack, bias1, bias2, (bf16_t*)out16, len, K, dil, slope,

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(M_NT, 1) void mrf32_post_kernel(const MrfArgs a) {
       if (idx < LROWS * CH8) {
         const int pc = (ch ^ swz(row)) * 16;
         *(uint4*)(TL + row * RS + pc) = xv[it];
-        *(uint4*)(XL + row * RS + pc) = lrelu8<F16>(xv[it], slope);
+        *(uint4*)(XL + row * RS + pc) = lrelu8_fast<F16>(xv[it], slope);
       }
     }
   }
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(M_NT, 1) void mrf32_post_kernel(const MrfArgs a) {
                 float x0, x1, x2, x3;
                 unpack2<F16>(x16[c][s].x, x0, x1); unpack2<F16>(x16[c][s].y, x2, x3);
                 xr[c][s] = f32x4{x0, x1, x2, x3};
-                *(uint2*)(XL + own[c] + s * NW * 16 * RS) = make_uint2(lrelu2<F16>(x16[c][s].x, slope), lrelu2<F16>(x16[c][s].y, slope));
+                *(uint2*)(XL + own[c] + s * NW * 16 * RS) = make_uint2(lrelu2_fast<F16>(x16[c][s].x, slope), lrelu2_fast<F16>(x16[c][s].y, slope));
               } else {
                 *(uint2*)(XL + own[c] + s * NW * 16 * RS) = y;          // the activated MRF average: conv_post's input
               }
@@ -334,6 +334,7 @@ extern "C" int ttsk_hifi_mrf32_post(const void* x16, float* out, void* stage_out
                "ttsk_hifi_mrf32_post: built for C = 32, resblock kernel sizes (3, 7, 11), conv_post k = 7 (got C=%d, k=(%d,%d,%d), post %d)", C, k0, k1,
                k2, k_post);
   TTSK_REQUIRE(B > 0 && len > 0 && B <= 65535, "ttsk_hifi_mrf32_post: bad sizes B=%d len=%d", B, len);
+  TTSK_REQUIRE(slope > 0.f && slope < 1.f, "ttsk_hifi_mrf32_post: LeakyReLU slope %g outside (0, 1)", slope);
   MrfArgs a;
   a.x = (const bf16_t*)x16; a.out = out; a.stage_out = (bf16_t*)stage_out16;
   for (int i = 0; i < 18; ++i) {

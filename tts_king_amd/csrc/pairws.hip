@@ -71,27 +71,11 @@ struct WsGeom {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int WS_PAD = 0x7F000000;                     // a buffer offset past every utterance (< 2^30 bytes each): such a load returns 0, such a store is dropped
 
-// LeakyReLU of two packed 16-bit values, bit for bit lrelu2<F16> (x > 0 ? x : round16(float(x) * slope)) for 0 < slope < 1.  fp16: float(x) * slope is ONE
-// v_fma_mix_f32 per element (the conversion rides in the operand), the select is one packed max — x >= slope * x exactly when x >= 0, also after the
-// rounding: 4 VALU instructions per pair instead of 9.  The window pass below runs this 16.5 k times per tile.
-template <bool F16> __device__ __forceinline__ unsigned lrelu2_fast(unsigned w, float sl) {
-  if constexpr (F16) {
-    float lo, hi;
-    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(w), "v"(sl));
-    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(w), "v"(sl));
-    const unsigned p = pack2<true>(lo, hi);
-    unsigned r;
-    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(w), "v"(p));
-    return r;
-  } else {
-    return lrelu2<false>(w, sl);
-  }
-}
-
 template <int K, int D, int MODE, bool F16>
 __global__ __launch_bounds__(512, 2) void pair_ws_kernel(const WsArgs a) {
   using G = WsGeom<K, D>;
-  constexpr int HK = G::HK, RS = WS_RS, XROWS = G::XROWS, NPIECE = G::NPIECE, PPW = G::PPW, PF = G::PF, DR = G::DR, NFR = 2 * K;
+  constexpr int HK = G::HK, RS = WS_RS, XROWS = G::XROWS, NPIECE = G::NPIECE, PPW = G::PPW, DR = G::DR, NFR = 2 * K;
+  constexpr int PF = (K >= 11 && MODE != 0) ? 1 : G::PF;      // (k = 11 with the running sum's rows as well: one frame tile ahead is all the registers allow, and a tile is ~1 us there)
   constexpr bool PRE = K < 11;        // the window pieces' per-lane offsets kept in registers (k = 11: recomputed per tile, the weights need the room)
   __shared__ __attribute__((aligned(16))) unsigned char smem[G::SMEM];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: M0, scalar branches)
@@ -369,6 +353,7 @@ extern "C" int ttsk_hifi_conv_pair_ws(const void* x16, const void* w1_pack, cons
   TTSK_REQUIRE(B > 0 && len > 0 && B <= 65535 && x16 != out16, "ttsk_hifi_conv_pair_ws: bad sizes / in-place output");
   TTSK_REQUIRE(ttsk_hifi_conv_pair_ws_supported(C, K, dil), "ttsk_hifi_conv_pair_ws: no instance for C=%d K=%d dil=%d", C, K, dil);
   TTSK_REQUIRE(mode >= 0 && mode <= 2 && (final_slope > 0.f || mode != 2), "ttsk_hifi_conv_pair_ws: bad mode / final_slope");
+  TTSK_REQUIRE(slope > 0.f && slope < 1.f, "ttsk_hifi_conv_pair_ws: LeakyReLU slope %g outside (0, 1)", slope);
   TTSK_REQUIRE(((((uintptr_t)x16) | ((uintptr_t)w1_pack) | ((uintptr_t)w2_pack) | ((uintptr_t)bias1) | ((uintptr_t)bias2) | ((uintptr_t)out16)) & 15) == 0,
                "ttsk_hifi_conv_pair_ws: 16-byte alignment");
   const int tiles_per_utt = (len + WS_TT - 1) / WS_TT;

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock1_kernel(const RbArgs a) {
       if (idx < LROWS * CH8) {
         const int pc = (ch ^ swz(row)) * 16;
         *(uint4*)(TL + row * RS + pc) = xv[it];
-        *(uint4*)(XL + row * RS + pc) = lrelu8<F16>(xv[it], slope);
+        *(uint4*)(XL + row * RS + pc) = lrelu8_fast<F16>(xv[it], slope);
       }
     }
   }
@@ -350,6 +350,7 @@ extern "C" int ttsk_hifi_resblock1(const void* x16, void* out16, int f16, const 
   TTSK_REQUIRE(x16 && out16 && weights && biases && dilations, "ttsk_hifi_resblock1: null pointer");
   TTSK_REQUIRE(B > 0 && len > 0 && B <= 65535, "ttsk_hifi_resblock1: bad sizes B=%d len=%d", B, len);
   TTSK_REQUIRE(mode >= 0 && mode <= 2, "ttsk_hifi_resblock1: mode");
+  TTSK_REQUIRE(slope > 0.f && slope < 1.f, "ttsk_hifi_resblock1: LeakyReLU slope %g outside (0, 1)", slope);
   TTSK_REQUIRE(dilations[0] >= 1 && dilations[1] >= 1 && dilations[2] >= 1 && dilations[0] + dilations[1] + dilations[2] <= 9 &&
                    dilations[0] <= 5 && dilations[1] <= 5 && dilations[2] <= 5,
                "ttsk_hifi_resblock1: dilations (%d,%d,%d) exceed the tile halo built for (1,3,5)", dilations[0], dilations[1], dilations[2]);

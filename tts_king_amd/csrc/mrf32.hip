@@ -183,8 +183,11 @@ __global__ __launch_bounds__(M_NT, 1) void mrf32_post_kernel(const MrfArgs a) {
   };
 
   // One ResBlock1 (three conv pairs) with kernel size K, as block number rb of the three; gs0 = its first conv's index of the 18.
-  auto block = [&](auto Kc, const int rb) __attribute__((always_inline)) {
+  // `innerc`: the whole tile (halo included) lies inside the utterance, so no position is conv zero padding and the `* okf` of every epilogue is a
+  // multiplication by one: left out (a fifth of the epilogues' VALU instructions, and at C = 32 the epilogues issue as many cycles as the MFMAs)
+  auto block = [&](auto Kc, const int rb, auto innerc) __attribute__((always_inline)) {
     constexpr int K = decltype(Kc)::value, HK = (K - 1) / 2;
+    constexpr bool INNER = decltype(innerc)::value;
     const int gs0 = 6 * rb;
     // the block's outputs are needed on rows [60, 452) (conv_post's reach); conv j's on that range widened by what the later convs
     // consume: rows [S, ROWS - S) after `S += HK * d`.  The k = 11 block starts at 0: it needs the whole tile.
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(M_NT, 1) void mrf32_post_kernel(const MrfArgs a) {
             for (int c = 0; c < NC; ++c) {
               f32x4 v = acc[c][s] + bv[c];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope) * okf;
+              for (int e = 0; e < 4; ++e) v[e] = INNER ? fmaxf(v[e], v[e] * slope) : fmaxf(v[e], v[e] * slope) * okf;
               *(uint2*)(TL + own[c] + s * NW * 16 * RS) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
             }
           }
@@ -238,7 +241,8 @@ __global__ __launch_bounds__(M_NT, 1) void mrf32_post_kernel(const MrfArgs a) {
               const float okf = frame_ok(s);
 #pragma unroll
               for (int c = 0; c < NC; ++c) {
-                f32x4 v = (acc[c][s] + bv[c] + xr[c][s]) * okf;
+                f32x4 v = acc[c][s] + bv[c] + xr[c][s];
+                if (!INNER) v = v * okf;
                 xr[c][s] = v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope);
@@ -254,7 +258,8 @@ __global__ __launch_bounds__(M_NT, 1) void mrf32_post_kernel(const MrfArgs a) {
             const float okf = frame_ok(s);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-              const f32x4 v = (acc[c][s] + bv[c] + xr[c][s]) * okf;
+              f32x4 v = acc[c][s] + bv[c] + xr[c][s];
+              if (!INNER) v = v * okf;
               uint2 y = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
               if (rb > 0) {
                 const unsigned yw[2] = {y.x, y.y}, ow[2] = {ysum[c][s].x, ysum[c][s].y};
@@ -287,9 +292,15 @@ __global__ __launch_bounds__(M_NT, 1) void mrf32_post_kernel(const MrfArgs a) {
       }
     }
   };
-  block(std::integral_constant<int, K0>{}, 0);
-  block(std::integral_constant<int, K1>{}, 1);
-  block(std::integral_constant<int, K2>{}, 2);
+  if (t0 - HP >= 0 && t0 - HP + M_ROWS <= len) {
+    block(std::integral_constant<int, K0>{}, 0, std::true_type{});
+    block(std::integral_constant<int, K1>{}, 1, std::true_type{});
+    block(std::integral_constant<int, K2>{}, 2, std::true_type{});
+  } else {
+    block(std::integral_constant<int, K0>{}, 0, std::false_type{});
+    block(std::integral_constant<int, K1>{}, 1, std::false_type{});
+    block(std::integral_constant<int, K2>{}, 2, std::false_type{});
+  }
 
   // ---- XL rows [60, 452) hold lrelu(mean, 0.01) for frames t0 - 3 .. t0 + 389 (zero outside the utterance): conv_post + tanh, one
   //      output sample per thread, in ttsk_hifi_conv_post's summation order

@@ -11,14 +11,14 @@ def one(pattern):
     if not m: raise SystemExit("missing " + pattern)
     return m[0]
 copies = {
-    "bench.json": "%s_bench.json", "fs2_trace/*kernel_stats.csv": "%s_bench_kernel_stats.csv", "hifi_trace/*kernel_stats.csv": "%s_hifigan_kernel_stats.csv",
+    "bench.json": "%s_bench.json", "bench_line.json": "%s_bench_line.json", "fs2_trace/*kernel_stats.csv": "%s_bench_kernel_stats.csv", "hifi_trace/*kernel_stats.csv": "%s_hifigan_kernel_stats.csv",
     "mfma_util.json": "%s_mfma_util.json", "pmc_traffic.json": "%s_pmc_traffic.json", "pmc_traffic_hifi.json": "%s_pmc_traffic_hifi.json",
-    "step_timeline.txt": "%s_step_timeline.txt", "step_timeline_real.txt": "%s_step_timeline_real.txt",
+    "step_timeline.txt": "%s_step_timeline.txt", "step_timeline_real.txt": "%s_step_timeline_real.txt", "chain_cost.json": "%s_chain_cost.json",
 }
 for pat, dst in copies.items():
     d = os.path.join("profiles", dst % tag)
     shutil.copyfile(one(pat), d)
-    if d.endswith(".json") and "bench.json" not in d:
+    if d.endswith(".json") and "_bench.json" not in d and "_bench_line.json" not in d:
         j = json.load(open(d))
         if j.get("csrc_fingerprint") != fp:
             raise SystemExit("%s was measured on source %s, the tree is %s" % (d, j.get("csrc_fingerprint"), fp))

@@ -3,7 +3,8 @@
 # the FS2 step and of the HiFi-GAN batch, the HBM-traffic PMC passes and the MFMA-utilisation PMC passes.
 # usage (GPU box): bash tools/round_profiles.sh <tag>   -> gpurun_out/round_<tag>/...
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r}; O=$R/gpurun_out/round_$TAG; mkdir -p $O; cd $R; export TMPDIR=/tmp
-timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+timeout 1500 python bench.py > $O/bench_line.json 2> $O/bench.err; echo "bench rc=$?"
+cp gpurun_out/bench_full.json $O/bench.json      # the long form (the line on stdout is the compact one the driver reads)
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fs2_trace -o fs2 -- /usr/bin/python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-mel --no-e2e --no-hifi --no-extra > $O/fs2_trace.log 2>&1; echo "fs2 trace rc=$?"
 T=$(find $O/fs2_trace -name "*kernel_trace.csv" | head -1)
@@ -16,6 +17,8 @@ cd $R
 bash tools/pmc_bench.sh > $O/pmc_bench.log 2>&1; cp gpurun_out/pmc_bench/pmc_traffic.json $O/ 2>/dev/null; echo "pmc traffic rc=$?"
 bash tools/pmc_mfma.sh > $O/pmc_mfma.log 2>&1; cp gpurun_out/pmc_mfma/mfma_util.json $O/ 2>/dev/null; echo "pmc mfma rc=$?"
 bash tools/pmc_hifi.sh > $O/pmc_hifi.log 2>&1; cp gpurun_out/pmc_hifi/pmc_traffic.json $O/pmc_traffic_hifi.json 2>/dev/null; echo "pmc hifi rc=$?"
+bash tools/chain_cost.sh > $O/chain_cost.log 2>&1; cp gpurun_out/chain_cost/chain_cost.json $O/ 2>/dev/null; echo "chain cost rc=$?"
+rm -rf gpurun_out/chain_cost/step gpurun_out/chain_cost/alone gpurun_out/chain_cost/graph
 rm -rf gpurun_out/pmc_hifi/fetch gpurun_out/pmc_hifi/write
 rm -rf gpurun_out/pmc_bench/fetch gpurun_out/pmc_bench/write gpurun_out/pmc_mfma/fs2 gpurun_out/pmc_mfma/hifi
 ls -la $O

@@ -14,7 +14,10 @@ STAGE_MFLOP = {"conv_pre": 0.573, "ups0": 4.194, "ups1": 8.389, "ups2": 4.194, "
                "mrf0": 132.12, "mrf1": 264.24, "mrf2": 132.12, "mrf3": 66.06, "conv_post": 0.115}
 # rocprofv3 symbols of each stage's kernels (profiles/r*_pmc_traffic_hifi.json is keyed by symbol): (substring, launches per forward)
 STAGE_KERNELS = {"mrf0": [("conv_pair256_kernel", 9)], "mrf1": [("conv_pair_kernel", 9)],
-                 "mrf2": [("conv_pair_fs_kernel<64", 6), ("resblock1_kernel<64, 3", 1)],
+                 # round 6: the C = 64 stage is nine launches of the weights-stationary pair kernel <K, dilation, MRF mode> (csrc/pairws.hip)
+                 "mrf2": [("pair_ws_kernel<3, 1, 0", 1), ("pair_ws_kernel<3, 3, 0", 1), ("pair_ws_kernel<3, 5, 0", 1), ("pair_ws_kernel<7, 1, 0", 1),
+                          ("pair_ws_kernel<7, 3, 0", 1), ("pair_ws_kernel<7, 5, 1", 1), ("pair_ws_kernel<11, 1, 0", 1), ("pair_ws_kernel<11, 3, 0", 1),
+                          ("pair_ws_kernel<11, 5, 2", 1)],
                  "mrf3": [("resblock1_kernel<32, 3", 1), ("resblock1_kernel<32, 7", 1), ("resblock1_kernel<32, 11", 1), ("mrf32_post_kernel", 1)],
                  "ups0": [("win_conv_kernel<512, 128", 1)], "ups1": [("win_conv_kernel<256, 224", 1)],
                  "ups2": [("ups2_kernel<128, 64", 1)], "ups3": [("ups2_kernel<64, 32", 1)], "conv_post": [("conv_post_kernel", 1)]}

@@ -552,7 +552,7 @@ def test_generator_with_and_without_the_weights_stationary_pairs_agrees_bit_for_
     to three pair launches, which round the block's intermediate tensors to 16 bits: that stage is compared within the fused-vs-pairs bar)."""
     gen = build(cfg, 5)
     mel = make_mel(2, 40, seed=9).to(DEV)
-    gen.pair_ws = True
+    gen.pair_ws, gen.pair_ws_min_tiles = True, 1          # (the test's stage tensors are far below the size from which the kernel is the default)
     a = gen(mel)
     gen.pair_ws = False
     b = gen(mel)

@@ -7,6 +7,7 @@
 // 256x128x64 step moves 48 KiB per 4.2 MFLOP and both tile configurations are bound by the CU's operand fetch rate,
 // 25-28 % MFMA utilisation).  Here a workgroup loads its frames x channels ONCE and per tap only the weights (fragment-major
 // pack, coalesced).  D[cout][frame] orientation, fragment layouts and padding are those of resblock.hip.
+#include <type_traits>
 #include "common.h"
 #include "tapring.h"
 #include <cstdlib>
@@ -261,14 +262,13 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
   TTSK_STAMP(2);
 
   // ---- c1 over the 112 frames of the t window
+  // (round 6: the accumulators are not zeroed — 104 x 4 v_mov per wave and workgroup, and every VALU instruction costs a quarter of an MFMA here,
+  // DESIGN.md 8.2 — the first tap's first k-step multiplies onto the constant 0 instead: same sums, bit for bit)
   f32x4 acc[CT][NF1];
-#pragma unroll
-  for (int cc = 0; cc < CT; ++cc)
-#pragma unroll
-    for (int i = 0; i < NF1; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   {
     const unsigned char* inl = XW + (l15 + CP_XH - CP_TH) * RS + q * 16;      // t-window row r <-> x-window row r + 25
-    auto tap1 = [&](int g, const bf16x8 (&w)[KS][CT]) __attribute__((always_inline)) {
+    auto tap1 = [&](auto firstc, int g, const bf16x8 (&w)[KS][CT]) __attribute__((always_inline)) {
       const unsigned char* inp = inl + (g - HK) * d * RS;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -276,33 +276,51 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
         for (int i = 0; i < NF1; ++i) {
           const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
 #pragma unroll
-          for (int cc = 0; cc < CT; ++cc) acc[cc][i] = mfma16<F16>(w[ks][cc], Bf, acc[cc][i]);
+          for (int cc = 0; cc < CT; ++cc) acc[cc][i] = mfma16<F16>(w[ks][cc], Bf, (decltype(firstc)::value && ks == 0) ? zero4 : acc[cc][i]);
         }
       }
     };
-    // K is odd: taps 0 .. K-2 in pairs, then tap K-1 on set a (c2 starts on set b)
+    // K is odd and >= 3: taps 0 .. K-2 in pairs (the first pair peeled: its first tap starts the sums), then tap K-1 on set a (c2 starts on set b)
+    tap1(std::true_type{}, 0, wa);
+    load_w(2, wa);
+    tap1(std::false_type{}, 1, wb);
+    load_w(3, wb);
 #pragma unroll 1
-    for (int g = 0; g + 1 < K; g += 2) {
-      tap1(g, wa);
+    for (int g = 2; g + 1 < K; g += 2) {
+      tap1(std::false_type{}, g, wa);
       load_w(g + 2, wa);
-      tap1(g + 1, wb);
+      tap1(std::false_type{}, g + 1, wb);
       load_w(g + 3, wb);
     }
-    tap1(K - 1, wa);
+    tap1(std::false_type{}, K - 1, wa);
     load_w(K + 1, wa);
   }
   TTSK_STAMP(3);
   // t = lrelu(c1 + b1) as fp16 rows of the t window; frames outside [0, len) are c2's zero padding
+  // (a tile whose t window lies inside the utterance has no zero padding to write: no compare, no select — and the conversions pack in pairs)
+  if (t0 - CP_TH >= 0 && t0 - CP_TH + CP_TROWS <= len) {
 #pragma unroll
-  for (int i = 0; i < NF1; ++i) {
-    const int t = t0 - CP_TH + i * 16 + l15;
-    const bool live = t >= 0 && t < len;
+    for (int i = 0; i < NF1; ++i) {
 #pragma unroll
-    for (int cc = 0; cc < CT; ++cc) {
-      f32x4 v = acc[cc][i] + bv1[cc];
+      for (int cc = 0; cc < CT; ++cc) {
+        f32x4 v = acc[cc][i] + bv1[cc];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = live ? fmaxf(v[e], v[e] * a.slope) : 0.f;
-      *(uint2*)(TW + (i * 16 + l15) * RS + ((wave * CT + cc) * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * a.slope);
+        *(uint2*)(TW + (i * 16 + l15) * RS + ((wave * CT + cc) * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NF1; ++i) {
+      const int t = t0 - CP_TH + i * 16 + l15;
+      const bool live = t >= 0 && t < len;
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc) {
+        f32x4 v = acc[cc][i] + bv1[cc];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = live ? fmaxf(v[e], v[e] * a.slope) : 0.f;
+        *(uint2*)(TW + (i * 16 + l15) * RS + ((wave * CT + cc) * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+      }
     }
   }
   __syncthreads();
@@ -325,13 +343,9 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
   }
   // ---- c2 (dilation 1) over the tile's 96 frames; sequence taps K .. 2K-1: tap K is on set b, K+1 on set a, ...
   f32x4 acc2[CT][NF2];
-#pragma unroll
-  for (int cc = 0; cc < CT; ++cc)
-#pragma unroll
-    for (int i = 0; i < NF2; ++i) acc2[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
     const unsigned char* inl = TW + (l15 + CP_TH) * RS + q * 16;
-    auto tap2 = [&](int g, const bf16x8 (&w)[KS][CT]) __attribute__((always_inline)) {
+    auto tap2 = [&](auto firstc, int g, const bf16x8 (&w)[KS][CT]) __attribute__((always_inline)) {
       const unsigned char* inp = inl + (g - HK) * RS;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -339,18 +353,22 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
         for (int i = 0; i < NF2; ++i) {
           const bf16x8 Bf = *(const bf16x8*)(inp + i * 16 * RS + ks * 64);
 #pragma unroll
-          for (int cc = 0; cc < CT; ++cc) acc2[cc][i] = mfma16<F16>(w[ks][cc], Bf, acc2[cc][i]);
+          for (int cc = 0; cc < CT; ++cc) acc2[cc][i] = mfma16<F16>(w[ks][cc], Bf, (decltype(firstc)::value && ks == 0) ? zero4 : acc2[cc][i]);
         }
       }
     };
+    tap2(std::true_type{}, 0, wb);
+    load_w(K + 2, wb);
+    tap2(std::false_type{}, 1, wa);
+    if (3 < K) load_w(K + 3, wa);
 #pragma unroll 1
-    for (int g = 0; g + 1 < K; g += 2) {
-      tap2(g, wb);
+    for (int g = 2; g + 1 < K; g += 2) {
+      tap2(std::false_type{}, g, wb);
       if (g + 2 < K) load_w(K + g + 2, wb);
-      tap2(g + 1, wa);
+      tap2(std::false_type{}, g + 1, wa);
       if (g + 3 < K) load_w(K + g + 3, wa);
     }
-    tap2(K - 1, wb);
+    tap2(std::false_type{}, K - 1, wb);
   }
 
   TTSK_STAMP(5);
@@ -467,11 +485,7 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
   __syncthreads();
 
   // ---- c1 over the 112 frames of the t window
-  f32x4 acc[CT][NF1];
-#pragma unroll
-  for (int cc = 0; cc < CT; ++cc)
-#pragma unroll
-    for (int i = 0; i < NF1; ++i) acc[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[CT][NF1];      // (not zeroed: the first half-tap starts the sums, tapring.h FIRST)
   {
     const unsigned char* inl = XW + (l15 + CP_XH - CP_TH) * RS + q * 16;
     // (one 8-wave workgroup per CU: the two waves of a SIMD are in the same phase and hide nothing for each other — the activation
@@ -482,24 +496,41 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
     auto tap1 = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
       tap_ring<F16, KH, CT, NF1, RS>(acc, ring, w, smem, inp1(g), inp1(min(g + 1, K2 - 1)));
     };
+    tap_ring<F16, KH, CT, NF1, RS, true>(acc, ring, wa, smem, inp1(0), inp1(1));
+    load_w(2, wa);
+    tap1(1, wb);
+    load_w(3, wb);
 #pragma unroll 1
-    for (int g = 0; g < K2; g += 2) {      // the last two loads are c2's first two half-taps
+    for (int g = 2; g < K2; g += 2) {      // the last two loads are c2's first two half-taps
       tap1(g, wa);
       load_w(g + 2, wa);
       tap1(g + 1, wb);
       load_w(g + 3, wb);
     }
   }
+  if (t0 - CP_TH >= 0 && t0 - CP_TH + CP_TROWS <= len) {      // (the t window inside the utterance: no zero padding to write, no compare, no select)
 #pragma unroll
-  for (int i = 0; i < NF1; ++i) {
-    const int t = t0 - CP_TH + i * 16 + l15;
-    const bool live = t >= 0 && t < len;
+    for (int i = 0; i < NF1; ++i) {
 #pragma unroll
-    for (int cc = 0; cc < CT; ++cc) {
-      f32x4 v = acc[cc][i] + bv1[cc];
+      for (int cc = 0; cc < CT; ++cc) {
+        f32x4 v = acc[cc][i] + bv1[cc];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = live ? fmaxf(v[e], v[e] * a.slope) : 0.f;
-      *(uint2*)(TW + (i * 16 + l15) * RS + ((wave * CT + cc) * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * a.slope);
+        *(uint2*)(TW + (i * 16 + l15) * RS + ((wave * CT + cc) * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NF1; ++i) {
+      const int t = t0 - CP_TH + i * 16 + l15;
+      const bool live = t >= 0 && t < len;
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc) {
+        f32x4 v = acc[cc][i] + bv1[cc];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = live ? fmaxf(v[e], v[e] * a.slope) : 0.f;
+        *(uint2*)(TW + (i * 16 + l15) * RS + ((wave * CT + cc) * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+      }
     }
   }
   __syncthreads();
@@ -518,10 +549,6 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
   }
   // ---- c2 (dilation 1) over the tile's 96 frames
   f32x4 acc2[CT][NF2];
-#pragma unroll
-  for (int cc = 0; cc < CT; ++cc)
-#pragma unroll
-    for (int i = 0; i < NF2; ++i) acc2[cc][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
     const unsigned char* inl = TW + (l15 + CP_TH) * RS + q * 16;
     auto inp2 = [&](int g) __attribute__((always_inline)) { return (unsigned)(inl - smem) + ((g >> 1) - HK) * RS + (g & 1) * (KH * 64); };
@@ -530,8 +557,12 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
     auto tap2 = [&](int g, const bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
       tap_ring<F16, KH, CT, NF2, RS>(acc2, ring, w, smem, inp2(g), inp2(min(g + 1, K2 - 1)));
     };
+    tap_ring<F16, KH, CT, NF2, RS, true>(acc2, ring, wa, smem, inp2(0), inp2(1));
+    load_w(K2 + 2, wa);
+    tap2(1, wb);
+    load_w(K2 + 3, wb);
 #pragma unroll 1
-    for (int g = 0; g < K2; g += 2) {
+    for (int g = 2; g < K2; g += 2) {
       tap2(g, wa);
       if (g + 2 < K2) load_w(K2 + g + 2, wa);
       tap2(g + 1, wb);

@@ -67,16 +67,19 @@ __device__ __forceinline__ void ring_prime(bf16x8 (&ring)[NF], const unsigned ch
 }
 // acc += w (x) window at `inp`; on return the ring holds the first k-step's fragments at `nxt` (the next step's window position; the
 // last step passes any readable position)
-template <bool F16, int KS, int CT, int NF, int RS>
+// FIRST: this step starts the sums — its first k-step multiplies onto the constant 0 instead of onto accumulators somebody had to zero (CT * NF * 4
+// v_mov per conv, and a VALU instruction costs a quarter of an MFMA: DESIGN.md 8.2); same sums, bit for bit.
+template <bool F16, int KS, int CT, int NF, int RS, bool FIRST = false>
 __device__ __forceinline__ void tap_ring(f32x4 (&acc)[CT][NF], bf16x8 (&ring)[NF], const bf16x8 (&w)[KS][CT], const unsigned char* lds, unsigned inp,
                                          unsigned nxt) {
   const LdsPos<NF, RS, KS> pi(inp), pn(nxt);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int idx = 0; idx < KS * NF; ++idx) {
     const int ks = idx / NF, i = idx % NF;
     const bf16x8 Bf = ring[i];
 #pragma unroll
-    for (int cc = 0; cc < CT; ++cc) acc[cc][i] = mfma16<F16>(w[ks][cc], Bf, acc[cc][i]);
+    for (int cc = 0; cc < CT; ++cc) acc[cc][i] = mfma16<F16>(w[ks][cc], Bf, (FIRST && ks == 0) ? zero4 : acc[cc][i]);
     ring[i] = ks + 1 < KS ? pi.frag(lds, i, ks + 1) : pn.frag(lds, i, 0);
   }
 #pragma unroll

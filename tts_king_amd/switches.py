@@ -16,6 +16,9 @@ TABLE = {
                                  "late = every all-reduce after the last weight-gradient launch"),
     "TTSK_DIST_TIMEOUT_S": ("300", "data parallel: bound on every collective of the job in seconds (parallel.init_distributed): a rank that waits "
                                    "longer fails, the job exits non-zero"),
+    "TTSK_CTRL_TIMEOUT_S": ("21600", "data parallel: bound on control-plane waits in seconds (parallel.ControlPlane: validation sums, the barrier behind rank 0's "
+                                     "checkpoint write); separate from, and much larger than, TTSK_DIST_TIMEOUT_S"),
+    "TTSK_TEST_CHILD": ("", "tests only: set in the child pytest process of tests/conftest.py: isolated"),
     "TTSK_DP_GRAPH": ("1", "bench.py --gpus N: capture the data-parallel step (RCCL all-reduces included) in a hipGraph; 0 = eager launches"),
     "TTSK_HIFI_UPS8": ("1", "HiFi-GAN: stride-8 upsamplers and 128 -> 64 on the window-conv kernel; 0 = polyphase GEMMs / streaming kernel"),
     "TTSK_CPU_THREADS": ("16", "bench.py: threads of the CPU baseline leg (capped at the host's cores)"),

@@ -16,7 +16,8 @@ pytestmark = pytest.mark.skipif(not os.path.exists(isa_scan.HIPCC), reason="hipc
 CASES = {
     "ffn_conv.hip": [("win_conv_kernelILi256ELi112ELb0ELb1ELi8ELi2ELb0", 4, 168), ("win_conv_kernelILi512ELi64ELb1ELb1ELi8ELi2ELb0", 4, 96)],
     "flash_attn.hip": [("flash_fwd_t_kernel", 6, 32), ("flash_bwd_t_kernel", 12, 112)],
-    "layernorm.hip": [("ln_bwd256_proj_kernelILi4ELb1", 10, 224), ("ln_bwd256_proj_kernelILi1ELb0", 6, 32)],
+    # (round 6: ...ELb1ELi2 = the SPLIT instance, two output groups per workgroup: the upstream projection's 96 MFMAs + two groups' 64)
+    "layernorm.hip": [("ln_bwd256_proj_kernelILi4ELb1ELi1", 10, 224), ("ln_bwd256_proj_kernelILi4ELb1ELi2", 8, 160), ("ln_bwd256_proj_kernelILi1ELb0", 6, 32)],
 }
 
 

@@ -428,7 +428,7 @@ __device__ __forceinline__ float rows4_sum(float v) {
 // e * 17 + l with 17 odd: conflict-free both ways.  After rows4_sum every row group holds the totals: group g stores e = 4 g .. 4 g + 3.
 constexpr int LNB_RED_LD = 16 * 17, LNB_RED = 3 * LNB_RED_LD;
 __device__ __forceinline__ void lnb256_partials(const LnBwdArgs& a, float sbias[16], float sgam[16], float sbeta[16], float (*red)[LNB_RED],
-                                                int wave, int grp, int c0) {
+                                                int wave, int grp, int c0, int pblock = -1, bool write = true) {
   constexpr int D = 256;
 #pragma unroll
   for (int e = 0; e < 16; ++e) { sbias[e] = rows4_sum(sbias[e]); sgam[e] = rows4_sum(sgam[e]); sbeta[e] = rows4_sum(sbeta[e]); }
@@ -444,7 +444,8 @@ __device__ __forceinline__ void lnb256_partials(const LnBwdArgs& a, float sbias[
     }
   }
   __syncthreads();
-  float* P = a.partials + (int64_t)blockIdx.x * 3 * D;
+  if (!write) return;                      // (a workgroup that only replicates the rows for its share of the projection: SPLIT)
+  float* P = a.partials + (int64_t)(pblock < 0 ? (int)blockIdx.x : pblock) * 3 * D;
   for (int c = threadIdx.x; c < 3 * D; c += LNB_WAVES * 64) {
     const int pos = (c >> 8) * LNB_RED_LD + (c & 15) * 17 + ((c & 255) >> 4);
     float t = 0.f;
@@ -594,13 +595,20 @@ struct LnbProjArgs {
 #ifdef TTSK_STAMPS
 #define LNB_STAMP(i)                                                                                   \
   do {                                                                                                 \
-    if (p.stamps && threadIdx.x == 0) p.stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    if (SPLIT == 1 && p.stamps && threadIdx.x == 0) p.stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); /* (the tool's buffer is sized for whole tiles) */ \
   } while (0)
 #else
 #define LNB_STAMP(i) do {} while (0)       // the product library carries no stamp code and no global state for it
 #endif
 
-template <int NG, bool PRE>
+// SPLIT (round 6, NG = 4 on the phoneme side: 32 tiles of 32 rows leave 7/8 of the chip idle and each workgroup streams all of w_2's 0.5 MB): the
+// tile's four 256-channel output groups go to SPLIT workgroups (blockIdx = tile * SPLIT + part), NG / SPLIT groups each.  Each repeats the tile's
+// upstream projection and LayerNorm backward (cheap beside its share of the weight stream); part 0 alone writes the row outputs (dz, dy) and the
+// partial sums.  No seam, no reduction: every output element is computed by exactly one workgroup in the unsplit order — bit-identical.
+// SPLIT = 2: in the train step these launches run beside the decoder's weight gradients, which hold 192 of the 256 CUs — 64 workgroups fit the
+// rest in one round (four per tile ran two rounds there: 30-33 us against the unsplit 26-28).
+constexpr int LNB_SPLIT_MAX_TILES = 63, LNB_SPLIT = 2;
+template <int NG, bool PRE, int SPLIT = 1>
 __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const LnbProjArgs p) {
   constexpr int D = 256;
   static_assert(LNB_WAVES * 64 == P32_NT && P32_D == D, "proj32.h is built for 8 waves and 256 channels");
@@ -612,10 +620,13 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const
   float (*red)[LNB_RED] = (float (*)[LNB_RED])smem;
   unsigned char* xs = smem + LNB_WAVES * LNB_RED * 4;     // dy rows (bf16): the GEMM's B operand
   unsigned char* os = xs + P32_TT * P32_RS;               // one channel group's output rows (bf16)
-  const LnBwdArgs& a = p.ln;
+  static_assert(NG % SPLIT == 0, "whole groups per workgroup");
+  const int part = (int)blockIdx.x % SPLIT, tile = (int)blockIdx.x / SPLIT;
+  LnBwdArgs a = p.ln;
+  if (SPLIT > 1 && part != 0) a.dz = a.dy = nullptr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = lane >> 4, l = lane & 15, c0 = l * 16;
-  const int m0 = blockIdx.x * P32_TT;
+  const int m0 = tile * P32_TT;
   Proj32W W;
   LNB_STAMP(0);
   if (PRE) pre768_gemm(p.pre_x, p.pre_w, m0, a.rows, smem, dtile);
@@ -645,8 +656,8 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const
     LNB_STAMP(2);
     // group 0's weight fragments: requested behind the rows' own loads (loads return in order: in front of them they delayed every
     // row), with the partial sums and their barrier (~3 us) to arrive
-    proj32_prefetch(p.w, p.Cout, wave, lane, W);
-    lnb256_partials(a, sbias, sgam, sbeta, red, wave, grp, c0);        // (its barrier also publishes xs)
+    proj32_prefetch(p.w, p.Cout, wave, lane, W, part * (NG / SPLIT));
+    lnb256_partials(a, sbias, sgam, sbeta, red, wave, grp, c0, tile, part == 0);        // (its barrier also publishes xs)
     LNB_STAMP(3);
   }
   uint4 gpre[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};       // the group's gate chunks (w_2's saved ReLU output, cold in HBM)
@@ -672,7 +683,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const
       }
     }
   };
-  proj32_run<NG>(xs, os, p.w, p.Cout, nullptr, W, tid, [&](int cg, int rr, int ch, uint4 v, int it) __attribute__((always_inline)) {
+  proj32_run<NG / SPLIT>(xs, os, p.w, p.Cout, nullptr, W, tid, [&](int cg, int rr, int ch, uint4 v, int it) __attribute__((always_inline)) {
     const int row = m0 + rr;
     float dacc = 0.f;
     if (row < a.rows) {
@@ -699,7 +710,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64, 1) void ln_bwd256_proj_kernel(const
         p.delta[((int64_t)b * 2 + (ch >> 4)) * a.seg_len + t] = dacc;
       }
     }
-  }, pre);
+  }, pre, part * (NG / SPLIT));
   LNB_STAMP(4);
 }
 
@@ -1014,11 +1025,17 @@ extern "C" int ttsk_layernorm_bwd_proj(const void* dout, const float* slabs, int
   p.stamps = g_lnb_stamps;
 #endif
   const dim3 grid(nblk), block(LNB_WAVES * 64);
+  // Few tiles (the phoneme side: 1,024 rows = 32 tiles on 256 CUs) and four output groups: one workgroup per (tile, group) — a quarter of
+  // the weight stream each, four times the workgroups (SPLIT above).  From 64 tiles on the chip is better filled by whole tiles.
+  const bool split = Cout == 1024 && nblk <= LNB_SPLIT_MAX_TILES;
+  const dim3 grid4(nblk * LNB_SPLIT);
   if (pre_x) {
     if (Cout == 256) hipLaunchKernelGGL((ln_bwd256_proj_kernel<1, true>), grid, block, 0, (hipStream_t)stream, p);
+    else if (split) hipLaunchKernelGGL((ln_bwd256_proj_kernel<4, true, LNB_SPLIT>), grid4, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((ln_bwd256_proj_kernel<4, true>), grid, block, 0, (hipStream_t)stream, p);
   } else {
     if (Cout == 256) hipLaunchKernelGGL((ln_bwd256_proj_kernel<1, false>), grid, block, 0, (hipStream_t)stream, p);
+    else if (split) hipLaunchKernelGGL((ln_bwd256_proj_kernel<4, false, LNB_SPLIT>), grid4, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((ln_bwd256_proj_kernel<4, false>), grid, block, 0, (hipStream_t)stream, p);
   }
   TTSK_CHECK_LAUNCH();

@@ -22,9 +22,9 @@ __device__ __forceinline__ void proj32_load(const bf16_t* __restrict__ w, int Co
   frags_load<P32_KH, P32_CT>(dst, weights_rsrc(w, (P32_D / 32) * kstep_bytes), (wave * P32_CT) * 1024 + lane * 16, cg * 16 * 1024 + g * P32_KH * kstep_bytes,
                              kstep_bytes);
 }
-__device__ __forceinline__ void proj32_prefetch(const bf16_t* __restrict__ w, int Cout, int wave, int lane, Proj32W& W) {
-  proj32_load(w, Cout, 0, 0, wave, lane, W.a);
-  proj32_load(w, Cout, 0, 1, wave, lane, W.b);
+__device__ __forceinline__ void proj32_prefetch(const bf16_t* __restrict__ w, int Cout, int wave, int lane, Proj32W& W, int cg0 = 0) {
+  proj32_load(w, Cout, cg0, 0, wave, lane, W.a);
+  proj32_load(w, Cout, cg0, 1, wave, lane, W.b);
 }
 
 // xs must be visible to the workgroup (a barrier behind its writers) and W prefetched.  bias: fp32 [Cout] or null.  Every thread calls
@@ -36,9 +36,10 @@ struct Proj32NoPre { __device__ __forceinline__ void operator()(int) const {} };
 // `pre(cg)` runs at the start of group cg, before anything else of the group is requested: the place to ask for what epi(cg, ...)
 // will need from memory (a gate) — loads return in order, so it must go out before the next group's weight fragments, and it then has
 // the group's contraction and staging to arrive instead of standing between the staging barrier and the stores.
+// `cg0`: the first of the NG groups this workgroup runs (round 6: the groups of one tile split over workgroups, layernorm.hip SPLIT).
 template <int NG, class Epi, class Pre = Proj32NoPre>
 __device__ __forceinline__ void proj32_run(const unsigned char* xs, unsigned char* os, const bf16_t* __restrict__ w, int Cout,
-                                           const float* __restrict__ bias, Proj32W& W, int tid, Epi&& epi, Pre&& pre = Pre()) {
+                                           const float* __restrict__ bias, Proj32W& W, int tid, Epi&& epi, Pre&& pre = Pre(), int cg0 = 0) {
   constexpr int NF = P32_TT / 16;
   const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
   const unsigned char* inl = xs + l15 * P32_RS + q * 16;
@@ -52,10 +53,10 @@ __device__ __forceinline__ void proj32_run(const unsigned char* xs, unsigned cha
   for (int cg = 0; cg < NG; ++cg) {
     Proj32W& cur = (cg & 1) ? V : W;
     Proj32W& nxt = (cg & 1) ? W : V;
-    pre(cg);
+    pre(cg0 + cg);
     if (cg + 1 < NG) {
-      proj32_load(w, Cout, cg + 1, 0, wave, lane, nxt.a);
-      proj32_load(w, Cout, cg + 1, 1, wave, lane, nxt.b);
+      proj32_load(w, Cout, cg0 + cg + 1, 0, wave, lane, nxt.a);
+      proj32_load(w, Cout, cg0 + cg + 1, 1, wave, lane, nxt.b);
     }
     __builtin_amdgcn_sched_barrier(0);             // the requests stay ahead of the contraction
     f32x4 acc[P32_CT][NF];
@@ -73,7 +74,7 @@ __device__ __forceinline__ void proj32_run(const unsigned char* xs, unsigned cha
     for (int cc = 0; cc < P32_CT; ++cc) {
       const int col = (wave * P32_CT + cc) * 16 + q * 4;
       f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (bias) bv = *(const f32x4*)(bias + cg * P32_D + col);
+      if (bias) bv = *(const f32x4*)(bias + (cg0 + cg) * P32_D + col);
 #pragma unroll
       // 8-byte units XOR-swizzled by (row >> 2) & 3: the 16 lanes of a store (16 rows, one unit column; row stride 136 dwords = 8
       // mod 32) would hit 4 bank pairs four deep; with the swizzle they cover all 32 banks once
@@ -91,7 +92,7 @@ __device__ __forceinline__ void proj32_run(const unsigned char* xs, unsigned cha
       const int sw = (rr >> 2) & 3;                // the row's unit swizzle: bit 1 moves the chunk, bit 0 swaps its halves
       uint4 v = *(const uint4*)(os + rr * P32_RS + ((ch ^ (sw >> 1)) << 4));
       if (sw & 1) v = make_uint4(v.z, v.w, v.x, v.y);
-      epi(cg, rr, ch, v, it);
+      epi(cg0 + cg, rr, ch, v, it);
     }
     if (cg + 1 < NG) __syncthreads();          // the next group overwrites the staging rows
   }

@@ -24,7 +24,9 @@ template <int CIN, int COUT, bool F16>
 __global__ __launch_bounds__(256) void ups2_kernel(const UpArgs a) {
   constexpr int TT = 256;                       // input frames per workgroup
   constexpr int XR = TT + 2;                    // + one halo frame per side
-  constexpr int XRS = CIN * 2 + 16;             // padded row stride: 16 lanes x 16 B land in 16 different bank groups
+  constexpr int XRS = CIN * 2 + 32;             // row stride = 2 mod 4 sixteen-byte units: the 16 lanes of a ds_read_b128 group (8 rows at k-chunk q, the 8 OTHER
+                                                // rows at q + 1) cover all 16 units; + 16 (an odd stride, round 2) collided two ways on every fragment read: 49 % of this
+                                                // kernel's LDS cycles at 64 channels (profiles/r05_mfma_util.json)
   constexpr int KS = CIN / 32, NC = COUT / 16;
   constexpr int WBYTES = 4 * KS * NC * 1024;    // all taps as A fragments [tap][k-step][cout tile][lane][8]
   constexpr int ORS = COUT * 2 + 16;            // output staging row stride
@@ -51,16 +53,19 @@ __global__ __launch_bounds__(256) void ups2_kernel(const UpArgs a) {
   }
 #pragma unroll
   for (int i = 0; i < NWL; ++i) {
-    // fragment f = ((tap * KS + ks) * NC + c), lane l: W[tap][c*16 + (l & 15)][ks*32 + (l >> 4)*8 .. +8]
+    // fragment f = ((tap * KS + ks) * NC + c), lane l: W[tap][co][ks*32 + (l >> 4)*8 .. +8] with the tile's rows PERMUTED: row m = l & 15 of tile c is
+    // output channel co = NC*4 * (m >> 2) + 4 c + (m & 3), so that a lane's NC accumulator tiles (rows 4 lg .. 4 lg + 3 each) are NC*4 CONSECUTIVE
+    // channels of one frame: 16-byte staging stores, conflict-free at the 16-byte-multiple row stride (8-byte columns 160 bytes apart collided four ways)
     const int e = i * 256 + tid, f = e >> 6, l = e & 63;
     const int c = f % NC, ks = (f / NC) % KS, tap = f / (NC * KS);
-    wv[i] = *(const uint4*)(a.w + ((int64_t)(tap * COUT + c * 16 + (l & 15)) * CIN + ks * 32 + (l >> 4) * 8));
+    const int co = NC * 4 * ((l & 15) >> 2) + 4 * c + (l & 3);
+    wv[i] = *(const uint4*)(a.w + ((int64_t)(tap * COUT + co) * CIN + ks * 32 + (l >> 4) * 8));
   }
   float bv[NC][4];
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bv[c][r] = a.bias[c * 16 + lg * 4 + r];
+    for (int r = 0; r < 4; ++r) bv[c][r] = a.bias[NC * 4 * lg + 4 * c + r];
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
     const int idx = i * 256 + tid, row = idx / CH8, ch = idx - row * CH8;
@@ -118,19 +123,35 @@ __global__ __launch_bounds__(256) void ups2_kernel(const UpArgs a) {
 #pragma unroll
       for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
+        for (int c = 0; c < NC; c += 2) {        // two tiles = 8 consecutive channels = one 16-byte store
           const int ft = (tp * 2 + u) * 4 + wave;
           const int orow = 2 * (ft * 16 + l15) + ph;
-          *(uint2*)(XW + orow * ORS + (c * 16 + lg * 4) * 2) = make_uint2(packed[tp][u][ph][c][0], packed[tp][u][ph][c][1]);
+          *(uint4*)(XW + orow * ORS + (NC * 4 * lg + 4 * c) * 2) =
+              make_uint4(packed[tp][u][ph][c][0], packed[tp][u][ph][c][1], packed[tp][u][ph][c + 1][0], packed[tp][u][ph][c + 1][1]);
         }
   __syncthreads();
   // ---- 2*TT output frames of COUT channels: one contiguous block of the (B, 2T, COUT) tensor
   constexpr int OCH8 = COUT / 8;
   bf16_t* __restrict__ ob = a.out + ((int64_t)b * 2 * T + 2 * t0) * COUT;
   const int nrows = (2 * (T - t0)) < 2 * TT ? 2 * (T - t0) : 2 * TT;
-  for (int idx = tid; idx < nrows * OCH8; idx += 256) {
-    const int row = idx / OCH8, ch = idx - row * OCH8;
-    *(uint4*)(ob + (int64_t)row * COUT + ch * 8) = *(const uint4*)(XW + row * ORS + ch * 16);
+  if constexpr (OCH8 == 4) {
+    // A wave copies 16 rows x 4 chunks = 1 KiB of the output per pass.  Which lane takes which (row, chunk) is free (the global store is the same
+    // contiguous KiB), so it follows the LDS: a ds_read_b128 is served in four groups of 16 lanes — {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the
+    // same + 32 — and at an 80-byte row stride 16 DIFFERENT rows of one chunk column cover all 16 sixteen-byte units (5 is odd), while the row-major
+    // assignment put rows r, r + 3, r + 5, r + 6 in a group: two-way conflicts on every read.
+    const int l = lane & 31;
+    const int grp = ((l >= 4 && l < 12) || (l >= 16 && l < 20) || l >= 28) ? 1 : 0;
+    const int j = grp ? (l < 12 ? l - 4 : (l < 20 ? l - 8 : l - 16)) : (l < 4 ? l : (l < 16 ? l - 8 : l - 12));
+    const int ch = grp + 2 * (lane >> 5);
+    for (int r0 = wave * 16; r0 < nrows; r0 += 64) {
+      const int row = r0 + j;
+      if (row < nrows) *(uint4*)(ob + (int64_t)row * COUT + ch * 8) = *(const uint4*)(XW + row * ORS + ch * 16);
+    }
+  } else {
+    for (int idx = tid; idx < nrows * OCH8; idx += 256) {
+      const int row = idx / OCH8, ch = idx - row * OCH8;
+      *(uint4*)(ob + (int64_t)row * COUT + ch * 8) = *(const uint4*)(XW + row * ORS + ch * 16);
+    }
   }
 }
 

@@ -510,23 +510,28 @@ def test_fused_last_stage_full_size_and_generator(cfg):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("K,dil,B,ln,dt", [(3, 1, 2, 700, torch.float16), (3, 3, 1, 192, torch.float16), (3, 5, 3, 193, torch.bfloat16), (7, 1, 1, 191, torch.float16),
-                                           (7, 3, 2, 1000, torch.float16), (7, 5, 2, 385, torch.bfloat16), (11, 1, 1, 5, torch.float16), (11, 3, 3, 383, torch.float16),
-                                           (11, 5, 2, 1000, torch.float16), (11, 5, 1, 1, torch.bfloat16), (7, 3, 8, 4099, torch.float16), (11, 5, 4, 12288, torch.float16)])
-def test_weights_stationary_pair_is_bit_identical_to_the_pair_kernel(K, dil, B, ln, dt):
+WS_PAIR_CASES = [(3, 1, 2, 700, torch.float16), (3, 3, 1, 192, torch.float16), (3, 5, 3, 193, torch.bfloat16), (7, 1, 1, 191, torch.float16),
+                 (7, 3, 2, 1000, torch.float16), (7, 5, 2, 385, torch.bfloat16), (11, 1, 1, 5, torch.float16), (11, 3, 3, 383, torch.float16),
+                 (11, 5, 2, 1000, torch.float16), (11, 5, 1, 1, torch.bfloat16), (7, 3, 8, 4099, torch.float16), (11, 5, 4, 12288, torch.float16),
+                 (3, 1, 2, 700, torch.float16, 128), (3, 3, 1, 96, torch.float16, 128), (3, 5, 3, 97, torch.bfloat16, 128),
+                 (3, 1, 1, 3, torch.bfloat16, 128), (3, 3, 3, 191, torch.float16, 128), (3, 5, 8, 4099, torch.float16, 128)]
+
+
+@pytest.mark.parametrize("K,dil,B,ln,dt,C", [c if len(c) == 6 else c + (64,) for c in WS_PAIR_CASES])
+def test_weights_stationary_pair_is_bit_identical_to_the_pair_kernel(K, dil, B, ln, dt, C):
     """ttsk_hifi_conv_pair_ws (round 6, csrc/pairws.hip: persistent workgroups, both convs' weights in registers, c1 of tile s beside c2 of
-    tile s - 1; hifi/models.py:88-95) against ttsk_hifi_conv_pair at C = 64: same roundings and accumulation order, so bit-identical — in all three
+    tile s - 1; hifi/models.py:88-95) against ttsk_hifi_conv_pair at C = 64 (every kernel size) and C = 128 (k = 3): same roundings and accumulation order, so bit-identical — in all three
     MRF modes (:190-197), at one tile, ragged tiles, more tiles than workgroups (every workgroup walks several, runs crossing utterances) and with the
     grid capped to 1, 3 and 7 workgroups (uneven runs); and against fp64 on the same 16-bit operands."""
     from tts_king_amd import ops
-    C = 64
     g = torch.Generator().manual_seed(K * 1000 + ln + dil)
     x = torch.randn(B, ln, C, generator=g).to(dt).to(DEV)
     w1 = torch.randn(C, C, K, generator=g) * (C * K) ** -0.5
     w2 = torch.randn(C, C, K, generator=g) * (C * K) ** -0.5
     b1, b2 = (0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
     p1, p2 = ops.pack_resblock_weight(w1.to(DEV), dtype=dt), ops.pack_resblock_weight(w2.to(DEV), dtype=dt)
-    assert ops.hifi_conv_pair_ws_supported(C, K, dil, ln) and not ops.hifi_conv_pair_ws_supported(128, K, dil) and not ops.hifi_conv_pair_ws_supported(C, 5, 1)
+    assert ops.hifi_conv_pair_ws_supported(C, K, dil, ln) and not ops.hifi_conv_pair_ws_supported(128, 7, dil) and not ops.hifi_conv_pair_ws_supported(256, K, dil)
+    assert not ops.hifi_conv_pair_ws_supported(C, 5, 1)
     want = ops.hifi_conv_pair(x, p1, b1, p2, b2, K, dil)
     for cap in (0, 1, 3, 7):
         got = ops.hifi_conv_pair(x, p1, b1, p2, b2, K, dil, ws=True, max_wgs=cap)

@@ -100,8 +100,8 @@ class Generator(nn.Module):
         self.window_conv = True      # window-conv kernel at the C = 128 stage; False = implicit-GEMM convs
         self.conv_pair = True        # each (c1, c2) pair of a ResBlock1 as one launch (ttsk_hifi_conv_pair) at C = 128 ...
         self.conv_pair_small = True  # ... and at C = 64 / 32, instead of the six-conv fused kernel
-        self.pair_ws = True          # C = 64: the pairs on the weights-stationary persistent kernel (csrc/pairws.hip, round 6), every kernel size
-        self.pair_ws_min_tiles = 1024    # ... for stage tensors of at least this many 192-frame tiles
+        self.pair_ws = True          # the pairs on the weights-stationary persistent kernel (csrc/pairws.hip, round 6): C = 64 every kernel size, C = 128 k = 3
+        self.pair_ws_min_tiles = 1024    # ... for stage tensors of at least this many of its tiles (192 frames at C = 64, 96 at C = 128)
         self.fused = True            # fused ResBlock1 kernel where an instance exists (C in {32,64}); False = conv-by-conv
         self.stream_upsample = True  # stride-2 upsamplers (128->64, 64->32) on the streaming kernel; False = polyphase implicit GEMMs
         self.window_upsample = switches.get("TTSK_HIFI_UPS8") != "0"   # stride-8 upsamplers and 128 -> 64 on the window-conv kernel (fp16); 0 = polyphase GEMMs / streaming kernel
@@ -214,9 +214,10 @@ class Generator(nn.Module):
             ws, bs = packs[j]
             mode = 0 if j == 0 else (2 if j == nk - 1 else 1)
             fs = nxt_slope if j == nk - 1 else 1.0
-            # the persistent kernel walks runs of 192-frame tiles, one workgroup per CU, and pays a pipeline fill and drain of one tile each per launch:
-            # worth it from ~4 tiles per CU on (the bench batch: 8); one utterance of 5 s is 299 tiles at this stage and stays on the round-5 kernels
-            ws_kernel = (self.pair_ws and a.is_contiguous() and a.shape[0] * ((a.shape[1] + 191) // 192) >= self.pair_ws_min_tiles and
+            # the persistent kernel walks runs of 192-frame tiles (96 at C = 128), one workgroup per CU, and pays a pipeline fill and drain of one tile each per
+            # launch: worth it from ~4 tiles per CU on (the bench batch: 8); one utterance of 5 s is 299 tiles at the last stage and stays on the round-5 kernels
+            tt = ops.hifi_conv_pair_ws_tile(a.shape[2])
+            ws_kernel = (self.pair_ws and a.is_contiguous() and a.shape[0] * ((a.shape[1] + tt - 1) // tt) >= self.pair_ws_min_tiles and
                          all(ops.hifi_conv_pair_ws_supported(a.shape[2], rb.k, d, a.shape[1]) for d in rb.dilation))
             if rb.k in fused_for and not ws_kernel:
                 ops.hifi_resblock1(a, ws, bs, rb.dilation, out, rb.k, mode=mode, scale=1.0 / nk, slope=LRELU_SLOPE, final_slope=fs)

@@ -1702,6 +1702,11 @@ def hifi_conv_pair_supported(Cn, K, dil):
     return bool(L.load().ttsk_hifi_conv_pair_supported(Cn, K, dil))
 
 
+def hifi_conv_pair_ws_tile(Cn):
+    """Frames per tile of ttsk_hifi_conv_pair_ws at Cn channels (csrc/pairws.hip WsGeom::TT)."""
+    return 192 if Cn <= 64 else 96
+
+
 def hifi_conv_pair_ws_supported(Cn, K, dil, ln=0):
     """The weights-stationary pair kernel (csrc/pairws.hip) covers (C, K, dil) and utterances of `ln` frames (32-bit buffer offsets per utterance)."""
     return bool(L.load().ttsk_hifi_conv_pair_ws_supported(Cn, K, dil)) and ln * Cn * 2 < 2 ** 30
@@ -1710,7 +1715,7 @@ def hifi_conv_pair_ws_supported(Cn, K, dil, ln=0):
 def hifi_conv_pair(x, w1_pack, bias1, w2_pack, bias2, K, dilation, slope=0.1, out=None, mode=0, scale=1.0, final_slope=1.0, ws=False, max_wgs=0):
     """y = c2(lrelu(c1_{K,dil}(lrelu(x)) + b1)) + b2 + x in one launch (C = 128; hifi/models.py:88-95, one dilation of ResBlock1).
     mode 0: out = y; 1: out += y; 2: out = lrelu((out + y) * scale, final_slope) (the MRF average, :190-197; ttsk_hifi_resblock1's modes).
-    ws: the weights-stationary persistent kernel (C = 64; ttsk_hifi_conv_pair_ws, bit-identical)."""
+    ws: the weights-stationary persistent kernel (C = 64, or C = 128 with K = 3; ttsk_hifi_conv_pair_ws, bit-identical)."""
     _dev(x, w1_pack, bias1, w2_pack, bias2, out)
     Bn, ln, Cn = x.shape
     if out is None:

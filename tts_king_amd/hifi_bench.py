@@ -13,11 +13,11 @@ HIFI_FLOP_PER_FRAME = 614.11e6          # SURVEY.md §8d (verified with torch.ut
 STAGE_MFLOP = {"conv_pre": 0.573, "ups0": 4.194, "ups1": 8.389, "ups2": 4.194, "ups3": 2.097,
                "mrf0": 132.12, "mrf1": 264.24, "mrf2": 132.12, "mrf3": 66.06, "conv_post": 0.115}
 # rocprofv3 symbols of each stage's kernels (profiles/r*_pmc_traffic_hifi.json is keyed by symbol): (substring, launches per forward)
-STAGE_KERNELS = {"mrf0": [("conv_pair256_kernel", 9)], "mrf1": [("conv_pair_kernel", 9)],
-                 # round 6: the C = 64 stage is nine launches of the weights-stationary pair kernel <K, dilation, MRF mode> (csrc/pairws.hip)
-                 "mrf2": [("pair_ws_kernel<3, 1, 0", 1), ("pair_ws_kernel<3, 3, 0", 1), ("pair_ws_kernel<3, 5, 0", 1), ("pair_ws_kernel<7, 1, 0", 1),
-                          ("pair_ws_kernel<7, 3, 0", 1), ("pair_ws_kernel<7, 5, 1", 1), ("pair_ws_kernel<11, 1, 0", 1), ("pair_ws_kernel<11, 3, 0", 1),
-                          ("pair_ws_kernel<11, 5, 2", 1)],
+STAGE_KERNELS = {"mrf0": [("conv_pair256_kernel", 9)],
+                 # round 6: the weights-stationary pair kernel <C, K, dilation, MRF mode> (csrc/pairws.hip): the C = 64 stage's nine launches and the k = 3
+                 # block of the C = 128 stage (k = 7 / 11 there stay on conv_pair_kernel)
+                 "mrf1": [("conv_pair_kernel", 6), ("pair_ws_kernel<128, 3, 1, 0", 1), ("pair_ws_kernel<128, 3, 3, 0", 1), ("pair_ws_kernel<128, 3, 5, 0", 1)],
+                 "mrf2": [("pair_ws_kernel<64, %d, %d, %d" % (k, d, m), 1) for k, m5 in ((3, 0), (7, 1), (11, 2)) for d, m in ((1, 0), (3, 0), (5, m5))],
                  "mrf3": [("resblock1_kernel<32, 3", 1), ("resblock1_kernel<32, 7", 1), ("resblock1_kernel<32, 11", 1), ("mrf32_post_kernel", 1)],
                  "ups0": [("win_conv_kernel<512, 128", 1)], "ups1": [("win_conv_kernel<256, 224", 1)],
                  "ups2": [("ups2_kernel<128, 64", 1)], "ups3": [("ups2_kernel<64, 32", 1)], "conv_post": [("conv_post_kernel", 1)]}

@@ -15,7 +15,7 @@ b = torch.randn(Cn, device=DEV)
 lib = L.load()
 lib.ttsk_hifi_conv_pair_set_stamps.argtypes = [C.c_void_p]
 nwg = B * ((ln + 95) // 96)
-for K in (3, 11):
+for K in (7, 11):
     w = (torch.randn(Cn, Cn, K, device=DEV) * (Cn * K) ** -0.5)
     pack = ops.pack_resblock_weight(w, dtype=torch.float16)
     for _ in range(3):

@@ -216,14 +216,24 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
   const int HK = (K - 1) / 2;
   const bf16_t* __restrict__ xb = a.x + (int64_t)bi * len * C;
 
+  // The wave's 32 output channels, rows of the A operand PERMUTED (round 6, as csrc/pairws.hip): row l15 of tile cc is channel
+  // 32 * wave + 8 * (l15 >> 2) + 4 * cc + (l15 & 3), so that a lane's 4 + 4 accumulator rows of the two tiles are 8 CONSECUTIVE channels of
+  // one frame — one 16-byte LDS / global store per frame tile and lane instead of two 8-byte ones (whose rows collided four ways in LDS:
+  // 17 % of the kernel's LDS cycles), and the output needs no staging tile, barrier and copy-out.  Same products, same order: bit-identical.
   bf16x8 wa[KS][CT], wb[KS][CT];
-  const int woff = (wave * CT) * 1024 + lane * 16;
+  int woff[CT];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc) {
+    const int co = 32 * wave + 8 * (l15 >> 2) + 4 * cc + (l15 & 3);
+    woff[cc] = (co >> 4) * 1024 + ((co & 15) + 16 * q) * 16;
+  }
+  const int co8 = 32 * wave + 8 * q;          // this lane's 8 output channels
   auto load_w = [&](int g, bf16x8 (&w)[KS][CT]) __attribute__((always_inline)) {      // tap g of the 2K-tap sequence c1 | c2
-    const unsigned char* src = (const unsigned char*)(g < K ? a.w1 : a.w2) + (int64_t)(g < K ? g : g - K) * CW_WTAP + woff;
+    const unsigned char* src = (const unsigned char*)(g < K ? a.w1 : a.w2) + (int64_t)(g < K ? g : g - K) * CW_WTAP;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(src + (ks * NC + cc) * 1024);
+      for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(src + ks * NC * 1024 + woff[cc]);
   };
   TTSK_STAMP(0);
 
@@ -254,8 +264,8 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
   f32x4 bv1[CT], bv2[CT];
 #pragma unroll
   for (int cc = 0; cc < CT; ++cc) {
-    bv1[cc] = *(const f32x4*)(a.b1 + (wave * CT + cc) * 16 + q * 4);
-    bv2[cc] = *(const f32x4*)(a.b2 + (wave * CT + cc) * 16 + q * 4);
+    bv1[cc] = *(const f32x4*)(a.b1 + co8 + 4 * cc);
+    bv2[cc] = *(const f32x4*)(a.b2 + co8 + 4 * cc);
   }
   TTSK_STAMP(1);
   __syncthreads();
@@ -301,44 +311,46 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
   if (t0 - CP_TH >= 0 && t0 - CP_TH + CP_TROWS <= len) {
 #pragma unroll
     for (int i = 0; i < NF1; ++i) {
+      unsigned o[4];
 #pragma unroll
       for (int cc = 0; cc < CT; ++cc) {
         f32x4 v = acc[cc][i] + bv1[cc];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * a.slope);
-        *(uint2*)(TW + (i * 16 + l15) * RS + ((wave * CT + cc) * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+        o[cc * 2] = pack2<F16>(v[0], v[1]);
+        o[cc * 2 + 1] = pack2<F16>(v[2], v[3]);
       }
+      *(uint4*)(TW + (i * 16 + l15) * RS + co8 * 2) = make_uint4(o[0], o[1], o[2], o[3]);
     }
   } else {
 #pragma unroll
     for (int i = 0; i < NF1; ++i) {
       const int t = t0 - CP_TH + i * 16 + l15;
       const bool live = t >= 0 && t < len;
+      unsigned o[4];
 #pragma unroll
       for (int cc = 0; cc < CT; ++cc) {
         f32x4 v = acc[cc][i] + bv1[cc];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = live ? fmaxf(v[e], v[e] * a.slope) : 0.f;
-        *(uint2*)(TW + (i * 16 + l15) * RS + ((wave * CT + cc) * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+        o[cc * 2] = pack2<F16>(v[0], v[1]);
+        o[cc * 2 + 1] = pack2<F16>(v[2], v[3]);
       }
+      *(uint4*)(TW + (i * 16 + l15) * RS + co8 * 2) = make_uint4(o[0], o[1], o[2], o[3]);
     }
   }
   __syncthreads();
 
   TTSK_STAMP(4);
   // raw x (residual) and, in the accumulating modes, the current `out`: requested now, consumed after c2's taps
-  uint2 rres[CT][NF2], rout[CT][NF2];
+  uint4 rres[NF2], rout[NF2];
 #pragma unroll
   for (int i = 0; i < NF2; ++i) {
     const int t = t0 + i * 16 + l15;
-#pragma unroll
-    for (int cc = 0; cc < CT; ++cc) {
-      const int co = (wave * CT + cc) * 16 + q * 4;
-      rres[cc][i] = rout[cc][i] = make_uint2(0u, 0u);
-      if (t < len) {
-        rres[cc][i] = *(const uint2*)(xb + (int64_t)t * C + co);
-        if (a.mode) rout[cc][i] = *(const uint2*)(a.out + ((int64_t)bi * len + t) * C + co);
-      }
+    rres[i] = rout[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (t < len) {
+      rres[i] = *(const uint4*)(xb + (int64_t)t * C + co8);
+      if (a.mode) rout[i] = *(const uint4*)(a.out + ((int64_t)bi * len + t) * C + co8);
     }
   }
   // ---- c2 (dilation 1) over the tile's 96 frames; sequence taps K .. 2K-1: tap K is on set b, K+1 on set a, ...
@@ -372,23 +384,25 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
   }
 
   TTSK_STAMP(5);
-  // ---- epilogue: + b2 + raw x (re-read: the lines are in L2), staged through the x window (dead since the barrier above)
+  // ---- epilogue: + b2 + raw x (+ the running sum), 16 bytes per frame tile and lane straight to memory
+  bf16_t* __restrict__ ob = a.out + (int64_t)bi * len * C;
 #pragma unroll
   for (int i = 0; i < NF2; ++i) {
     const int t = t0 + i * 16 + l15;
+    const unsigned rw[4] = {rres[i].x, rres[i].y, rres[i].z, rres[i].w}, ow[4] = {rout[i].x, rout[i].y, rout[i].z, rout[i].w};
+    unsigned o[4];
 #pragma unroll
     for (int cc = 0; cc < CT; ++cc) {
-      const int co = (wave * CT + cc) * 16 + q * 4;
       f32x4 v = acc2[cc][i] + bv2[cc];
       {
         float r0, r1, r2, r3;
-        unpack2<F16>(rres[cc][i].x, r0, r1); unpack2<F16>(rres[cc][i].y, r2, r3);
+        unpack2<F16>(rw[cc * 2], r0, r1); unpack2<F16>(rw[cc * 2 + 1], r2, r3);
         v += f32x4{r0, r1, r2, r3};
       }
       if (a.mode) {
         {
           float o0, o1, o2, o3;
-          unpack2<F16>(rout[cc][i].x, o0, o1); unpack2<F16>(rout[cc][i].y, o2, o3);
+          unpack2<F16>(ow[cc * 2], o0, o1); unpack2<F16>(ow[cc * 2 + 1], o2, o3);
           v += f32x4{o0, o1, o2, o3};
         }
         if (a.mode == 2) {
@@ -396,20 +410,12 @@ __global__ __launch_bounds__(C2_NT, 2) void conv_pair_kernel(const PairArgs a) {
           for (int e = 0; e < 4; ++e) { v[e] *= a.scale; v[e] = fmaxf(v[e], v[e] * a.final_slope); }
         }
       }
-      *(uint2*)(XW + (i * 16 + l15) * RS + co * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+      o[cc * 2] = pack2<F16>(v[0], v[1]);
+      o[cc * 2 + 1] = pack2<F16>(v[2], v[3]);
     }
+    if (t < len) *(uint4*)(ob + (int64_t)t * C + co8) = make_uint4(o[0], o[1], o[2], o[3]);
   }
-  __syncthreads();
   TTSK_STAMP(6);
-  bf16_t* __restrict__ ob = a.out + (int64_t)bi * len * C;
-  constexpr int NCO = TT * CH8 / NT;     // 6
-#pragma unroll
-  for (int it = 0; it < NCO; ++it) {
-    const int idx = it * NT + tid;
-    const int rr = idx / CH8, ch = idx - rr * CH8;
-    const int t = t0 + rr;
-    if (t < len) *(uint4*)(ob + (int64_t)t * C + ch * 8) = *(const uint4*)(XW + rr * RS + ch * 16);
-  }
   TTSK_STAMP(7);
 }
 
@@ -442,14 +448,21 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
 
   // half-tap g of the sequence c1 (2K half-taps) | c2 (2K): tap (g mod 2K) / 2, channel half g & 1
   bf16x8 wa[KH][CT], wb[KH][CT];
-  const int woff = (wave * CT) * 1024 + lane * 16;
+  // (the A operand's rows permuted as in conv_pair_kernel: a lane's accumulator rows of its two tiles are 8 consecutive channels of one frame)
+  int woff[CT];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc) {
+    const int co = 32 * wave + 8 * (l15 >> 2) + 4 * cc + (l15 & 3);
+    woff[cc] = (co >> 4) * 1024 + ((co & 15) + 16 * q) * 16;
+  }
+  const int co8 = 32 * wave + 8 * q;
   auto load_w = [&](int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
     const int gl = g < K2 ? g : g - K2;
-    const unsigned char* src = (const unsigned char*)(g < K2 ? a.w1 : a.w2) + (int64_t)(gl >> 1) * C256_TAP + (gl & 1) * (KH * NC * 1024) + woff;
+    const unsigned char* src = (const unsigned char*)(g < K2 ? a.w1 : a.w2) + (int64_t)(gl >> 1) * C256_TAP + (gl & 1) * (KH * NC * 1024);
 #pragma unroll
     for (int ks = 0; ks < KH; ++ks)
 #pragma unroll
-      for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(src + (ks * NC + cc) * 1024);
+      for (int cc = 0; cc < CT; ++cc) w[ks][cc] = *(const bf16x8*)(src + ks * NC * 1024 + woff[cc]);
   };
 
   {  // ---- x window: lrelu(x) rows t0 - 33 .. t0 + 129, zeros outside the utterance.  The window is sized for dilation 5 (c1 reaches 25
@@ -479,8 +492,8 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
   f32x4 bv1[CT], bv2[CT];
 #pragma unroll
   for (int cc = 0; cc < CT; ++cc) {
-    bv1[cc] = *(const f32x4*)(a.b1 + (wave * CT + cc) * 16 + q * 4);
-    bv2[cc] = *(const f32x4*)(a.b2 + (wave * CT + cc) * 16 + q * 4);
+    bv1[cc] = *(const f32x4*)(a.b1 + co8 + 4 * cc);
+    bv2[cc] = *(const f32x4*)(a.b2 + co8 + 4 * cc);
   }
   __syncthreads();
 
@@ -511,41 +524,44 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
   if (t0 - CP_TH >= 0 && t0 - CP_TH + CP_TROWS <= len) {      // (the t window inside the utterance: no zero padding to write, no compare, no select)
 #pragma unroll
     for (int i = 0; i < NF1; ++i) {
+      unsigned o[4];
 #pragma unroll
       for (int cc = 0; cc < CT; ++cc) {
         f32x4 v = acc[cc][i] + bv1[cc];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * a.slope);
-        *(uint2*)(TW + (i * 16 + l15) * RS + ((wave * CT + cc) * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+        o[cc * 2] = pack2<F16>(v[0], v[1]);
+        o[cc * 2 + 1] = pack2<F16>(v[2], v[3]);
       }
+      *(uint4*)(TW + (i * 16 + l15) * RS + co8 * 2) = make_uint4(o[0], o[1], o[2], o[3]);
     }
   } else {
 #pragma unroll
     for (int i = 0; i < NF1; ++i) {
       const int t = t0 - CP_TH + i * 16 + l15;
       const bool live = t >= 0 && t < len;
+      unsigned o[4];
 #pragma unroll
       for (int cc = 0; cc < CT; ++cc) {
         f32x4 v = acc[cc][i] + bv1[cc];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = live ? fmaxf(v[e], v[e] * a.slope) : 0.f;
-        *(uint2*)(TW + (i * 16 + l15) * RS + ((wave * CT + cc) * 16 + q * 4) * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+        o[cc * 2] = pack2<F16>(v[0], v[1]);
+        o[cc * 2 + 1] = pack2<F16>(v[2], v[3]);
       }
+      *(uint4*)(TW + (i * 16 + l15) * RS + co8 * 2) = make_uint4(o[0], o[1], o[2], o[3]);
     }
   }
   __syncthreads();
 
   // raw x (residual): requested now, consumed after c2's taps (the accumulate operand of modes 1 / 2 is read in the epilogue:
   // its registers would spill here)
-  uint2 rres[CT][NF2];
+  uint4 rres[NF2];
 #pragma unroll
   for (int i = 0; i < NF2; ++i) {
     const int t = t0 + i * 16 + l15;
-#pragma unroll
-    for (int cc = 0; cc < CT; ++cc) {
-      rres[cc][i] = make_uint2(0u, 0u);
-      if (t < len) rres[cc][i] = *(const uint2*)(xb + (int64_t)t * C + (wave * CT + cc) * 16 + q * 4);
-    }
+    rres[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (t < len) rres[i] = *(const uint4*)(xb + (int64_t)t * C + co8);
   }
   // ---- c2 (dilation 1) over the tile's 96 frames
   f32x4 acc2[CT][NF2];
@@ -569,25 +585,30 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
       if (g + 3 < K2) load_w(K2 + g + 3, wb);
     }
   }
-  __syncthreads();          // every wave is done with the t window; the x window has been dead since c1: the output is staged there
-
+  // ---- epilogue: + b2 + raw x (+ the running sum), 16 bytes per frame tile and lane straight to memory (no staging tile, no barrier)
+  bf16_t* __restrict__ ob = a.out + (int64_t)bi * len * C;
 #pragma unroll
   for (int i = 0; i < NF2; ++i) {
     const int t = t0 + i * 16 + l15;
+    const unsigned rw[4] = {rres[i].x, rres[i].y, rres[i].z, rres[i].w};
+    unsigned ow[4] = {0u, 0u, 0u, 0u};
+    if (a.mode && t < len) {
+      const uint4 ov = *(const uint4*)(ob + (int64_t)t * C + co8);
+      ow[0] = ov.x; ow[1] = ov.y; ow[2] = ov.z; ow[3] = ov.w;
+    }
+    unsigned o[4];
 #pragma unroll
     for (int cc = 0; cc < CT; ++cc) {
-      const int co = (wave * CT + cc) * 16 + q * 4;
       f32x4 v = acc2[cc][i] + bv2[cc];
       {
         float r0, r1, r2, r3;
-        unpack2<F16>(rres[cc][i].x, r0, r1); unpack2<F16>(rres[cc][i].y, r2, r3);
+        unpack2<F16>(rw[cc * 2], r0, r1); unpack2<F16>(rw[cc * 2 + 1], r2, r3);
         v += f32x4{r0, r1, r2, r3};
       }
       if (a.mode) {
-        if (t < len) {
-          const uint2 o = *(const uint2*)(a.out + ((int64_t)bi * len + t) * C + co);
+        {
           float o0, o1, o2, o3;
-          unpack2<F16>(o.x, o0, o1); unpack2<F16>(o.y, o2, o3);
+          unpack2<F16>(ow[cc * 2], o0, o1); unpack2<F16>(ow[cc * 2 + 1], o2, o3);
           v += f32x4{o0, o1, o2, o3};
         }
         if (a.mode == 2) {
@@ -595,18 +616,10 @@ __global__ __launch_bounds__(C256_NT, 1) void conv_pair256_kernel(const PairArgs
           for (int e = 0; e < 4; ++e) { v[e] *= a.scale; v[e] = fmaxf(v[e], v[e] * a.final_slope); }
         }
       }
-      *(uint2*)(XW + (i * 16 + l15) * RS + co * 2) = make_uint2(pack2<F16>(v[0], v[1]), pack2<F16>(v[2], v[3]));
+      o[cc * 2] = pack2<F16>(v[0], v[1]);
+      o[cc * 2 + 1] = pack2<F16>(v[2], v[3]);
     }
-  }
-  __syncthreads();
-  bf16_t* __restrict__ ob = a.out + (int64_t)bi * len * C;
-  constexpr int NCO = TT * CH8 / NT;     // 6
-#pragma unroll
-  for (int it = 0; it < NCO; ++it) {
-    const int idx = it * NT + tid;
-    const int rr = idx / CH8, ch = idx - rr * CH8;
-    const int t = t0 + rr;
-    if (t < len) *(uint4*)(ob + (int64_t)t * C + ch * 8) = *(const uint4*)(XW + rr * RS + ch * 16);
+    if (t < len) *(uint4*)(ob + (int64_t)t * C + co8) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
 

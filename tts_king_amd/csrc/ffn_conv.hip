@@ -83,6 +83,12 @@ struct WcArgs {
   const float* resid32;
   bf16_t* out16;        // fp32 output only: a bf16 copy of the rows as well, or null (mel_linear: the mel for the loss + the PostNet's input)
   float lrelu_slope;    // > 0 (and relu == 0): out = max(v, slope * v) — HiFi-GAN's conv_pre, whose only reader is the first upsampler's LeakyReLU
+  // round 6: the plain 256-channel instances of 112-frame tiles (w_1's forward and input gradient: 13 of the step's launches) fetch the rows of their A
+  // operand permuted — row l15 of tile cc = channel 32 * wave + 8 * (l15 >> 2) + 4 * cc + (l15 & 3) of the group — so that a lane's 4 + 4 accumulator
+  // rows are 8 consecutive channels of one frame, and every wave stores its results straight from the registers when ITS taps are done: no barrier
+  // behind the tap loop (the wave in slot 0 of a SIMD used to wait 8 us there for the one in slot 1), no staging tile, no copy-out.  Same products in the
+  // same order: bit-identical.  Set by the launcher when nothing else rides on the staged tile (gate, delta, statistics, bf16 copy).
+  int direct;
 #ifdef TTSK_STAMPS
   unsigned long long* stamps;   // diagnostic build only (make stamps; ttsk_win_conv_set_stamps): 24 slots per workgroup
 #endif
@@ -262,12 +268,20 @@ __global__ __launch_bounds__(NWV * 64, (F16 && NWV == 4 && CIN == 128) ? 2 : 1) 
   // weight fragments by buffer loads (tapring.h): one per-lane byte offset for the whole kernel, the step's distance in a scalar register
   const __amdgpu_buffer_rsrc_t wres = weights_rsrc(wbase, K * ks_total * 32 * a.Cout * 2);
   const int wlane = PACKED ? (cg * (COUT / 16) + wave * CT) * 1024 + lane * 16 : ((cg * COUT + wave * CT * 16 + l15) * K * C + q * 8) * 2;
+  constexpr bool CAN_DIRECT = PACKED && !F16 && CIN == 256 && TT == 112 && NWV == 8 && CTV == 2;
+  const bool direct = CAN_DIRECT && a.direct;
+  int wl[CT];                                                    // PACKED: this lane's byte offset into a (tap, k-step) of the pack, per cout tile
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc) {
+    const int co = 32 * wave + 8 * (l15 >> 2) + 4 * cc + (l15 & 3);
+    wl[cc] = direct ? (cg * (COUT / 16) + (co >> 4)) * 1024 + ((co & 15) + 16 * q) * 16 : wlane + cc * 1024;
+  }
   const int kstep_bytes = (a.Cout / 16) * 1024;                  // PACKED: bytes per (tap, k-step)
   bf16x8 wa[KH][CT], wb[KH][CT], wc[KH][CT];      // three register sets: a step's weights are requested two steps (>= 1 us) ahead
   auto load_w = [&](int g, bf16x8 (&w)[KH][CT]) __attribute__((always_inline)) {
     const int tap = g / NP, part = g - tap * NP;
     if (PACKED) {
-      frags_load<KH, CT>(w, wres, wlane, (tap * ks_total + ks_base + part * KH) * kstep_bytes, kstep_bytes);
+      frags_load<KH, CT>(w, wres, wl, (tap * ks_total + ks_base + part * KH) * kstep_bytes, kstep_bytes);
     } else {
       const int soff = (tap * C + part * (KH * 32)) * 2;
 #pragma unroll
@@ -310,7 +324,7 @@ __global__ __launch_bounds__(NWV * 64, (F16 && NWV == 4 && CIN == 128) ? 2 : 1) 
   f32x4 bv[CT];
 #pragma unroll
   for (int cc = 0; cc < CT; ++cc)
-    bv[cc] = a.bias ? *(const f32x4*)(a.bias + cg * COUT + (wave * CT + cc) * 16 + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bv[cc] = a.bias ? *(const f32x4*)(a.bias + cg * COUT + (direct ? 32 * wave + 8 * q + 4 * cc : (wave * CT + cc) * 16 + q * 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
   WC_STAMP(1);
   __syncthreads();
   WC_STAMP(2);
@@ -372,6 +386,40 @@ __global__ __launch_bounds__(NWV * 64, (F16 && NWV == 4 && CIN == 128) ? 2 : 1) 
     a.stamps[(int64_t)blockIdx.x * 24 + 16 + wave] = __builtin_amdgcn_s_getreg(63492);      // slots 16..23: HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], ...)
   }
 #endif
+  if constexpr (CAN_DIRECT) {
+    if (direct) {        // this wave's 32 channels x TT frames from its registers to memory, 16 (bf16) / 2 x 16 (fp32) bytes per frame tile and lane
+      const int co8 = cg * COUT + 32 * wave + 8 * q;
+      const int64_t row0 = (int64_t)bi * S;
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int t = t0 + i * 16 + l15;
+        f32x4 v[2] = {acc[0][i] + bv[0], acc[1][i] + bv[1]};
+        if (a.relu) {
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[cc][e] = fmaxf(v[cc][e], 0.f);
+        }
+        if (t < S) {
+          if constexpr (OUT32) {
+            float* p = (float*)a.out + sp * a.out_split + (row0 + t) * a.Cout + co8;
+            *(f32x4*)p = v[0];
+            *(f32x4*)(p + 4) = v[1];
+          } else {
+            if (a.resid32) {        // (the fp32 residual joins the accumulators: the sum is rounded once)
+              const float* rp = a.resid32 + (row0 + t) * a.Cout + co8;
+              v[0] += *(const f32x4*)rp;
+              v[1] += *(const f32x4*)(rp + 4);
+            }
+            *(uint4*)((bf16_t*)a.out + (row0 + t) * a.Cout + co8) =
+                make_uint4(pack2<F16>(v[0][0], v[0][1]), pack2<F16>(v[0][2], v[0][3]), pack2<F16>(v[1][0], v[1][1]), pack2<F16>(v[1][2], v[1][3]));
+          }
+        }
+      }
+      WC_STAMP(5);
+      return;
+    }
+  }
   // (BatchNorm-backward statistics, see the end of the kernel: the layer-below rows this thread will need are requested now, so that
   // they arrive during the staging and the stores)
   f32x4 bnb_v[8];
@@ -675,6 +723,8 @@ int launch_win_conv(const WcArgs& a0, int B, int S, int Cin, int out_f32, int pa
     else hipLaunchKernelGGL((win_conv_kernel<256, 64, false, true, 4, 1>), g4, dim3(256), 0, s, a);
     return 0;
   }
+  // (the 112-frame instances with nothing riding on the staged output tile store straight from the registers: WcArgs::direct)
+  a.direct = packed && !short_seq && Cin == 256 && !a.gate && !a.delta && !a.stats && !a.bnb_x && !a.out16 && !a.ups_cout && !(a.lrelu_slope > 0.f);
   if (Cin == 256 && out_f32) {
     if (short_seq) hipLaunchKernelGGL((win_conv_kernel<256, 64, true, true>), grid, dim3(WC_NT), 0, s, a);
     else hipLaunchKernelGGL((win_conv_kernel<256, 112, true, true>), grid, dim3(WC_NT), 0, s, a);

@@ -37,6 +37,15 @@ __device__ __forceinline__ void frags_load(bf16x8 (&w)[KS][CT], __amdgpu_buffer_
     for (int cc = 0; cc < CT; ++cc) w[ks][cc] = frag_load(r, lane_off + cc * 1024, step_off + ks * kstep_bytes);
 }
 
+// ... with one byte offset per cout tile (a kernel that permutes the rows of its A operand: ffn_conv.hip's direct-store epilogue)
+template <int KS, int CT>
+__device__ __forceinline__ void frags_load(bf16x8 (&w)[KS][CT], __amdgpu_buffer_rsrc_t r, const int (&lane_off)[CT], int step_off, int kstep_bytes) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc) w[ks][cc] = frag_load(r, lane_off[cc], step_off + ks * kstep_bytes);
+}
+
 // A window position is a byte offset into the workgroup's LDS array (this lane's row and 16-byte column of the window, rows RS bytes
 // apart).  LdsPos turns it into address registers that go through an empty asm, so that they stay THE address registers of the step's
 // reads and every (frame tile, k-step) distance lands in the instruction's 16-bit offset field (one register per TPB frame tiles: what

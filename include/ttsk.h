@@ -478,11 +478,11 @@ int ttsk_hifi_conv_pair_supported(int C, int K, int dil);
 int ttsk_hifi_conv_pair(const void* x16, const void* w1_pack, const float* bias1, const void* w2_pack, const float* bias2, void* out16,
                         int f16, int B, int len, int C, int K, int dil, float slope, int mode, float scale, float final_slope,
                         void* stream);
-/* The same pair at C = 64 with the weights STATIONARY in registers (round 6, csrc/pairws.hip; hifi/models.py:88-95, :190-197): one
- * persistent 8-wave workgroup per CU walks a contiguous run of 192-frame tiles; four waves hold c1's weights and four c2's for the whole
+/* The same pair at C = 64 (and at C = 128 for K = 3) with the weights STATIONARY in registers (round 6, csrc/pairws.hip; hifi/models.py:88-95,
+ * :190-197): one persistent 8-wave workgroup per CU walks a contiguous run of 192-frame tiles (96 at C = 128); four waves hold c1's weights and four c2's for the whole
  * launch (32 output channels x K taps x 64 input channels = 16 K registers per lane), the c1 waves produce tile s's lrelu(c1) window in LDS
  * while the c2 waves consume tile s - 1's; the next tile's x window is in flight under the MFMAs.  Arguments, modes and results as
- * ttsk_hifi_conv_pair (bit-identical to it); K in {3, 7, 11}, dil in {1, 3, 5}; tensors below 2 GiB (32-bit buffer offsets);
+ * ttsk_hifi_conv_pair (bit-identical to it); C = 64: K in {3, 7, 11}, C = 128: K = 3; dil in {1, 3, 5}; tensors below 2 GiB (32-bit buffer offsets);
  * max_wgs: grid cap (0 = one workgroup per CU). */
 int ttsk_hifi_conv_pair_ws_supported(int C, int K, int dil);
 int ttsk_hifi_conv_pair_ws(const void* x16, const void* w1_pack, const float* bias1, const void* w2_pack, const float* bias2, void* out16,

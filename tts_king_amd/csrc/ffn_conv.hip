@@ -411,7 +411,7 @@ __global__ __launch_bounds__(NWV * 64, (F16 && NWV == 4 && CIN == 128) ? 2 : 1) 
               v[0] += *(const f32x4*)rp;
               v[1] += *(const f32x4*)(rp + 4);
             }
-            *(uint4*)((bf16_t*)a.out + (row0 + t) * a.Cout + co8) =
+            *(uint4*)((bf16_t*)a.out + sp * a.out_split + (row0 + t) * a.Cout + co8) =
                 make_uint4(pack2<F16>(v[0][0], v[0][1]), pack2<F16>(v[0][2], v[0][3]), pack2<F16>(v[1][0], v[1][1]), pack2<F16>(v[1][2], v[1][3]));
           }
         }

@@ -25,6 +25,7 @@ constexpr int STAGE = A_BYTES + B_BYTES;          // 36 KiB
 constexpr int CS_LD = 260;                        // fp32 epilogue tile leading dimension
 constexpr int SMEM = NSTAGE * STAGE;              // 144 KiB ring (the epilogue tile 32 x 260 x 4 = 33,280 B reuses it)
 constexpr int OOB = 0x7FFFFFFF;
+constexpr int WL_SPLIT_MAX_TILES = 64;            // win_ln_kernel<1024, PROJ>: up to this many 32-row tiles, a tile's three projection groups go to three workgroups
 
 struct GemmLnArgs {
   const bf16_t* A;        // [M][lda] bf16
@@ -75,7 +76,7 @@ __device__ __forceinline__ void drop4(float v[4], uint64_t seed, uint64_t step, 
 // xs2 (may be null): LDS tile [32][P32_RS] that receives the output rows as well (zero rows past M), proj32.h's B operand.
 template <int RW>
 __device__ __forceinline__ void ln_rows_epilogue(const GemmLnArgs& a, const float* cs, int m0, int wave, int lane, const uint2 (&resv)[RW],
-                                                 unsigned char* xs2 = nullptr) {
+                                                 unsigned char* xs2 = nullptr, bool write = true /* false: the rows go to xs2 only (win_ln_kernel's SPLIT parts > 0) */) {
   const int M = a.M, c = lane * 4;
   const uint64_t seed = a.rng ? a.rng[0] : 0, step = a.rng ? a.rng[1] : 0;
   const f32x4 bi = *(const f32x4*)(a.bias + c);
@@ -95,7 +96,7 @@ __device__ __forceinline__ void ln_rows_epilogue(const GemmLnArgs& a, const floa
     if (a.p_pre > 0.f) drop4(z[rr], seed, step, a.site_pre, (unsigned)(((int64_t)row * BN + c) >> 2), thr, scale);
     z[rr][0] += __uint_as_float(resv[rr].x << 16); z[rr][1] += __uint_as_float(resv[rr].x & 0xFFFF0000u);
     z[rr][2] += __uint_as_float(resv[rr].y << 16); z[rr][3] += __uint_as_float(resv[rr].y & 0xFFFF0000u);
-    if (a.z_save && live) *(uint2*)(a.z_save + (int64_t)row * BN + c) = make_uint2(pack_bf2(z[rr][0], z[rr][1]), pack_bf2(z[rr][2], z[rr][3]));
+    if (a.z_save && live && write) *(uint2*)(a.z_save + (int64_t)row * BN + c) = make_uint2(pack_bf2(z[rr][0], z[rr][1]), pack_bf2(z[rr][2], z[rr][3]));
     s[rr] = z[rr][0] + z[rr][1] + z[rr][2] + z[rr][3];
   }
 #pragma unroll
@@ -118,14 +119,14 @@ __device__ __forceinline__ void ln_rows_epilogue(const GemmLnArgs& a, const floa
       continue;
     }
     const float mean = s[rr], rstd = rsqrtf(q[rr] * (1.f / BN) + a.eps);
-    if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+    if (lane == 0 && write) { a.mean[row] = mean; a.rstd[row] = rstd; }
     bool masked = false;
     if (a.lens) { const int b = row / a.seg_len, t = row - b * a.seg_len; masked = t >= a.lens[b]; }
     float o4[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) o4[e] = masked ? 0.f : (z[rr][e] - mean) * rstd * g[e] + bt[e];
     const uint2 ov = make_uint2(pack_bf2(o4[0], o4[1]), pack_bf2(o4[2], o4[3]));
-    *(uint2*)(a.out + (int64_t)row * BN + c) = ov;
+    if (write) *(uint2*)(a.out + (int64_t)row * BN + c) = ov;
     if (xs2) *(uint2*)(xs2 + (wave * RW + rr) * P32_RS + c * 2) = ov;
   }
 }
@@ -251,7 +252,10 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_ln_kernel(const GemmLnArgs a)
 // major pack (ttsk_win_conv_pack_*: [k-step][cout tile][lane][8]), one step = 128 input channels = 8 fragments, three register sets, no
 // barrier in the loop; then the fp32 tile and ln_rows_epilogue as above.  W still crosses L2 -> CU once per workgroup (128 / 512 KiB), but
 // as 1 KiB contiguous fragments into registers instead of through the LDS ring with a barrier per 64 channels.
-template <int CIN, bool PROJ>
+// SPLIT (round 6; the phoneme side: 32 tiles on 256 CUs): the three 256-channel groups of the projection behind the LayerNorm go to SPLIT workgroups per
+// tile, each repeating the tile's contraction and LayerNorm and streaming ITS group of the projection's weights; part 0 alone writes the rows, the statistics
+// and the saved LayerNorm input.  No seam, bit-identical.
+template <int CIN, bool PROJ, int SPLIT = 1>
 __global__ __launch_bounds__(512, (CIN == 256 && !PROJ) ? 2 : 1) void win_ln_kernel(const GemmLnArgs a) {
   constexpr int TT = BM, RS = CIN * 2 + 32, NT = 512, CH8 = CIN / 8, KH = 4, CT = 2, NF = TT / 16, NS = CIN / 128, RW = BM / 8;
   constexpr int XBYTES = TT * RS, CBYTES = BM * CS_LD * 4;
@@ -260,7 +264,8 @@ __global__ __launch_bounds__(512, (CIN == 256 && !PROJ) ? 2 : 1) void win_ln_ker
   __shared__ __attribute__((aligned(16))) unsigned char ptile[PROJ ? 2 * P32_TT * P32_RS : 16];      // output rows (B operand) | staging rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.x * BM;
+  const int part = SPLIT > 1 ? (int)blockIdx.x % SPLIT : 0;
+  const int m0 = (SPLIT > 1 ? (int)blockIdx.x / SPLIT : (int)blockIdx.x) * BM;
   const int M = a.M;
   WL_STAMP(0);
   // weight fragments by buffer loads, activation fragments a step ahead of their MFMAs (tapring.h)
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(512, (CIN == 256 && !PROJ) ? 2 : 1) void win_ln_ker
   }
   WL_STAMP(3);
   Proj32W PW;
-  if (PROJ) proj32_prefetch(a.pw, a.pCout, wave, lane, PW);      // the next projection's first fragments arrive behind the LayerNorm rows
+  if (PROJ) proj32_prefetch(a.pw, a.pCout, wave, lane, PW, part * (3 / SPLIT));      // the next projection's first fragments arrive behind the LayerNorm rows
   __syncthreads();                         // every wave is done with the rows of A: they become the fp32 tile
   WL_STAMP(4);
   float* cs = (float*)smem;
@@ -345,13 +350,13 @@ __global__ __launch_bounds__(512, (CIN == 256 && !PROJ) ? 2 : 1) void win_ln_ker
 #pragma unroll
     for (int cc = 0; cc < CT; ++cc) *(f32x4*)(cs + (i * 16 + l15) * CS_LD + (wave * CT + cc) * 16 + q * 4) = acc[cc][i];
   __syncthreads();
-  ln_rows_epilogue<RW>(a, cs, m0, wave, lane, resv, PROJ ? ptile : nullptr);
+  ln_rows_epilogue<RW>(a, cs, m0, wave, lane, resv, PROJ ? ptile : nullptr, part == 0);
   WL_STAMP(5);
   if (PROJ) {
     __syncthreads();
-    proj32_run<3>(ptile, ptile + P32_TT * P32_RS, a.pw, a.pCout, a.pbias, PW, tid, [&](int cg, int rr, int ch, uint4 v, int) __attribute__((always_inline)) {
+    proj32_run<3 / SPLIT>(ptile, ptile + P32_TT * P32_RS, a.pw, a.pCout, a.pbias, PW, tid, [&](int cg, int rr, int ch, uint4 v, int) __attribute__((always_inline)) {
       if (m0 + rr < M) *(uint4*)(a.pout + (int64_t)(m0 + rr) * a.pCout + cg * BN + ch * 8) = v;
-    });
+    }, Proj32NoPre(), part * (3 / SPLIT));
   }
   WL_STAMP(6);
 }
@@ -411,6 +416,7 @@ static int win_ln_launch(const void* A, int lda, const void* W_packed, const flo
   const dim3 grid((M + BM - 1) / BM);
   if (proj_w) {
     if (K == 256) hipLaunchKernelGGL((win_ln_kernel<256, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    else if (grid.x <= WL_SPLIT_MAX_TILES) hipLaunchKernelGGL((win_ln_kernel<1024, true, 3>), dim3(grid.x * 3), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((win_ln_kernel<1024, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
   } else {
     if (K == 256) hipLaunchKernelGGL((win_ln_kernel<256, false>), grid, dim3(512), 0, (hipStream_t)stream, a);
